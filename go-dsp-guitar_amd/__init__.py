@@ -1,0 +1,288 @@
+"""go-dsp-guitar's batch-mode effects pipeline on MI355X: Python plumbing over libgdg.so.
+
+The product is the C-ABI shared library (include/gdg.h, csrc/*.hip); this module only loads
+it with ctypes and offers thin conveniences for tests and bench.py.  There is no CPU compute
+path here: if the library or a GPU is missing, calls fail loudly.
+
+The directory name contains a hyphen (it mirrors the reference's repo name), so import it
+through __graft_entry__.load_package() which registers it as `go_dsp_guitar_amd`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgdg.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+GDG_OK, GDG_ERR_INVALID, GDG_ERR_UNSUPPORTED, GDG_ERR_HIP, GDG_ERR_NO_DEVICE, GDG_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+
+UNIT_NAMES = [
+    "signal_generator", "noise_gate", "bandpass", "auto_wah", "auto_yoy", "compressor", "octaver",
+    "excess", "fuzz", "overdrive", "distortion", "tone_stack", "chorus", "flanger", "phaser",
+    "tremolo", "ring_modulator", "delay", "reverb", "power_amp", "cabinet",
+]
+UNIT = {name: i for i, name in enumerate(UNIT_NAMES)}
+
+K_FIR_FWD, K_FIR_MAC, K_FIR_INV, K_SEGMENT, K_TUNER, K_SPATIALIZER = range(6)
+KERNEL_KINDS = ["fir_fwd", "fir_mac", "fir_inv", "segment", "tuner", "spatializer"]
+
+# every symbol include/gdg.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "gdg_version", "gdg_device_count", "gdg_ctx_create", "gdg_ctx_destroy", "gdg_last_error", "gdg_ctx_channels",
+    "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
+    "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_device",
+    "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
+    "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_analyze", "gdg_tuner_note_name",
+    "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device",
+]
+
+
+class GdgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gdg error %d: %s" % (code, msg))
+        self.code = code
+
+
+class TunerResult(C.Structure):
+    _fields_ = [("frequency", C.c_double), ("note_index", C.c_int32), ("cents", C.c_int8)]
+
+
+def build(force=False):
+    """Compile libgdg.so for gfx950 with hipcc (recipe: csrc/Makefile).  Works without a GPU."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-C", CSRC])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libgdg.so (raises if it was never built: there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GdgError(GDG_ERR_NO_DEVICE, "libgdg.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u32, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_double
+        sig = {
+            "gdg_version": (C.c_char_p, []),
+            "gdg_device_count": (i32, []),
+            "gdg_ctx_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
+            "gdg_ctx_destroy": (i32, [vp]),
+            "gdg_last_error": (C.c_char_p, [vp]),
+            "gdg_ctx_channels": (i32, [vp]),
+            "gdg_ctx_stream": (vp, [vp]),
+            "gdg_ctx_synchronize": (i32, [vp]),
+            "gdg_unit_create": (i32, [vp, i32, i32, C.POINTER(i32)]),
+            "gdg_unit_destroy": (i32, [vp, i32]),
+            "gdg_unit_set_param": (i32, [vp, i32, i32, C.c_int32]),
+            "gdg_unit_get_param": (i32, [vp, i32, i32, C.POINTER(C.c_int32)]),
+            "gdg_unit_set_fir": (i32, [vp, i32, vp, i32]),
+            "gdg_unit_reset": (i32, [vp, i32]),
+            "gdg_chain_set": (i32, [vp, i32, vp, vp, i32]),
+            "gdg_process": (i32, [vp, vp, vp, i32, u32]),
+            "gdg_process_device": (i32, [vp, vp, vp, i32, u32]),
+            "gdg_device_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+            "gdg_device_free": (i32, [vp, vp]),
+            "gdg_copy_to_device": (i32, [vp, vp, vp, C.c_size_t]),
+            "gdg_copy_to_host": (i32, [vp, vp, vp, C.c_size_t]),
+            "gdg_profile_enable": (i32, [vp, i32]),
+            "gdg_profile_read": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(i32)]),
+            "gdg_tuner_enqueue": (i32, [vp, vp, i32, u32]),
+            "gdg_tuner_enqueue_device": (i32, [vp, vp, i32, u32]),
+            "gdg_tuner_analyze": (i32, [vp, C.POINTER(TunerResult)]),
+            "gdg_tuner_note_name": (C.c_char_p, [i32]),
+            "gdg_spatializer_set_position": (i32, [vp, i32, dbl, dbl, dbl]),
+            "gdg_spatializer_set_sample_rate": (i32, [vp, u32]),
+            "gdg_spatialize": (i32, [vp, vp, vp, vp, i32]),
+            "gdg_spatialize_device": (i32, [vp, vp, vp, i32]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return lib().gdg_device_count()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceBuffer:
+    """A [rows][cols] float64 array in the context's device memory (plain device pointer underneath)."""
+
+    def __init__(self, ctx, rows, cols):
+        self.ctx, self.rows, self.cols = ctx, rows, cols
+        p = C.c_void_p()
+        ctx._check(lib().gdg_device_alloc(ctx._h, rows * cols * 8, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, a):
+        a = _f64(a)
+        assert a.size == self.rows * self.cols
+        self.ctx._check(lib().gdg_copy_to_device(self.ctx._h, self.ptr, a.ctypes.data, a.nbytes))
+
+    def download(self):
+        out = np.empty((self.rows, self.cols), dtype=np.float64)
+        self.ctx._check(lib().gdg_copy_to_host(self.ctx._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().gdg_device_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One shard of channels on one GPU (gdg_ctx)."""
+
+    def __init__(self, n_channels, max_frames=8192, device=0):
+        self.n_channels, self.max_frames, self.device = n_channels, max_frames, device
+        h = C.c_void_p()
+        rc = lib().gdg_ctx_create(n_channels, max_frames, device, C.byref(h))
+        if rc != GDG_OK:
+            raise GdgError(rc, "gdg_ctx_create failed (no usable HIP device?)")
+        self._h = h
+        self._chains = [[] for _ in range(n_channels)]      # [(handle, bypass)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gdg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != GDG_OK:
+            raise GdgError(rc, lib().gdg_last_error(self._h).decode())
+
+    # -- units / chains ------------------------------------------------------------------------
+    def unit_create(self, channel, unit_type):
+        if isinstance(unit_type, str):
+            unit_type = UNIT[unit_type]
+        h = C.c_int(-1)
+        self._check(lib().gdg_unit_create(self._h, channel, unit_type, C.byref(h)))
+        return h.value
+
+    def unit_destroy(self, handle):
+        self._check(lib().gdg_unit_destroy(self._h, handle))
+
+    def unit_set_param(self, handle, idx, value):
+        self._check(lib().gdg_unit_set_param(self._h, handle, idx, int(value)))
+
+    def unit_get_param(self, handle, idx):
+        v = C.c_int32(0)
+        self._check(lib().gdg_unit_get_param(self._h, handle, idx, C.byref(v)))
+        return v.value
+
+    def unit_set_fir(self, handle, taps):
+        t = _f64(taps)
+        self._check(lib().gdg_unit_set_fir(self._h, handle, t.ctypes.data if t.size else None, t.size))
+
+    def unit_reset(self, handle):
+        self._check(lib().gdg_unit_reset(self._h, handle))
+
+    def chain_set(self, channel, handles, bypass=None):
+        n = len(handles)
+        bypass = [False] * n if bypass is None else bypass
+        hs = (C.c_int * max(n, 1))(*handles)
+        bs = (C.c_uint8 * max(n, 1))(*[1 if b else 0 for b in bypass])
+        self._check(lib().gdg_chain_set(self._h, channel, hs, bs, n))
+        self._chains[channel] = list(zip(handles, bypass))
+
+    def append_unit(self, channel, unit_type, params=None, fir=None, bypass=False):
+        """AppendUnit + SetBypass + parameter set-up in one go (test convenience)."""
+        h = self.unit_create(channel, unit_type)
+        if params is not None:
+            for i, v in enumerate(params):
+                self.unit_set_param(h, i, v)
+        if fir is not None:
+            self.unit_set_fir(h, fir)
+        chain = self._chains[channel] + [(h, bypass)]
+        self.chain_set(channel, [c[0] for c in chain], [c[1] for c in chain])
+        return h
+
+    # -- processing --------------------------------------------------------------------------------
+    def process(self, x, sample_rate):
+        """x: [n_channels][frames] host array -> same-shaped output (gdg_process, blocking)."""
+        x = _f64(x)
+        assert x.ndim == 2 and x.shape[0] == self.n_channels
+        frames = x.shape[1]
+        out = np.empty_like(x)
+        ins = (C.c_void_p * self.n_channels)(*[x[c].ctypes.data for c in range(self.n_channels)])
+        outs = (C.c_void_p * self.n_channels)(*[out[c].ctypes.data for c in range(self.n_channels)])
+        self._check(lib().gdg_process(self._h, ins, outs, frames, sample_rate))
+        return out
+
+    def process_device(self, d_in, d_out, frames, sample_rate):
+        """Device-resident block; d_in / d_out are plain device pointers (ints) or DeviceBuffers."""
+        pi = d_in.ptr if isinstance(d_in, DeviceBuffer) else d_in
+        po = d_out.ptr if isinstance(d_out, DeviceBuffer) else d_out
+        self._check(lib().gdg_process_device(self._h, pi, po, frames, sample_rate))
+
+    def synchronize(self):
+        self._check(lib().gdg_ctx_synchronize(self._h))
+
+    def alloc(self, rows, cols):
+        return DeviceBuffer(self, rows, cols)
+
+    @property
+    def stream(self):
+        return lib().gdg_ctx_stream(self._h)
+
+    # -- profiling ------------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(lib().gdg_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, kind):
+        ms, n = C.c_double(0.0), C.c_int(0)
+        self._check(lib().gdg_profile_read(self._h, kind, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- tuner / spatializer ---------------------------------------------------------------------------
+    def tuner_enqueue(self, x, sample_rate):
+        x = _f64(x)
+        assert x.ndim == 2 and x.shape[0] == self.n_channels
+        ptrs = (C.c_void_p * self.n_channels)(*[x[c].ctypes.data for c in range(self.n_channels)])
+        self._check(lib().gdg_tuner_enqueue(self._h, ptrs, x.shape[1], sample_rate))
+
+    def tuner_enqueue_device(self, d_x, frames, sample_rate):
+        p = d_x.ptr if isinstance(d_x, DeviceBuffer) else d_x
+        self._check(lib().gdg_tuner_enqueue_device(self._h, p, frames, sample_rate))
+
+    def tuner_analyze(self):
+        res = (TunerResult * self.n_channels)()
+        self._check(lib().gdg_tuner_analyze(self._h, res))
+        return [{"frequency": r.frequency, "note_index": r.note_index, "cents": r.cents,
+                 "note": lib().gdg_tuner_note_name(r.note_index).decode()} for r in res]
+
+    def spatializer_set_position(self, channel, azimuth, distance, level):
+        self._check(lib().gdg_spatializer_set_position(self._h, channel, azimuth, distance, level))
+
+    def spatializer_set_sample_rate(self, rate):
+        self._check(lib().gdg_spatializer_set_sample_rate(self._h, rate))
+
+    def spatialize(self, x):
+        x = _f64(x)
+        assert x.ndim == 2 and x.shape[0] == self.n_channels
+        n = x.shape[1]
+        ptrs = (C.c_void_p * self.n_channels)(*[x[c].ctypes.data for c in range(self.n_channels)])
+        left, right = np.empty(n), np.empty(n)
+        self._check(lib().gdg_spatialize(self._h, ptrs, left.ctypes.data, right.ctypes.data, n))
+        return left, right
+
+    def spatialize_device(self, d_x, d_out_lr, frames):
+        pi = d_x.ptr if isinstance(d_x, DeviceBuffer) else d_x
+        po = d_out_lr.ptr if isinstance(d_out_lr, DeviceBuffer) else d_out_lr
+        self._check(lib().gdg_spatialize_device(self._h, pi, po, frames))

@@ -1,0 +1,878 @@
+/*
+ * api.cpp -- host side of libgdg.so: the C-ABI of include/gdg.h on top of the HIP kernels.
+ *
+ * What happens here: unit/chain bookkeeping, derivation of the per-unit constants in the
+ * reference's arithmetic, device state management (with the reference's "re-make => zero"
+ * semantics), compilation of the per-channel chains into batched launches
+ * [segment | FIR | segment | FIR ...] across all channels of the shard, and launch.
+ * There is no CPU compute path in this file: every sample is produced by a HIP kernel.
+ */
+#include "../../include/gdg.h"
+#include "gdg_internal.h"
+#include "aa_taps.h"
+#include "go_consts.h"
+#include "notes.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#define NUM_FILTERS 8
+
+/* ---- parameter tables (defaults), effects/<unit>.go create*() ------------------------------------ */
+static const int g_param_count[GDG_UNIT_COUNT] = { 6, 3, 3, 5, 4, 3, 7, 3, 7, 6, 4, 4, 2, 2, 3, 3, 1, 3, 1, 1, 1 };
+static const int32_t g_param_default[GDG_UNIT_COUNT][GDG_MAX_PARAMS] = {
+    { 100, 0, 0, 440, 100, 0 }, { -20, -40, 50 }, { 0, 300, 3000 }, { 1, -40, -10, 300, 6000 },
+    { 1, -40, -10, 100 }, { 1, 30, -20 }, { 1, -20, -20, -20, -20, -20, -20 }, { 0, 0, 0 },
+    { 1, 50, 0, 0, 100, 0, 0 }, { 0, 0, 100, 0, 1, 0 }, { 0, 0, 0, 0 }, { 0, -2, -5, -5 },
+    { 100, 30 }, { 100, 10 }, { 100, 10, 45 }, { 100, 50, -10 }, { 100 }, { 200, -5, -5 }, { 50 }, { 14 }, { 0 },
+};
+
+struct Unit {
+    bool alive = false;
+    int type = 0, channel = 0;
+    int32_t params[GDG_MAX_PARAMS] = { 0 };
+    /* segment state */
+    double *d_ds = nullptr;
+    int *d_is = nullptr;
+    double *d_hist = nullptr;
+    size_t hist_len = 0;
+    long long hist_key = -1;          /* what the current history layout was built for */
+    int os_frames[2] = { -1, -1 };    /* frame size the 2x / 4x oversampler last saw */
+    int bp_half_order = -1;
+    /* FIR */
+    std::vector<double> taps;
+    bool fir_dirty = true;
+    bool fir_live = false;
+    int fir_P = 0, fir_K = 0;
+    uint32_t fir_sr = 0;
+    double *d_prev = nullptr;
+    double2 *d_fdl = nullptr, *d_H = nullptr, *d_Y = nullptr;
+    int *d_pos = nullptr;
+};
+
+struct Slot { int handle; bool bypass; };
+
+struct StepDesc {
+    bool is_fir;
+    int n;
+    size_t offset;                    /* byte offset of its descriptor array inside the plan blob */
+};
+
+struct ProfEvent { int kind; hipEvent_t a, b; };
+
+struct gdg_ctx {
+    int nch = 0, max_frames = 0, device = 0;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    std::vector<Unit> units;
+    std::vector<std::vector<Slot>> chains;
+    bool dirty = true;
+    /* cached plan */
+    int plan_frames = 0;
+    uint32_t plan_sr = 0;
+    const double *plan_in = nullptr;
+    double *plan_out = nullptr;
+    std::vector<StepDesc> steps;
+    std::vector<unsigned char> blob;
+    unsigned char *d_blob = nullptr;
+    size_t d_blob_cap = 0;
+    size_t units_offset = 0;
+    /* buffers */
+    double *d_w0 = nullptr, *d_w1 = nullptr, *d_scratch = nullptr;
+    double *d_stage_in = nullptr, *d_stage_out = nullptr;
+    double *h_stage_in = nullptr, *h_stage_out = nullptr;
+    int *d_error = nullptr;
+    /* tables */
+    std::map<int, std::pair<double2 *, double2 *>> fir_tables;
+    double *d_os = nullptr;
+    gdg_os_tables os;
+    /* profiling */
+    bool profiling = false;
+    std::vector<ProfEvent> prof;
+    std::vector<hipEvent_t> event_pool;
+    /* tuner / spatializer */
+    double *d_tuner_ring = nullptr;
+    int tuner_wp = 0;
+    uint32_t tuner_sr = 0;
+    std::vector<double> sp_az, sp_dist, sp_level;
+    uint32_t sp_hist_sr = 96000;
+    double *d_sp_hist = nullptr;
+    int sp_hist_len = 0;
+};
+
+static int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) return fail(ctx, GDG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static double decibels_to_factor(int32_t decibels) {          /* effects/effects.go:389-394 */
+    double e = 0.05 * (double)decibels;
+    return pow(10.0, e);
+}
+
+static double lanczos_kernel(double x, double a) {             /* resample/resample.go:10-31 */
+    if (x == 0) return 1.0;
+    if ((-a < x) && (x < a)) {
+        double pi_x = M_PI * x;
+        double pi_xa = pi_x / a;
+        double pi_x_squared = pi_x * pi_x;
+        double prod = sin(pi_x) * sin(pi_xa);
+        double arg = a * prod;
+        return arg / pi_x_squared;
+    }
+    return 0.0;
+}
+
+extern "C" {
+
+const char *gdg_version(void) { return "gdg 0.1 gfx950 hip"; }
+
+int gdg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
+    if (!out) return GDG_ERR_INVALID;
+    *out = nullptr;
+    if (n_channels <= 0 || max_frames <= 0) return GDG_ERR_INVALID;
+    if (max_frames > GDG_MAX_FRAMES) return GDG_ERR_UNSUPPORTED;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GDG_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return GDG_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return GDG_ERR_NO_DEVICE;
+    gdg_ctx *ctx = new gdg_ctx();
+    ctx->nch = n_channels;
+    ctx->max_frames = max_frames;
+    ctx->device = device;
+    ctx->chains.resize((size_t)n_channels);
+    ctx->sp_az.assign((size_t)n_channels, 0.0);
+    ctx->sp_dist.assign((size_t)n_channels, 0.0);
+    ctx->sp_level.assign((size_t)n_channels, 1.0);
+    size_t row = (size_t)n_channels * (size_t)max_frames * sizeof(double);
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_w0, row) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_w1, row) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_scratch, row) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_error, sizeof(int)) == hipSuccess;
+    ok = ok && hipMemset(ctx->d_error, 0, sizeof(int)) == hipSuccess;
+    /* oversampling tables: 77 + 155 taps, 6 + 18 Lanczos-3 weights (resample.go:36-66 evaluated once per phase) */
+    std::vector<double> tab(77 + 155 + 6 + 18);
+    for (int k = 0; k < 39; k++) { tab[k] = GDG_AA2_HALF[k]; tab[76 - k] = GDG_AA2_HALF[k]; }
+    for (int k = 0; k < 78; k++) { tab[77 + k] = GDG_AA4_HALF[k]; tab[77 + 154 - k] = GDG_AA4_HALF[k]; }
+    for (int q = 0; q < 6; q++) tab[232 + q] = lanczos_kernel((double)(2 - q) + 0.5, 3.0);
+    for (int r = 1; r < 4; r++)
+        for (int q = 0; q < 6; q++) tab[238 + (r - 1) * 6 + q] = lanczos_kernel((double)(2 - q) + 0.25 * (double)r, 3.0);
+    ok = ok && hipMalloc((void **)&ctx->d_os, tab.size() * sizeof(double)) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->d_os, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { gdg_ctx_destroy(ctx); return GDG_ERR_HIP; }
+    ctx->os.taps2 = ctx->d_os;
+    ctx->os.taps4 = ctx->d_os + 77;
+    ctx->os.lanczos2 = ctx->d_os + 232;
+    ctx->os.lanczos4 = ctx->d_os + 238;
+    *out = ctx;
+    return GDG_OK;
+}
+
+static void free_unit(Unit &u) {
+    hipFree(u.d_ds); hipFree(u.d_is); hipFree(u.d_hist);
+    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_H); hipFree(u.d_Y); hipFree(u.d_pos);
+    u = Unit();
+}
+
+int gdg_ctx_destroy(gdg_ctx *ctx) {
+    if (!ctx) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &u : ctx->units) if (u.alive) free_unit(u);
+    for (auto &kv : ctx->fir_tables) { hipFree(kv.second.first); hipFree(kv.second.second); }
+    for (auto &p : ctx->prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error);
+    hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
+    hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
+    if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
+    if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GDG_OK;
+}
+
+const char *gdg_last_error(const gdg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int gdg_ctx_channels(const gdg_ctx *ctx) { return ctx ? ctx->nch : 0; }
+void *gdg_ctx_stream(const gdg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+/* ---- units ------------------------------------------------------------------------------------- */
+
+static Unit *get_unit(gdg_ctx *ctx, int handle) {
+    if (!ctx || handle < 0 || handle >= (int)ctx->units.size() || !ctx->units[(size_t)handle].alive) return nullptr;
+    return &ctx->units[(size_t)handle];
+}
+
+int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle) {
+    if (!ctx || !handle) return GDG_ERR_INVALID;
+    if (channel < 0 || channel >= ctx->nch) return fail(ctx, GDG_ERR_INVALID, "channel %d out of range", channel);
+    if (unit_type < 0 || unit_type >= GDG_UNIT_COUNT) return fail(ctx, GDG_ERR_INVALID, "Failed to create effects unit.");
+    hipSetDevice(ctx->device);
+    size_t h = 0;
+    while (h < ctx->units.size() && ctx->units[h].alive) h++;
+    if (h == ctx->units.size()) ctx->units.emplace_back();
+    Unit &u = ctx->units[h];
+    u = Unit();
+    u.alive = true;
+    u.type = unit_type;
+    u.channel = channel;
+    memcpy(u.params, g_param_default[unit_type], sizeof(u.params));
+    HIP_TRY(ctx, hipMalloc((void **)&u.d_ds, GDG_DS_LEN * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&u.d_is, GDG_IS_LEN * sizeof(int)));
+    HIP_TRY(ctx, hipMemsetAsync(u.d_ds, 0, GDG_DS_LEN * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(u.d_is, 0, GDG_IS_LEN * sizeof(int), ctx->stream));
+    *handle = (int)h;
+    return GDG_OK;
+}
+
+int gdg_unit_destroy(gdg_ctx *ctx, int handle) {
+    Unit *u = get_unit(ctx, handle);
+    if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &chain : ctx->chains)
+        chain.erase(std::remove_if(chain.begin(), chain.end(), [&](const Slot &s) { return s.handle == handle; }), chain.end());
+    free_unit(*u);
+    ctx->dirty = true;
+    return GDG_OK;
+}
+
+int gdg_unit_set_param(gdg_ctx *ctx, int handle, int param_index, int32_t value) {
+    Unit *u = get_unit(ctx, handle);
+    if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
+    if (param_index < 0 || param_index >= g_param_count[u->type]) return fail(ctx, GDG_ERR_INVALID, "bad parameter index %d", param_index);
+    if (u->params[param_index] != value) {
+        u->params[param_index] = value;
+        ctx->dirty = true;
+    }
+    return GDG_OK;
+}
+
+int gdg_unit_get_param(gdg_ctx *ctx, int handle, int param_index, int32_t *value) {
+    Unit *u = get_unit(ctx, handle);
+    if (!u || !value) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
+    if (param_index < 0 || param_index >= g_param_count[u->type]) return fail(ctx, GDG_ERR_INVALID, "bad parameter index %d", param_index);
+    *value = u->params[param_index];
+    return GDG_OK;
+}
+
+int gdg_unit_set_fir(gdg_ctx *ctx, int handle, const double *taps, int n_taps) {
+    Unit *u = get_unit(ctx, handle);
+    if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
+    if (u->type != GDG_UNIT_POWERAMP) return fail(ctx, GDG_ERR_INVALID, "unit %d is not a power amp", handle);
+    if (n_taps < 0 || (n_taps > 0 && !taps)) return fail(ctx, GDG_ERR_INVALID, "bad taps");
+    u->taps.assign(taps, taps + n_taps);
+    u->fir_dirty = true;            /* new filter => fresh state (effects/poweramp.go:132-181) */
+    u->fir_live = false;
+    ctx->dirty = true;
+    return GDG_OK;
+}
+
+static int zero_unit_state(gdg_ctx *ctx, Unit &u) {
+    HIP_TRY(ctx, hipMemsetAsync(u.d_ds, 0, GDG_DS_LEN * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(u.d_is, 0, GDG_IS_LEN * sizeof(int), ctx->stream));
+    if (u.d_hist) HIP_TRY(ctx, hipMemsetAsync(u.d_hist, 0, u.hist_len * sizeof(double), ctx->stream));
+    u.fir_dirty = true;
+    u.fir_live = false;
+    return GDG_OK;
+}
+
+int gdg_unit_reset(gdg_ctx *ctx, int handle) {
+    Unit *u = get_unit(ctx, handle);
+    if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
+    hipSetDevice(ctx->device);
+    ctx->dirty = true;
+    return zero_unit_state(ctx, *u);
+}
+
+int gdg_chain_set(gdg_ctx *ctx, int channel, const int *handles, const uint8_t *bypass, int n) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (channel < 0 || channel >= ctx->nch) return fail(ctx, GDG_ERR_INVALID, "channel %d out of range", channel);
+    if (n < 0 || (n > 0 && (!handles || !bypass))) return fail(ctx, GDG_ERR_INVALID, "bad chain");
+    std::vector<Slot> chain;
+    for (int i = 0; i < n; i++) {
+        Unit *u = get_unit(ctx, handles[i]);
+        if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d in chain", handles[i]);
+        if (u->channel != channel) return fail(ctx, GDG_ERR_INVALID, "unit %d belongs to channel %d", handles[i], u->channel);
+        for (auto &s : chain) if (s.handle == handles[i]) return fail(ctx, GDG_ERR_INVALID, "unit %d appears twice", handles[i]);
+        chain.push_back(Slot{ handles[i], bypass[i] != 0 });
+    }
+    ctx->chains[(size_t)channel] = chain;
+    ctx->dirty = true;
+    return GDG_OK;
+}
+
+/* ---- plan ----------------------------------------------------------------------------------------- */
+
+static int ensure_hist(gdg_ctx *ctx, Unit &u, size_t len, long long key) {
+    if (u.hist_key == key && u.hist_len == len) return GDG_OK;
+    if (u.d_hist) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(u.d_hist); u.d_hist = nullptr; }
+    u.hist_len = len;
+    u.hist_key = key;
+    if (len > 0) {
+        HIP_TRY(ctx, hipMalloc((void **)&u.d_hist, len * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(u.d_hist, 0, len * sizeof(double), ctx->stream));
+    }
+    return GDG_OK;
+}
+
+static int zero_is(gdg_ctx *ctx, Unit &u, int first, int count) {
+    HIP_TRY(ctx, hipMemsetAsync(u.d_is + first, 0, (size_t)count * sizeof(int), ctx->stream));
+    return GDG_OK;
+}
+
+/* Fill the device-side description of one non-FIR unit; (re)build its history for this rate / frame size. */
+static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate, gdg_seg_unit &d) {
+    memset(&d, 0, sizeof(d));
+    d.type = u.type;
+    for (int i = 0; i < GDG_MAX_PARAMS; i++) d.ip[i] = u.params[i];
+    const int32_t *p = u.params;
+    const double sr = (double)sample_rate;
+    int rc = GDG_OK;
+    switch (u.type) {
+    case GDG_UNIT_COMPRESSOR: {
+        d.dp[0] = decibels_to_factor(p[1]);
+        d.dp[1] = decibels_to_factor(p[2]);
+        d.dp[2] = exp(-20.0 / sr);
+        d.dp[3] = 1.0 - d.dp[2];
+        break;
+    }
+    case GDG_UNIT_OVERDRIVE:
+    case GDG_UNIT_DISTORTION:
+    case GDG_UNIT_EXCESS: {
+        int os_idx;
+        if (u.type == GDG_UNIT_OVERDRIVE) {
+            d.dp[0] = decibels_to_factor(p[0] + p[1]);
+            d.dp[1] = 0.01 * (double)p[2];
+            d.dp[2] = 1.0 - d.dp[1];
+            d.dp[3] = decibels_to_factor(p[3]);
+            d.ip[4] = p[4];
+            os_idx = p[5];
+        } else if (u.type == GDG_UNIT_DISTORTION) {
+            d.dp[0] = decibels_to_factor(p[0] + p[1]);
+            d.dp[3] = decibels_to_factor(p[2]);
+            os_idx = p[3];
+        } else {
+            d.dp[0] = decibels_to_factor(p[0]);
+            d.dp[3] = decibels_to_factor(p[1]);
+            os_idx = p[2];
+        }
+        int f = (os_idx == 1) ? 2 : (os_idx == 2) ? 4 : 1;
+        d.jp[0] = f;
+        if (f > 1) {
+            /* one history block per oversampler object (oversamplerTwo / oversamplerFour keep separate state) */
+            const size_t len2 = 8 + 76, len4 = 8 + 154;
+            rc = ensure_hist(ctx, u, len2 + len4, 1);
+            if (rc != GDG_OK) return rc;
+            double *base = u.d_hist + (f == 2 ? 0 : len2);
+            int which = (f == 2) ? 0 : 1;
+            if (u.os_frames[which] != frames) {
+                /* bufferPreUpsampling is re-made when the frame size changes (oversampling.go:86-89) */
+                if (u.os_frames[which] >= 0) HIP_TRY(ctx, hipMemsetAsync(base, 0, 8 * sizeof(double), ctx->stream));
+                u.os_frames[which] = frames;
+            }
+            d.hist = base;
+        }
+        break;
+    }
+    case GDG_UNIT_TONESTACK: {
+        static const double freqs[5] = { 20.0, 300.0, 3000.0, 6000.0, 20000.0 };
+        double m2pi_sr = -GO_MATH_TWO_PI / sr;
+        for (int j = 0; j < 4; j++) {
+            d.dp[j] = decibels_to_factor(p[j]);
+            d.dp[4 + j] = 1.0 - exp(m2pi_sr * freqs[j]);
+            d.dp[8 + j] = 1.0 - exp(m2pi_sr * freqs[j + 1]);
+        }
+        break;
+    }
+    case GDG_UNIT_CABINET: {
+        static const double f[7] = { 300.0, 120.0, 80.0, 3000.0, 4000.0, 5000.0, 6000.0 };
+        double m2pi_sr = -GO_MATH_TWO_PI / sr;
+        for (int j = 0; j < 7; j++) d.dp[j] = 1.0 - exp(m2pi_sr * f[j]);
+        break;
+    }
+    case GDG_UNIT_CHORUS: {
+        double depth = 0.1 * (double)p[0];
+        if (depth < 0.0) depth = 0.0; else if (depth > 10.0) depth = 10.0;
+        d.dp[0] = depth;
+        d.dp[1] = GO_MATH_PI_THOUSANDTH * (double)p[1];
+        d.dp[2] = sr;
+        int C = (int)floor((0.05 * sr) + 0.5);
+        d.jp[0] = C;
+        if (u.hist_key != C) rc = zero_is(ctx, u, 0, 1);
+        if (rc == GDG_OK) rc = ensure_hist(ctx, u, (size_t)C, C);
+        d.hist = u.d_hist;
+        break;
+    }
+    case GDG_UNIT_FLANGER:
+    case GDG_UNIT_PHASER: {
+        double depth = 0.01 * (double)p[0];
+        if (depth < 0.0) depth = 0.0; else if (depth > 1.0) depth = 1.0;
+        d.dp[0] = depth;
+        d.dp[1] = GO_MATH_TWO_PI_HUNDREDTH * (double)p[1];
+        d.dp[2] = sr;
+        d.dp[3] = 1.0 / sr;
+        d.dp[4] = 0.5;
+        d.dp[5] = 0.5;
+        if (u.type == GDG_UNIT_PHASER) {
+            double radians = GO_MATH_DEGREE_TO_RADIANS * (double)p[2];
+            d.dp[5] = 0.5 * sin(radians);
+            d.dp[4] = 1.0 - fabs(d.dp[5]);
+        }
+        int C = (int)floor((0.002 * sr) + 0.5);
+        d.jp[0] = C;
+        if (u.hist_key != C) rc = zero_is(ctx, u, 0, 1);
+        if (rc == GDG_OK) rc = ensure_hist(ctx, u, (size_t)C, C);
+        d.hist = u.d_hist;
+        break;
+    }
+    case GDG_UNIT_DELAY: {
+        double seconds = 0.001 * (double)p[0];
+        int D = (int)floor((seconds * sr) + 0.5);
+        d.dp[0] = decibels_to_factor(p[1]);
+        d.dp[1] = decibels_to_factor(p[2]);
+        d.jp[0] = D;
+        if (u.hist_key != D) rc = zero_is(ctx, u, 0, 1);
+        if (rc == GDG_OK) rc = ensure_hist(ctx, u, (size_t)D, D);
+        d.hist = u.d_hist;
+        break;
+    }
+    case GDG_UNIT_RINGMODULATOR: {
+        double angular = GO_MATH_TWO_PI * (double)p[0];
+        d.dp[0] = angular / sr;
+        break;
+    }
+    case GDG_UNIT_TREMOLO: {
+        double frequency = 0.1 * (double)p[0];
+        double period_f = sr / frequency;
+        uint32_t period = (uint32_t)period_f;
+        double phase = 0.01 * (double)p[1];
+        uint32_t unatt = (uint32_t)(period_f * phase);
+        uint32_t att = period - unatt;
+        d.dp[0] = decibels_to_factor(p[2]);
+        d.jp[0] = (int)unatt;
+        d.jp[1] = (int)att;
+        break;
+    }
+    case GDG_UNIT_SIGNALGENERATOR: {
+        d.dp[0] = (0.01 * (double)p[0]) * decibels_to_factor(p[1]);
+        double fac_signal_gain = decibels_to_factor(p[5]);
+        d.dp[1] = (0.01 * (double)p[4]) * fac_signal_gain;
+        d.dp[2] = GO_MATH_TWO_PI * ((double)p[3] / sr);
+        break;
+    }
+    case GDG_UNIT_REVERB: {
+        static const double ap_delays[3] = { 0.04204, 0.01348, 0.00452 };
+        static const double tap_times[4] = { 0.19196, 0.19996, 0.21596, 0.23204 };
+        double wet = 0.01 * (double)p[0];
+        d.dp[0] = 1.0 - wet;
+        d.dp[1] = 0.5 * wet;
+        uint32_t max_index = 0;
+        for (int i = 0; i < 4; i++) {
+            uint32_t t = (uint32_t)round(tap_times[i] * sr);
+            d.jp[i] = (int)t;
+            if (t > max_index) max_index = t;
+        }
+        d.jp[4] = (int)max_index;
+        size_t len = max_index;
+        for (int i = 0; i < 3; i++) {
+            int D = (int)round(ap_delays[i] * sr);
+            d.jp[5 + i] = D;
+            len += (size_t)(D > 1 ? D - 1 : 0);
+        }
+        /* the reference rebuilds every reverb buffer when the sample rate changes (reverb.go:207-271) */
+        if (u.hist_key != (long long)sample_rate) rc = zero_is(ctx, u, 0, 4);
+        if (rc == GDG_OK) rc = ensure_hist(ctx, u, len, (long long)sample_rate);
+        d.hist = u.d_hist;
+        break;
+    }
+    default:
+        return fail(ctx, GDG_ERR_UNSUPPORTED, "unit type %d has no HIP implementation yet", u.type);
+    }
+    if (rc != GDG_OK) return rc;
+    d.ds = u.d_ds;
+    d.is = u.d_is;
+    return GDG_OK;
+}
+
+static int fir_tables(gdg_ctx *ctx, int P, double2 **tw, double2 **tw2) {
+    auto it = ctx->fir_tables.find(P);
+    if (it == ctx->fir_tables.end()) {
+        double2 *a = nullptr, *b = nullptr;
+        HIP_TRY(ctx, gdg_fir_tables_create(P, &a, &b));
+        it = ctx->fir_tables.emplace(P, std::make_pair(a, b)).first;
+    }
+    *tw = it->second.first;
+    *tw2 = it->second.second;
+    return GDG_OK;
+}
+
+/* (Re)build the partitioned spectra and zero the convolution state of one power amp for partition P. */
+static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
+    if (u.fir_sr != sample_rate) {
+        /* poweramp.go:191-203: a sample-rate change recompiles the filter, i.e. fresh state */
+        u.fir_sr = sample_rate;
+        u.fir_dirty = true;
+        u.fir_live = false;
+    }
+    if (!u.fir_dirty && u.fir_P == P) return GDG_OK;
+    if (!u.fir_dirty && u.fir_P != P && u.fir_live)
+        return fail(ctx, GDG_ERR_UNSUPPORTED, "frame size changed from %d to %d while a power amp holds convolution state; reset the unit first", u.fir_P, P);
+    int L = (int)u.taps.size();
+    int K = (L + P - 1) / P;
+    if (K < 1) K = 1;                 /* filter.Empty: one all-zero partition => zeros out */
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_H); hipFree(u.d_Y); hipFree(u.d_pos);
+    u.d_prev = nullptr; u.d_fdl = nullptr; u.d_H = nullptr; u.d_Y = nullptr; u.d_pos = nullptr;
+    size_t spec = (size_t)K * (size_t)P * sizeof(double2);
+    HIP_TRY(ctx, hipMalloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&u.d_fdl, spec));
+    HIP_TRY(ctx, hipMalloc((void **)&u.d_H, spec));
+    HIP_TRY(ctx, hipMalloc((void **)&u.d_Y, (size_t)P * sizeof(double2)));
+    HIP_TRY(ctx, hipMalloc((void **)&u.d_pos, sizeof(int)));
+    HIP_TRY(ctx, hipMemsetAsync(u.d_prev, 0, 2 * (size_t)P * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(u.d_fdl, 0, spec, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(u.d_H, 0, spec, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(u.d_pos, 0, sizeof(int), ctx->stream));
+    if (L > 0) {
+        double2 *tw, *tw2;
+        int rc = fir_tables(ctx, P, &tw, &tw2);
+        if (rc != GDG_OK) return rc;
+        std::vector<double> padded((size_t)K * (size_t)P, 0.0);
+        memcpy(padded.data(), u.taps.data(), (size_t)L * sizeof(double));
+        double *d_taps = nullptr;
+        gdg_fir_irjob *d_jobs = nullptr;
+        std::vector<gdg_fir_irjob> jobs((size_t)K);
+        HIP_TRY(ctx, hipMalloc((void **)&d_taps, padded.size() * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
+        for (int k = 0; k < K; k++) { jobs[(size_t)k].a = d_taps + (size_t)k * P; jobs[(size_t)k].out = u.d_H + (size_t)k * P; }
+        HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
+        /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
+        HIP_TRY(ctx, gdg_launch_fir_ir(P, d_jobs, K, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(d_taps);
+        hipFree(d_jobs);
+    }
+    u.fir_P = P;
+    u.fir_K = K;
+    u.fir_dirty = false;
+    u.fir_live = false;
+    return GDG_OK;
+}
+
+struct Op { bool is_fir; std::vector<int> handles; };
+
+static int build_plan(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
+    const int nch = ctx->nch;
+    /* per channel: ops placed on a common grid of slots: 2k = segment k, 2k+1 = FIR k */
+    std::map<int, std::vector<std::pair<int, Op>>> by_slot;           /* slot -> (channel, op) */
+    std::vector<int> n_ops((size_t)nch, 0);
+    bool any_fir = false;
+    for (int c = 0; c < nch; c++) {
+        std::vector<int> seg;
+        int k = 0, count = 0;
+        for (auto &s : ctx->chains[(size_t)c]) {
+            if (s.bypass) continue;                                   /* signal.go:390-401 */
+            Unit &u = ctx->units[(size_t)s.handle];
+            if (u.type == GDG_UNIT_POWERAMP) {
+                if (!seg.empty()) { by_slot[2 * k].push_back({ c, Op{ false, seg } }); seg.clear(); count++; }
+                by_slot[2 * k + 1].push_back({ c, Op{ true, { s.handle } } });
+                count++;
+                k++;
+                any_fir = true;
+            } else {
+                if (!gdg_seg_supported(u.type)) return fail(ctx, GDG_ERR_UNSUPPORTED, "unit type %d has no HIP implementation yet", u.type);
+                seg.push_back(s.handle);
+            }
+        }
+        if (!seg.empty()) { by_slot[2 * k].push_back({ c, Op{ false, seg } }); count++; }
+        if (count == 0) { by_slot[0].push_back({ c, Op{ false, {} } }); count = 1; }     /* empty chain: copy */
+        n_ops[(size_t)c] = count;
+    }
+    if (any_fir) {
+        int l = 0;
+        while ((1 << l) < frames) l++;
+        if ((1 << l) != frames || frames < GDG_MIN_FIR_FRAMES)
+            return fail(ctx, GDG_ERR_UNSUPPORTED, "a chain with a power amp needs a power-of-two frame size in [%d, %d], got %d", GDG_MIN_FIR_FRAMES, GDG_MAX_FRAMES, frames);
+    }
+    /* blob layout: [step 0 descs][step 1 descs]...[seg units] */
+    std::vector<gdg_seg_unit> seg_units;
+    std::vector<std::vector<gdg_seg_chan>> seg_descs;
+    std::vector<std::vector<gdg_fir_chan>> fir_descs;
+    std::vector<int> done((size_t)nch, 0);
+    std::vector<const double *> cur((size_t)nch);
+    for (int c = 0; c < nch; c++) cur[(size_t)c] = d_in + (size_t)c * frames;
+    ctx->steps.clear();
+    for (auto &kv : by_slot) {
+        bool is_fir = (kv.first & 1) != 0;
+        std::vector<gdg_seg_chan> sd;
+        std::vector<gdg_fir_chan> fd;
+        for (auto &entry : kv.second) {
+            int c = entry.first;
+            Op &op = entry.second;
+            bool last = (done[(size_t)c] + 1 == n_ops[(size_t)c]);
+            double *dst;
+            if (last) dst = d_out + (size_t)c * frames;
+            else dst = ((done[(size_t)c] & 1) ? ctx->d_w1 : ctx->d_w0) + (size_t)c * ctx->max_frames;
+            if (is_fir) {
+                Unit &u = ctx->units[(size_t)op.handles[0]];
+                int rc = prepare_fir(ctx, u, frames, sample_rate);
+                if (rc != GDG_OK) return rc;
+                gdg_fir_chan f;
+                memset(&f, 0, sizeof(f));
+                f.src = cur[(size_t)c]; f.dst = dst; f.prev = u.d_prev; f.fdl = u.d_fdl; f.H = u.d_H; f.Y = u.d_Y;
+                f.pos = u.d_pos; f.K = u.fir_K;
+                fd.push_back(f);
+                u.fir_live = true;
+            } else {
+                gdg_seg_chan s;
+                memset(&s, 0, sizeof(s));
+                s.src = cur[(size_t)c]; s.dst = dst;
+                s.scratch = ctx->d_scratch + (size_t)c * ctx->max_frames;
+                s.unit_begin = (int)seg_units.size();
+                s.unit_count = (int)op.handles.size();
+                for (int h : op.handles) {
+                    gdg_seg_unit du;
+                    int rc = prepare_unit(ctx, ctx->units[(size_t)h], frames, sample_rate, du);
+                    if (rc != GDG_OK) return rc;
+                    seg_units.push_back(du);
+                }
+                sd.push_back(s);
+            }
+            cur[(size_t)c] = dst;
+            done[(size_t)c]++;
+        }
+        StepDesc st;
+        st.is_fir = is_fir;
+        st.n = is_fir ? (int)fd.size() : (int)sd.size();
+        st.offset = 0;
+        ctx->steps.push_back(st);
+        seg_descs.push_back(sd);
+        fir_descs.push_back(fd);
+    }
+    /* serialise */
+    ctx->blob.clear();
+    auto append = [&](const void *p, size_t bytes) {
+        size_t off = (ctx->blob.size() + 255) & ~(size_t)255;
+        ctx->blob.resize(off + bytes);
+        if (bytes) memcpy(ctx->blob.data() + off, p, bytes);
+        return off;
+    };
+    for (size_t i = 0; i < ctx->steps.size(); i++) {
+        if (ctx->steps[i].is_fir) ctx->steps[i].offset = append(fir_descs[i].data(), fir_descs[i].size() * sizeof(gdg_fir_chan));
+        else ctx->steps[i].offset = append(seg_descs[i].data(), seg_descs[i].size() * sizeof(gdg_seg_chan));
+    }
+    ctx->units_offset = append(seg_units.data(), seg_units.size() * sizeof(gdg_seg_unit));
+    if (ctx->blob.size() > ctx->d_blob_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->d_blob);
+        ctx->d_blob = nullptr;
+        ctx->d_blob_cap = ctx->blob.size() * 2 + 4096;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_blob, ctx->d_blob_cap));
+    } else {
+        /* the previous plan may still be in use by launches in flight */
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (!ctx->blob.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, ctx->blob.data(), ctx->blob.size(), hipMemcpyHostToDevice, ctx->stream));
+    ctx->plan_frames = frames;
+    ctx->plan_sr = sample_rate;
+    ctx->plan_in = d_in;
+    ctx->plan_out = d_out;
+    ctx->dirty = false;
+    return GDG_OK;
+}
+
+/* ---- profiling -------------------------------------------------------------------------------------- */
+
+static hipEvent_t take_event(gdg_ctx *ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    gdg_ctx *ctx; int kind; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(gdg_ctx *c, int k) : ctx(c), kind(k) {
+        if (ctx->profiling) { a = take_event(ctx); b = take_event(ctx); hipEventRecord(a, ctx->stream); }
+    }
+    ~ProfScope() {
+        if (ctx->profiling) { hipEventRecord(b, ctx->stream); ctx->prof.push_back(ProfEvent{ kind, a, b }); }
+    }
+};
+
+int gdg_profile_enable(gdg_ctx *ctx, int enable) {
+    if (!ctx) return GDG_ERR_INVALID;
+    ctx->profiling = enable != 0;
+    return GDG_OK;
+}
+
+int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
+    if (!ctx || kind < 0 || kind >= GDG_K_COUNT) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    int n = 0;
+    std::vector<ProfEvent> keep;
+    for (auto &p : ctx->prof) {
+        if (p.kind != kind) { keep.push_back(p); continue; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { total += ms; n++; }
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->prof.swap(keep);
+    if (total_ms) *total_ms = total;
+    if (launches) *launches = n;
+    return GDG_OK;
+}
+
+/* ---- processing --------------------------------------------------------------------------------------- */
+
+int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
+    if (!ctx || !d_in || !d_out) return GDG_ERR_INVALID;
+    if (d_in == d_out) return fail(ctx, GDG_ERR_INVALID, "in-place processing is not supported");
+    if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    if (sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
+    hipSetDevice(ctx->device);
+    if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate || ctx->plan_in != d_in || ctx->plan_out != d_out) {
+        int rc = build_plan(ctx, d_in, d_out, frames, sample_rate);
+        if (rc != GDG_OK) { ctx->dirty = true; return rc; }
+    }
+    const gdg_seg_unit *d_units = reinterpret_cast<const gdg_seg_unit *>(ctx->d_blob + ctx->units_offset);
+    for (auto &st : ctx->steps) {
+        if (st.n == 0) continue;
+        if (st.is_fir) {
+            const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset);
+            double2 *tw, *tw2;
+            int rc = fir_tables(ctx, frames, &tw, &tw2);
+            if (rc != GDG_OK) return rc;
+            { ProfScope ps(ctx, GDG_K_FIR_FWD); HIP_TRY(ctx, gdg_launch_fir_fwd(frames, d, st.n, tw, tw2, ctx->stream)); }
+            { ProfScope ps(ctx, GDG_K_FIR_MAC); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, st.n, ctx->stream)); }
+            { ProfScope ps(ctx, GDG_K_FIR_INV); HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, st.n, tw, tw2, ctx->stream)); }
+        } else {
+            const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset);
+            ProfScope ps(ctx, GDG_K_SEGMENT);
+            HIP_TRY(ctx, gdg_launch_seg(d, st.n, d_units, frames, ctx->os, ctx->d_error, ctx->stream));
+        }
+    }
+    return GDG_OK;
+}
+
+static int check_device_error(gdg_ctx *ctx) {
+    int e = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&e, ctx->d_error, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e != 0) {
+        hipMemsetAsync(ctx->d_error, 0, sizeof(int), ctx->stream);
+        return fail(ctx, GDG_ERR_UNSUPPORTED, "segment kernel met unit type %d without a HIP implementation", e - 1);
+    }
+    return GDG_OK;
+}
+
+int gdg_ctx_synchronize(gdg_ctx *ctx) {
+    if (!ctx) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    return check_device_error(ctx);
+}
+
+static int ensure_staging(gdg_ctx *ctx) {
+    if (ctx->d_stage_in) return GDG_OK;
+    size_t bytes = (size_t)ctx->nch * (size_t)ctx->max_frames * sizeof(double);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stage_in, bytes));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stage_out, bytes));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_stage_in, bytes, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_stage_out, bytes, hipHostMallocDefault));
+    return GDG_OK;
+}
+
+int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int frames, uint32_t sample_rate) {
+    if (!ctx || !in || !out) return GDG_ERR_INVALID;
+    if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    hipSetDevice(ctx->device);
+    int rc = ensure_staging(ctx);
+    if (rc != GDG_OK) return rc;
+    size_t bytes = (size_t)ctx->nch * (size_t)frames * sizeof(double);
+    for (int c = 0; c < ctx->nch; c++) memcpy(ctx->h_stage_in + (size_t)c * frames, in[c], (size_t)frames * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, ctx->h_stage_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = gdg_process_device(ctx, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage_out, ctx->d_stage_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    rc = check_device_error(ctx);
+    if (rc != GDG_OK) return rc;
+    for (int c = 0; c < ctx->nch; c++) memcpy(out[c], ctx->h_stage_out + (size_t)c * frames, (size_t)frames * sizeof(double));
+    return GDG_OK;
+}
+
+/* ---- device memory helpers --------------------------------------------------------------------------------- */
+
+int gdg_device_alloc(gdg_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMalloc(d_ptr, bytes));
+    return GDG_OK;
+}
+
+int gdg_device_free(gdg_ctx *ctx, void *d_ptr) {
+    if (!ctx) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return GDG_OK;
+}
+
+int gdg_copy_to_device(gdg_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+/* ---- tuner / spatializer: implemented in a later milestone of this round ---------------------------------------- */
+
+int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *, int, uint32_t) { return fail(ctx, GDG_ERR_UNSUPPORTED, "tuner: not implemented yet"); }
+int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *, int, uint32_t) { return fail(ctx, GDG_ERR_UNSUPPORTED, "tuner: not implemented yet"); }
+int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *) { return fail(ctx, GDG_ERR_UNSUPPORTED, "tuner: not implemented yet"); }
+const char *gdg_tuner_note_name(int note_index) { return (note_index >= 0 && note_index < GDG_NOTE_COUNT) ? GDG_NOTE_NAMES[note_index] : "Unknown"; }
+int gdg_spatializer_set_position(gdg_ctx *ctx, int, double, double, double) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
+int gdg_spatializer_set_sample_rate(gdg_ctx *ctx, uint32_t) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
+int gdg_spatialize(gdg_ctx *ctx, const double *const *, double *, double *, int) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
+int gdg_spatialize_device(gdg_ctx *ctx, const double *, double *, int) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
+
+}  /* extern "C" */

@@ -1,0 +1,463 @@
+/*
+ * fir.hip -- the FFT convolution behind the power amp (effects/poweramp.go:186-216 ->
+ * filter/filter.go:342-515 -> fft/fft.go:744-990), redesigned for gfx950.
+ *
+ * The reference runs an UNPARTITIONED overlap-add: one 2*nextpow2(L)-point real FFT pair per
+ * frame and channel.  Here the same y = clip(x * h) is computed as a uniformly partitioned
+ * overlap-save convolution with partition P = frame:
+ *
+ *   fir_fwd   one workgroup per channel: [x_{t-1} | x_t] (2P reals) -> packed P-point complex
+ *             Stockham FFT held entirely in registers + LDS (P = 8192: 16 points per thread,
+ *             512 threads, 139 KiB of LDS -- only possible with CDNA4's 160 KiB) -> half spectrum
+ *             written to slot pos % K of the channel's frequency-domain delay line (FDL) in HBM.
+ *   fir_mac   Y[b] = sum_k FDL[(pos - k) % K][b] * H[k][b]: pure streaming, 16 B per lane per
+ *             load, 2K loads in flight per lane.  This is the HBM-bound kernel (the roofline one).
+ *   fir_inv   one workgroup per channel: Y -> packed inverse FFT -> second half -> clip -> out.
+ *
+ * FP64 throughout; no MFMA (there is no dense contraction here).  Spectra are stored as P
+ * complex128 per slot: bin 0 carries (Re X[0], Re X[P]) since both are real.
+ */
+#include "gdg_internal.h"
+#include <math.h>
+#include <vector>
+
+typedef double2 cplx;
+
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+#define GDG_C1 0.92387953251128673848      /* cos(pi/8) */
+#define GDG_S1 0.38268343236508978178      /* sin(pi/8) */
+#define GDG_RH 0.70710678118654752440      /* sqrt(1/2) */
+
+/* multiply by W_16^M = exp(-2 pi i M / 16) (forward) or its conjugate (inverse), M known at compile time */
+template <int M, bool INV>
+__device__ __forceinline__ cplx mul_w16(cplx a) {
+    constexpr int m = M & 15;
+    if constexpr (m == 0) {
+        return a;
+    } else if constexpr (m == 4) {
+        return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+    } else if constexpr (m == 2) {
+        return INV ? make_double2((a.x - a.y) * GDG_RH, (a.x + a.y) * GDG_RH)
+                   : make_double2((a.x + a.y) * GDG_RH, (a.y - a.x) * GDG_RH);
+    } else if constexpr (m == 6) {
+        return INV ? make_double2((-a.x - a.y) * GDG_RH, (a.x - a.y) * GDG_RH)
+                   : make_double2((a.y - a.x) * GDG_RH, (-a.x - a.y) * GDG_RH);
+    } else {
+        constexpr double wr = (m == 1) ? GDG_C1 : (m == 3) ? GDG_S1 : (m == 5) ? -GDG_S1 : -GDG_C1;
+        constexpr double wi_f = (m == 1) ? -GDG_S1 : (m == 3) ? -GDG_C1 : (m == 5) ? -GDG_C1 : -GDG_S1;
+        constexpr double wi = INV ? -wi_f : wi_f;
+        return make_double2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+    }
+}
+
+/* small DFTs on registers, natural order in and out (radix-2 decimation in time, fully unrolled) */
+template <int R, bool INV> struct Dft;
+
+template <int R, int K, bool INV> struct DftCombine {
+    static __device__ __forceinline__ void run(cplx (&v)[R], const cplx (&e)[R / 2], const cplx (&o)[R / 2]) {
+        if constexpr (K < R / 2) {
+            cplx t = mul_w16<K * (16 / R), INV>(o[K]);
+            v[K] = cadd(e[K], t);
+            v[K + R / 2] = csub(e[K], t);
+            DftCombine<R, K + 1, INV>::run(v, e, o);
+        }
+    }
+};
+
+template <bool INV> struct Dft<2, INV> {
+    static __device__ __forceinline__ void run(cplx (&v)[2]) {
+        cplx a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+template <int R, bool INV> struct Dft {
+    static __device__ __forceinline__ void run(cplx (&v)[R]) {
+        cplx e[R / 2], o[R / 2];
+#pragma unroll
+        for (int i = 0; i < R / 2; i++) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+        Dft<R / 2, INV>::run(e);
+        Dft<R / 2, INV>::run(o);
+        DftCombine<R, 0, INV>::run(v, e, o);
+    }
+};
+
+/* pass schedule: log2 radices, largest first (so that the radix-16 pass has no twiddles) */
+__host__ __device__ constexpr int sched_lr(int logn, int p) {
+    switch (logn) {
+    case 13: return p == 0 ? 4 : (p < 4 ? 3 : 0);
+    case 12: return p < 3 ? 4 : 0;
+    case 11: return p < 2 ? 4 : (p == 2 ? 3 : 0);
+    case 10: return p == 0 ? 4 : (p < 3 ? 3 : 0);
+    case 9: return p < 3 ? 3 : 0;
+    case 8: return p < 2 ? 4 : 0;
+    case 7: return p == 0 ? 4 : (p == 1 ? 3 : 0);
+    case 6: return p < 2 ? 3 : 0;
+    default: return 0;
+    }
+}
+__host__ __device__ constexpr int sched_lns(int logn, int p) {
+    int s = 0;
+    for (int i = 0; i < p; i++) s += sched_lr(logn, i);
+    return s;
+}
+__host__ __device__ constexpr int sched_npass(int logn) {
+    int n = 0;
+    while (n < 4 && sched_lr(logn, n) != 0) n++;
+    return n;
+}
+
+#define GDG_PAD(e) ((e) + ((e) >> 4))
+
+template <int LOGN> struct FftCfg {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int T = N / 16;
+    static constexpr int LDS = N + N / 16 + 16;
+};
+
+/* registers <- LDS for one pass: butterfly j = tid + T*b takes elements j + t*N/R */
+template <int LOGN, int LOGR>
+__device__ __forceinline__ void pass_load(cplx (&v)[16], const double *sre, const double *sim, int tid) {
+    constexpr int N = 1 << LOGN, T = N / 16, R = 1 << LOGR, B = 16 / R;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int j = tid + T * b;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            int e = j + t * (N / R);
+            v[b * R + t] = make_double2(sre[GDG_PAD(e)], sim[GDG_PAD(e)]);
+        }
+    }
+}
+
+/* twiddle + radix-R DFT on the registers */
+template <int LOGN, int LOGR, int LOGNS, bool INV>
+__device__ __forceinline__ void pass_compute(cplx (&v)[16], const cplx *__restrict__ tw, int tid) {
+    constexpr int N = 1 << LOGN, T = N / 16, R = 1 << LOGR, B = 16 / R, NS = 1 << LOGNS;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int j = tid + T * b;
+        cplx u[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) u[t] = v[b * R + t];
+        if constexpr (NS > 1) {
+            int kk = j & (NS - 1);
+            constexpr int stepm = N / (NS * R);
+#pragma unroll
+            for (int t = 1; t < R; t++) {
+                cplx w = tw[kk * t * stepm];
+                if constexpr (INV) w.y = -w.y;
+                u[t] = cmul(u[t], w);
+            }
+        }
+        Dft<R, INV>::run(u);
+#pragma unroll
+        for (int t = 0; t < R; t++) v[b * R + t] = u[t];
+    }
+}
+
+/* registers -> LDS, Stockham auto-sort addressing */
+template <int LOGN, int LOGR, int LOGNS>
+__device__ __forceinline__ void pass_store(const cplx (&v)[16], double *sre, double *sim, int tid) {
+    constexpr int N = 1 << LOGN, T = N / 16, R = 1 << LOGR, B = 16 / R, NS = 1 << LOGNS;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int j = tid + T * b;
+        int base = ((j >> LOGNS) << (LOGNS + LOGR)) + (j & (NS - 1));
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            int e = base + t * NS;
+            sre[GDG_PAD(e)] = v[b * R + t].x;
+            sim[GDG_PAD(e)] = v[b * R + t].y;
+        }
+    }
+}
+
+/* passes FIRST..LAST-1 entirely through LDS (input already in LDS, output left in LDS) */
+template <int LOGN, int P, int LAST, bool INV>
+__device__ __forceinline__ void run_lds_passes(cplx (&v)[16], double *sre, double *sim, const cplx *tw, int tid) {
+    if constexpr (P < LAST) {
+        constexpr int LR = sched_lr(LOGN, P), LNS = sched_lns(LOGN, P);
+        pass_load<LOGN, LR>(v, sre, sim, tid);
+        __syncthreads();
+        pass_compute<LOGN, LR, LNS, INV>(v, tw, tid);
+        pass_store<LOGN, LR, LNS>(v, sre, sim, tid);
+        __syncthreads();
+        run_lds_passes<LOGN, P + 1, LAST, INV>(v, sre, sim, tw, tid);
+    }
+}
+
+/*
+ * Forward: real [a | b] (2N reals) -> packed half spectrum (N complex).
+ * IRJOB = false: a = prev ring half, b = current frame; writes FDL slot and the other prev half.
+ * IRJOB = true : a = one zero-padded IR partition, b = zeros; result scaled (1/(2P) folded into H).
+ */
+template <int LOGN, bool IRJOB>
+__global__ void __launch_bounds__(FftCfg<LOGN>::T)
+fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__restrict__ jobs, double scale,
+               const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
+    __shared__ double sre[FftCfg<LOGN>::LDS];
+    __shared__ double sim[FftCfg<LOGN>::LDS];
+    const int tid = threadIdx.x;
+    const double *a, *bsrc;
+    double *prev_out = nullptr;
+    cplx *out;
+    if constexpr (IRJOB) {
+        gdg_fir_irjob jb = jobs[blockIdx.x];
+        a = jb.a;
+        bsrc = nullptr;
+        out = jb.out;
+    } else {
+        gdg_fir_chan ch = chans[blockIdx.x];
+        int pos = *ch.pos;
+        a = ch.prev + (size_t)((pos + 1) & 1) * N;       /* previous frame */
+        prev_out = ch.prev + (size_t)(pos & 1) * N;       /* where this frame is kept for the next call */
+        bsrc = ch.src;
+        out = ch.fdl + (size_t)(pos % ch.K) * N;
+    }
+
+    /* pass 0 straight from global memory: packed element e = (r[2e], r[2e+1]) */
+    constexpr int LR0 = sched_lr(LOGN, 0), R0 = 1 << LR0, B0 = 16 / R0;
+    cplx v[16];
+#pragma unroll
+    for (int b = 0; b < B0; b++) {
+        int j = tid + T * b;
+#pragma unroll
+        for (int t = 0; t < R0; t++) {
+            int e = j + t * (N / R0);
+            cplx val;
+            if (e < N / 2) {
+                val = *reinterpret_cast<const cplx *>(a + 2 * e);
+            } else {
+                if constexpr (IRJOB) val = make_double2(0.0, 0.0);
+                else {
+                    val = *reinterpret_cast<const cplx *>(bsrc + 2 * (e - N / 2));
+                    *reinterpret_cast<cplx *>(prev_out + 2 * (e - N / 2)) = val;
+                }
+            }
+            v[b * R0 + t] = val;
+        }
+    }
+    pass_compute<LOGN, LR0, 0, false>(v, tw, tid);
+    pass_store<LOGN, LR0, 0>(v, sre, sim, tid);
+    __syncthreads();
+    run_lds_passes<LOGN, 1, sched_npass(LOGN), false>(v, sre, sim, tw, tid);
+
+    /* un-pack: X[k] and X[N-k] from Z[k], Z[N-k] (Z natural order in LDS) */
+    constexpr int ITER = (N / 2) / T;      /* = 8 */
+#pragma unroll
+    for (int i = 0; i < ITER; i++) {
+        int k = tid + T * i;
+        if (k == 0) {
+            double zx = sre[0], zy = sim[0];
+            out[0] = make_double2((zx + zy) * scale, (zx - zy) * scale);
+            double hx = sre[GDG_PAD(N / 2)], hy = sim[GDG_PAD(N / 2)];
+            out[N / 2] = make_double2(hx * scale, -hy * scale);
+        } else {
+            int n = N - k;
+            cplx zk = make_double2(sre[GDG_PAD(k)], sim[GDG_PAD(k)]);
+            cplx zn = make_double2(sre[GDG_PAD(n)], sim[GDG_PAD(n)]);
+            cplx A = make_double2(zk.x + zn.x, zk.y - zn.y);
+            cplx Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+            cplx cw = cmul(tw2[k], Bv);
+            double hs = 0.5 * scale;
+            out[k] = make_double2((A.x + cw.y) * hs, (A.y - cw.x) * hs);
+            out[n] = make_double2((A.x - cw.y) * hs, (-A.y - cw.x) * hs);
+        }
+    }
+}
+
+/* Y[b] = sum_k FDL[(pos - k) mod K][b] * H[k][b]; bin 0 is the (DC, Nyquist) pair of reals */
+template <int UNROLL>
+__global__ void __launch_bounds__(256)
+fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
+    gdg_fir_chan ch = chans[blockIdx.y];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P) return;
+    const int K = ch.K;
+    const int cur = (*ch.pos) % K;
+    const cplx *__restrict__ fdl = ch.fdl + b;
+    const cplx *__restrict__ H = ch.H + b;
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;     /* complex product sum / component-wise product sum */
+    int k = 0;
+    for (; k + UNROLL <= K; k += UNROLL) {
+        cplx x[UNROLL], h[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            int slot = cur - (k + u);
+            if (slot < 0) slot += K;
+            x[u] = fdl[(size_t)slot * P];
+            h[u] = H[(size_t)(k + u) * P];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            ar += x[u].x * h[u].x - x[u].y * h[u].y;
+            ai += x[u].x * h[u].y + x[u].y * h[u].x;
+            br += x[u].x * h[u].x;
+            bi += x[u].y * h[u].y;
+        }
+    }
+    for (; k < K; k++) {
+        int slot = cur - k;
+        if (slot < 0) slot += K;
+        cplx x = fdl[(size_t)slot * P], h = H[(size_t)k * P];
+        ar += x.x * h.x - x.y * h.y;
+        ai += x.x * h.y + x.y * h.x;
+        br += x.x * h.x;
+        bi += x.y * h.y;
+    }
+    ch.Y[b] = (b == 0) ? make_double2(br, bi) : make_double2(ar, ai);
+}
+
+/* Inverse: packed half spectrum Y -> second half of the 2N-point real sequence -> clip -> dst */
+template <int LOGN>
+__global__ void __launch_bounds__(FftCfg<LOGN>::T)
+fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
+    __shared__ double sre[FftCfg<LOGN>::LDS];
+    __shared__ double sim[FftCfg<LOGN>::LDS];
+    const int tid = threadIdx.x;
+    gdg_fir_chan ch = chans[blockIdx.x];
+    const cplx *__restrict__ Y = ch.Y;
+
+    constexpr int ITER = (N / 2) / T;
+#pragma unroll
+    for (int i = 0; i < ITER; i++) {
+        int k = tid + T * i;
+        if (k == 0) {
+            cplx y = Y[0];
+            sre[0] = y.x + y.y;
+            sim[0] = y.x - y.y;
+            cplx h = Y[N / 2];
+            sre[GDG_PAD(N / 2)] = 2.0 * h.x;
+            sim[GDG_PAD(N / 2)] = -2.0 * h.y;
+        } else {
+            int n = N - k;
+            cplx yk = Y[k], yn = Y[n];
+            cplx A = make_double2(yk.x + yn.x, yk.y - yn.y);
+            cplx Bv = make_double2(yk.x - yn.x, yk.y + yn.y);
+            cplx w = tw2[k];
+            w.y = -w.y;
+            cplx O = cmul(Bv, w);
+            sre[GDG_PAD(k)] = A.x - O.y;
+            sim[GDG_PAD(k)] = A.y + O.x;
+            sre[GDG_PAD(n)] = A.x + O.y;
+            sim[GDG_PAD(n)] = -A.y + O.x;
+        }
+    }
+    __syncthreads();
+
+    cplx v[16];
+    constexpr int NP = sched_npass(LOGN);
+    run_lds_passes<LOGN, 0, NP - 1, true>(v, sre, sim, tw, tid);
+
+    /* last pass: its outputs n = j + t*N/R are already in natural order; only n >= N/2 is kept */
+    constexpr int LR = sched_lr(LOGN, NP - 1), LNS = sched_lns(LOGN, NP - 1), R = 1 << LR, B = 16 / R;
+    pass_load<LOGN, LR>(v, sre, sim, tid);
+    pass_compute<LOGN, LR, LNS, true>(v, tw, tid);
+    double *__restrict__ dst = ch.dst;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int j = tid + T * b;
+#pragma unroll
+        for (int t = R / 2; t < R; t++) {
+            int n = j + t * (N / R);
+            cplx z = v[b * R + t];
+            /* filter/filter.go:487-493: the emitted samples are clipped to [-1, 1] */
+            z.x = fmin(1.0, fmax(-1.0, z.x));
+            z.y = fmin(1.0, fmax(-1.0, z.y));
+            *reinterpret_cast<cplx *>(dst + 2 * (n - N / 2)) = z;
+        }
+    }
+    if (tid == 0) {
+        int pos = *ch.pos + 1;
+        int wrap = 2 * ch.K;
+        *ch.pos = (pos >= wrap) ? pos - wrap : pos;
+    }
+}
+
+/* ---- host side ------------------------------------------------------------------------------- */
+
+static int ilog2_exact(int P) {
+    int l = 0;
+    while ((1 << l) < P) l++;
+    return ((1 << l) == P) ? l : -1;
+}
+
+/* twiddle tables: tw[m] = exp(-2 pi i m / P), m < P;  tw2[k] = exp(-i pi k / P), k <= P/2 */
+hipError_t gdg_fir_tables_create(int P, cplx **d_tw, cplx **d_tw2) {
+    std::vector<cplx> tw((size_t)P), tw2((size_t)P / 2 + 1);
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (int m = 0; m < P; m++) {
+        long double ang = -2.0L * pi * (long double)m / (long double)P;
+        tw[m] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    for (int k = 0; k <= P / 2; k++) {
+        long double ang = -pi * (long double)k / (long double)P;
+        tw2[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    hipError_t e = hipMalloc((void **)d_tw, sizeof(cplx) * tw.size());
+    if (e != hipSuccess) return e;
+    e = hipMalloc((void **)d_tw2, sizeof(cplx) * tw2.size());
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(*d_tw, tw.data(), sizeof(cplx) * tw.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*d_tw2, tw2.data(), sizeof(cplx) * tw2.size(), hipMemcpyHostToDevice);
+}
+
+#define GDG_DISPATCH_LOGN(L, STMT)                                                                  \
+    switch (L) {                                                                                    \
+    case 6: { constexpr int LG = 6; STMT; break; }                                                  \
+    case 7: { constexpr int LG = 7; STMT; break; }                                                  \
+    case 8: { constexpr int LG = 8; STMT; break; }                                                  \
+    case 9: { constexpr int LG = 9; STMT; break; }                                                  \
+    case 10: { constexpr int LG = 10; STMT; break; }                                                \
+    case 11: { constexpr int LG = 11; STMT; break; }                                                \
+    case 12: { constexpr int LG = 12; STMT; break; }                                                \
+    case 13: { constexpr int LG = 13; STMT; break; }                                                \
+    default: return hipErrorInvalidValue;                                                           \
+    }
+
+template <int LG> static void launch_fwd(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, hipStream_t s) {
+    fir_fwd_kernel<LG, false><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, nullptr, 1.0, tw, tw2);
+}
+template <int LG> static void launch_ir(const gdg_fir_irjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
+    fir_fwd_kernel<LG, true><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(nullptr, d_jobs, scale, tw, tw2);
+}
+template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, hipStream_t s) {
+    fir_inv_kernel<LG><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
+}
+
+hipError_t gdg_launch_fir_fwd(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
+    if (n_chans <= 0) return hipSuccess;
+    int L = ilog2_exact(P);
+    GDG_DISPATCH_LOGN(L, launch_fwd<LG>(d_chans, n_chans, d_tw, d_tw2, s));
+    return hipGetLastError();
+}
+
+hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
+    if (n_jobs <= 0) return hipSuccess;
+    int L = ilog2_exact(P);
+    GDG_DISPATCH_LOGN(L, launch_ir<LG>(d_jobs, n_jobs, scale, d_tw, d_tw2, s));
+    return hipGetLastError();
+}
+
+hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s) {
+    if (n_chans <= 0) return hipSuccess;
+    int threads = P < 256 ? P : 256;
+    dim3 grid((unsigned)((P + threads - 1) / threads), (unsigned)n_chans);
+    fir_mac_kernel<4><<<grid, dim3(threads), 0, s>>>(d_chans, P);
+    return hipGetLastError();
+}
+
+hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
+    if (n_chans <= 0) return hipSuccess;
+    int L = ilog2_exact(P);
+    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, s));
+    return hipGetLastError();
+}

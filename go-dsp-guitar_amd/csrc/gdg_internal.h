@@ -1,0 +1,97 @@
+/*
+ * gdg_internal.h -- structures shared by the host side (api.cpp) and the HIP kernels.
+ * Not part of the ABI.
+ */
+#ifndef GDG_INTERNAL_H
+#define GDG_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GDG_MAX_FRAMES 8192          /* controller/controller.go:36 BLOCK_SIZE; one frame must fit the LDS */
+#define GDG_MIN_FIR_FRAMES 64
+
+/* ------------------------------------------------------------------------------------------------
+ * FIR (power amp) -- uniformly partitioned overlap-save convolution, partition = frame.
+ *
+ * Per FIR unit and channel, in HBM:
+ *   prev  [P]            last frame's input (overlap-save history)
+ *   fdl   [K][P] cplx    frequency-domain delay line, slot s holds the packed half spectrum
+ *                        (P complex128; bin 0 carries (Re X[0], Re X[P])) of [x_{t-1} | x_t]
+ *   H     [K][P] cplx    packed half spectra of the IR partitions, pre-scaled by 1/(2P)
+ *   Y     [P]    cplx    accumulated product spectrum (scratch between MAC and inverse)
+ *   pos   int            frame counter; slot of the current frame = pos % K
+ * ---------------------------------------------------------------------------------------------- */
+struct gdg_fir_chan {
+    const double *src;       /* current frame, P samples */
+    double *dst;             /* output frame, P samples */
+    double *prev;
+    double2 *fdl;
+    const double2 *H;
+    double2 *Y;
+    int *pos;
+    int K;
+    int pad;
+};
+
+/* one forward transform job used to build the IR spectra: [a | zeros] -> out */
+struct gdg_fir_irjob {
+    const double *a;         /* P samples (zero padded on the host) */
+    double2 *out;            /* P complex */
+};
+
+/* launchers implemented in fir.hip; all return hipError_t */
+hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
+hipError_t gdg_launch_fir_fwd(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
+hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s);
+hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
+hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segments -- the per-sample units between FIR units, fused into one launch (seg.hip).
+ * One workgroup per channel; the frame lives in LDS; per-unit state lives in HBM:
+ *   ds   [GDG_DS_LEN] doubles   small state (envelopes, capacitor voltages, LFO phase ...)
+ *   is   [GDG_IS_LEN] ints      FSM state, ring write positions
+ *   hist [..] doubles           input-history / all-pass rings (length depends on the sample rate)
+ * dp / jp carry constants derived on the host from the resolved parameters in exactly the
+ * reference's arithmetic (e.g. 10^(dB/20), 1 - exp(-2 pi f / sr)), so that only per-sample
+ * transcendental calls differ between host libm and device ocml.  Layout per unit type: seg.hip.
+ * ---------------------------------------------------------------------------------------------- */
+#define GDG_DS_LEN 32
+#define GDG_IS_LEN 8
+#define GDG_DP_LEN 32
+#define GDG_JP_LEN 8
+
+struct gdg_seg_unit {
+    int type;
+    int pad;
+    int ip[8];                /* resolved parameters (numeric value / discrete index) */
+    int jp[GDG_JP_LEN];       /* derived integers */
+    double dp[GDG_DP_LEN];    /* derived doubles */
+    double *ds;
+    int *is;
+    double *hist;
+};
+
+struct gdg_seg_chan {
+    const double *src;
+    double *dst;
+    double *scratch;          /* one frame of per-channel global scratch */
+    int unit_begin;
+    int unit_count;
+};
+
+/* oversampling tables shared by all channels (device memory) */
+struct gdg_os_tables {
+    const double *taps2;      /* 77  */
+    const double *taps4;      /* 155 */
+    const double *lanczos2;   /* [1][6] weights of the half-sample phase */
+    const double *lanczos4;   /* [3][6] weights of phases 1/4, 2/4, 3/4 */
+};
+
+hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames,
+                          gdg_os_tables os, int *d_error, hipStream_t s);
+/* 1 when seg.hip implements the unit type */
+int gdg_seg_supported(int unit_type);
+
+#endif

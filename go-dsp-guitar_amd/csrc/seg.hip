@@ -1,0 +1,681 @@
+/*
+ * seg.hip -- the serial per-sample stage: every effects.Unit.Process() that is not the FIR power
+ * amp, fused per channel into ONE launch per chain segment (the units between two FIR units).
+ *
+ * Design (gfx950): one workgroup of 256 threads (4 wavefronts) per channel; the frame (<= 8192
+ * float64) is loaded once from HBM into LDS, ping-pongs between two LDS buffers from unit to
+ * unit and is written once (16 B per sample of frame traffic, plus each unit's own state).
+ * The 160 KiB LDS of CDNA4 is what lets two 8192-sample FP64 frames plus a 26 KiB tile live
+ * on-chip.  Recurrences are not run sample by sample by one lane:
+ *   - one-pole sections and the "level" follower are affine maps, the peak follower is a
+ *     max-affine map; both compose associatively, so every thread reduces its 32-sample chunk
+ *     to one map, the 256 maps are scanned across the workgroup (DPP/shuffle inside a wave, LDS
+ *     across the four waves) and every thread then replays its chunk from the exact incoming
+ *     state IN THE REFERENCE'S OPERATION ORDER (so only the chunk-start state carries scan
+ *     rounding, ~1e-16 relative);
+ *   - feed-forward delays (chorus, flanger, phaser, delay, reverb taps) read the unit's INPUT
+ *     history and are embarrassingly parallel; history lives in an HBM ring per unit;
+ *   - the reverb all-passes are true feedback loops of length M >= 99 samples: processed in
+ *     tiles of M samples, all lanes busy inside a tile;
+ *   - 2x/4x oversampling never leaves the CU: Lanczos-3 up-sampling (precomputed 6-tap polyphase
+ *     weights), the waveshaper and the 77/155-tap decimator run tile by tile through LDS.
+ *
+ * Compiled with -ffp-contract=off: Go never fuses multiply-add.
+ */
+#include "gdg_internal.h"
+#include "go_consts.h"
+#include "../../include/gdg.h"
+#include <math.h>
+
+#define SEG_T 256
+#define SEG_LBUF (8192 + 256 + 8)
+#define SEG_SCR 3328
+#define LX(e) ((e) + ((e) >> 5))
+
+#define ATTENUATION_HALF_DECIBEL 0.9440608762859234   /* oversampling/oversampling.go:13 */
+
+__device__ __forceinline__ double clip1(double v) { return v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v); }
+
+/* ---- workgroup scan of (A, B) maps:  affine x -> A x + B   or   max-affine x -> max(A x, B) ---- */
+template <bool MAXOP>
+__device__ __forceinline__ void compose(double &A, double &B, double A1, double B1) {
+    /* (A, B) := "first (A1, B1), then (A, B)" */
+    double nb = A * B1;
+    B = MAXOP ? fmax(nb, B) : nb + B;
+    A = A * A1;
+}
+
+/*
+ * In: this thread's chunk map (A, B).  Out: (Ap, Bp) = composition of the maps of all threads
+ * with a lower index (identity for thread 0).  tmp: 2 * C * 4 doubles of LDS.
+ */
+template <int C, bool MAXOP>
+__device__ __forceinline__ void block_scan(const double (&A)[C], const double (&B)[C], double (&Ap)[C], double (&Bp)[C], double *tmp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double a[C], b[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { a[c] = A[c]; b[c] = B[c]; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            double ao = __shfl_up(a[c], d, 64), bo = __shfl_up(b[c], d, 64);
+            if (lane >= d) compose<MAXOP>(a[c], b[c], ao, bo);
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < C; c++) { tmp[(wave * C + c) * 2] = a[c]; tmp[(wave * C + c) * 2 + 1] = b[c]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        double ae = __shfl_up(a[c], 1, 64), be = __shfl_up(b[c], 1, 64);
+        if (lane == 0) { ae = 1.0; be = 0.0; }
+        double aw = 1.0, bw = 0.0;                 /* maps of the preceding waves */
+        for (int w = 0; w < wave; w++) {
+            double a2 = tmp[(w * C + c) * 2], b2 = tmp[(w * C + c) * 2 + 1];
+            compose<MAXOP>(a2, b2, aw, bw);
+            aw = a2; bw = b2;
+        }
+        compose<MAXOP>(ae, be, aw, bw);            /* first the preceding waves, then the lanes below */
+        Ap[c] = ae; Bp[c] = be;
+    }
+    __syncthreads();
+}
+
+template <bool MAXOP>
+__device__ __forceinline__ double apply_map(double A, double B, double s) {
+    double v = A * s;
+    return MAXOP ? fmax(v, B) : v + B;
+}
+
+/* ---- history rings in HBM --------------------------------------------------------------------
+ * A ring of capacity C holds the last C inputs of a unit: oldest at wp, newest at wp - 1.
+ * Sample with frame-relative index idx (-C <= idx < 0) is ring[(wp + idx) mod C].
+ */
+__device__ __forceinline__ double ring_read(const double *ring, int C, int wp, int idx) {
+    int p = wp + idx;
+    if (p < 0) p += C;
+    return ring[p];
+}
+
+/* append the frame held in LDS buffer `in` to the ring (all threads), then thread 0 advances wp */
+__device__ __forceinline__ void ring_append(double *ring, int C, int *wp_ptr, const double *in, int N) {
+    if (C <= 0) return;
+    const int wp = *wp_ptr;
+    int first = N > C ? N - C : 0;
+    for (int i = first + (int)threadIdx.x; i < N; i += SEG_T) {
+        int p = (wp + i) % C;
+        ring[p] = in[LX(i)];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *wp_ptr = (wp + N) % C;
+}
+
+/* the reference's fractional delay read (e.g. effects/flanger.go:63-90): both weights are 1 when the delay is integral */
+__device__ __forceinline__ double frac_delay(const double *in, const double *ring, int C, int wp, int i, double delay_samples) {
+    double early = floor(delay_samples), late = ceil(delay_samples);
+    int ie = i - (int)early, il = i - (int)late;
+    double se = (ie >= 0) ? in[LX(ie)] : ring_read(ring, C, wp, ie);
+    double sl = (il >= 0) ? in[LX(il)] : ring_read(ring, C, wp, il);
+    double we = 1.0 - (delay_samples - early);
+    double wl = 1.0 - (late - delay_samples);
+    return (we * se) + (wl * sl);
+}
+
+/* ---- envelope follower shared by compressor / fuzz / octaver / auto-wah / auto-yoy -------------
+ * (e.g. effects/compressor.go:37-58).  follow 0 = "envelope" (peak), 1 = "level", other = 1.0.
+ * Leaves env[i] (the follower value AFTER sample i) in dst[LX(i)] and returns nothing; the new
+ * state is written by the thread that owns the last sample.
+ */
+__device__ __forceinline__ void envelope_to(const double *in, double *dst, int N, int follow, double d_inv, double d,
+                                            double *state, double *tmp) {
+    const int tid = threadIdx.x;
+    const int m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    double s0 = *state;
+    __syncthreads();                                /* everybody has read the state before it is rewritten */
+    if (follow != 0 && follow != 1) {
+        for (int i = c0; i < c1; i++) dst[LX(i)] = 1.0;
+        if (c1 == N && c0 < N) *state = 1.0;
+        return;
+    }
+    double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+    if (follow == 0) {
+        for (int i = c0; i < c1; i++) { A[0] *= d_inv; B[0] *= d_inv; double a = fabs(in[LX(i)]); if (a > B[0]) B[0] = a; }
+        block_scan<1, true>(A, B, Ap, Bp, tmp);
+        double e = apply_map<true>(Ap[0], Bp[0], s0);
+        for (int i = c0; i < c1; i++) {
+            e *= d_inv;
+            double a = fabs(in[LX(i)]);
+            if (a > e) e = a;
+            dst[LX(i)] = e;
+        }
+        if (c1 == N && c0 < N) *state = e;
+    } else {
+        for (int i = c0; i < c1; i++) { A[0] *= d_inv; double diff = fabs(in[LX(i)]) - B[0]; B[0] += diff * d; }
+        block_scan<1, false>(A, B, Ap, Bp, tmp);
+        double e = apply_map<false>(Ap[0], Bp[0], s0);
+        for (int i = c0; i < c1; i++) {
+            double diff = fabs(in[LX(i)]) - e;
+            e += diff * d;
+            dst[LX(i)] = e;
+        }
+        if (c1 == N && c0 < N) *state = e;
+    }
+}
+
+/* ---- compressor: effects/compressor.go:18-84 ---------------------------------------------------
+ * ip0 follow; dp0 gain limit factor, dp1 target factor, dp2 exp(-20/sr), dp3 1 - dp2; ds0 envelope */
+__device__ void unit_compressor(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    envelope_to(in, out, N, U->ip[0], U->dp[2], U->dp[3], U->ds, tmp);
+    const double limit = U->dp[0], target = U->dp[1];
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    for (int i = c0; i < c1; i++) {
+        double gain = target / out[LX(i)];
+        if (gain > limit) gain = limit;
+        out[LX(i)] = clip1(gain * in[LX(i)]);
+    }
+}
+
+/* ---- memoryless waveshapers ---------------------------------------------------------------------- */
+struct Shaper { int type; int valve; double gain, drive, clean, level; };
+
+__device__ __forceinline__ double shape(const Shaper &S, double sample) {
+    if (S.type == GDG_UNIT_OVERDRIVE) {             /* effects/overdrive.go:57-76 */
+        double arg = S.gain * sample;
+        double dist = 0.0;
+        if (S.valve == 0) {
+            double aarg = GO_MATH_QUARTER_PI * arg;
+            dist = GO_MATH_TWO_OVER_PI * atan(aarg);
+        } else if (S.valve == 1) {
+            double x = exp(-arg);
+            dist = (2.0 / (1.0 + x)) - 1.0;
+        }
+        double mix = (S.drive * dist) + (S.clean * sample);
+        return S.level * mix;
+    } else if (S.type == GDG_UNIT_DISTORTION) {     /* effects/distortion.go:34-47 */
+        return S.level * clip1(S.gain * sample);
+    } else {                                        /* excess, effects/excess.go:33-64 */
+        double pre = S.gain * sample;
+        double abs_pre = fabs(pre);
+        bool exceeded = abs_pre > 1.0;
+        bool negative = pre < 0.0;
+        double fl = floor(abs_pre + 1.0);
+        int section = (int)(0.5 * fl);
+        bool section_odd = (section % 2) != 0;
+        bool inverted = section_odd != (exceeded && negative);
+        double excess = fmod(abs_pre + 1.0, 2.0);
+        if (exceeded) pre = inverted ? 1.0 - excess : excess - 1.0;
+        return S.level * pre;
+    }
+}
+
+/*
+ * overdrive / distortion / excess incl. the oversampling wrapper (e.g. effects/overdrive.go:83-144,
+ * oversampling/oversampling.go:54-184, resample/resample.go:148-176).
+ * dp0 gain, dp1 drive, dp2 clean, dp3 level; ip[4] valve (overdrive); jp0 factor (1, 2, 4).
+ * hist: [0..7] the last 8 inputs, [8 .. 8+TAPS-2] the last TAPS-1 waveshaped oversampled samples.
+ */
+__device__ void unit_shaper(const gdg_seg_unit *U, const double *in, double *out, int N, double *scr, const gdg_os_tables &os) {
+    Shaper S;
+    S.type = U->type; S.valve = U->ip[4];
+    S.gain = U->dp[0]; S.drive = U->dp[1]; S.clean = U->dp[2]; S.level = U->dp[3];
+    const int tid = threadIdx.x;
+    const int f = U->jp[0];
+    if (f <= 1) {
+        for (int i = tid; i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
+        return;
+    }
+    const int TAPS = (f == 2) ? 77 : 155;
+    const double *taps = (f == 2) ? os.taps2 : os.taps4;
+    const double *lw = (f == 2) ? os.lanczos2 : os.lanczos4;
+    double *hist = U->hist;
+    const int TILE = (SEG_SCR - TAPS) / f;          /* output samples per tile */
+    /* stream sample s[k]: k < 0 from the 8-sample history, else the frame */
+    auto s_at = [&](int k) -> double { return k >= 0 ? in[LX(k)] : hist[8 + k]; };
+    for (int o0 = 0; o0 < N; o0 += TILE) {
+        const int S_out = min(TILE, N - o0);
+        const int m0 = f * o0 - (TAPS - 1);         /* first oversampled index needed */
+        const int cnt = f * S_out + (TAPS - 1);
+        for (int q = tid; q < cnt; q += SEG_T) {
+            int m = m0 + q;
+            double w;
+            if (m < 0) {
+                w = hist[8 + (TAPS - 1) + m];       /* tail of the previous call */
+            } else {
+                int i = m / f, r = m - i * f;
+                double up;
+                if (r == 0) {
+                    up = s_at(i - 4);               /* resample.go:160-164: exact input sample */
+                } else {
+                    const double *wq = lw + (r - 1) * 6;
+                    up = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 6; t++) up += s_at(i - 6 + t) * wq[t];
+                }
+                w = shape(S, up);
+            }
+            scr[q] = w;
+        }
+        __syncthreads();
+        for (int o = tid; o < S_out; o += SEG_T) {
+            /* filter.Process semantics: clip(sum_k h[k] w[n-k]) at the oversampled rate, keep every f-th */
+            int q = f * o + (TAPS - 1);
+            double acc = 0.0;
+            for (int k = 0; k < TAPS; k++) acc += taps[k] * scr[q - k];
+            out[LX(o0 + o)] = ATTENUATION_HALF_DECIBEL * clip1(acc);
+        }
+        if (o0 + TILE >= N) {
+            /* keep the last TAPS-1 oversampled samples; needs cnt >= TAPS-1 which always holds */
+            for (int q = tid; q < TAPS - 1; q += SEG_T) hist[8 + q] = scr[cnt - (TAPS - 1) + q];
+        }
+        __syncthreads();
+    }
+    /* last 8 inputs (concatenation with the old history when N < 8) */
+    double keep = 0.0;
+    if (tid < 8) keep = s_at(N - 8 + tid);
+    __syncthreads();
+    if (tid < 8) hist[tid] = keep;
+}
+
+/* ---- tone stack: effects/tonestack.go:19-100 ------------------------------------------------------
+ * dp0..3 band factors, dp4..7 (1 - exp(-2 pi fA/sr)), dp8..11 (1 - exp(-2 pi fB/sr)); ds0..3 hcv, ds4..7 lcv */
+__device__ void unit_tonestack(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    double fac[4], aH[4], aL[4], h0[4], l0[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { fac[j] = U->dp[j]; aH[j] = U->dp[4 + j]; aL[j] = U->dp[8 + j]; h0[j] = U->ds[j]; l0[j] = U->ds[4 + j]; }
+    __syncthreads();
+    double A[4], B[4], Ap[4], Bp[4];
+    /* pass 1: chunk maps of the four high-pass capacitors */
+#pragma unroll
+    for (int j = 0; j < 4; j++) { A[j] = 1.0; B[j] = 0.0; }
+    for (int i = c0; i < c1; i++) {
+        double x = in[LX(i)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { A[j] *= (1.0 - aH[j]); double diff = x - B[j]; B[j] += diff * aH[j]; }
+    }
+    block_scan<4, false>(A, B, Ap, Bp, tmp);
+    double h[4], hs[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { hs[j] = apply_map<false>(Ap[j], Bp[j], h0[j]); h[j] = hs[j]; }
+    /* pass 2: exact high-pass, chunk maps of the four low-pass capacitors */
+#pragma unroll
+    for (int j = 0; j < 4; j++) { A[j] = 1.0; B[j] = 0.0; }
+    for (int i = c0; i < c1; i++) {
+        double x = in[LX(i)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double diff = x - h[j];
+            h[j] += diff * aH[j];
+            A[j] *= (1.0 - aL[j]);
+            diff -= B[j];
+            B[j] += diff * aL[j];
+        }
+    }
+    block_scan<4, false>(A, B, Ap, Bp, tmp);
+    double l[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { l[j] = apply_map<false>(Ap[j], Bp[j], l0[j]); h[j] = hs[j]; }
+    /* pass 3: the reference's loop body from the exact chunk-start state */
+    for (int i = c0; i < c1; i++) {
+        double x = in[LX(i)];
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double diff = x - h[j];
+            h[j] += diff * aH[j];
+            diff -= l[j];
+            double pre = l[j];
+            l[j] += diff * aL[j];
+            sum += fac[j] * pre;
+        }
+        out[LX(i)] = clip1(sum);
+    }
+    if (c1 == N && c0 < N) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { U->ds[j] = h[j]; U->ds[4 + j] = l[j]; }
+    }
+}
+
+/* ---- cabinet (IIR): effects/cabinet.go:27-162 -------------------------------------------------------
+ * dp0..2 high-pass (1 - exp(-2 pi f/sr)) for 300/120/80 Hz, dp3..6 low-pass for 3/4/5/6 kHz; ds0..2 hcv, ds3..6 lcv */
+__device__ void unit_cabinet(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    for (int i = c0; i < c1; i++) out[LX(i)] = in[LX(i)];
+    /* stage p: zero-state chunk map from its input sequence (held in `out`), scan, exact replay in place */
+    for (int p = 0; p < 7; p++) {
+        const double ap = U->dp[p];
+        const double s0 = U->ds[p];               /* read by everybody before the scan's barriers, written after them */
+        double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+        for (int i = c0; i < c1; i++) { A[0] *= (1.0 - ap); double diff = out[LX(i)] - B[0]; B[0] += diff * ap; }
+        block_scan<1, false>(A, B, Ap, Bp, tmp);
+        double s = apply_map<false>(Ap[0], Bp[0], s0);
+        if (p < 3) {
+            for (int i = c0; i < c1; i++) { double diff = out[LX(i)] - s; out[LX(i)] = diff; s += diff * ap; }
+        } else {
+            for (int i = c0; i < c1; i++) { double diff = out[LX(i)] - s; out[LX(i)] = s; s += diff * ap; }
+        }
+        if (c1 == N && c0 < N) U->ds[p] = s;
+    }
+    for (int i = c0; i < c1; i++) out[LX(i)] = clip1(out[LX(i)]);
+}
+
+/* ---- chorus: effects/chorus.go:19-131 ------------------------------------------------------------------
+ * dp0 depth (0..10), dp1 angular speed, dp2 sample rate; jp0 ring capacity; ds0 previousPhase; is0 ring wp */
+__device__ void unit_chorus(const gdg_seg_unit *U, const double *in, double *out, int N) {
+    const double depth = U->dp[0], angular = U->dp[1], sr = U->dp[2];
+    const int C = U->jp[0], wp = U->is[0];
+    const double prev = U->ds[0];
+    const double *ring = U->hist;
+    for (int i = threadIdx.x; i < N; i += SEG_T) {
+        double time = (double)i / sr;
+        double zero_phase = fmod(prev + (angular * time), GO_MATH_TWO_PI);
+        double effected = 0.0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            double phase = fmod(zero_phase + (GO_MATH_TWO_PI_FIFTH * (double)j), GO_MATH_TWO_PI);
+            double offset = depth * sin(phase);
+            double delay_time = 0.001 * (40.0 + offset);
+            double delay_samples = delay_time * sr;
+            effected += 0.2 * frac_delay(in, ring, C, wp, i, delay_samples);
+        }
+        out[LX(i)] = (0.5 * in[LX(i)]) + (0.5 * effected);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double buffer_time = (double)C / sr;          /* quirk: advances by the buffer length, not by N */
+        U->ds[0] = fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI);
+    }
+    ring_append(U->hist, C, &U->is[0], in, N);
+}
+
+/* ---- flanger / phaser: effects/flanger.go:19-119, effects/phaser.go:19-125 --------------------------------
+ * dp0 depth (0..1), dp1 angular speed, dp2 sr, dp3 1/sr, dp4 dry factor, dp5 wet factor; jp0 ring capacity */
+__device__ void unit_flanger(const gdg_seg_unit *U, const double *in, double *out, int N) {
+    const double depth = U->dp[0], angular = U->dp[1], sr = U->dp[2], sr_inv = U->dp[3];
+    const double mix_dry = U->dp[4], mix_wet = U->dp[5];
+    const int C = U->jp[0], wp = U->is[0];
+    const double prev = U->ds[0];
+    const double *ring = U->hist;
+    for (int i = threadIdx.x; i < N; i += SEG_T) {
+        double time = (double)i * sr_inv;
+        double phase = fmod(prev + (angular * time), GO_MATH_TWO_PI);
+        double offset = depth * sin(phase);
+        double delay_time = 0.001 * (depth + offset);
+        double delay_samples = delay_time * sr;
+        double delayed = frac_delay(in, ring, C, wp, i, delay_samples);
+        out[LX(i)] = (mix_dry * in[LX(i)]) + (mix_wet * delayed);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double duration = (double)C * sr_inv;
+        U->ds[0] = fmod(prev + (angular * duration), GO_MATH_TWO_PI);
+    }
+    ring_append(U->hist, C, &U->is[0], in, N);
+}
+
+/* ---- delay: effects/delay.go:18-89 ------------------------------------------------------------------------
+ * dp0 feedback factor, dp1 level factor; jp0 delay in samples (= ring capacity) */
+__device__ void unit_delay(const gdg_seg_unit *U, const double *in, double *out, int N) {
+    const double feedback = U->dp[0], level = U->dp[1];
+    const int D = U->jp[0], wp = U->is[0];
+    const double *ring = U->hist;
+    for (int i = threadIdx.x; i < N; i += SEG_T) {
+        int idx = i - D;
+        double delayed = (idx >= 0) ? in[LX(idx)] : ring_read(ring, D, wp, idx);
+        out[LX(i)] = clip1(level * (in[LX(i)] + (feedback * delayed)));
+    }
+    __syncthreads();
+    ring_append(U->hist, D, &U->is[0], in, N);
+}
+
+/* ---- ring modulator: effects/ringmodulator.go:18-45.  dp0 phase increment per sample; ds0 phase ---------- */
+__device__ void unit_ringmod(const gdg_seg_unit *U, const double *in, double *out, int N) {
+    const double fraction = U->dp[0], phase = U->ds[0];
+    for (int i = threadIdx.x; i < N; i += SEG_T) {
+        double cur = fmod(phase + ((double)i * fraction), GO_MATH_TWO_PI);
+        out[LX(i)] = sin(cur) * in[LX(i)];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) U->ds[0] = fmod(phase + ((double)N * fraction), GO_MATH_TWO_PI);
+}
+
+/* ---- tremolo: effects/tremolo.go:15-65 ----------------------------------------------------------------------
+ * dp0 attenuation factor; jp0 samplesUnattenuated, jp1 samplesAttenuated (uint32); is0 attenuated, is1 inStateSince.
+ * The counter FSM is data independent: thread 0 walks it in runs (a run ends where the reference flips state). */
+__device__ void unit_tremolo(const gdg_seg_unit *U, const double *in, double *out, int N, double *scr) {
+    const double fac = U->dp[0];
+    int *runs = reinterpret_cast<int *>(scr);          /* pairs (start, attenuated), terminated by start = N */
+    if (threadIdx.x == 0) {
+        const unsigned on = (unsigned)U->jp[0], off = (unsigned)U->jp[1];
+        int att = U->is[0];
+        unsigned cnt = (unsigned)U->is[1];
+        int i = 0, nr = 0;
+        const int max_runs = (SEG_SCR * 2 - 4) / 2;
+        while (i < N) {
+            unsigned thr = att ? off : on;
+            if (cnt >= thr) { att = !att; cnt = 0; }
+            unsigned thr2 = att ? off : on;
+            unsigned k = (thr2 > cnt) ? thr2 - cnt : 1u;
+            if (k < 1u) k = 1u;
+            if (k > (unsigned)(N - i)) k = (unsigned)(N - i);
+            if (nr < max_runs) { runs[2 * nr] = i; runs[2 * nr + 1] = att; nr++; }
+            cnt += k;
+            i += (int)k;
+        }
+        runs[2 * nr] = N; runs[2 * nr + 1] = 0;
+        U->is[0] = att;
+        U->is[1] = (int)cnt;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += SEG_T) {
+        int r = 0;
+        while (runs[2 * (r + 1)] <= i) r++;
+        double v = in[LX(i)];
+        if (runs[2 * r + 1]) v *= fac;
+        out[LX(i)] = v;
+    }
+}
+
+/* ---- signal generator: effects/signalgenerator.go:20-153 ------------------------------------------------------
+ * ip2 signal type; dp0 input factor, dp1 signal factor, dp2 phase increment; ds0 phase; is0 LCG state, is1 LCG seeded */
+__device__ __forceinline__ unsigned lcg_mulmod(unsigned a, unsigned b) {
+    return (unsigned)(((unsigned long long)a * (unsigned long long)b) % 2147483647ull);
+}
+__device__ void unit_siggen(const gdg_seg_unit *U, const double *in, double *out, int N) {
+    const int type = U->ip[2];
+    const double fac_in = U->dp[0], fac_sig = U->dp[1], inc = U->dp[2], phase = U->ds[0];
+    if (type == 4) {                                    /* "noise": random/random.go LCG, seed 1337 */
+        unsigned x0 = U->is[1] ? (unsigned)U->is[0] : (unsigned)((64979ull * 1337ull + 83ull) % 2147483647ull);
+        __syncthreads();
+        const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+        const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+        /* jump ahead: x_{c0} = 16807^c0 * x0 mod (2^31 - 1) */
+        unsigned p = 1u, base = 16807u;
+        for (int e = c0; e > 0; e >>= 1) { if (e & 1) p = lcg_mulmod(p, base); base = lcg_mulmod(base, base); }
+        unsigned x = lcg_mulmod(p, x0);
+        for (int i = c0; i < c1; i++) {
+            x = lcg_mulmod(16807u, x);
+            double r = (double)x / 2147483646.0;
+            double uniform = (1.0 - (2.0 * r));
+            out[LX(i)] = (fac_in * in[LX(i)]) + (fac_sig * uniform);
+        }
+        if (c1 == N && c0 < N) { U->is[0] = (int)x; U->is[1] = 1; }
+        return;
+    }
+    for (int i = threadIdx.x; i < N; i += SEG_T) {
+        double cur = fmod(phase + ((double)i * inc), GO_MATH_TWO_PI);
+        double signal = 0.0;
+        switch (type) {
+        case 0: signal = sin(cur); break;
+        case 1: signal = (cur < M_PI) ? (GO_MATH_TWO_OVER_PI * cur) - 1.0 : 3.0 - (GO_MATH_TWO_OVER_PI * cur); break;
+        case 2: { double d = M_PI - cur; signal = d < 0.0 ? -1.0 : (d > 0.0 ? 1.0 : 0.0); break; }
+        case 3: signal = cur / M_PI; if (cur > M_PI) signal -= 2.0; break;
+        }
+        out[LX(i)] = (fac_in * in[LX(i)]) + (fac_sig * signal);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ph = phase + ((double)N * inc);
+        U->ds[0] = fmod(ph, GO_MATH_TWO_PI);
+    }
+}
+
+/* ---- reverb: effects/reverb.go:41-116, :179-338 ------------------------------------------------------------------
+ * dp0 dry, dp1 0.5 * wet; jp0..3 tap offsets, jp4 delay-line ring capacity, jp5..7 all-pass ring sizes D_k.
+ * hist: [delay-line ring | all-pass 1 ring | all-pass 2 ring | all-pass 3 ring]; is0 delay-line wp, is1..3 all-pass ring pos.
+ * An all-pass ring of size D delays by M = D - 1 samples (write at ptr, read at ptr + 1, reverb.go:51-58).
+ * Here each ring keeps the last M values of p[n] = in[n] - g p[n - M]; o[n] = g p[n] + p[n - M].
+ */
+#define REVERB_QMAX (GDG_MAX_FRAMES / SEG_T)
+__device__ void unit_reverb(const gdg_seg_unit *U, const double *in, double *out, int N) {
+    const int tid = threadIdx.x;
+    const double dry = U->dp[0], half_wet = U->dp[1];
+    const double coeff[4] = { 0.1855, 0.18325, 0.17875, 0.17425 };
+    const double g = 0.7;
+    int taps[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) taps[j] = U->jp[j];
+    const int DL = U->jp[4];
+    double *dl_ring = U->hist;
+    const int dl_wp = U->is[0];
+    double dlr[REVERB_QMAX];
+    /* tapped delay line over the input history (reverb.go:65-116) */
+#pragma unroll
+    for (int q = 0; q < REVERB_QMAX; q++) {
+        int i = tid + q * SEG_T;
+        double pre = 0.0;
+        if (i < N) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int idx = i - taps[j];
+                double cur = 0.0;
+                if (idx >= 0) cur = in[LX(idx)];
+                else if (idx >= -DL) cur = ring_read(dl_ring, DL, dl_wp, idx);
+                pre += coeff[j] * cur;
+            }
+            out[LX(i)] = pre;
+        }
+        dlr[q] = pre;
+    }
+    __syncthreads();
+    double *ring = dl_ring + DL;
+    for (int k = 0; k < 3; k++) {
+        const int D = U->jp[5 + k];
+        const int M = D - 1;
+        const int rp = U->is[1 + k];                   /* position of the oldest value p[-M] */
+        if (M >= 1) {
+            /* recurrence in place, tile by tile: inside a tile of M samples nothing depends on the tile itself */
+            for (int n0 = 0; n0 < N; n0 += M) {
+                int n1 = min(N, n0 + M);
+                for (int n = n0 + tid; n < n1; n += SEG_T) {
+                    double pm = (n >= M) ? out[LX(n - M)] : ring[(rp + n) % M];
+                    out[LX(n)] = out[LX(n)] - (g * pm);
+                }
+                __syncthreads();
+            }
+            /* o[n] into registers (needs the OLD ring), then refresh the ring, then overwrite p by o */
+            double o[REVERB_QMAX];
+#pragma unroll
+            for (int q = 0; q < REVERB_QMAX; q++) {
+                int n = tid + q * SEG_T;
+                o[q] = 0.0;
+                if (n < N) {
+                    double pm = (n >= M) ? out[LX(n - M)] : ring[(rp + n) % M];
+                    o[q] = (g * out[LX(n)]) + pm;
+                }
+            }
+            __syncthreads();
+            if (N >= M) {
+                for (int i = tid; i < M; i += SEG_T) ring[i] = out[LX(N - M + i)];
+                if (tid == 0) U->is[1 + k] = 0;
+            } else {
+                for (int n = tid; n < N; n += SEG_T) ring[(rp + n) % M] = out[LX(n)];
+                if (tid == 0) U->is[1 + k] = (rp + N) % M;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < REVERB_QMAX; q++) {
+                int n = tid + q * SEG_T;
+                if (n < N) out[LX(n)] = o[q];
+            }
+            __syncthreads();
+        }
+        ring += (M > 0 ? M : 0);
+    }
+#pragma unroll
+    for (int q = 0; q < REVERB_QMAX; q++) {
+        int i = tid + q * SEG_T;
+        if (i < N) {
+            double sum = dlr[q] + out[LX(i)];
+            out[LX(i)] = clip1((dry * in[LX(i)]) + (half_wet * sum));
+        }
+    }
+    __syncthreads();
+    ring_append(dl_ring, DL, &U->is[0], in, N);
+}
+
+/* ---- the segment kernel ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(SEG_T) __attribute__((amdgpu_waves_per_eu(1, 1)))
+seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, gdg_os_tables os, int *d_error) {
+    __shared__ double s_a[SEG_LBUF];
+    __shared__ double s_b[SEG_LBUF];
+    __shared__ double s_scr[SEG_SCR];
+    __shared__ double s_tmp[64];
+    const gdg_seg_chan ch = chans[blockIdx.x];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = ch.src[i];
+    __syncthreads();
+    double *in = s_a, *out = s_b;
+    for (int u = 0; u < ch.unit_count; u++) {
+        const gdg_seg_unit *U = units + ch.unit_begin + u;
+        switch (U->type) {
+        case GDG_UNIT_COMPRESSOR: unit_compressor(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_OVERDRIVE:
+        case GDG_UNIT_DISTORTION:
+        case GDG_UNIT_EXCESS: unit_shaper(U, in, out, N, s_scr, os); break;
+        case GDG_UNIT_TONESTACK: unit_tonestack(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_CABINET: unit_cabinet(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_CHORUS: unit_chorus(U, in, out, N); break;
+        case GDG_UNIT_FLANGER:
+        case GDG_UNIT_PHASER: unit_flanger(U, in, out, N); break;
+        case GDG_UNIT_DELAY: unit_delay(U, in, out, N); break;
+        case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, in, out, N); break;
+        case GDG_UNIT_TREMOLO: unit_tremolo(U, in, out, N, s_scr); break;
+        case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, in, out, N); break;
+        case GDG_UNIT_REVERB: unit_reverb(U, in, out, N); break;
+        default:
+            if (tid == 0) atomicExch(d_error, 1 + U->type);
+            for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
+            break;
+        }
+        __syncthreads();
+        double *t = in; in = out; out = t;
+    }
+    for (int i = tid; i < N; i += SEG_T) ch.dst[i] = in[LX(i)];
+}
+
+int gdg_seg_supported(int unit_type) {
+    switch (unit_type) {
+    case GDG_UNIT_COMPRESSOR: case GDG_UNIT_OVERDRIVE: case GDG_UNIT_DISTORTION: case GDG_UNIT_EXCESS:
+    case GDG_UNIT_TONESTACK: case GDG_UNIT_CABINET: case GDG_UNIT_CHORUS: case GDG_UNIT_FLANGER:
+    case GDG_UNIT_PHASER: case GDG_UNIT_DELAY: case GDG_UNIT_RINGMODULATOR: case GDG_UNIT_TREMOLO:
+    case GDG_UNIT_SIGNALGENERATOR: case GDG_UNIT_REVERB:
+        return 1;
+    default:
+        return 0;
+    }
+}
+
+hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames,
+                          gdg_os_tables os, int *d_error, hipStream_t s) {
+    if (n_chans <= 0) return hipSuccess;
+    hipLaunchKernelGGL(seg_kernel, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, os, d_error);
+    return hipGetLastError();
+}

@@ -1,0 +1,171 @@
+/*
+ * gdg.h -- C-ABI of libgdg.so: the MI355X-native (HIP, gfx950) batch implementation of
+ * go-dsp-guitar's per-channel effects pipeline.
+ *
+ * This is the drop-in boundary.  A cgo shim (go-dsp-guitar_amd/go/, shown in INTEGRATION.md)
+ * keeps the reference's Go interfaces effects.Unit (effects/effects.go:83-91) and
+ * signal.Chain (signal/signal.go:21-36) and forwards to the entry points below; name lookup,
+ * range checks and error strings stay on the host side, only resolved integers, taps and
+ * sample buffers cross the ABI.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * One context = one GPU = one shard of channels.  Channels are independent, so an N-GPU
+ * host creates N contexts and never needs a collective.
+ *
+ * Conventions
+ *   - every function returns GDG_OK (0) or a negative GDG_ERR_* code; gdg_last_error() gives
+ *     a message for the calling thread's last failure on that context;
+ *   - there is NO CPU fallback: without a usable HIP device gdg_ctx_create fails with
+ *     GDG_ERR_NO_DEVICE, and a chain that contains something the HIP path cannot run fails
+ *     with GDG_ERR_UNSUPPORTED instead of silently computing elsewhere;
+ *   - unit_type values are the reference's UNIT_* iota (effects/effects.go:21-43);
+ *   - parameter indices follow the declaration order of each unit's create*() table in
+ *     effects/<unit>.go; numeric parameters carry their int32 value, discrete parameters the
+ *     index into the reference's DiscreteValues list (e.g. oversampling: 0 "- NONE -", 1 "2", 2 "4").
+ */
+#ifndef GDG_H
+#define GDG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDG_OK                0
+#define GDG_ERR_INVALID      -1   /* bad handle, index or argument */
+#define GDG_ERR_UNSUPPORTED  -2   /* valid in the reference, not runnable on the HIP path (yet) */
+#define GDG_ERR_HIP          -3   /* a HIP runtime call failed */
+#define GDG_ERR_NO_DEVICE    -4   /* no usable gfx950 device */
+#define GDG_ERR_NOMEM        -5
+
+enum gdg_unit_type {              /* effects/effects.go:21-43 */
+    GDG_UNIT_SIGNALGENERATOR = 0, GDG_UNIT_NOISEGATE, GDG_UNIT_BANDPASS, GDG_UNIT_AUTOWAH,
+    GDG_UNIT_AUTOYOY, GDG_UNIT_COMPRESSOR, GDG_UNIT_OCTAVER, GDG_UNIT_EXCESS, GDG_UNIT_FUZZ,
+    GDG_UNIT_OVERDRIVE, GDG_UNIT_DISTORTION, GDG_UNIT_TONESTACK, GDG_UNIT_CHORUS,
+    GDG_UNIT_FLANGER, GDG_UNIT_PHASER, GDG_UNIT_TREMOLO, GDG_UNIT_RINGMODULATOR,
+    GDG_UNIT_DELAY, GDG_UNIT_REVERB, GDG_UNIT_POWERAMP, GDG_UNIT_CABINET, GDG_UNIT_COUNT
+};
+
+#define GDG_MAX_PARAMS 8
+
+typedef struct gdg_ctx gdg_ctx;
+
+/* ---- library / context ----------------------------------------------------------------------- */
+
+/* "gdg <version> gfx950 hip" */
+const char *gdg_version(void);
+
+/* Number of HIP devices visible to the process (0 when there is none / no driver). */
+int gdg_device_count(void);
+
+/*
+ * Create the shard of n_channels channels on HIP device `device`.  max_frames bounds the
+ * frames argument of gdg_process* (the reference's batch loop uses BLOCK_SIZE = 8192,
+ * controller/controller.go:36).  Replaces: N x signal.CreateChain (controller.go:3267-3269),
+ * spatializer.Create (:3273) and tuner.Create (:3279) for this shard.
+ */
+int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out);
+int gdg_ctx_destroy(gdg_ctx *ctx);
+const char *gdg_last_error(const gdg_ctx *ctx);
+int gdg_ctx_channels(const gdg_ctx *ctx);
+/* The hipStream_t all of this context's work is enqueued on (as void*), for event timing. */
+void *gdg_ctx_stream(const gdg_ctx *ctx);
+/* Block until everything enqueued so far has finished. */
+int gdg_ctx_synchronize(gdg_ctx *ctx);
+
+/* ---- effects units: effects.CreateUnit / Set*Value / state ----------------------------------- */
+
+/* effects.CreateUnit(unitType) (effects/effects.go:443-516); parameters start at the reference's defaults. */
+int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle);
+int gdg_unit_destroy(gdg_ctx *ctx, int handle);
+/* Resolved value of one parameter (the host side has already done effects.go:144-384's checks). */
+int gdg_unit_set_param(gdg_ctx *ctx, int handle, int param_index, int32_t value);
+int gdg_unit_get_param(gdg_ctx *ctx, int handle, int param_index, int32_t *value);
+/*
+ * Power amp only: the compiled composite FIR (what effects/poweramp.go:25-127 compile()
+ * returns; Normalize/Reduce/Add stay on the host).  n_taps == 0 is filter.Empty (zeros out,
+ * filter/filter.go:366-367).  Like the reference's recompile (poweramp.go:132-181) this
+ * replaces the filter and therefore resets the convolution state.
+ */
+int gdg_unit_set_fir(gdg_ctx *ctx, int handle, const double *taps, int n_taps);
+/* Zero all DSP state of a unit (what re-creating the unit does in the reference). */
+int gdg_unit_reset(gdg_ctx *ctx, int handle);
+
+/*
+ * signal.Chain slot list of one channel (signal/signal.go:52-157): handles in processing
+ * order with their bypass flags.  Bypassed slots are skipped and do not advance their state
+ * (signal.go:390-401).  State stays with the unit handle, not with the slot index.
+ */
+int gdg_chain_set(gdg_ctx *ctx, int channel, const int *handles, const uint8_t *bypass, int n);
+
+/* ---- processing: signal.Chain.Process for all channels of the shard at once ------------------- */
+
+/*
+ * One block of `frames` samples for every channel (what controller.process() fans out to its
+ * N workers, controller/controller.go:2682-2705).  in[c] / out[c] are host buffers of `frames`
+ * float64 each; the call stages them through pinned memory, runs the batch and blocks until
+ * out is written.  in[c] is not modified.
+ */
+int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int frames, uint32_t sample_rate);
+
+/*
+ * Same, device-resident: d_in / d_out are device pointers to [n_channels][frames] float64
+ * (row-major, row stride = frames).  Enqueued on gdg_ctx_stream() and NOT synchronised;
+ * d_in == d_out is not allowed.
+ */
+int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate);
+
+/* Device memory helpers for callers that have no HIP runtime of their own (e.g. the Go shim). */
+int gdg_device_alloc(gdg_ctx *ctx, size_t bytes, void **d_ptr);
+int gdg_device_free(gdg_ctx *ctx, void *d_ptr);
+int gdg_copy_to_device(gdg_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- per-kernel timing on the context's stream (HIP events), for bench.py's roofline ---------- */
+
+enum gdg_kernel_kind {
+    GDG_K_FIR_FWD = 0,   /* forward real FFT of the input partition -> frequency-domain delay line */
+    GDG_K_FIR_MAC,       /* sum over partitions of FDL x IR spectra (the HBM-bound kernel) */
+    GDG_K_FIR_INV,       /* inverse real FFT, clip, write */
+    GDG_K_SEGMENT,       /* fused per-sample units between FIR units */
+    GDG_K_TUNER,
+    GDG_K_SPATIALIZER,
+    GDG_K_COUNT
+};
+/* enable != 0: bracket every kernel launch with a HIP event pair from now on (costs a little). */
+int gdg_profile_enable(gdg_ctx *ctx, int enable);
+/* Drain the recorded pairs: total milliseconds and launch count of one kernel kind; resets it. */
+int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches);
+
+/* ---- tuner: tuner.Process / tuner.Analyze, one tuner per channel of the shard ------------------ */
+
+typedef struct {
+    double frequency;     /* tuner.Result.Frequency() */
+    int32_t note_index;   /* index into the 61-note table (tuner/tuner.go:79-324), -1 = "Unknown" */
+    int8_t cents;         /* tuner.Result.Cents() (truncated, tuner.go:557) */
+} gdg_tuner_result;
+
+/* tuner.Process for every channel: enqueue `frames` samples per channel into the 96000-sample rings. */
+int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *samples, int frames, uint32_t sample_rate);
+int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *d_samples, int frames, uint32_t sample_rate);
+/* tuner.Analyze for every channel; results has n_channels entries.  Blocks. */
+int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results);
+const char *gdg_tuner_note_name(int note_index);
+
+/* ---- spatializer: partial N -> 2 mixdown of this shard ----------------------------------------- */
+
+int gdg_spatializer_set_position(gdg_ctx *ctx, int channel, double azimuth, double distance, double level);
+/* spatializer.SetSampleRate (rebuilds the history buffers; keeps the reference's 96000 quirk). */
+int gdg_spatializer_set_sample_rate(gdg_ctx *ctx, uint32_t rate);
+/*
+ * spatializer.Process over the shard's channels WITHOUT the aux input: the host adds the
+ * partial left/right pairs of all shards and then the aux buffer (spatializer.go:300-310).
+ */
+int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, double *out_right, int frames);
+int gdg_spatialize_device(gdg_ctx *ctx, const double *d_in, double *d_out_lr, int frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
