@@ -511,6 +511,76 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         d.hist = u.d_hist;
         break;
     }
+    case GDG_UNIT_FUZZ: {
+        if (p[6] != 0) return fail(ctx, GDG_ERR_UNSUPPORTED, "fuzz with oversampling has no HIP implementation yet");
+        d.dp[0] = 0.01 * (double)p[1];
+        d.dp[1] = decibels_to_factor(p[2] + p[3]);
+        d.dp[2] = 0.01 * (double)p[4];
+        d.dp[3] = 1.0 - d.dp[2];
+        d.dp[4] = decibels_to_factor(p[5]);
+        d.dp[5] = exp(-20.0 / sr);
+        d.dp[6] = 1.0 - d.dp[5];
+        break;
+    }
+    case GDG_UNIT_AUTOYOY: {
+        int32_t level_a = p[1], level_b = p[2];
+        double depth_a = 0.0, depth_b = 0.01 * (double)p[3];
+        if (level_a > level_b) { std::swap(level_a, level_b); std::swap(depth_a, depth_b); }
+        double la = (double)level_a, lb = (double)level_b;
+        double sr_inv = 1.0 / sr;
+        d.dp[0] = la; d.dp[1] = lb; d.dp[2] = depth_a; d.dp[3] = depth_b;
+        d.dp[4] = (depth_b - depth_a) / (lb - la);
+        d.dp[5] = exp(-20.0 * sr_inv);
+        d.dp[6] = 1.0 - d.dp[5];
+        d.dp[7] = sr;
+        int C = (int)floor((0.01 * sr) + 0.5);
+        d.jp[0] = C;
+        if (u.hist_key != C) rc = zero_is(ctx, u, 0, 1);
+        if (rc == GDG_OK) rc = ensure_hist(ctx, u, (size_t)C, C);
+        d.hist = u.d_hist;
+        break;
+    }
+    case GDG_UNIT_AUTOWAH: {
+        int32_t level_a = p[1], level_b = p[2], freq_a = p[3], freq_b = p[4];
+        if (level_a > level_b) { std::swap(level_a, level_b); std::swap(freq_a, freq_b); }
+        double la = (double)level_a, lb = (double)level_b, fa = (double)freq_a, fb = (double)freq_b;
+        d.dp[0] = la; d.dp[1] = lb; d.dp[2] = fa; d.dp[3] = fb;
+        d.dp[4] = (fb - fa) / (lb - la);
+        d.dp[5] = exp(-20.0 / sr);
+        d.dp[6] = 1.0 - d.dp[5];
+        d.dp[7] = sr;
+        break;
+    }
+    case GDG_UNIT_BANDPASS: {
+        static const int orders[4] = { 2, 4, 6, 8 };
+        int half = (p[0] >= 0 && p[0] < 4) ? orders[p[0]] >> 1 : 0;
+        int32_t fa = p[1], fb = p[2];
+        if (fa > fb) std::swap(fa, fb);
+        double m2pi_sr = -GO_MATH_TWO_PI / sr;
+        d.dp[0] = 1.0 - exp(m2pi_sr * (double)fa);
+        d.dp[1] = 1.0 - exp(m2pi_sr * (double)fb);
+        d.jp[0] = half;
+        if (u.bp_half_order != half) {
+            /* bandpass.go:40-49: both capacitor slices are re-made when the order changes */
+            if (u.bp_half_order >= 0) HIP_TRY(ctx, hipMemsetAsync(u.d_ds, 0, 8 * sizeof(double), ctx->stream));
+            u.bp_half_order = half;
+        }
+        break;
+    }
+    case GDG_UNIT_OCTAVER: {
+        for (int i = 0; i < 6; i++) d.dp[i] = decibels_to_factor(p[1 + i]);
+        d.dp[6] = exp(-20.0 / sr);
+        d.dp[7] = 1.0 - d.dp[6];
+        break;
+    }
+    case GDG_UNIT_NOISEGATE: {
+        d.dp[0] = decibels_to_factor(p[0]);
+        d.dp[1] = decibels_to_factor(p[1]);
+        double hold_seconds = 0.001 * (double)p[2];
+        d.jp[0] = (int)(uint32_t)floor((hold_seconds * sr) + 0.5);
+        d.jp[1] = (p[0] < p[1]) ? 1 : 0;
+        break;
+    }
     default:
         return fail(ctx, GDG_ERR_UNSUPPORTED, "unit type %d has no HIP implementation yet", u.type);
     }

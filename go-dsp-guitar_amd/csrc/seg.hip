@@ -621,6 +621,286 @@ __device__ void unit_reverb(const gdg_seg_unit *U, const double *in, double *out
     ring_append(dl_ring, DL, &U->is[0], in, N);
 }
 
+/* ---- generic one-pole section on an in-place sequence ----------------------------------------------------------------
+ * state recurrence (every reference unit writes it the same way):  diff = v - s;  s += diff * a
+ * emitted value:  DIFF_OLD v - s_old (high-pass, effects/cabinet.go:114-118)   OLD s_old (low-pass, cabinet.go:135-139)
+ *                 NEW s_new (auto-wah low-pass, autowah.go:106-109)            DIFF_NEW v - s_new (coupling capacitor, fuzz.go:92-94)
+ * VAR: the coefficient varies per sample and is read from abuf (auto-wah). */
+enum { OP_DIFF_OLD = 0, OP_OLD = 1, OP_NEW = 2, OP_DIFF_NEW = 3 };
+
+template <int MODE, bool VAR>
+__device__ __forceinline__ void onepole(double *buf, const double *abuf, double a_const, double *state, int N, double *tmp) {
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    const double s0 = *state;                       /* read before the scan's barriers, rewritten after them */
+    double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+    for (int i = c0; i < c1; i++) {
+        double a = VAR ? abuf[LX(i)] : a_const;
+        A[0] *= (1.0 - a);
+        double diff = buf[LX(i)] - B[0];
+        B[0] += diff * a;
+    }
+    block_scan<1, false>(A, B, Ap, Bp, tmp);
+    double s = apply_map<false>(Ap[0], Bp[0], s0);
+    for (int i = c0; i < c1; i++) {
+        double a = VAR ? abuf[LX(i)] : a_const;
+        double v = buf[LX(i)];
+        double diff = v - s;
+        double s_old = s;
+        s += diff * a;
+        double o;
+        if (MODE == OP_DIFF_OLD) o = diff;
+        else if (MODE == OP_OLD) o = s_old;
+        else if (MODE == OP_NEW) o = s;
+        else o = v - s;
+        buf[LX(i)] = o;
+    }
+    if (c1 == N && c0 < N) *state = s;
+}
+
+/* ---- workgroup scan of small integer maps (FSM compositions) ------------------------------------------------------------ */
+struct IMap { int f[5]; };
+
+template <class Compose>
+__device__ __forceinline__ IMap block_scan_imap(IMap mine, IMap identity, Compose comp, int *itmp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    IMap a = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        IMap o;
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = __shfl_up(a.f[k], d, 64);
+        if (lane >= d) a = comp(o, a);              /* first the lower lanes, then this one */
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) itmp[wave * 5 + k] = a.f[k];
+    }
+    __syncthreads();
+    IMap e;
+#pragma unroll
+    for (int k = 0; k < 5; k++) e.f[k] = __shfl_up(a.f[k], 1, 64);
+    if (lane == 0) e = identity;
+    IMap w = identity;
+    for (int q = 0; q < wave; q++) {
+        IMap t;
+#pragma unroll
+        for (int k = 0; k < 5; k++) t.f[k] = itmp[q * 5 + k];
+        w = comp(w, t);
+    }
+    e = comp(w, e);
+    __syncthreads();
+    return e;
+}
+
+/* ---- fuzz without oversampling: effects/fuzz.go:24-108 ------------------------------------------------------------------------
+ * ip0 follow; dp0 bias, dp1 gain, dp2 fuzz, dp3 1 - fuzz, dp4 level, dp5 exp(-20/sr), dp6 1 - dp5; ds0 envelope, ds1 coupling cap */
+__device__ void unit_fuzz(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
+    const double bias = U->dp[0], gain = U->dp[1], fuzz = U->dp[2], fuzz_inv = U->dp[3], level = U->dp[4];
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    for (int i = c0; i < c1; i++) {
+        double sample = in[LX(i)];
+        double bias_voltage = bias * out[LX(i)];
+        double pre = clip1(gain * (sample - bias_voltage));
+        double fuzz_fraction = fuzz * pre;
+        double clean_fraction = fuzz_inv * sample;
+        out[LX(i)] = fuzz_fraction + clean_fraction;
+    }
+    onepole<OP_DIFF_NEW, false>(out, nullptr, U->dp[6], &U->ds[1], N, tmp);
+    for (int i = c0; i < c1; i++) out[LX(i)] = level * clip1(out[LX(i)]);
+}
+
+/* ---- auto-yoy: effects/autoyoy.go:19-157 ----------------------------------------------------------------------------------------
+ * ip0 follow; dp0 level A, dp1 level B, dp2 depth A, dp3 depth B, dp4 slope, dp5 exp(-20/sr), dp6 1 - dp5, dp7 sr; jp0 ring capacity */
+__device__ void unit_autoyoy(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
+    const double la = U->dp[0], lb = U->dp[1], da = U->dp[2], db = U->dp[3], slope = U->dp[4], sr = U->dp[7];
+    const int C = U->jp[0], wp = U->is[0];
+    const double *ring = U->hist;
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    for (int i = c0; i < c1; i++) {
+        double level = 20.0 * log10(out[LX(i)]);
+        double delay_fac;
+        if (level <= la) delay_fac = da;
+        else if (level >= lb) delay_fac = db;
+        else delay_fac = da + (slope * (level - la));
+        double delay_time = 0.01 * delay_fac;
+        double delay_samples = delay_time * sr;
+        double delayed = frac_delay(in, ring, C, wp, i, delay_samples);
+        out[LX(i)] = (0.5 * in[LX(i)]) + (0.5 * delayed);
+    }
+    __syncthreads();
+    ring_append(U->hist, C, &U->is[0], in, N);
+}
+
+/* ---- auto-wah: effects/autowah.go:20-130 -------------------------------------------------------------------------------------------
+ * ip0 follow; dp0 level A, dp1 level B, dp2 freq A, dp3 freq B, dp4 slope, dp5 exp(-20/sr), dp6 1 - dp5, dp7 sr;
+ * ds0 envelope, ds1..8 hcv, ds9..16 lcv.  CLOBBERS its input buffer (it is free: the next unit overwrites it anyway). */
+__device__ void unit_autowah(const gdg_seg_unit *U, double *in, double *out, int N, double *tmp) {
+    envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
+    const double la = U->dp[0], lb = U->dp[1], fa = U->dp[2], fb = U->dp[3], slope = U->dp[4], sr = U->dp[7];
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    for (int i = c0; i < c1; i++) {
+        double level = 20.0 * log10(out[LX(i)]);
+        double frequency;
+        if (level <= la) frequency = fa;
+        else if (level >= lb) frequency = fb;
+        else frequency = fa + (slope * (level - la));
+        double arg = -frequency / sr;
+        double alpha = 1.0 - exp(arg);
+        out[LX(i)] = in[LX(i)];                      /* the signal */
+        in[LX(i)] = alpha;                           /* the per-sample coefficient */
+    }
+    for (int j = 0; j < 8; j++) {
+        onepole<OP_DIFF_OLD, true>(out, in, 0.0, &U->ds[1 + j], N, tmp);
+        onepole<OP_NEW, true>(out, in, 0.0, &U->ds[9 + j], N, tmp);
+    }
+    for (int i = c0; i < c1; i++) out[LX(i)] = clip1(256.0 * out[LX(i)]);
+}
+
+/* ---- bandpass: effects/bandpass.go:20-98.  jp0 half order; dp0 high-pass coefficient, dp1 low-pass coefficient; ds0..3 hcv, ds4..7 lcv */
+__device__ void unit_bandpass(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    for (int i = c0; i < c1; i++) out[LX(i)] = in[LX(i)];
+    const int half = U->jp[0];
+    for (int j = 0; j < half; j++) {
+        onepole<OP_DIFF_OLD, false>(out, nullptr, U->dp[0], &U->ds[j], N, tmp);
+        onepole<OP_OLD, false>(out, nullptr, U->dp[1], &U->ds[4 + j], N, tmp);
+        for (int i = c0; i < c1; i++) out[LX(i)] = clip1(out[LX(i)]);     /* the clip between stages (bandpass.go:85-91) */
+    }
+}
+
+/* ---- octaver: effects/octaver.go:21-139 -----------------------------------------------------------------------------------------------
+ * ip0 follow; dp0 up, dp1 clean, dp2 dist, dp3 down1, dp4 down2, dp5 hysteresis factors, dp6 exp(-20/sr), dp7 1 - dp6;
+ * ds0 envelope, ds1 coupling cap; is0 previousPolarity (-1, 0, 1), is1 octaveRegister.
+ * The polarity FSM is scanned as a map  pp_in -> (pp_out, register increment):  f = {has, s1, drest, pp_out}. */
+__device__ void unit_octaver(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    envelope_to(in, out, N, U->ip[0], U->dp[6], U->dp[7], &U->ds[0], tmp);
+    const double f_up = U->dp[0], f_clean = U->dp[1], f_dist = U->dp[2], f_d1 = U->dp[3], f_d2 = U->dp[4], f_hyst = U->dp[5];
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    const int pp0 = U->is[0], reg0 = U->is[1];
+    IMap mine = { { 0, 0, 0, 0, 0 } }, ident = { { 0, 0, 0, 0, 0 } };
+    for (int i = c0; i < c1; i++) {
+        double sample = in[LX(i)];
+        int s = sample < 0.0 ? -1 : (sample > 0.0 ? 1 : 0);
+        double hysteresis = out[LX(i)] * f_hyst;
+        if (s != 0 && fabs(sample) > hysteresis) {
+            if (!mine.f[0]) { mine.f[0] = 1; mine.f[1] = s; mine.f[2] = 0; mine.f[3] = s; }
+            else if (s != mine.f[3]) { mine.f[2]++; mine.f[3] = s; }
+        }
+    }
+    auto comp = [](const IMap &f, const IMap &g) -> IMap {
+        if (!g.f[0]) return f;
+        if (!f.f[0]) return g;
+        IMap r = f;
+        r.f[2] = f.f[2] + (f.f[3] != g.f[1] ? 1 : 0) + g.f[2];
+        r.f[3] = g.f[3];
+        return r;
+    };
+    IMap pre = block_scan_imap(mine, ident, comp, reinterpret_cast<int *>(tmp));
+    int pp = pp0;
+    unsigned reg = (unsigned)reg0;
+    if (pre.f[0]) { reg = (reg + (unsigned)pre.f[2] + (pp0 != pre.f[1] ? 1u : 0u)) & 7u; pp = pre.f[3]; }
+    for (int i = c0; i < c1; i++) {
+        double sample = in[LX(i)];
+        double sample_abs = fabs(sample);
+        double envelope = out[LX(i)];
+        double square = sample * sample;
+        int s = sample < 0.0 ? -1 : (sample > 0.0 ? 1 : 0);
+        double sign = (double)s;
+        double hysteresis = envelope * f_hyst;
+        if ((s != 0) && (s != pp) && (sample_abs > hysteresis)) { reg = (reg + 1u) & 7u; pp = s; }
+        double first_down = (reg & 2u) ? -1.0 : 1.0;
+        double second_down = (reg & 4u) ? -1.0 : 1.0;
+        double p = f_clean * sample;
+        if (envelope > 0.0001) p += f_up * (square / envelope);
+        p += f_dist * (sign * envelope);
+        p += f_d1 * (first_down * envelope);
+        p += f_d2 * (second_down * envelope);
+        out[LX(i)] = p;
+    }
+    if (c1 == N && c0 < N) { U->is[0] = pp; U->is[1] = (int)reg; }
+    onepole<OP_DIFF_NEW, false>(out, nullptr, U->dp[7], &U->ds[1], N, tmp);
+    for (int i = c0; i < c1; i++) out[LX(i)] = clip1(out[LX(i)]);
+}
+
+/* ---- noise gate: effects/noisegate.go:19-96 ------------------------------------------------------------------------------------------------
+ * dp0 open factor, dp1 close factor; jp0 hold samples, jp1 pass-through (threshold_open < threshold_close); is0 gateOpen, is1 onHoldSince.
+ * FSM map (open_in, since_in) -> (open_out, since_out):  f = {has_reset, off, forced, fv, T}
+ *   since_out = has_reset ? off : since_in + off;   open_out = forced ? fv : (open_in && since_in < T)
+ * (every sample above the open threshold is also above the close threshold, so before the first reset only closing can happen). */
+#define GATE_INF 0x3fffffff
+__device__ void unit_noisegate(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+    if (U->jp[1]) {
+        for (int i = c0; i < c1; i++) out[LX(i)] = in[LX(i)];
+        __syncthreads();
+        if (tid == 0) { U->is[0] = 1; U->is[1] = 0; }
+        return;
+    }
+    const double fac_open = U->dp[0], fac_close = U->dp[1];
+    const int hold = U->jp[0];
+    const int open0 = U->is[0], since0 = U->is[1];
+    IMap mine = { { 0, 0, 0, 0, GATE_INF } }, ident = { { 0, 0, 0, 0, GATE_INF } };
+    {
+        int has = 0, r1 = 0, since = 0, forced = 0, fv = 0;
+        for (int i = c0; i < c1; i++) {
+            double a = fabs(in[LX(i)]);
+            if (!has) {
+                if (a > fac_close) { has = 1; r1 = i - c0; } else continue;
+            }
+            if (a > fac_open) { forced = 1; fv = 1; }
+            if (a > fac_close) since = 0;
+            if (since >= hold) { forced = 1; fv = 0; }
+            since++;
+        }
+        int len = c1 - c0;
+        int prefix = has ? r1 : len;
+        int T = GATE_INF;
+        if (prefix > 0) { T = hold - prefix + 1; if (T < 0) T = 0; }
+        mine.f[0] = has; mine.f[1] = has ? since : len; mine.f[2] = forced; mine.f[3] = fv; mine.f[4] = T;
+    }
+    auto comp = [](const IMap &f, const IMap &g) -> IMap {
+        IMap r;
+        r.f[0] = (g.f[0] || f.f[0]) ? 1 : 0;
+        r.f[1] = g.f[0] ? g.f[1] : f.f[1] + g.f[1];
+        r.f[2] = 0; r.f[3] = 0; r.f[4] = GATE_INF;
+        if (g.f[2]) { r.f[2] = 1; r.f[3] = g.f[3]; }
+        else if (f.f[0]) {
+            int cond2 = f.f[1] < g.f[4];
+            if (f.f[2]) { r.f[2] = 1; r.f[3] = (f.f[3] && cond2) ? 1 : 0; }
+            else if (cond2) { r.f[4] = f.f[4]; }
+            else { r.f[2] = 1; r.f[3] = 0; }
+        } else {
+            int t2 = g.f[4];
+            if (t2 != GATE_INF) { t2 -= f.f[1]; if (t2 < 0) t2 = 0; }
+            r.f[4] = f.f[4] < t2 ? f.f[4] : t2;
+        }
+        return r;
+    };
+    IMap pre = block_scan_imap(mine, ident, comp, reinterpret_cast<int *>(tmp));
+    int since = pre.f[0] ? pre.f[1] : since0 + pre.f[1];
+    int gate = pre.f[2] ? pre.f[3] : ((open0 && since0 < pre.f[4]) ? 1 : 0);
+    for (int i = c0; i < c1; i++) {
+        double sample = in[LX(i)];
+        double a = fabs(sample);
+        if (a > fac_open) gate = 1;
+        if (a > fac_close) since = 0;
+        if (since >= hold) gate = 0;
+        double fac = gate ? 1.0 : 0.0;
+        out[LX(i)] = fac * sample;
+        since++;
+    }
+    if (c1 == N && c0 < N) { U->is[0] = gate; U->is[1] = since; }
+}
+
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(SEG_T) __attribute__((amdgpu_waves_per_eu(1, 1)))
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, gdg_os_tables os, int *d_error) {
@@ -650,6 +930,12 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         case GDG_UNIT_TREMOLO: unit_tremolo(U, in, out, N, s_scr); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, in, out, N); break;
         case GDG_UNIT_REVERB: unit_reverb(U, in, out, N); break;
+        case GDG_UNIT_FUZZ: unit_fuzz(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_AUTOYOY: unit_autoyoy(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_AUTOWAH: unit_autowah(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_BANDPASS: unit_bandpass(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_OCTAVER: unit_octaver(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_NOISEGATE: unit_noisegate(U, in, out, N, s_tmp); break;
         default:
             if (tid == 0) atomicExch(d_error, 1 + U->type);
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
@@ -666,7 +952,8 @@ int gdg_seg_supported(int unit_type) {
     case GDG_UNIT_COMPRESSOR: case GDG_UNIT_OVERDRIVE: case GDG_UNIT_DISTORTION: case GDG_UNIT_EXCESS:
     case GDG_UNIT_TONESTACK: case GDG_UNIT_CABINET: case GDG_UNIT_CHORUS: case GDG_UNIT_FLANGER:
     case GDG_UNIT_PHASER: case GDG_UNIT_DELAY: case GDG_UNIT_RINGMODULATOR: case GDG_UNIT_TREMOLO:
-    case GDG_UNIT_SIGNALGENERATOR: case GDG_UNIT_REVERB:
+    case GDG_UNIT_SIGNALGENERATOR: case GDG_UNIT_REVERB: case GDG_UNIT_FUZZ: case GDG_UNIT_AUTOYOY:
+    case GDG_UNIT_AUTOWAH: case GDG_UNIT_BANDPASS: case GDG_UNIT_OCTAVER: case GDG_UNIT_NOISEGATE:
         return 1;
     default:
         return 0;

@@ -96,6 +96,13 @@ UNIT_CASES = [
     ("signal_generator", None), ("signal_generator", [50, -6, 1, 1000, 80, -3]), ("signal_generator", [100, 0, 2, 123, 50, 0]),
     ("signal_generator", [100, 0, 3, 5000, 50, 0]), ("signal_generator", [30, 0, 4, 440, 100, -10]),
     ("reverb", None), ("reverb", [100]), ("reverb", [0]),
+    ("fuzz", None), ("fuzz", [0, -30, 10, 20, 60, -3, 0]), ("fuzz", [1, 100, 0, 30, 100, 0, 0]),
+    ("auto_yoy", None), ("auto_yoy", [0, -10, -50, 40]),
+    ("auto_wah", None), ("auto_wah", [0, -5, -45, 200, 9000]),
+    ("bandpass", None), ("bandpass", [3, 5000, 100]), ("bandpass", [1, 40, 18000]),
+    ("octaver", None), ("octaver", [0, -6, -12, -3, 0, -6, -30]), ("octaver", [1, -60, 0, -60, -3, -3, 0]),
+    ("noise_gate", None), ("noise_gate", [-10, -14, 5]), ("noise_gate", [-30, -20, 50]), ("noise_gate", [-6, -40, 0]),
+    ("noise_gate", [-3, -8, 1]),
 ]
 
 
