@@ -101,10 +101,16 @@ struct gdg_ctx {
     double *d_tuner_ring = nullptr;
     int tuner_wp = 0;
     uint32_t tuner_sr = 0;
+    double *d_note_freqs = nullptr;
+    gdg_tuner_out *d_tuner_out = nullptr;
+    double2 *d_tuner_work = nullptr, *d_tuner_twn = nullptr, *d_tuner_twm = nullptr;
     std::vector<double> sp_az, sp_dist, sp_level;
     uint32_t sp_hist_sr = 96000;
     double *d_sp_hist = nullptr;
     int sp_hist_len = 0;
+    gdg_spat_chan *d_sp_chan = nullptr;
+    double *d_sp_partial = nullptr, *d_sp_out = nullptr;
+    bool sp_dirty = true;
 };
 
 static int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {
@@ -210,6 +216,8 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error);
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
+    hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
+    hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_partial); hipFree(ctx->d_sp_out);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -875,7 +883,7 @@ int gdg_ctx_synchronize(gdg_ctx *ctx) {
 
 static int ensure_staging(gdg_ctx *ctx) {
     if (ctx->d_stage_in) return GDG_OK;
-    size_t bytes = (size_t)ctx->nch * (size_t)ctx->max_frames * sizeof(double);
+    size_t bytes = (size_t)std::max(ctx->nch, 2) * (size_t)ctx->max_frames * sizeof(double);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stage_in, bytes));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stage_out, bytes));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_stage_in, bytes, hipHostMallocDefault));
@@ -934,15 +942,199 @@ int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
     return GDG_OK;
 }
 
-/* ---- tuner / spatializer: implemented in a later milestone of this round ---------------------------------------- */
+/* ---- tuner: tuner.Process / tuner.Analyze for every channel of the shard ------------------------------------------ */
 
-int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *, int, uint32_t) { return fail(ctx, GDG_ERR_UNSUPPORTED, "tuner: not implemented yet"); }
-int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *, int, uint32_t) { return fail(ctx, GDG_ERR_UNSUPPORTED, "tuner: not implemented yet"); }
-int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *) { return fail(ctx, GDG_ERR_UNSUPPORTED, "tuner: not implemented yet"); }
+static int ensure_tuner(gdg_ctx *ctx) {
+    if (ctx->d_tuner_ring) return GDG_OK;
+    size_t ring_bytes = (size_t)ctx->nch * GDG_TUNER_RING * sizeof(double);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_ring, ring_bytes));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_tuner_ring, 0, ring_bytes, ctx->stream));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_note_freqs, GDG_NOTE_COUNT * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_note_freqs, GDG_NOTE_FREQS, GDG_NOTE_COUNT * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_out, (size_t)ctx->nch * sizeof(gdg_tuner_out)));
+    ctx->tuner_wp = 0;
+    return GDG_OK;
+}
+
+int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *d_samples, int frames, uint32_t sample_rate) {
+    if (!ctx || !d_samples || frames < 0) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure_tuner(ctx);
+    if (rc != GDG_OK) return rc;
+    { ProfScope ps(ctx, GDG_K_TUNER); HIP_TRY(ctx, gdg_launch_tuner_enqueue(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, d_samples, frames, frames, ctx->stream)); }
+    if (frames < GDG_TUNER_RING) ctx->tuner_wp = (ctx->tuner_wp + frames) % GDG_TUNER_RING;
+    ctx->tuner_sr = sample_rate;          /* tuner.go:582-587 */
+    return GDG_OK;
+}
+
+static int ensure_staging(gdg_ctx *ctx);
+
+int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *samples, int frames, uint32_t sample_rate) {
+    if (!ctx || !samples) return GDG_ERR_INVALID;
+    if (frames < 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    hipSetDevice(ctx->device);
+    int rc = ensure_staging(ctx);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < ctx->nch; c++) memcpy(ctx->h_stage_in + (size_t)c * frames, samples[c], (size_t)frames * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, ctx->h_stage_in, (size_t)ctx->nch * frames * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = gdg_tuner_enqueue_device(ctx, ctx->d_stage_in, frames, sample_rate);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
+    if (!ctx || !results) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure_tuner(ctx);
+    if (rc != GDG_OK) return rc;
+    if (!ctx->d_tuner_work) {
+        /* two complex work arrays of 131072 points per channel (2 x 2 MiB) */
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_work, (size_t)ctx->nch * 2 * (GDG_TUNER_FFT / 2) * sizeof(double2)));
+        HIP_TRY(ctx, gdg_tuner_tables_create(&ctx->d_tuner_twn, &ctx->d_tuner_twm));
+    }
+    double2 *tw512, *tw256, *unused;
+    rc = fir_tables(ctx, 512, &tw512, &unused);
+    if (rc == GDG_OK) rc = fir_tables(ctx, 256, &tw256, &unused);
+    if (rc != GDG_OK) return rc;
+    {
+        ProfScope ps(ctx, GDG_K_TUNER);
+        HIP_TRY(ctx, gdg_launch_tuner_analyze(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, (double)ctx->tuner_sr, ctx->d_tuner_work,
+                                              ctx->d_tuner_twn, ctx->d_tuner_twm, tw512, tw256, ctx->d_note_freqs, GDG_NOTE_COUNT,
+                                              ctx->d_tuner_out, ctx->stream));
+    }
+    std::vector<gdg_tuner_out> host((size_t)ctx->nch);
+    HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->d_tuner_out, host.size() * sizeof(gdg_tuner_out), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < ctx->nch; c++) {
+        results[c].frequency = host[(size_t)c].frequency;
+        results[c].note_index = host[(size_t)c].note_index;
+        results[c].cents = (int8_t)host[(size_t)c].cents;
+    }
+    return GDG_OK;
+}
+
 const char *gdg_tuner_note_name(int note_index) { return (note_index >= 0 && note_index < GDG_NOTE_COUNT) ? GDG_NOTE_NAMES[note_index] : "Unknown"; }
-int gdg_spatializer_set_position(gdg_ctx *ctx, int, double, double, double) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
-int gdg_spatializer_set_sample_rate(gdg_ctx *ctx, uint32_t) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
-int gdg_spatialize(gdg_ctx *ctx, const double *const *, double *, double *, int) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
-int gdg_spatialize_device(gdg_ctx *ctx, const double *, double *, int) { return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer: not implemented yet"); }
+
+/* ---- spatializer: spatializer.Process over the shard ---------------------------------------------------------------- */
+
+#define SPAT_GROUP_DELAY 6.3e-4                   /* spatializer/spatializer.go:23 */
+#define SPAT_DEFAULT_RATE 96000                   /* spatializer.go:20; the delay computation never leaves this rate */
+
+static int ensure_spatializer(gdg_ctx *ctx) {
+    if (ctx->d_sp_hist) return GDG_OK;
+    ctx->sp_hist_len = (int)ceil((double)ctx->sp_hist_sr * SPAT_GROUP_DELAY);
+    size_t hist_bytes = (size_t)ctx->nch * (size_t)ctx->sp_hist_len * sizeof(double);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_hist, hist_bytes));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_sp_hist, 0, hist_bytes, ctx->stream));
+    if (!ctx->d_sp_chan) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_chan, (size_t)ctx->nch * sizeof(gdg_spat_chan)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_partial, (size_t)gdg_spat_groups(ctx->nch) * 2 * (size_t)ctx->max_frames * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_out, 2 * (size_t)ctx->max_frames * sizeof(double)));
+    }
+    ctx->sp_dirty = true;
+    return GDG_OK;
+}
+
+int gdg_spatializer_set_position(gdg_ctx *ctx, int channel, double azimuth, double distance, double level) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (channel < 0 || channel >= ctx->nch) return fail(ctx, GDG_ERR_INVALID, "Cannot set azimuth for channel %d: Only %d channels exist.", channel, ctx->nch);
+    if (distance < 0.0 || distance > 10.0) return fail(ctx, GDG_ERR_INVALID, "Failed to set distance: Value must be within [0, 10].");
+    if (level < 0.0 || level > 1.0) return fail(ctx, GDG_ERR_INVALID, "Failed to set level: Value must be within [0, 1].");
+    ctx->sp_az[(size_t)channel] = azimuth;
+    ctx->sp_dist[(size_t)channel] = distance;
+    ctx->sp_level[(size_t)channel] = level;
+    ctx->sp_dirty = true;
+    return GDG_OK;
+}
+
+int gdg_spatializer_set_sample_rate(gdg_ctx *ctx, uint32_t rate) {
+    if (!ctx) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    /* spatializer.go:418-431: new (zeroed) history buffers of ceil(rate * 6.3e-4) samples; this.sampleRate stays 96000 */
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->d_sp_hist);
+    ctx->d_sp_hist = nullptr;
+    ctx->sp_hist_sr = rate;
+    return ensure_spatializer(ctx);
+}
+
+static int upload_spat_chans(gdg_ctx *ctx) {
+    std::vector<gdg_spat_chan> host((size_t)ctx->nch);
+    const double sample_rate = (double)SPAT_DEFAULT_RATE;
+    const int H = ctx->sp_hist_len;
+    for (int c = 0; c < ctx->nch; c++) {
+        /* spatializer.go:170-240, statement by statement */
+        double azimuth = GO_MATH_DEGREE_TO_RADIANS * ctx->sp_az[(size_t)c];
+        double distance = ctx->sp_dist[(size_t)c], level = ctx->sp_level[(size_t)c];
+        double sin_az = sin(azimuth), cos_az = cos(azimuth);
+        double x_pos = distance * sin_az, y_pos = distance * cos_az;
+        double x_left = fabs(x_pos + (GO_HALF_EFFECTIVE_DISTANCE));
+        double x_right = fabs(x_pos - (GO_HALF_EFFECTIVE_DISTANCE));
+        double y_dist = fabs(y_pos);
+        double y_sq = y_dist * y_dist;
+        double xl_sq = x_left * x_left;
+        double dist_left = sqrt(xl_sq + y_sq);
+        double pre_left = 1.0 / dist_left;
+        if (pre_left > 1.0) pre_left = 1.0;
+        double xr_sq = x_right * x_right;
+        double dist_right = sqrt(xr_sq + y_sq);
+        double pre_right = 1.0 / dist_right;
+        if (pre_right > 1.0) pre_right = 1.0;
+        double dist_diff = dist_left - dist_right;
+        double delay_time = GO_GROUP_DELAY_OVER_EFFECTIVE_DISTANCE * dist_diff;
+        double delay_samples = fabs(delay_time) * sample_rate;
+        double early = floor(delay_samples), late = ceil(delay_samples);
+        int early_i = (int)early, late_i = (int)late;
+        if (early_i >= H) early_i = H - 1;
+        if (late_i >= H) late_i = H - 1;
+        gdg_spat_chan &d = host[(size_t)c];
+        d.fac_left = level * pre_left;
+        d.fac_right = level * pre_right;
+        d.w_early = 1.0 - (delay_samples - early);
+        d.w_late = 1.0 - (late - delay_samples);
+        d.mode = (delay_time == 0.0) ? 0 : (delay_time > 0.0 ? 1 : 2);
+        d.early = early_i;
+        d.late = late_i;
+        d.pad = 0;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_sp_chan, host.data(), host.size() * sizeof(gdg_spat_chan), hipMemcpyHostToDevice));
+    ctx->sp_dirty = false;
+    return GDG_OK;
+}
+
+int gdg_spatialize_device(gdg_ctx *ctx, const double *d_in, double *d_out_lr, int frames) {
+    if (!ctx || !d_in || !d_out_lr) return GDG_ERR_INVALID;
+    if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    hipSetDevice(ctx->device);
+    int rc = ensure_spatializer(ctx);
+    if (rc != GDG_OK) return rc;
+    if (ctx->sp_dirty) { rc = upload_spat_chans(ctx); if (rc != GDG_OK) return rc; }
+    ProfScope ps(ctx, GDG_K_SPATIALIZER);
+    HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_in, frames, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
+                                        d_out_lr, frames, ctx->max_frames, ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, double *out_right, int frames) {
+    if (!ctx || !in || !out_left || !out_right) return GDG_ERR_INVALID;
+    if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    hipSetDevice(ctx->device);
+    int rc = ensure_staging(ctx);
+    if (rc == GDG_OK) rc = ensure_spatializer(ctx);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < ctx->nch; c++) memcpy(ctx->h_stage_in + (size_t)c * frames, in[c], (size_t)frames * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, ctx->h_stage_in, (size_t)ctx->nch * frames * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = gdg_spatialize_device(ctx, ctx->d_stage_in, ctx->d_sp_out, frames);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage_out, ctx->d_sp_out, 2 * (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out_left, ctx->h_stage_out, (size_t)frames * sizeof(double));
+    memcpy(out_right, ctx->h_stage_out + frames, (size_t)frames * sizeof(double));
+    return GDG_OK;
+}
 
 }  /* extern "C" */

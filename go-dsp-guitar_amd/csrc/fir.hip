@@ -461,3 +461,5 @@ hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, c
     GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, s));
     return hipGetLastError();
 }
+
+#include "tuner_kernels.h"

@@ -94,4 +94,29 @@ hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_se
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);
 
+/* ------------------------------------------------------------------------------------------------
+ * Spatializer (spat.hip): per-channel constants derived on the host (spatializer.go:170-240).
+ * mode 0: no inter-aural delay, 1: left ear delayed (delayTime > 0), 2: right ear delayed.
+ * ---------------------------------------------------------------------------------------------- */
+struct gdg_spat_chan {
+    double fac_left, fac_right, w_early, w_late;
+    int mode, early, late, pad;
+};
+hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, double *d_hist, int H,
+                                  double *d_partial, double *d_out_lr, int frames, int max_frames, hipStream_t s);
+int gdg_spat_groups(int nch);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tuner (tuner.hip): one 96000-sample ring per channel; analysis = 262144-point real FFT
+ * autocorrelation as a four-step FFT over HBM (tuner/tuner.go:379-577).
+ * ---------------------------------------------------------------------------------------------- */
+#define GDG_TUNER_RING 96000          /* tuner/tuner.go:16 */
+#define GDG_TUNER_FFT 262144          /* nextpow2(2 * 96000), tuner.go:388-390 */
+struct gdg_tuner_out { double frequency; int note_index; int cents; };
+hipError_t gdg_launch_tuner_enqueue(double *d_rings, int nch, int wp, const double *d_samples, int stride, int frames, hipStream_t s);
+hipError_t gdg_tuner_tables_create(double2 **d_tw_n, double2 **d_tw_m);
+hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, double sample_rate, double2 *d_work,
+                                    const double2 *d_tw_n, const double2 *d_tw_m, const double2 *d_tw512, const double2 *d_tw256,
+                                    const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s);
+
 #endif

@@ -1,0 +1,98 @@
+"""GPU parity of the tuner (batched 262144-point real-FFT autocorrelation) and of the spatializer's
+N -> 2 mixdown against the oracle.  Run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from helpers import TOL_RMS, package, rms, synth_signal
+
+pytestmark = pytest.mark.gpu
+
+# the six guitar-string notes of tuner/tuner_test.go (its WAV fixtures are missing upstream): synthetic harmonic tones
+STRINGS = [("D2", 73.4162), ("A2", 110.0), ("D3", 146.8324), ("G3", 195.9978), ("H3", 246.9417), ("E4", 329.6276)]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = package()
+    assert p.device_count() > 0
+    return p
+
+
+def tone(freq, n, sr, detune_cents=0.0, phase=0.0):
+    f = freq * 2.0 ** (detune_cents / 1200.0)
+    t = np.arange(n) / float(sr)
+    return sum(a * np.sin(2 * np.pi * f * h * t + phase * h) for h, a in ((1, 0.5), (2, 0.25), (3, 0.12), (4, 0.06)))
+
+
+@pytest.mark.parametrize("sr,frames", [(96000, 8192), (192000, 8192), (44100, 1000)])
+def test_tuner_matches_oracle_on_string_tones(pkg, oracle, sr, frames):
+    nch = len(STRINGS)
+    total = 96000 + 3 * frames                      # wraps the ring
+    x = np.stack([tone(f, total, sr, detune_cents=3.0 * (i - 2), phase=0.3 * i) for i, (_, f) in enumerate(STRINGS)])
+    ctx = pkg.Context(nch, frames)
+    refs = [oracle.Tuner() for _ in range(nch)]
+    for b in range(0, total, frames):
+        blk = x[:, b:b + frames]
+        ctx.tuner_enqueue(blk, sr)
+        for c in range(nch):
+            refs[c].process(blk[c], sr)
+    got = ctx.tuner_analyze()
+    for c, (name, _) in enumerate(STRINGS):
+        want = refs[c].analyze()
+        assert got[c]["note"] == want["note"] == name
+        assert abs(want["cents"]) <= 5                                  # tuner_test.go:95-106 criterion
+        assert got[c]["cents"] == want["cents"]
+        assert abs(got[c]["frequency"] - want["frequency"]) / want["frequency"] <= 1e-9
+    ctx.close()
+
+
+def test_tuner_noise_and_silence(pkg, oracle):
+    sr, frames, nch = 48000, 4096, 3
+    ctx = pkg.Context(nch, frames)
+    refs = [oracle.Tuner() for _ in range(nch)]
+    x = np.stack([synth_signal(5, 30 * frames, sr), 0.3 * np.random.default_rng(3).standard_normal(30 * frames), synth_signal(40, 30 * frames, sr)])
+    for b in range(0, x.shape[1], frames):
+        ctx.tuner_enqueue(x[:, b:b + frames], sr)
+        for c in range(nch):
+            refs[c].process(x[c, b:b + frames], sr)
+    got = ctx.tuner_analyze()
+    for c in range(nch):
+        want = refs[c].analyze()
+        assert got[c]["note_index"] == want["note_index"]
+        assert abs(got[c]["frequency"] - want["frequency"]) / want["frequency"] <= 1e-9
+    ctx.close()
+
+
+@pytest.mark.parametrize("nch,frames,sr", [(5, 1024, 48000), (70, 8192, 192000), (3, 37, 96000)])
+def test_spatializer_matches_oracle(pkg, oracle, nch, frames, sr):
+    rng = np.random.default_rng(11)
+    ctx = pkg.Context(nch, frames)
+    ref = oracle.Spatializer(nch)
+    ctx.spatializer_set_sample_rate(sr)
+    ref.set_sample_rate(sr)
+    for c in range(nch):
+        az, dist, lvl = float(rng.uniform(-180, 180)), float(rng.uniform(0, 10)), float(rng.uniform(0, 1))
+        if c == 0:
+            az, dist, lvl = 0.0, 0.0, 1.0            # the defaults: gains clipped to 1, zero delay
+        if c == 1:
+            az, dist = 90.0, 0.05                    # largest inter-aural delay
+        ctx.spatializer_set_position(c, az, dist, lvl)
+        assert ref.set_azimuth(c, az) == 0 and ref.set_distance(c, dist) == 0 and ref.set_level(c, lvl) == 0
+    x = np.stack([synth_signal(c, frames * 4, sr) for c in range(nch)])
+    for b in range(0, x.shape[1], frames):
+        blk = x[:, b:b + frames]
+        gl, gr = ctx.spatialize(blk)
+        wl, wr = ref.process(blk)
+        assert rms(gl - wl) <= TOL_RMS and rms(gr - wr) <= TOL_RMS
+    ctx.close()
+
+
+def test_spatializer_rejects_out_of_range(pkg):
+    ctx = pkg.Context(2, 64)
+    with pytest.raises(pkg.GdgError):
+        ctx.spatializer_set_position(0, 0.0, 11.0, 1.0)
+    with pytest.raises(pkg.GdgError):
+        ctx.spatializer_set_position(0, 0.0, 1.0, 1.5)
+    with pytest.raises(pkg.GdgError):
+        ctx.spatializer_set_position(2, 0.0, 1.0, 1.0)
+    ctx.close()
