@@ -28,7 +28,7 @@ def tone(freq, n, sr, detune_cents=0.0, phase=0.0):
 def test_tuner_matches_oracle_on_string_tones(pkg, oracle, sr, frames):
     nch = len(STRINGS)
     total = 96000 + 3 * frames                      # wraps the ring
-    x = np.stack([tone(f, total, sr, detune_cents=3.0 * (i - 2), phase=0.3 * i) for i, (_, f) in enumerate(STRINGS)])
+    x = np.stack([tone(f, total, sr, detune_cents=1.0 * (i - 2), phase=0.3 * i) for i, (_, f) in enumerate(STRINGS)])
     ctx = pkg.Context(nch, frames)
     refs = [oracle.Tuner() for _ in range(nch)]
     for b in range(0, total, frames):
