@@ -33,7 +33,7 @@ KERNEL_KINDS = ["fir_fwd", "fir_mac", "fir_inv", "segment", "tuner", "spatialize
 ABI_SYMBOLS = [
     "gdg_version", "gdg_device_count", "gdg_ctx_create", "gdg_ctx_destroy", "gdg_last_error", "gdg_ctx_channels",
     "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
-    "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_device",
+    "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_subset", "gdg_process_device",
     "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
     "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_analyze", "gdg_tuner_note_name",
     "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device",
@@ -55,6 +55,7 @@ def build(force=False):
     if force:
         subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
     subprocess.check_call(["make", "-s", "-C", CSRC])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host")])     # C++ mirror of effects.Unit / signal.Chain
     return LIB_PATH
 
 
@@ -86,6 +87,7 @@ def lib():
             "gdg_unit_reset": (i32, [vp, i32]),
             "gdg_chain_set": (i32, [vp, i32, vp, vp, i32]),
             "gdg_process": (i32, [vp, vp, vp, i32, u32]),
+            "gdg_process_subset": (i32, [vp, vp, i32, vp, vp, i32, u32]),
             "gdg_process_device": (i32, [vp, vp, vp, i32, u32]),
             "gdg_device_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
             "gdg_device_free": (i32, [vp, vp]),
@@ -223,6 +225,18 @@ class Context:
         ins = (C.c_void_p * self.n_channels)(*[x[c].ctypes.data for c in range(self.n_channels)])
         outs = (C.c_void_p * self.n_channels)(*[out[c].ctypes.data for c in range(self.n_channels)])
         self._check(lib().gdg_process(self._h, ins, outs, frames, sample_rate))
+        return out
+
+    def process_subset(self, channels, x, sample_rate):
+        """x: [len(channels)][frames]; only the listed channels' chains run (gdg_process_subset)."""
+        x = _f64(x)
+        n = len(channels)
+        assert x.ndim == 2 and x.shape[0] == n
+        out = np.empty_like(x)
+        chans = (C.c_int * n)(*channels)
+        ins = (C.c_void_p * n)(*[x[i].ctypes.data for i in range(n)])
+        outs = (C.c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
+        self._check(lib().gdg_process_subset(self._h, chans, n, ins, outs, x.shape[1], sample_rate))
         return out
 
     def process_device(self, d_in, d_out, frames, sample_rate):

@@ -79,6 +79,7 @@ struct gdg_ctx {
     uint32_t plan_sr = 0;
     const double *plan_in = nullptr;
     double *plan_out = nullptr;
+    std::vector<int> plan_active, all_channels;
     std::vector<StepDesc> steps;
     std::vector<unsigned char> blob;
     unsigned char *d_blob = nullptr;
@@ -666,13 +667,16 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
 
 struct Op { bool is_fir; std::vector<int> handles; };
 
-static int build_plan(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
+/* `active`: the channels taking part in this call; row i of d_in / d_out belongs to channel active[i] */
+static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
     const int nch = ctx->nch;
     /* per channel: ops placed on a common grid of slots: 2k = segment k, 2k+1 = FIR k */
     std::map<int, std::vector<std::pair<int, Op>>> by_slot;           /* slot -> (channel, op) */
     std::vector<int> n_ops((size_t)nch, 0);
+    std::vector<int> row_of((size_t)nch, -1);
+    for (size_t i = 0; i < active.size(); i++) row_of[(size_t)active[i]] = (int)i;
     bool any_fir = false;
-    for (int c = 0; c < nch; c++) {
+    for (int c : active) {
         std::vector<int> seg;
         int k = 0, count = 0;
         for (auto &s : ctx->chains[(size_t)c]) {
@@ -705,7 +709,7 @@ static int build_plan(gdg_ctx *ctx, const double *d_in, double *d_out, int frame
     std::vector<std::vector<gdg_fir_chan>> fir_descs;
     std::vector<int> done((size_t)nch, 0);
     std::vector<const double *> cur((size_t)nch);
-    for (int c = 0; c < nch; c++) cur[(size_t)c] = d_in + (size_t)c * frames;
+    for (int c : active) cur[(size_t)c] = d_in + (size_t)row_of[(size_t)c] * frames;
     ctx->steps.clear();
     for (auto &kv : by_slot) {
         bool is_fir = (kv.first & 1) != 0;
@@ -716,7 +720,7 @@ static int build_plan(gdg_ctx *ctx, const double *d_in, double *d_out, int frame
             Op &op = entry.second;
             bool last = (done[(size_t)c] + 1 == n_ops[(size_t)c]);
             double *dst;
-            if (last) dst = d_out + (size_t)c * frames;
+            if (last) dst = d_out + (size_t)row_of[(size_t)c] * frames;
             else dst = ((done[(size_t)c] & 1) ? ctx->d_w1 : ctx->d_w0) + (size_t)c * ctx->max_frames;
             if (is_fir) {
                 Unit &u = ctx->units[(size_t)op.handles[0]];
@@ -834,15 +838,19 @@ int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
 
 /* ---- processing --------------------------------------------------------------------------------------- */
 
-int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
-    if (!ctx || !d_in || !d_out) return GDG_ERR_INVALID;
+static int ensure_staging(gdg_ctx *ctx);
+static int check_device_error(gdg_ctx *ctx);
+
+static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
     if (d_in == d_out) return fail(ctx, GDG_ERR_INVALID, "in-place processing is not supported");
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
     if (sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     hipSetDevice(ctx->device);
-    if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate || ctx->plan_in != d_in || ctx->plan_out != d_out) {
-        int rc = build_plan(ctx, d_in, d_out, frames, sample_rate);
+    if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate || ctx->plan_in != d_in || ctx->plan_out != d_out ||
+        ctx->plan_active != active) {
+        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate);
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }
+        ctx->plan_active = active;
     }
     const gdg_seg_unit *d_units = reinterpret_cast<const gdg_seg_unit *>(ctx->d_blob + ctx->units_offset);
     for (auto &st : ctx->steps) {
@@ -862,6 +870,12 @@ int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int fram
         }
     }
     return GDG_OK;
+}
+
+int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
+    if (!ctx || !d_in || !d_out) return GDG_ERR_INVALID;
+    if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
+    return process_rows(ctx, ctx->all_channels, d_in, d_out, frames, sample_rate);
 }
 
 static int check_device_error(gdg_ctx *ctx) {
@@ -891,22 +905,35 @@ static int ensure_staging(gdg_ctx *ctx) {
     return GDG_OK;
 }
 
-int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int frames, uint32_t sample_rate) {
-    if (!ctx || !in || !out) return GDG_ERR_INVALID;
+int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *const *in, double *const *out, int frames, uint32_t sample_rate) {
+    if (!ctx || !in || !out || !channels) return GDG_ERR_INVALID;
+    if (n <= 0 || n > ctx->nch) return fail(ctx, GDG_ERR_INVALID, "bad channel count %d", n);
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    std::vector<int> active(channels, channels + n);
+    std::vector<char> seen((size_t)ctx->nch, 0);
+    for (int c : active) {
+        if (c < 0 || c >= ctx->nch || seen[(size_t)c]) return fail(ctx, GDG_ERR_INVALID, "bad or repeated channel %d", c);
+        seen[(size_t)c] = 1;
+    }
     hipSetDevice(ctx->device);
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
-    size_t bytes = (size_t)ctx->nch * (size_t)frames * sizeof(double);
-    for (int c = 0; c < ctx->nch; c++) memcpy(ctx->h_stage_in + (size_t)c * frames, in[c], (size_t)frames * sizeof(double));
+    size_t bytes = (size_t)n * (size_t)frames * sizeof(double);
+    for (int i = 0; i < n; i++) memcpy(ctx->h_stage_in + (size_t)i * frames, in[i], (size_t)frames * sizeof(double));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, ctx->h_stage_in, bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = gdg_process_device(ctx, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate);
+    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate);
     if (rc != GDG_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage_out, ctx->d_stage_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
     rc = check_device_error(ctx);
     if (rc != GDG_OK) return rc;
-    for (int c = 0; c < ctx->nch; c++) memcpy(out[c], ctx->h_stage_out + (size_t)c * frames, (size_t)frames * sizeof(double));
+    for (int i = 0; i < n; i++) memcpy(out[i], ctx->h_stage_out + (size_t)i * frames, (size_t)frames * sizeof(double));
     return GDG_OK;
+}
+
+int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int frames, uint32_t sample_rate) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
+    return gdg_process_subset(ctx, ctx->all_channels.data(), ctx->nch, in, out, frames, sample_rate);
 }
 
 /* ---- device memory helpers --------------------------------------------------------------------------------- */

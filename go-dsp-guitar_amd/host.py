@@ -1,0 +1,233 @@
+"""ctypes binding of libgdg_host.so: the C++ mirror of effects.Unit / signal.Chain (host/gdg_host.hpp).
+
+Test and bench plumbing only; the mirrored interface itself is the C++ one (and its Go twin in go/).
+A Go `error` comes back as a Python exception (HostError) carrying the reference's message text.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgdg_host.so")
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host")])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HostError("libgdg_host.so is not built")
+        # libgdg.so first so that the host library's NEEDED entry resolves to the in-tree copy
+        C.CDLL(os.path.join(_HERE, "lib", "libgdg.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, cs = C.c_void_p, C.c_int, C.c_char_p
+        sig = {
+            "gdgh_engine_create": (vp, [i32, i32, i32]), "gdgh_engine_destroy": (None, [vp]),
+            "gdgh_engine_set_rendezvous": (None, [vp, i32, i32]), "gdgh_engine_last_error": (cs, [vp]),
+            "gdgh_engine_process_all": (cs, [vp, vp, vp, i32, C.c_uint32]),
+            "gdgh_irs_create": (vp, []), "gdgh_irs_destroy": (None, [vp]),
+            "gdgh_irs_add": (None, [vp, cs, C.c_uint32, C.c_int32, vp, i32]),
+            "gdgh_chain_create": (vp, [vp, vp]), "gdgh_chain_destroy": (None, [vp]),
+            "gdgh_chain_append_unit": (cs, [vp, i32, C.POINTER(i32)]), "gdgh_chain_remove_unit": (cs, [vp, i32]),
+            "gdgh_chain_move_up": (cs, [vp, i32]), "gdgh_chain_move_down": (cs, [vp, i32]),
+            "gdgh_chain_unit_type": (cs, [vp, i32, C.POINTER(i32)]), "gdgh_chain_set_bypass": (cs, [vp, i32, i32]),
+            "gdgh_chain_get_bypass": (cs, [vp, i32, C.POINTER(i32)]),
+            "gdgh_chain_set_discrete": (cs, [vp, i32, cs, cs]), "gdgh_chain_get_discrete": (cs, [vp, i32, cs, vp, i32]),
+            "gdgh_chain_set_numeric": (cs, [vp, i32, cs, C.c_int32]), "gdgh_chain_get_numeric": (cs, [vp, i32, cs, C.POINTER(C.c_int32)]),
+            "gdgh_chain_length": (i32, [vp]), "gdgh_chain_parameters": (cs, [vp, i32, vp, i32]),
+            "gdgh_chain_process": (None, [vp, vp, i32, vp, i32, C.c_uint32]),
+            "gdgh_unit_create": (vp, [i32]), "gdgh_unit_destroy": (None, [vp]),
+            "gdgh_unit_set_numeric": (cs, [vp, cs, C.c_int32]), "gdgh_unit_set_discrete": (cs, [vp, cs, cs]),
+            "gdgh_unit_process": (None, [vp, vp, vp, i32, C.c_uint32]),
+            "gdgh_filter_compile": (i32, [vp, i32, C.c_uint32, C.c_int32, C.c_uint32, C.c_int32, vp, i32]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _err(msg):
+    if msg is not None:
+        raise HostError(msg.decode())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class ImpulseResponses:
+    """filter.ImpulseResponses filled from memory (the reference imports WAV files, out of scope)."""
+
+    def __init__(self):
+        self._h = lib().gdgh_irs_create()
+
+    def add(self, name, sample_rate, compensation_db, taps):
+        t = _f64(taps)
+        lib().gdgh_irs_add(self._h, name.encode(), sample_rate, compensation_db, t.ctypes.data, t.size)
+
+
+class Engine:
+    def __init__(self, n_channels, max_frames=8192, device=0):
+        self._h = lib().gdgh_engine_create(n_channels, max_frames, device)
+        self.n_channels = n_channels
+        self.chains = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for c in self.chains:
+                c._close()
+            lib().gdgh_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_rendezvous(self, expected, timeout_ms):
+        lib().gdgh_engine_set_rendezvous(self._h, expected, timeout_ms)
+
+    def last_error(self):
+        return lib().gdgh_engine_last_error(self._h).decode()
+
+    def create_chain(self, irs=None):
+        h = lib().gdgh_chain_create(self._h, irs._h if irs is not None else None)
+        if not h:
+            raise HostError("CreateChain failed")
+        c = Chain(h, irs)
+        self.chains.append(c)
+        return c
+
+    def process_all(self, x, sample_rate):
+        x = _f64(x)
+        n = x.shape[0]
+        out = np.empty_like(x)
+        ins = (C.c_void_p * n)(*[x[i].ctypes.data for i in range(n)])
+        outs = (C.c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
+        _err(lib().gdgh_engine_process_all(self._h, ins, outs, x.shape[1], sample_rate))
+        return out
+
+
+class Chain:
+    """signal.Chain: the 14 methods of signal/signal.go:21-36."""
+
+    def __init__(self, handle, irs):
+        self._h = handle
+        self._irs = irs          # keep the library alive
+
+    def _close(self):
+        if self._h:
+            lib().gdgh_chain_destroy(self._h)
+            self._h = None
+
+    def AppendUnit(self, unit_type):
+        i = C.c_int(-1)
+        _err(lib().gdgh_chain_append_unit(self._h, unit_type, C.byref(i)))
+        return i.value
+
+    def RemoveUnit(self, i):
+        _err(lib().gdgh_chain_remove_unit(self._h, i))
+
+    def MoveUp(self, i):
+        _err(lib().gdgh_chain_move_up(self._h, i))
+
+    def MoveDown(self, i):
+        _err(lib().gdgh_chain_move_down(self._h, i))
+
+    def UnitType(self, i):
+        t = C.c_int(-1)
+        _err(lib().gdgh_chain_unit_type(self._h, i, C.byref(t)))
+        return t.value
+
+    def SetBypass(self, i, bypass):
+        _err(lib().gdgh_chain_set_bypass(self._h, i, 1 if bypass else 0))
+
+    def GetBypass(self, i):
+        b = C.c_int(0)
+        _err(lib().gdgh_chain_get_bypass(self._h, i, C.byref(b)))
+        return bool(b.value)
+
+    def SetDiscreteValue(self, i, name, value):
+        _err(lib().gdgh_chain_set_discrete(self._h, i, name.encode(), value.encode()))
+
+    def GetDiscreteValue(self, i, name):
+        buf = C.create_string_buffer(512)
+        _err(lib().gdgh_chain_get_discrete(self._h, i, name.encode(), buf, 512))
+        return buf.value.decode()
+
+    def SetNumericValue(self, i, name, value):
+        _err(lib().gdgh_chain_set_numeric(self._h, i, name.encode(), int(value)))
+
+    def GetNumericValue(self, i, name):
+        v = C.c_int32(0)
+        _err(lib().gdgh_chain_get_numeric(self._h, i, name.encode(), C.byref(v)))
+        return v.value
+
+    def Parameters(self, i):
+        buf = C.create_string_buffer(1 << 16)
+        _err(lib().gdgh_chain_parameters(self._h, i, buf, 1 << 16))
+        out = []
+        for line in buf.value.decode().splitlines():
+            name, typ, unit, mn, mx, num, idx, vals = line.split("|")
+            out.append({"Name": name, "Type": int(typ), "PhysicalUnit": unit, "Minimum": int(mn), "Maximum": int(mx),
+                        "NumericValue": int(num), "DiscreteValueIndex": int(idx), "DiscreteValues": vals.split(";") if vals else []})
+        return out
+
+    def Length(self):
+        return lib().gdgh_chain_length(self._h)
+
+    def Process(self, x, sample_rate, n_out=None):
+        x = _f64(x)
+        n_out = x.size if n_out is None else n_out
+        out = np.full(n_out, np.nan)
+        lib().gdgh_chain_process(self._h, x.ctypes.data, x.size, out.ctypes.data, n_out, sample_rate)
+        return out
+
+
+class Unit:
+    """A stand-alone effects.Unit (runs on a private one-channel context)."""
+
+    def __init__(self, unit_type):
+        self._h = lib().gdgh_unit_create(unit_type)
+        if not self._h:
+            raise HostError("Failed to create effects unit.")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gdgh_unit_destroy(self._h)
+            self._h = None
+
+    def SetNumericValue(self, name, value):
+        _err(lib().gdgh_unit_set_numeric(self._h, name.encode(), int(value)))
+
+    def SetDiscreteValue(self, name, value):
+        _err(lib().gdgh_unit_set_discrete(self._h, name.encode(), value.encode()))
+
+    def Process(self, x, sample_rate):
+        x = _f64(x)
+        out = np.empty_like(x)
+        lib().gdgh_unit_process(self._h, x.ctypes.data, out.ctypes.data, x.size, sample_rate)
+        return out
+
+
+def filter_compile(taps, sample_rate, compensation_db, order, level_db):
+    """Reduce(order) -> Normalize -> Multiply(level) of one IR, as poweramp.compile does per slot."""
+    t = _f64(taps)
+    cap = max(t.size, order if order else 0) + 8
+    out = np.zeros(cap)
+    n = lib().gdgh_filter_compile(t.ctypes.data, t.size, sample_rate, compensation_db, order, level_db, out.ctypes.data, cap)
+    return out[:n]

@@ -1,0 +1,217 @@
+/*
+ * gdg_host.hpp -- host-side mirror of the reference's Go interfaces for the hot path, written in
+ * C++ because the build image has no Go toolchain (the Go shim a maintainer would compile is in
+ * ../go/ and INTEGRATION.md; it has the same structure as this file).
+ *
+ *   effects::Unit       <->  effects.Unit       (effects/effects.go:83-91)     7 methods
+ *   effects::Parameter  <->  effects.Parameter  (effects/effects.go:69-78)
+ *   signal::Chain       <->  signal.Chain       (signal/signal.go:21-36)       14 methods
+ *   filter::Filter / ImpulseResponses  <->  filter.Filter / filter.ImpulseResponses (filter/filter.go:64-95)
+ *
+ * Same names, argument meaning and error strings.  Go's `error` is a std::string here (empty =
+ * nil).  Parameter tables, name lookup, range checks and the power-amp filter compile
+ * (Reduce / Normalize / Multiply / Add, effects/poweramp.go:25-127) live here; only resolved
+ * integers, taps and sample buffers cross the C-ABI of include/gdg.h.  All audio is computed by
+ * libgdg.so on the GPU: nothing in this file processes samples.
+ */
+#ifndef GDG_HOST_HPP
+#define GDG_HOST_HPP
+
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct gdg_ctx;
+
+#define GDG_HOST_MAX_FRAMES 8192      /* controller/controller.go:36 BLOCK_SIZE */
+
+namespace gdg {
+
+using Error = std::string;          /* "" == nil */
+
+namespace filter {
+
+class Filter {
+public:
+    Filter(std::vector<double> coeffs, uint32_t sampleRate, double gainCompensation, std::string name);
+    std::pair<std::shared_ptr<Filter>, Error> Add(const std::shared_ptr<Filter> &other) const;   /* filter.go:167-253 */
+    std::vector<double> Coefficients() const;                                                     /* :258-265 */
+    std::shared_ptr<Filter> Multiply(double scalar) const;                                        /* :270-323 */
+    std::shared_ptr<Filter> Normalize() const;                                                    /* :328-336 */
+    std::shared_ptr<Filter> Reduce(uint32_t order) const;                                         /* :520-604 */
+    uint32_t SampleRate() const { return sampleRate_; }                                           /* :609-613 */
+    const std::string &Name() const { return name_; }
+private:
+    std::vector<double> data_;
+    uint32_t sampleRate_;
+    double gainCompensation_;
+    std::string name_;
+};
+
+std::shared_ptr<Filter> Empty(uint32_t sampleRate);                                               /* :807-845 */
+std::shared_ptr<Filter> FromCoefficients(const std::vector<double> &coeffs, uint32_t sampleRate, const std::string &name);  /* :850-890 */
+std::vector<uint32_t> SampleRates();                                                              /* :895-900 */
+
+/* filter.ImpulseResponses (filter.go:64-67).  The reference fills it from ir/index.json + WAV files
+ * (filter.Import, host I/O, out of scope); here entries are added from memory. */
+class ImpulseResponses {
+public:
+    void Add(const std::string &name, uint32_t sampleRate, int32_t compensationDecibels, const std::vector<double> &taps);
+    std::shared_ptr<Filter> CreateFilter(const std::string &name, uint32_t sampleRate) const;    /* :619-658 */
+    std::vector<std::string> Names() const;                                                       /* :663-699 */
+private:
+    struct Entry { std::string name; uint32_t sampleRate; double gainCompensation; std::vector<double> data; };
+    std::vector<Entry> responses_;
+};
+
+}  // namespace filter
+
+namespace effects {
+
+enum { PARAMETER_TYPE_INVALID = 0, PARAMETER_TYPE_DISCRETE, PARAMETER_TYPE_NUMERIC };   /* effects.go:11-15 */
+enum {                                                                                     /* effects.go:21-43 */
+    UNIT_SIGNALGENERATOR = 0, UNIT_NOISEGATE, UNIT_BANDPASS, UNIT_AUTOWAH, UNIT_AUTOYOY, UNIT_COMPRESSOR, UNIT_OCTAVER,
+    UNIT_EXCESS, UNIT_FUZZ, UNIT_OVERDRIVE, UNIT_DISTORTION, UNIT_TONESTACK, UNIT_CHORUS, UNIT_FLANGER, UNIT_PHASER,
+    UNIT_TREMOLO, UNIT_RINGMODULATOR, UNIT_DELAY, UNIT_REVERB, UNIT_POWERAMP, UNIT_CABINET, UNIT_COUNT
+};
+constexpr int NUM_FILTERS = 8;                 /* effects.go:62 */
+extern const char *const STRING_NONE;          /* "- NONE -" */
+
+struct Parameter {                             /* effects.go:69-78 */
+    std::string Name;
+    int32_t Type = PARAMETER_TYPE_INVALID;
+    std::string PhysicalUnit;
+    int32_t Minimum = -1, Maximum = -1, NumericValue = -1;
+    int DiscreteValueIndex = -1;
+    std::vector<std::string> DiscreteValues;
+};
+
+class Unit {                                   /* effects.go:83-91 + unitStruct :96-100 */
+public:
+    explicit Unit(int unitType);
+    ~Unit();
+    std::vector<Parameter> Parameters() const;
+    /* Stand-alone Process of a unit that is not in a chain: runs it as a one-slot chain on a private
+     * one-channel context (device 0).  Units owned by a Chain are processed through Chain::Process. */
+    void Process(const double *in, double *out, size_t n, uint32_t sampleRate);
+    int Type() const { return unitType_; }
+    Error SetDiscreteValue(const std::string &name, const std::string &value);
+    std::pair<std::string, Error> GetDiscreteValue(const std::string &name) const;
+    Error SetNumericValue(const std::string &name, int32_t value);
+    std::pair<int32_t, Error> GetNumericValue(const std::string &name) const;
+
+    /* ---- plumbing used by signal::Chain / Engine (not part of the mirrored interface) ---- */
+    struct Backing { gdg_ctx *ctx = nullptr; int handle = -1; bool owns_ctx = false; };
+    Backing backing;
+    uint64_t paramVersion = 1, pushedParamVersion = 0;     /* resolved-integer parameters */
+    uint64_t firVersion = 0, pushedFirVersion = 0;         /* power amp: current composite filter */
+    std::vector<double> firTaps;                           /* taps of currentFilter (empty: zeros out) */
+    uint32_t sampleRate = 0;                               /* power amp: poweramp.sampleRate */
+    const filter::ImpulseResponses *impulseResponses = nullptr;
+    void resolved(int32_t out[8]) const;                   /* numeric values / discrete indices of the first <= 8 parameters */
+    void onSampleRate(uint32_t sampleRate);                /* poweramp.go:191-203 */
+private:
+    friend Error PreparePowerAmp(Unit &unit, const filter::ImpulseResponses *responses);
+    Error setDiscrete(const std::string &name, const std::string &value);
+    Error setNumeric(const std::string &name, int32_t value);
+    std::pair<std::shared_ptr<filter::Filter>, Error> compile(uint32_t sampleRate) const;   /* poweramp.go:25-127 */
+    void recompile();
+    int unitType_;
+    mutable std::mutex mutex_;
+    std::vector<Parameter> params_;
+};
+
+std::shared_ptr<Unit> CreateUnit(int unitType);                                            /* effects.go:443-516 */
+Error PreparePowerAmp(Unit &unit, const filter::ImpulseResponses *responses);               /* poweramp.go:221-289 */
+std::vector<std::string> ParameterTypes();                                                  /* effects.go:521-533 */
+std::vector<std::string> UnitTypes();                                                       /* effects.go:538-568 */
+
+}  // namespace effects
+
+class Engine;
+
+namespace signal {
+
+class Chain {                                  /* signal.go:21-36 */
+public:
+    std::pair<int, Error> AppendUnit(int unitType);
+    Error RemoveUnit(int id);
+    Error MoveUp(int id);
+    Error MoveDown(int id);
+    std::pair<int, Error> UnitType(int id) const;
+    Error SetBypass(int id, bool bypass);
+    std::pair<bool, Error> GetBypass(int id) const;
+    Error SetDiscreteValue(int id, const std::string &name, const std::string &value);
+    std::pair<std::string, Error> GetDiscreteValue(int id, const std::string &name) const;
+    Error SetNumericValue(int id, const std::string &name, int32_t value);
+    std::pair<int32_t, Error> GetNumericValue(int id, const std::string &name) const;
+    std::pair<std::vector<effects::Parameter>, Error> Parameters(int id) const;
+    int Length() const;
+    /* len(in) != len(out) is a silent no-op (signal.go:366).  Blocks until the batch this call joined has run. */
+    void Process(const double *in, size_t nIn, double *out, size_t nOut, uint32_t sampleRate);
+
+    int channel() const { return channel_; }
+private:
+    friend class gdg::Engine;
+    struct Slot { std::shared_ptr<effects::Unit> unit; bool bypass; };
+    Chain(Engine *engine, int channel, const filter::ImpulseResponses *responses) : engine_(engine), channel_(channel), responses_(responses) {}
+    Engine *engine_;
+    int channel_;
+    const filter::ImpulseResponses *responses_;
+    mutable std::mutex mutex_;
+    std::vector<Slot> slots_;
+    uint64_t layoutVersion_ = 1, pushedLayoutVersion_ = 0;
+    std::vector<std::shared_ptr<effects::Unit>> retired_;   /* removed units whose device state must be released */
+};
+
+/* signal.CreateChain(responses) (signal.go:419-431): the next free channel of the default engine. */
+std::shared_ptr<Chain> CreateChain(const filter::ImpulseResponses *responses);
+
+}  // namespace signal
+
+/*
+ * One shard of channels on one GPU.  controller.process() has exactly N Chain.Process calls in
+ * flight at a time (controller.go:2682-2705, N worker goroutines :3339-3341), so Chain::Process is
+ * a rendezvous: every call deposits its buffers, the last arrival launches ONE batched
+ * gdg_process_subset for all of them, everybody returns together.  If fewer than the expected
+ * number of calls arrive within the timeout, the calls that did arrive are processed as a subset.
+ */
+class Engine {
+public:
+    Engine(int nChannels, int maxFrames, int device);
+    ~Engine();
+    static Engine &Default();                              /* configured by Configure() or GDG_CHANNELS / GDG_DEVICE */
+    static void Configure(int nChannels, int maxFrames, int device);
+    std::pair<std::shared_ptr<signal::Chain>, Error> CreateChain(const filter::ImpulseResponses *responses);
+    void SetRendezvous(int expected, int timeoutMs) { expected_ = expected; timeoutMs_ = timeoutMs; }
+    /* direct batch call for callers that already hold all channels' buffers (bench, tests) */
+    Error ProcessAll(const double *const *in, double *const *out, int frames, uint32_t sampleRate);
+    std::string LastError() const;
+    int channels() const { return nChannels_; }
+    gdg_ctx *context();                                    /* creates the device context on first use */
+
+private:
+    friend class signal::Chain;
+    struct Pending { signal::Chain *chain; const double *in; double *out; int frames; uint32_t sampleRate; };
+    void process(signal::Chain *chain, const double *in, double *out, int frames, uint32_t sampleRate);
+    void runBatch(std::vector<Pending> batch);
+    Error sync(const std::vector<signal::Chain *> &chains, uint32_t sampleRate);
+    int nChannels_, maxFrames_, device_;
+    gdg_ctx *ctx_ = nullptr;
+    std::vector<std::shared_ptr<signal::Chain>> chains_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Pending> pending_;
+    bool executing_ = false;
+    uint64_t generation_ = 0;
+    int expected_ = 0, timeoutMs_ = 50;
+    std::string lastError_;
+};
+
+}  // namespace gdg
+
+#endif

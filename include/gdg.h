@@ -110,6 +110,14 @@ int gdg_chain_set(gdg_ctx *ctx, int channel, const int *handles, const uint8_t *
 int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int frames, uint32_t sample_rate);
 
 /*
+ * Same for a subset of the shard's channels: in[i] / out[i] belong to channel channels[i]; the
+ * chains of all other channels are left untouched (their state does not advance).  This is what
+ * the host shim's rendezvous falls back to when fewer than N Chain.Process calls are in flight.
+ */
+int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *const *in, double *const *out,
+                       int frames, uint32_t sample_rate);
+
+/*
  * Same, device-resident: d_in / d_out are device pointers to [n_channels][frames] float64
  * (row-major, row stride = frames).  Enqueued on gdg_ctx_stream() and NOT synchronised;
  * d_in == d_out is not allowed.

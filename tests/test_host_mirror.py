@@ -1,0 +1,255 @@
+"""The host-side mirror of effects.Unit / signal.Chain (go-dsp-guitar_amd/host/): parameter tables,
+error strings and chain editing checked on the CPU; Process() checked against the oracle on the GPU.
+
+The expected error texts are the reference's own format strings (effects/effects.go:144-384,
+signal/signal.go:52-357); the parameter tables are tests/golden/params.json (extracted from the
+create*() functions by tests/golden/make_params_golden.py)."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from helpers import TOL_RMS, rms, synth_ir, synth_signal
+
+TYPE = {"PARAMETER_TYPE_DISCRETE": 1, "PARAMETER_TYPE_NUMERIC": 2}
+
+
+@pytest.fixture(scope="module")
+def host():
+    pkg = entry.load_package()
+    pkg.build()
+    from go_dsp_guitar_amd import host as h
+    h.build()
+    return h
+
+
+@pytest.fixture(scope="module")
+def params():
+    with open(os.path.join(entry.ROOT, "tests", "golden", "params.json")) as f:
+        return json.load(f)
+
+
+def test_parameter_tables_match_reference(host, params):
+    eng = host.Engine(1)
+    ch = eng.create_chain()
+    for t in range(21):
+        i = ch.AppendUnit(t)
+        assert i == t
+        assert ch.UnitType(i) == t
+        assert ch.GetBypass(i) is True                       # signal.go:74: new units start bypassed
+        got = ch.Parameters(i)
+        want = params[str(t)]["params"]
+        assert len(got) == len(want), params[str(t)]["unit"]
+        for g, w in zip(got, want):
+            assert g["Name"] == w["Name"]
+            assert g["Type"] == TYPE[w["Type"]]
+            assert g["PhysicalUnit"] == w["PhysicalUnit"]
+            assert (g["Minimum"], g["Maximum"], g["NumericValue"]) == (w["Minimum"], w["Maximum"], w["NumericValue"])
+            assert g["DiscreteValueIndex"] == w["DiscreteValueIndex"]
+            assert g["DiscreteValues"] == w["DiscreteValues"]
+    assert ch.Length() == 21
+    eng.close()
+
+
+def test_set_get_and_error_strings(host):
+    eng = host.Engine(1)
+    ch = eng.create_chain()
+    i = ch.AppendUnit(9)                                      # overdrive
+    ch.SetNumericValue(i, "gain", 20)
+    assert ch.GetNumericValue(i, "gain") == 20
+    ch.SetDiscreteValue(i, "valve", "ECC82 (12AU7)")
+    assert ch.GetDiscreteValue(i, "valve") == "ECC82 (12AU7)"
+    cases = [
+        (lambda: ch.SetNumericValue(i, "gain", 31), "Failed to set numeric value: Parameter 'gain' must be between '-30' and '30' - got '31'."),
+        (lambda: ch.SetNumericValue(i, "nope", 1), "Failed to set numeric value: Could not find parameter with name 'nope'."),
+        (lambda: ch.SetNumericValue(i, "valve", 1), "Failed to set numeric value: Parameter 'valve' is not numeric."),
+        (lambda: ch.SetDiscreteValue(i, "valve", "EL34"), "Failed to set discrete value: Value 'EL34' is not valid for parameter 'valve'."),
+        (lambda: ch.SetDiscreteValue(i, "gain", "x"), "Failed to set discrete value: Parameter 'gain' is not discrete."),
+        (lambda: ch.SetDiscreteValue(i, "nope", "x"), "Failed to set discrete value: Could not find parameter with name 'nope'."),
+        (lambda: ch.GetNumericValue(i, "valve"), "Failed to get numeric value: Parameter 'valve' is not numeric."),
+        (lambda: ch.GetDiscreteValue(i, "gain"), "Failed to get discrete value: Parameter 'gain' is not discrete."),
+        (lambda: ch.GetDiscreteValue(i, "nope"), "Failed to get discrete value: Could not find parameter with name 'nope'."),
+        (lambda: ch.AppendUnit(21), "Failed to create effects unit."),
+        (lambda: ch.RemoveUnit(5), "Cannot remove unit 5."),
+        (lambda: ch.MoveUp(0), "Cannot move unit 0 up."),
+        (lambda: ch.MoveDown(0), "Cannot move unit 0 down."),
+        (lambda: ch.UnitType(3), "Cannot get unit type: No unit 3."),
+        (lambda: ch.SetBypass(3, True), "Cannot enable bypass: No unit 3."),
+        (lambda: ch.SetBypass(3, False), "Cannot disable bypass: No unit 3."),
+        (lambda: ch.GetBypass(-1), "Cannot get bypass value: No unit -1."),
+        (lambda: ch.SetDiscreteValue(7, "a", "b"), "Cannot set discrete value: No unit 7."),
+        (lambda: ch.GetDiscreteValue(7, "a"), "Cannot get discrete value: No unit 7."),
+        (lambda: ch.SetNumericValue(7, "a", 1), "Cannot set numeric value: No unit 7."),
+        (lambda: ch.GetNumericValue(7, "a"), "Cannot get numeric value: No unit 7."),
+        (lambda: ch.Parameters(7), "Cannot get parameters: No unit 7."),
+    ]
+    for fn, msg in cases:
+        with pytest.raises(host.HostError) as e:
+            fn()
+        assert str(e.value) == msg
+    assert ch.GetNumericValue(i, "gain") == 20               # a rejected value leaves the parameter unchanged
+    eng.close()
+
+
+def test_chain_editing(host):
+    eng = host.Engine(1)
+    ch = eng.create_chain()
+    for t in (5, 9, 11, 20):
+        ch.AppendUnit(t)
+    ch.MoveUp(2)
+    assert [ch.UnitType(i) for i in range(4)] == [5, 11, 9, 20]
+    ch.MoveDown(0)
+    assert [ch.UnitType(i) for i in range(4)] == [11, 5, 9, 20]
+    ch.RemoveUnit(1)
+    assert [ch.UnitType(i) for i in range(3)] == [11, 9, 20]
+    ch.SetBypass(1, False)
+    assert [ch.GetBypass(i) for i in range(3)] == [True, False, True]
+    eng.close()
+
+
+def test_power_amp_parameters_follow_the_ir_library(host):
+    irs = host.ImpulseResponses()
+    for sr in (48000, 96000):
+        irs.add("Guitar: A", sr, -20, synth_ir(300, seed=1))
+        irs.add("Guitar: B", sr, -25, synth_ir(500, seed=2))
+    eng = host.Engine(1)
+    ch = eng.create_chain(irs)
+    i = ch.AppendUnit(19)
+    p = ch.Parameters(i)
+    assert [q["Name"] for q in p] == ["filter_order"] + [n for k in range(1, 9) for n in ("filter_%d" % k, "level_%d" % k)]
+    assert p[1]["DiscreteValues"] == ["- NONE -", "Guitar: A", "Guitar: B"]      # poweramp.go:256-281
+    assert (p[2]["Minimum"], p[2]["Maximum"], p[2]["NumericValue"]) == (-60, 0, 0)
+    ch.SetDiscreteValue(i, "filter_3", "Guitar: B")
+    assert ch.GetDiscreteValue(i, "filter_3") == "Guitar: B"
+    with pytest.raises(host.HostError):
+        ch.SetDiscreteValue(i, "filter_3", "Guitar: C")
+    eng.close()
+
+
+def test_filter_compile_matches_oracle(host, oracle):
+    """Reduce -> Normalize -> Multiply (poweramp.go:88-96) against the oracle's filter algebra."""
+    taps = synth_ir(3000, seed=5)
+    for order, comp, level in ((0, -20, 0), (4096, -25, -6), (1024, -10, -3), (256, 0, 0)):
+        got = host.filter_compile(taps, 48000, comp, order, level)
+        f = oracle.Filter(taps, 48000, 10.0 ** (0.05 * comp))
+        if order:
+            f = f.reduce(order)
+        want = f.normalize().multiply(10.0 ** (0.05 * level)).coefficients()
+        assert len(got) == len(want)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------
+def _full_chain(ch, ref, oracle, sr, irs_taps):
+    spec = [(5, {"gain_limit": 30, "target_level": -20}), (9, {"gain": 20}), (11, {}), (12, {}), (19, None), (20, {}), (18, {"mix": 50})]
+    for t, numeric in spec:
+        i = ch.AppendUnit(t)
+        if t == 19:
+            ch.SetDiscreteValue(i, "filter_1", "Cab")
+            ch.SetNumericValue(i, "level_1", -3)
+            ch.SetDiscreteValue(i, "filter_2", "Room")
+        else:
+            for k, v in numeric.items():
+                ch.SetNumericValue(i, k, v)
+        ch.SetBypass(i, False)
+    # the same chain on the oracle; the composite filter is compiled with the oracle's own filter algebra
+    a = oracle.Filter(irs_taps["Cab"], sr, 10.0 ** (0.05 * -20)).normalize().multiply(10.0 ** (0.05 * -3))
+    b = oracle.Filter(irs_taps["Room"], sr, 10.0 ** (0.05 * -10)).normalize().multiply(1.0)
+    composite = oracle.Filter([], sr).add(a).add(b)
+    ref.append_unit("compressor", params=[1, 30, -20])
+    ref.append_unit("overdrive", params=[0, 20, 100, 0, 1, 0])
+    ref.append_unit("tone_stack")
+    ref.append_unit("chorus")
+    ref.append_unit("power_amp", fir=composite.coefficients())
+    ref.append_unit("cabinet")
+    ref.append_unit("reverb", params=[50])
+
+
+@pytest.mark.gpu
+def test_chain_process_rendezvous_matches_oracle(host, oracle):
+    """N concurrent Chain.Process calls (one thread per channel, like the controller's worker goroutines)."""
+    sr, frames, nch, blocks = 48000, 1024, 4, 4
+    taps = {"Cab": synth_ir(2000, seed=3), "Room": synth_ir(5000, seed=4)}
+    irs = host.ImpulseResponses()
+    irs.add("Cab", sr, -20, taps["Cab"])
+    irs.add("Room", sr, -10, taps["Room"])
+    eng = host.Engine(nch, frames)
+    chains, refs = [], []
+    for c in range(nch):
+        ch, ref = eng.create_chain(irs), oracle.Chain()
+        _full_chain(ch, ref, oracle, sr, taps)
+        chains.append(ch)
+        refs.append(ref)
+    eng.set_rendezvous(nch, 2000)
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(nch)])
+    got = np.zeros_like(x)
+    for b in range(blocks):
+        sl = slice(b * frames, (b + 1) * frames)
+
+        def work(c):
+            got[c, sl] = chains[c].Process(x[c, sl], sr)
+
+        threads = [threading.Thread(target=work, args=(c,)) for c in range(nch)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    assert eng.last_error() == ""
+    for c in range(nch):
+        want = np.concatenate([refs[c].process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+        assert rms(got[c] - want) <= TOL_RMS
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_partial_rendezvous_processes_only_the_callers(host, oracle):
+    sr, frames = 48000, 512
+    eng = host.Engine(3, frames)
+    chains, refs = [], []
+    for c in range(3):
+        ch, ref = eng.create_chain(), oracle.Chain()
+        i = ch.AppendUnit(11)
+        ch.SetBypass(i, False)
+        ref.append_unit("tone_stack")
+        chains.append(ch)
+        refs.append(ref)
+    eng.set_rendezvous(3, 20)                                 # only one caller shows up: subset after the timeout
+    x = synth_signal(1, frames * 3, sr)
+    for b in range(3):
+        blk = x[b * frames:(b + 1) * frames]
+        got = chains[1].Process(blk, sr)
+        assert rms(got - refs[1].process(blk, sr)) <= TOL_RMS
+    # length mismatch is a silent no-op (signal.go:366): the output buffer is left untouched
+    out = chains[0].Process(x[:frames], sr, n_out=frames - 1)
+    assert np.all(np.isnan(out))
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_standalone_unit_process_and_process_all(host, oracle):
+    sr, frames = 96000, 2048
+    u = host.Unit(11)
+    u.SetNumericValue("middle", -9)
+    ref = oracle.Unit("tone_stack")
+    ref.set_params([0, -9, -5, -5])
+    x = synth_signal(2, frames * 2, sr)
+    for b in range(2):
+        blk = x[b * frames:(b + 1) * frames]
+        assert rms(u.Process(blk, sr) - ref.process(blk, sr)) <= TOL_RMS
+    eng = host.Engine(2, frames)
+    refs = []
+    for c in range(2):
+        ch = eng.create_chain()
+        i = ch.AppendUnit(20)
+        ch.SetBypass(i, False)
+        r = oracle.Chain()
+        r.append_unit("cabinet")
+        refs.append(r)
+    xx = np.stack([synth_signal(c, frames, sr) for c in range(2)])
+    got = eng.process_all(xx, sr)
+    for c in range(2):
+        assert rms(got[c] - refs[c].process(xx[c], sr)) <= TOL_RMS
+    eng.close()
