@@ -155,20 +155,14 @@ def main():
         step()
     ctx.synchronize()
     ctx.profile_enable(True)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    from go_dsp_guitar_amd import shard
+
+    def synchronize():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    # barrier + synchronize | exactly K steps | synchronize; MAX over ranks (tested on CPU with gloo)
+    elapsed = shard.timed_steps(step, args.steps, synchronize, dist if distributed else None, dev)
     ctx.profile_enable(False)
     kernels = {}
     for kind, name in enumerate(pkg.KERNEL_KINDS[:4]):
@@ -190,6 +184,16 @@ def main():
         fir_bytes_per_sample = 16.0 + 16.0 * (1 + 2 * K)              # SURVEY 8d B_conv with (P+1)/P -> 1 (packed bin 0)
         fir_gbs = fir_units * samples_per_step * fir_bytes_per_sample / (fir_ms * 1e-3) / 1e9 if fir_ms else None
         seg = kernels["segment"]
+        # HBM traffic from the PMC counters cannot be sampled from inside this process: it is taken from the committed
+        # rocprofv3 --pmc passes of the SAME workload (profiles/pmc_fir_mac.json), else null
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_fir_mac.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps):
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "Msamples/s through full chain incl. 64k-tap cab IR, 512ch@192kHz; %HBM roofline",
             "value": world * samples_per_step * args.steps / elapsed / 1e6,
@@ -214,7 +218,7 @@ def main():
                 "bound": "hbm", "kernel": "fir_mac_kernel",
                 "achieved": mac_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (mac_gbs / HBM_PEAK_GBS) if mac_gbs else None,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": mac_bytes, "avg_launch_ms": mac["avg_ms"], "launches": mac["launches"],
                 "fir_unit_all_three_kernels": {"bytes_per_channel_sample": fir_bytes_per_sample, "achieved": fir_gbs,
                                                "frac": (fir_gbs / HBM_PEAK_GBS) if fir_gbs else None},

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "gdg_version", "gdg_device_count", "gdg_ctx_create", "gdg_ctx_destroy", "gdg_last_error", "gdg_ctx_channels",
     "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
     "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_subset", "gdg_process_device",
-    "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
+    "gdg_staging_buffers", "gdg_process_staged", "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
     "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_analyze", "gdg_tuner_note_name",
     "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device",
 ]
@@ -89,6 +89,8 @@ def lib():
             "gdg_process": (i32, [vp, vp, vp, i32, u32]),
             "gdg_process_subset": (i32, [vp, vp, i32, vp, vp, i32, u32]),
             "gdg_process_device": (i32, [vp, vp, vp, i32, u32]),
+            "gdg_staging_buffers": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)]),
+            "gdg_process_staged": (i32, [vp, vp, i32, i32, u32]),
             "gdg_device_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
             "gdg_device_free": (i32, [vp, vp]),
             "gdg_copy_to_device": (i32, [vp, vp, vp, C.c_size_t]),
@@ -238,6 +240,20 @@ class Context:
         outs = (C.c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
         self._check(lib().gdg_process_subset(self._h, chans, n, ins, outs, x.shape[1], sample_rate))
         return out
+
+    def process_staged(self, channels, x, sample_rate):
+        """The cgo-friendly path: copy frames into the pinned slab rows, gdg_process_staged, copy rows out."""
+        x = _f64(x)
+        n, frames = x.shape
+        pin, pout, stride = C.c_void_p(), C.c_void_p(), C.c_int(0)
+        self._check(lib().gdg_staging_buffers(self._h, C.byref(pin), C.byref(pout), C.byref(stride)))
+        slab_in = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_double)), shape=(self.n_channels, stride.value))
+        slab_out = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_double)), shape=(self.n_channels, stride.value))
+        for i, c in enumerate(channels):
+            slab_in[c, :frames] = x[i]
+        chans = (C.c_int * n)(*channels)
+        self._check(lib().gdg_process_staged(self._h, chans, n, frames, sample_rate))
+        return np.stack([slab_out[c, :frames].copy() for c in channels])
 
     def process_device(self, d_in, d_out, frames, sample_rate):
         """Device-resident block; d_in / d_out are plain device pointers (ints) or DeviceBuffers."""

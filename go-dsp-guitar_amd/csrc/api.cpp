@@ -80,6 +80,8 @@ struct gdg_ctx {
     const double *plan_in = nullptr;
     double *plan_out = nullptr;
     std::vector<int> plan_active, all_channels;
+    int plan_stride = 0;
+    bool plan_by_channel = false;
     std::vector<StepDesc> steps;
     std::vector<unsigned char> blob;
     unsigned char *d_blob = nullptr;
@@ -668,13 +670,14 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
 struct Op { bool is_fir; std::vector<int> handles; };
 
 /* `active`: the channels taking part in this call; row i of d_in / d_out belongs to channel active[i] */
-static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
+static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
+                      int stride, bool rows_by_channel) {
     const int nch = ctx->nch;
     /* per channel: ops placed on a common grid of slots: 2k = segment k, 2k+1 = FIR k */
     std::map<int, std::vector<std::pair<int, Op>>> by_slot;           /* slot -> (channel, op) */
     std::vector<int> n_ops((size_t)nch, 0);
     std::vector<int> row_of((size_t)nch, -1);
-    for (size_t i = 0; i < active.size(); i++) row_of[(size_t)active[i]] = (int)i;
+    for (size_t i = 0; i < active.size(); i++) row_of[(size_t)active[i]] = rows_by_channel ? active[i] : (int)i;
     bool any_fir = false;
     for (int c : active) {
         std::vector<int> seg;
@@ -709,7 +712,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     std::vector<std::vector<gdg_fir_chan>> fir_descs;
     std::vector<int> done((size_t)nch, 0);
     std::vector<const double *> cur((size_t)nch);
-    for (int c : active) cur[(size_t)c] = d_in + (size_t)row_of[(size_t)c] * frames;
+    for (int c : active) cur[(size_t)c] = d_in + (size_t)row_of[(size_t)c] * stride;
     ctx->steps.clear();
     for (auto &kv : by_slot) {
         bool is_fir = (kv.first & 1) != 0;
@@ -720,7 +723,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
             Op &op = entry.second;
             bool last = (done[(size_t)c] + 1 == n_ops[(size_t)c]);
             double *dst;
-            if (last) dst = d_out + (size_t)row_of[(size_t)c] * frames;
+            if (last) dst = d_out + (size_t)row_of[(size_t)c] * stride;
             else dst = ((done[(size_t)c] & 1) ? ctx->d_w1 : ctx->d_w0) + (size_t)c * ctx->max_frames;
             if (is_fir) {
                 Unit &u = ctx->units[(size_t)op.handles[0]];
@@ -841,14 +844,18 @@ int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
 static int ensure_staging(gdg_ctx *ctx);
 static int check_device_error(gdg_ctx *ctx);
 
-static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
+static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
+                        int stride = 0, bool rows_by_channel = false) {
+    if (stride == 0) stride = frames;
     if (d_in == d_out) return fail(ctx, GDG_ERR_INVALID, "in-place processing is not supported");
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
     if (sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     hipSetDevice(ctx->device);
     if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate || ctx->plan_in != d_in || ctx->plan_out != d_out ||
-        ctx->plan_active != active) {
-        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate);
+        ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_by_channel != rows_by_channel) {
+        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, rows_by_channel);
+        ctx->plan_stride = stride;
+        ctx->plan_by_channel = rows_by_channel;
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }
         ctx->plan_active = active;
     }
@@ -934,6 +941,41 @@ int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int f
     if (!ctx) return GDG_ERR_INVALID;
     if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
     return gdg_process_subset(ctx, ctx->all_channels.data(), ctx->nch, in, out, frames, sample_rate);
+}
+
+/* pinned host slabs for callers that must not hand Go (or other managed) pointers to C: row c = channel c */
+int gdg_staging_buffers(gdg_ctx *ctx, double **in, double **out, int *row_stride) {
+    if (!ctx || !in || !out || !row_stride) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure_staging(ctx);
+    if (rc != GDG_OK) return rc;
+    *in = ctx->h_stage_in;
+    *out = ctx->h_stage_out;
+    *row_stride = ctx->max_frames;
+    return GDG_OK;
+}
+
+int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uint32_t sample_rate) {
+    if (!ctx || !channels) return GDG_ERR_INVALID;
+    if (n <= 0 || n > ctx->nch) return fail(ctx, GDG_ERR_INVALID, "bad channel count %d", n);
+    if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    std::vector<int> active(channels, channels + n);
+    std::vector<char> seen((size_t)ctx->nch, 0);
+    for (int c : active) {
+        if (c < 0 || c >= ctx->nch || seen[(size_t)c]) return fail(ctx, GDG_ERR_INVALID, "bad or repeated channel %d", c);
+        seen[(size_t)c] = 1;
+    }
+    hipSetDevice(ctx->device);
+    int rc = ensure_staging(ctx);
+    if (rc != GDG_OK) return rc;
+    const size_t stride = (size_t)ctx->max_frames;
+    for (int c : active)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in + (size_t)c * stride, ctx->h_stage_in + (size_t)c * stride, (size_t)frames * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true);
+    if (rc != GDG_OK) return rc;
+    for (int c : active)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage_out + (size_t)c * stride, ctx->d_stage_out + (size_t)c * stride, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return check_device_error(ctx);
 }
 
 /* ---- device memory helpers --------------------------------------------------------------------------------- */

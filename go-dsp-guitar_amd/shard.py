@@ -1,0 +1,53 @@
+"""Multi-GPU plumbing: channels are independent (controller/controller.go:3262-3269), so N GPUs are N
+shards with NO data-path collective.  torch.distributed (RCCL on the GPU box, gloo in the CPU tests) is
+used only for the barrier around the timed region and the max-over-ranks of the elapsed time.
+"""
+import time
+
+import numpy as np
+
+
+def channel_shard(n_total, world, rank):
+    """Contiguous block of channels of shard `rank`: [rank*N/world, (rank+1)*N/world)."""
+    start = (rank * n_total) // world
+    stop = ((rank + 1) * n_total) // world
+    return start, stop - start
+
+
+def timed_steps(step, steps, synchronize, dist=None, device=None):
+    """Barrier + synchronize, run `step` exactly `steps` times, synchronize; returns the MAX over ranks of the
+    elapsed seconds (the same number on every rank)."""
+    import torch
+    if dist is not None:
+        dist.barrier()
+    synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    return elapsed
+
+
+def aggregate_throughput(units_per_rank_step, world, steps, elapsed):
+    """Whole-job units per second: every rank processed the same amount (weak scaling)."""
+    return world * units_per_rank_step * steps / elapsed
+
+
+def combine_spatializer_partials(partials, aux=None):
+    """Host-side sum of the per-shard (left, right) pairs in shard order, then the aux input
+    (spatializer/spatializer.go:300-310)."""
+    left = np.zeros_like(partials[0][0])
+    right = np.zeros_like(partials[0][1])
+    for l, r in partials:
+        left += l
+        right += r
+    if aux is not None:
+        left += aux
+        right += aux
+    return left, right

@@ -118,6 +118,15 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
                        int frames, uint32_t sample_rate);
 
 /*
+ * Staged variant for hosts that may not hand their own pointers to C (cgo's pointer rules):
+ * gdg_staging_buffers returns two pinned host slabs (hipHostMalloc) whose row c (row_stride
+ * float64 apart) belongs to channel c; every worker copies its frame into its input row,
+ * gdg_process_staged runs the listed channels and fills their output rows.
+ */
+int gdg_staging_buffers(gdg_ctx *ctx, double **in, double **out, int *row_stride);
+int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uint32_t sample_rate);
+
+/*
  * Same, device-resident: d_in / d_out are device pointers to [n_channels][frames] float64
  * (row-major, row stride = frames).  Enqueued on gdg_ctx_stream() and NOT synchronised;
  * d_in == d_out is not allowed.

@@ -1,0 +1,91 @@
+"""The N > 1 path of bench.py on CPU: two processes, gloo backend, 127.0.0.1 rendez-vous.
+Checks the sharding (no channel lost or duplicated), the barrier + max-over-ranks timing and the
+whole-job aggregation; plus the host-side combination of per-shard spatializer partials (oracle only)."""
+import os
+import socket
+import time
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from helpers import synth_signal
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    entry.load_package()
+    from go_dsp_guitar_amd import shard
+    start, count = shard.channel_shard(512, world, rank)
+    sleep = 0.01 * (1 + 2 * rank)                       # rank 1 is three times slower: the job time is ITS time
+    elapsed = shard.timed_steps(lambda: time.sleep(sleep), 5, lambda: None, dist)
+    q.put((rank, start, count, elapsed))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_timing_and_sharding():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, c0, e0), (r1, s1, c1, e1) = res
+    assert (s0, c0, s1, c1) == (0, 256, 256, 256)
+    assert e0 == e1                                      # every rank reports the max over ranks
+    assert 0.15 <= e0 < 1.0                              # >= 5 x 30 ms of the slow rank
+    entry.load_package()
+    from go_dsp_guitar_amd import shard
+    assert shard.aggregate_throughput(256 * 8192, 2, 5, e0) == pytest.approx(2 * 256 * 8192 * 5 / e0)
+
+
+def test_shards_partition_any_channel_count():
+    entry.load_package()
+    from go_dsp_guitar_amd import shard
+    for total in (1, 7, 8, 64, 256, 512, 513):
+        for world in (1, 2, 4, 8):
+            blocks = [shard.channel_shard(total, world, r) for r in range(world)]
+            covered = [c for s, n in blocks for c in range(s, s + n)]
+            assert covered == list(range(total))
+
+
+def test_spatializer_partials_add_up_to_the_full_mix(oracle):
+    """8 shards of 4 channels each, mixed separately and added on the host, equal one 32-channel spatializer."""
+    entry.load_package()
+    from go_dsp_guitar_amd import shard
+    nch, n, sr, world = 32, 2048, 96000, 8
+    rng = np.random.default_rng(5)
+    x = np.stack([synth_signal(c, n, sr) for c in range(nch)])
+    pos = [(float(rng.uniform(-180, 180)), float(rng.uniform(0, 10)), float(rng.uniform(0, 1))) for _ in range(nch)]
+    aux = 0.1 * synth_signal(99, n, sr)
+    full = oracle.Spatializer(nch)
+    for c, (a, d, l) in enumerate(pos):
+        full.set_azimuth(c, a); full.set_distance(c, d); full.set_level(c, l)
+    want_l, want_r = full.process(x, aux=aux)
+    partials = []
+    for r in range(world):
+        s, cnt = shard.channel_shard(nch, world, r)
+        sp = oracle.Spatializer(cnt)
+        for i in range(cnt):
+            a, d, l = pos[s + i]
+            sp.set_azimuth(i, a); sp.set_distance(i, d); sp.set_level(i, l)
+        partials.append(sp.process(x[s:s + cnt]))
+    got_l, got_r = shard.combine_spatializer_partials(partials, aux)
+    np.testing.assert_allclose(got_l, want_l, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(got_r, want_r, rtol=0, atol=1e-13)
