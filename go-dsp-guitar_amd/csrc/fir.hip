@@ -19,6 +19,7 @@
  */
 #include "gdg_internal.h"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 typedef double2 cplx;
@@ -272,46 +273,71 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
     }
 }
 
-/* Y[b] = sum_k FDL[(pos - k) mod K][b] * H[k][b]; bin 0 is the (DC, Nyquist) pair of reals */
-template <int UNROLL>
+/* Y[b] = sum_k FDL[(pos - k) mod K][b] * H[k][b]; bin 0 is the (DC, Nyquist) pair of reals.
+ * UNROLL partitions are loaded before any is used (2 * UNROLL * BPT 16-byte loads in flight per lane);
+ * BPT adjacent bins per lane; NT: non-temporal loads (each spectrum is read exactly once per launch). */
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ cplx mac_load(const cplx *p) {
+    if constexpr (NT) {
+        v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+        return make_double2(v.x, v.y);
+    } else {
+        return *p;
+    }
+}
+
+template <int UNROLL, int BPT, bool NT>
 __global__ void __launch_bounds__(256)
 fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     gdg_fir_chan ch = chans[blockIdx.y];
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= P) return;
+    const int b0 = (blockIdx.x * blockDim.x + threadIdx.x) * BPT;
+    if (b0 >= P) return;
     const int K = ch.K;
     const int cur = (*ch.pos) % K;
-    const cplx *__restrict__ fdl = ch.fdl + b;
-    const cplx *__restrict__ H = ch.H + b;
-    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;     /* complex product sum / component-wise product sum */
+    const cplx *__restrict__ fdl = ch.fdl + b0;
+    const cplx *__restrict__ H = ch.H + b0;
+    double ar[BPT], ai[BPT], br = 0.0, bi = 0.0;       /* complex product sums; component-wise sum for bin 0 */
+#pragma unroll
+    for (int q = 0; q < BPT; q++) { ar[q] = 0.0; ai[q] = 0.0; }
     int k = 0;
     for (; k + UNROLL <= K; k += UNROLL) {
-        cplx x[UNROLL], h[UNROLL];
+        cplx x[UNROLL][BPT], h[UNROLL][BPT];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             int slot = cur - (k + u);
             if (slot < 0) slot += K;
-            x[u] = fdl[(size_t)slot * P];
-            h[u] = H[(size_t)(k + u) * P];
+#pragma unroll
+            for (int q = 0; q < BPT; q++) {
+                x[u][q] = mac_load<NT>(fdl + (size_t)slot * P + q);
+                h[u][q] = mac_load<NT>(H + (size_t)(k + u) * P + q);
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            ar += x[u].x * h[u].x - x[u].y * h[u].y;
-            ai += x[u].x * h[u].y + x[u].y * h[u].x;
-            br += x[u].x * h[u].x;
-            bi += x[u].y * h[u].y;
+#pragma unroll
+            for (int q = 0; q < BPT; q++) {
+                ar[q] += x[u][q].x * h[u][q].x - x[u][q].y * h[u][q].y;
+                ai[q] += x[u][q].x * h[u][q].y + x[u][q].y * h[u][q].x;
+            }
+            br += x[u][0].x * h[u][0].x;
+            bi += x[u][0].y * h[u][0].y;
         }
     }
     for (; k < K; k++) {
         int slot = cur - k;
         if (slot < 0) slot += K;
-        cplx x = fdl[(size_t)slot * P], h = H[(size_t)k * P];
-        ar += x.x * h.x - x.y * h.y;
-        ai += x.x * h.y + x.y * h.x;
-        br += x.x * h.x;
-        bi += x.y * h.y;
+#pragma unroll
+        for (int q = 0; q < BPT; q++) {
+            cplx x = fdl[(size_t)slot * P + q], h = H[(size_t)k * P + q];
+            ar[q] += x.x * h.x - x.y * h.y;
+            ai[q] += x.x * h.y + x.y * h.x;
+            if (q == 0) { br += x.x * h.x; bi += x.y * h.y; }
+        }
     }
-    ch.Y[b] = (b == 0) ? make_double2(br, bi) : make_double2(ar, ai);
+#pragma unroll
+    for (int q = 0; q < BPT; q++) ch.Y[b0 + q] = (b0 + q == 0) ? make_double2(br, bi) : make_double2(ar[q], ai[q]);
 }
 
 /* Inverse: packed half spectrum Y -> second half of the 2N-point real sequence -> clip -> dst */
@@ -447,11 +473,32 @@ hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, dou
     return hipGetLastError();
 }
 
+template <int UNROLL, int BPT, bool NT>
+static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s) {
+    int per_block = 256 * BPT;
+    int threads = P < per_block ? (P / BPT) : 256;
+    if (threads < 1) threads = 1;
+    dim3 grid((unsigned)((P + threads * BPT - 1) / (threads * BPT)), (unsigned)n_chans);
+    fir_mac_kernel<UNROLL, BPT, NT><<<grid, dim3(threads), 0, s>>>(d_chans, P);
+}
+
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
-    int threads = P < 256 ? P : 256;
-    dim3 grid((unsigned)((P + threads - 1) / threads), (unsigned)n_chans);
-    fir_mac_kernel<4><<<grid, dim3(threads), 0, s>>>(d_chans, P);
+    /* GDG_MAC_VARIANT: tuning knob for profiles/mac_variants.py; the default is the measured best */
+    static int variant = -1;
+    if (variant < 0) { const char *e = getenv("GDG_MAC_VARIANT"); variant = e ? atoi(e) : 0; }
+    switch (variant) {
+    case 1: launch_mac<8, 1, false>(P, d_chans, n_chans, s); break;
+    case 2: launch_mac<4, 1, true>(P, d_chans, n_chans, s); break;
+    case 3: launch_mac<8, 1, true>(P, d_chans, n_chans, s); break;
+    case 4: launch_mac<4, 2, false>(P, d_chans, n_chans, s); break;
+    case 5: launch_mac<4, 2, true>(P, d_chans, n_chans, s); break;
+    case 6: launch_mac<8, 2, true>(P, d_chans, n_chans, s); break;
+    case 7: launch_mac<2, 2, false>(P, d_chans, n_chans, s); break;
+    case 8: launch_mac<2, 4, true>(P, d_chans, n_chans, s); break;
+    case 9: launch_mac<4, 1, false>(P, d_chans, n_chans, s); break;
+    default: launch_mac<8, 1, true>(P, d_chans, n_chans, s); break;      /* measured best: profiles/mac_variants_r01.txt */
+    }
     return hipGetLastError();
 }
 

@@ -27,7 +27,8 @@
 #include "../../include/gdg.h"
 #include <math.h>
 
-#define SEG_T 256
+#define SEG_T 1024                        /* 16 waves = 4 per SIMD: hides the FP64 / LDS / HBM latencies of one workgroup per CU */
+#define SEG_WAVES (SEG_T / 64)
 #define SEG_LBUF (8192 + 256 + 8)
 #define SEG_SCR 3328
 #define LX(e) ((e) + ((e) >> 5))
@@ -35,6 +36,15 @@
 #define ATTENUATION_HALF_DECIBEL 0.9440608762859234   /* oversampling/oversampling.go:13 */
 
 __device__ __forceinline__ double clip1(double v) { return v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v); }
+
+/* math.Mod(x, 2 pi) for 0 <= x < ~8 pi (LFO phases): while x >= 2 pi the subtraction x - 2 pi is exact
+ * (Sterbenz), so this is bit-identical to fmod and costs two compares instead of ocml's general fmod */
+__device__ __forceinline__ double fmod_2pi(double x) {
+    if (x >= 4.0 * GO_MATH_TWO_PI || x < 0.0) return fmod(x, GO_MATH_TWO_PI);
+    if (x >= 2.0 * GO_MATH_TWO_PI) x -= 2.0 * GO_MATH_TWO_PI;
+    if (x >= GO_MATH_TWO_PI) x -= GO_MATH_TWO_PI;
+    return x;
+}
 
 /* ---- workgroup scan of (A, B) maps:  affine x -> A x + B   or   max-affine x -> max(A x, B) ---- */
 template <bool MAXOP>
@@ -373,14 +383,19 @@ __device__ void unit_chorus(const gdg_seg_unit *U, const double *in, double *out
     const int C = U->jp[0], wp = U->is[0];
     const double prev = U->ds[0];
     const double *ring = U->hist;
+    /* sin(zero_phase + j 2pi/5) by the angle-addition formula from ONE sincos (the five LFOs are 72 degrees apart):
+     * differs from the reference's sin(fmod(zero_phase + j 2pi/5, 2pi)) by ~1e-16, i.e. ~1e-13 samples of delay */
+    const double cj[5] = { 1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410, 0.30901699437494742410 };
+    const double sj[5] = { 0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917, -0.95105651629515357212 };
     for (int i = threadIdx.x; i < N; i += SEG_T) {
         double time = (double)i / sr;
-        double zero_phase = fmod(prev + (angular * time), GO_MATH_TWO_PI);
+        double zero_phase = fmod_2pi(prev + (angular * time));
+        double s0, c0;
+        sincos(zero_phase, &s0, &c0);
         double effected = 0.0;
 #pragma unroll
         for (int j = 0; j < 5; j++) {
-            double phase = fmod(zero_phase + (GO_MATH_TWO_PI_FIFTH * (double)j), GO_MATH_TWO_PI);
-            double offset = depth * sin(phase);
+            double offset = depth * ((s0 * cj[j]) + (c0 * sj[j]));
             double delay_time = 0.001 * (40.0 + offset);
             double delay_samples = delay_time * sr;
             effected += 0.2 * frac_delay(in, ring, C, wp, i, delay_samples);
@@ -405,7 +420,7 @@ __device__ void unit_flanger(const gdg_seg_unit *U, const double *in, double *ou
     const double *ring = U->hist;
     for (int i = threadIdx.x; i < N; i += SEG_T) {
         double time = (double)i * sr_inv;
-        double phase = fmod(prev + (angular * time), GO_MATH_TWO_PI);
+        double phase = fmod_2pi(prev + (angular * time));
         double offset = depth * sin(phase);
         double delay_time = 0.001 * (depth + offset);
         double delay_samples = delay_time * sr;
@@ -902,12 +917,12 @@ __device__ void unit_noisegate(const gdg_seg_unit *U, const double *in, double *
 }
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(SEG_T) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(SEG_T)
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, gdg_os_tables os, int *d_error) {
     __shared__ double s_a[SEG_LBUF];
     __shared__ double s_b[SEG_LBUF];
     __shared__ double s_scr[SEG_SCR];
-    __shared__ double s_tmp[64];
+    __shared__ double s_tmp[2 * 4 * SEG_WAVES];      /* scan scratch: (A, B) x up to 4 recurrences x waves */
     const gdg_seg_chan ch = chans[blockIdx.x];
     const int tid = threadIdx.x;
     for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = ch.src[i];

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Per-unit cost inside the fused segment kernel: 512 channels @ 192 kHz, 8192-frame blocks, one unit per
+chain, device-resident frames, HIP-event time of seg_kernel.  Run on the GPU box:
+
+    python profiles/seg_breakdown.py [unit ...] > gpurun_out/seg_breakdown.txt
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+import __graft_entry__ as entry  # noqa: E402
+from helpers import synth_signal  # noqa: E402
+
+CASES = [
+    ("(copy)", []),
+    ("compressor", [("compressor", None)]),
+    ("overdrive", [("overdrive", [0, 20, 100, 0, 1, 0])]),
+    ("overdrive 4x", [("overdrive", [0, 20, 100, 0, 1, 2])]),
+    ("tone_stack", [("tone_stack", None)]),
+    ("chorus", [("chorus", None)]),
+    ("cabinet", [("cabinet", None)]),
+    ("reverb", [("reverb", None)]),
+    ("flanger", [("flanger", None)]),
+    ("delay", [("delay", None)]),
+    ("noise_gate", [("noise_gate", None)]),
+    ("octaver", [("octaver", None)]),
+    ("auto_wah", [("auto_wah", None)]),
+    ("fuzz", [("fuzz", None)]),
+    ("bandpass 8", [("bandpass", [3, 300, 3000])]),
+    ("seg0 of bench", [("compressor", None), ("overdrive", [0, 20, 100, 0, 1, 0]), ("tone_stack", None), ("chorus", None)]),
+    ("seg1 of bench", [("cabinet", None), ("reverb", None)]),
+]
+
+
+def main():
+    pkg = entry.load_package()
+    nch, frames, sr, steps = 512, 8192, 192000, 10
+    only = set(sys.argv[1:])
+    x = np.stack([synth_signal(c, frames, sr) for c in range(nch)])
+    print("%-16s %10s %12s %12s" % ("chain", "avg_us", "Msamples/s", "GB/s@16B"))
+    for name, chain in CASES:
+        if only and name.split()[0] not in only:
+            continue
+        ctx = pkg.Context(nch, frames)
+        for c in range(nch):
+            for unit, params in chain:
+                ctx.append_unit(c, unit, params=params)
+        d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
+        d_in.upload(x)
+        for _ in range(2):
+            ctx.process_device(d_in, d_out, frames, sr)
+        ctx.synchronize()
+        ctx.profile_enable(True)
+        for _ in range(steps):
+            ctx.process_device(d_in, d_out, frames, sr)
+        ctx.synchronize()
+        ms, n = ctx.profile_read(pkg.K_SEGMENT)
+        us = ms / n * 1e3
+        print("%-16s %10.1f %12.0f %12.0f" % (name, us, nch * frames / us, nch * frames * 16 / us / 1e3))
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()
