@@ -523,14 +523,29 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         break;
     }
     case GDG_UNIT_FUZZ: {
-        if (p[6] != 0) return fail(ctx, GDG_ERR_UNSUPPORTED, "fuzz with oversampling has no HIP implementation yet");
+        int f = (p[6] == 1) ? 2 : (p[6] == 2) ? 4 : 1;
+        d.jp[0] = f;
         d.dp[0] = 0.01 * (double)p[1];
         d.dp[1] = decibels_to_factor(p[2] + p[3]);
         d.dp[2] = 0.01 * (double)p[4];
         d.dp[3] = 1.0 - d.dp[2];
         d.dp[4] = decibels_to_factor(p[5]);
-        d.dp[5] = exp(-20.0 / sr);
+        /* the follower and the coupling capacitor run at the OVERSAMPLED rate (fuzz.go:42-45, :167-168) */
+        double inner_rate = (double)((uint32_t)f * sample_rate);
+        d.dp[5] = exp(-20.0 / inner_rate);
         d.dp[6] = 1.0 - d.dp[5];
+        if (f > 1) {
+            const size_t len2 = 8 + 76, len4 = 8 + 154;
+            rc = ensure_hist(ctx, u, len2 + len4, 1);
+            if (rc != GDG_OK) return rc;
+            double *base = u.d_hist + (f == 2 ? 0 : len2);
+            int which = (f == 2) ? 0 : 1;
+            if (u.os_frames[which] != frames) {
+                if (u.os_frames[which] >= 0) HIP_TRY(ctx, hipMemsetAsync(base, 0, 8 * sizeof(double), ctx->stream));
+                u.os_frames[which] = frames;
+            }
+            d.hist = base;
+        }
         break;
     }
     case GDG_UNIT_AUTOYOY: {

@@ -59,19 +59,53 @@ __device__ __forceinline__ void compose(double &A, double &B, double A1, double 
  * In: this thread's chunk map (A, B).  Out: (Ap, Bp) = composition of the maps of all threads
  * with a lower index (identity for thread 0).  tmp: 2 * C * 4 doubles of LDS.
  */
+/* DPP row shift right by D lanes inside each 16-lane row (register-to-register, no LDS crossbar);
+ * lanes whose source falls outside the row keep their own value -- callers guard with (lane & 15) >= D */
+template <int D>
+__device__ __forceinline__ int row_shr_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x110 | D, 0xf, 0xf, false); }
+template <int D>
+__device__ __forceinline__ double row_shr(double v) {
+    int lo = row_shr_i<D>(__double2loint(v)), hi = row_shr_i<D>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+template <int C, bool MAXOP, int D>
+__device__ __forceinline__ void scan_row_step(double (&a)[C], double (&b)[C], int lane) {
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        double ao = row_shr<D>(a[c]), bo = row_shr<D>(b[c]);
+        if ((lane & 15) >= D) compose<MAXOP>(a[c], b[c], ao, bo);
+    }
+}
+
 template <int C, bool MAXOP>
 __device__ __forceinline__ void block_scan(const double (&A)[C], const double (&B)[C], double (&Ap)[C], double (&Bp)[C], double *tmp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
     double a[C], b[C];
 #pragma unroll
     for (int c = 0; c < C; c++) { a[c] = A[c]; b[c] = B[c]; }
+    /* inclusive scan inside each row of 16 lanes with DPP shifts */
+    scan_row_step<C, MAXOP, 1>(a, b, lane);
+    scan_row_step<C, MAXOP, 2>(a, b, lane);
+    scan_row_step<C, MAXOP, 4>(a, b, lane);
+    scan_row_step<C, MAXOP, 8>(a, b, lane);
+    /* row totals (lanes 15, 31, 47) -> prefix of the rows below, through scalar registers */
+    double pa[C], pb[C];                               /* composition of all lower rows of this lane's row */
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            double ao = __shfl_up(a[c], d, 64), bo = __shfl_up(b[c], d, 64);
-            if (lane >= d) compose<MAXOP>(a[c], b[c], ao, bo);
-        }
+    for (int c = 0; c < C; c++) {
+        double a0 = read_lane(a[c], 15), b0 = read_lane(b[c], 15);
+        double a1 = read_lane(a[c], 31), b1 = read_lane(b[c], 31);
+        double a2 = read_lane(a[c], 47), b2 = read_lane(b[c], 47);
+        compose<MAXOP>(a1, b1, a0, b0);                /* rows 0..1 */
+        compose<MAXOP>(a2, b2, a1, b1);                /* rows 0..2 */
+        pa[c] = (row == 1) ? a0 : (row == 2) ? a1 : a2;
+        pb[c] = (row == 1) ? b0 : (row == 2) ? b1 : b2;
+        if (row == 0) { pa[c] = 1.0; pb[c] = 0.0; }
+        else compose<MAXOP>(a[c], b[c], pa[c], pb[c]);
     }
     if (lane == 63) {
 #pragma unroll
@@ -80,8 +114,9 @@ __device__ __forceinline__ void block_scan(const double (&A)[C], const double (&
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        double ae = __shfl_up(a[c], 1, 64), be = __shfl_up(b[c], 1, 64);
-        if (lane == 0) { ae = 1.0; be = 0.0; }
+        /* exclusive value: the inclusive one of the lane below; at a row start that is the rows-below prefix */
+        double ae = row_shr<1>(a[c]), be = row_shr<1>(b[c]);
+        if ((lane & 15) == 0) { ae = pa[c]; be = pb[c]; }
         double aw = 1.0, bw = 0.0;                 /* maps of the preceding waves */
         for (int w = 0; w < wave; w++) {
             double a2 = tmp[(w * C + c) * 2], b2 = tmp[(w * C + c) * 2 + 1];
@@ -678,15 +713,34 @@ struct IMap { int f[5]; };
 
 template <class Compose>
 __device__ __forceinline__ IMap block_scan_imap(IMap mine, IMap identity, Compose comp, int *itmp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
     IMap a = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
+    {
         IMap o;
 #pragma unroll
-        for (int k = 0; k < 5; k++) o.f[k] = __shfl_up(a.f[k], d, 64);
-        if (lane >= d) a = comp(o, a);              /* first the lower lanes, then this one */
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<1>(a.f[k]);
+        if ((lane & 15) >= 1) a = comp(o, a);       /* first the lower lanes, then this one */
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<2>(a.f[k]);
+        if ((lane & 15) >= 2) a = comp(o, a);
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<4>(a.f[k]);
+        if ((lane & 15) >= 4) a = comp(o, a);
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<8>(a.f[k]);
+        if ((lane & 15) >= 8) a = comp(o, a);
     }
+    IMap t0, t1, t2, rowpre = identity;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        t0.f[k] = __builtin_amdgcn_readlane(a.f[k], 15);
+        t1.f[k] = __builtin_amdgcn_readlane(a.f[k], 31);
+        t2.f[k] = __builtin_amdgcn_readlane(a.f[k], 47);
+    }
+    t1 = comp(t0, t1);
+    t2 = comp(t1, t2);
+    if (row == 1) rowpre = t0; else if (row == 2) rowpre = t1; else if (row == 3) rowpre = t2;
+    if (row != 0) a = comp(rowpre, a);
     if (lane == 63) {
 #pragma unroll
         for (int k = 0; k < 5; k++) itmp[wave * 5 + k] = a.f[k];
@@ -694,8 +748,8 @@ __device__ __forceinline__ IMap block_scan_imap(IMap mine, IMap identity, Compos
     __syncthreads();
     IMap e;
 #pragma unroll
-    for (int k = 0; k < 5; k++) e.f[k] = __shfl_up(a.f[k], 1, 64);
-    if (lane == 0) e = identity;
+    for (int k = 0; k < 5; k++) e.f[k] = row_shr_i<1>(a.f[k]);
+    if ((lane & 15) == 0) e = rowpre;
     IMap w = identity;
     for (int q = 0; q < wave; q++) {
         IMap t;
@@ -725,6 +779,119 @@ __device__ void unit_fuzz(const gdg_seg_unit *U, const double *in, double *out, 
     }
     onepole<OP_DIFF_NEW, false>(out, nullptr, U->dp[6], &U->ds[1], N, tmp);
     for (int i = c0; i < c1; i++) out[LX(i)] = level * clip1(out[LX(i)]);
+}
+
+/* ---- fuzz WITH 2x / 4x oversampling: effects/fuzz.go:113-174 around fuzz.go:24-108 at the oversampled rate -----------------
+ * Same tiling as unit_shaper, but the shaper has memory (envelope follower + coupling capacitor run at f * sr), so every
+ * tile runs two workgroup scans over its f * S_out new oversampled samples, with the state carried from tile to tile in LDS.
+ * dp5 / dp6 are exp(-20 / (f sr)) and its complement; hist as in unit_shaper. */
+__device__ __forceinline__ void lin_chunk(int cnt, int &c0, int &c1) {
+    const int m = (cnt + SEG_T - 1) / SEG_T;
+    c0 = min(cnt, (int)threadIdx.x * m);
+    c1 = min(cnt, c0 + m);
+}
+
+/* follower over a linear LDS array: v[i] (input) -> env[i] in e[i]; state in *st (LDS) */
+__device__ __forceinline__ void envelope_lin(const double *v, double *e, int cnt, int follow, double d_inv, double d, double *st, double *tmp) {
+    int c0, c1;
+    lin_chunk(cnt, c0, c1);
+    const double s0 = *st;
+    double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+    if (follow == 0) {
+        for (int i = c0; i < c1; i++) { A[0] *= d_inv; B[0] *= d_inv; double a = fabs(v[i]); if (a > B[0]) B[0] = a; }
+        block_scan<1, true>(A, B, Ap, Bp, tmp);
+        double s = apply_map<true>(Ap[0], Bp[0], s0);
+        for (int i = c0; i < c1; i++) { s *= d_inv; double a = fabs(v[i]); if (a > s) s = a; e[i] = s; }
+        if (c1 == cnt && c0 < cnt) *st = s;
+    } else if (follow == 1) {
+        for (int i = c0; i < c1; i++) { A[0] *= d_inv; double diff = fabs(v[i]) - B[0]; B[0] += diff * d; }
+        block_scan<1, false>(A, B, Ap, Bp, tmp);
+        double s = apply_map<false>(Ap[0], Bp[0], s0);
+        for (int i = c0; i < c1; i++) { double diff = fabs(v[i]) - s; s += diff * d; e[i] = s; }
+        if (c1 == cnt && c0 < cnt) *st = s;
+    } else {
+        __syncthreads();
+        for (int i = c0; i < c1; i++) e[i] = 1.0;
+        if (c1 == cnt && c0 < cnt) *st = 1.0;
+    }
+    __syncthreads();
+}
+
+__device__ void unit_fuzz_os(const gdg_seg_unit *U, const double *in, double *out, int N, double *scr, double *tmp, const gdg_os_tables &os) {
+    const int tid = threadIdx.x;
+    const int f = U->jp[0];
+    const int follow = U->ip[0];
+    const double bias = U->dp[0], gain = U->dp[1], fuzz = U->dp[2], fuzz_inv = U->dp[3], level = U->dp[4];
+    const double d_inv = U->dp[5], d = U->dp[6];
+    const int TAPS = (f == 2) ? 77 : 155;
+    const double *taps = (f == 2) ? os.taps2 : os.taps4;
+    const double *lw = (f == 2) ? os.lanczos2 : os.lanczos4;
+    double *hist = U->hist;
+    /* scr: [w: TAPS-1 old + f*S_out new | e: f*S_out envelope values]; the two carried states live in tmp[120..121] */
+    const int TILE = ((SEG_SCR - TAPS) / 2) / f;
+    double *st = tmp + 120;
+    if (tid == 0) { st[0] = U->ds[0]; st[1] = U->ds[1]; }
+    __syncthreads();
+    auto s_at = [&](int k) -> double { return k >= 0 ? in[LX(k)] : hist[8 + k]; };
+    for (int o0 = 0; o0 < N; o0 += TILE) {
+        const int S_out = min(TILE, N - o0);
+        const int cnt = f * S_out;
+        double *w = scr + (TAPS - 1), *e = scr + (TAPS - 1) + f * TILE;
+        /* tail: the last TAPS-1 outputs of the shaper (previous call for the first tile, previous tile otherwise) */
+        if (o0 == 0) for (int q = tid; q < TAPS - 1; q += SEG_T) scr[q] = hist[8 + q];
+        for (int q = tid; q < cnt; q += SEG_T) {
+            int m = f * o0 + q;
+            int i = m / f, r = m - i * f;
+            double up;
+            if (r == 0) up = s_at(i - 4);
+            else {
+                const double *wq = lw + (r - 1) * 6;
+                up = 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; t++) up += s_at(i - 6 + t) * wq[t];
+            }
+            w[q] = up;
+        }
+        __syncthreads();
+        envelope_lin(w, e, cnt, follow, d_inv, d, &st[0], tmp);
+        int c0, c1;
+        lin_chunk(cnt, c0, c1);
+        for (int q = c0; q < c1; q++) {
+            double sample = w[q];
+            double bias_voltage = bias * e[q];
+            double pre = clip1(gain * (sample - bias_voltage));
+            w[q] = (fuzz * pre) + (fuzz_inv * sample);
+        }
+        {   /* coupling capacitor: diff = p - c; c += diff d; out = p - c (fuzz.go:92-94) */
+            const double s0 = st[1];
+            double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+            for (int q = c0; q < c1; q++) { A[0] *= (1.0 - d); double diff = w[q] - B[0]; B[0] += diff * d; }
+            block_scan<1, false>(A, B, Ap, Bp, tmp);
+            double s = apply_map<false>(Ap[0], Bp[0], s0);
+            for (int q = c0; q < c1; q++) { double diff = w[q] - s; s += diff * d; w[q] = level * clip1(w[q] - s); }
+            if (c1 == cnt && c0 < cnt) st[1] = s;
+        }
+        __syncthreads();
+        for (int o = tid; o < S_out; o += SEG_T) {
+            int q = f * o + (TAPS - 1);
+            double acc = 0.0;
+            for (int k = 0; k < TAPS; k++) acc += taps[k] * scr[q - k];
+            out[LX(o0 + o)] = ATTENUATION_HALF_DECIBEL * clip1(acc);
+        }
+        __syncthreads();
+        /* slide: the last TAPS-1 shaped samples become the head of the next tile (and of the next call) */
+        double keep = 0.0;
+        const bool mine = tid < TAPS - 1;
+        if (mine) keep = scr[cnt + tid];
+        __syncthreads();
+        if (mine) { scr[tid] = keep; if (o0 + TILE >= N) hist[8 + tid] = keep; }
+        __syncthreads();
+    }
+    double keep8 = 0.0;
+    if (tid < 8) keep8 = s_at(N - 8 + tid);
+    __syncthreads();
+    if (tid < 8) hist[tid] = keep8;
+    if (tid == 0) { U->ds[0] = st[0]; U->ds[1] = st[1]; }
 }
 
 /* ---- auto-yoy: effects/autoyoy.go:19-157 ----------------------------------------------------------------------------------------
@@ -945,7 +1112,10 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         case GDG_UNIT_TREMOLO: unit_tremolo(U, in, out, N, s_scr); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, in, out, N); break;
         case GDG_UNIT_REVERB: unit_reverb(U, in, out, N); break;
-        case GDG_UNIT_FUZZ: unit_fuzz(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_FUZZ:
+            if (U->jp[0] > 1) unit_fuzz_os(U, in, out, N, s_scr, s_tmp, os);
+            else unit_fuzz(U, in, out, N, s_tmp);
+            break;
         case GDG_UNIT_AUTOYOY: unit_autoyoy(U, in, out, N, s_tmp); break;
         case GDG_UNIT_AUTOWAH: unit_autowah(U, in, out, N, s_tmp); break;
         case GDG_UNIT_BANDPASS: unit_bandpass(U, in, out, N, s_tmp); break;

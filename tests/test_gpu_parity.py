@@ -97,6 +97,7 @@ UNIT_CASES = [
     ("signal_generator", [100, 0, 3, 5000, 50, 0]), ("signal_generator", [30, 0, 4, 440, 100, -10]),
     ("reverb", None), ("reverb", [100]), ("reverb", [0]),
     ("fuzz", None), ("fuzz", [0, -30, 10, 20, 60, -3, 0]), ("fuzz", [1, 100, 0, 30, 100, 0, 0]),
+    ("fuzz", [1, 50, 0, 20, 100, 0, 1]), ("fuzz", [0, 30, 10, 10, 70, -6, 2]), ("fuzz", [1, -50, 0, 30, 100, 0, 2]),
     ("auto_yoy", None), ("auto_yoy", [0, -10, -50, 40]),
     ("auto_wah", None), ("auto_wah", [0, -5, -45, 200, 9000]),
     ("bandpass", None), ("bandpass", [3, 5000, 100]), ("bandpass", [1, 40, 18000]),
