@@ -288,11 +288,11 @@ __device__ __forceinline__ cplx mac_load(const cplx *p) {
     }
 }
 
-template <int UNROLL, int BPT, bool NT>
-__global__ void __launch_bounds__(256)
+template <int UNROLL, int BPT, bool NT, bool SWAP = false>
+__global__ void __launch_bounds__(1024)
 fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
-    gdg_fir_chan ch = chans[blockIdx.y];
-    const int b0 = (blockIdx.x * blockDim.x + threadIdx.x) * BPT;
+    gdg_fir_chan ch = chans[SWAP ? blockIdx.x : blockIdx.y];
+    const int b0 = ((SWAP ? blockIdx.y : blockIdx.x) * blockDim.x + threadIdx.x) * BPT;
     if (b0 >= P) return;
     const int K = ch.K;
     const int cur = (*ch.pos) % K;
@@ -473,13 +473,14 @@ hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, dou
     return hipGetLastError();
 }
 
-template <int UNROLL, int BPT, bool NT>
-static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s) {
-    int per_block = 256 * BPT;
-    int threads = P < per_block ? (P / BPT) : 256;
+template <int UNROLL, int BPT, bool NT, bool SWAP = false>
+static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s, int block = 256) {
+    int per_block = block * BPT;
+    int threads = P < per_block ? (P / BPT) : block;
     if (threads < 1) threads = 1;
-    dim3 grid((unsigned)((P + threads * BPT - 1) / (threads * BPT)), (unsigned)n_chans);
-    fir_mac_kernel<UNROLL, BPT, NT><<<grid, dim3(threads), 0, s>>>(d_chans, P);
+    unsigned tiles = (unsigned)((P + threads * BPT - 1) / (threads * BPT));
+    dim3 grid = SWAP ? dim3((unsigned)n_chans, tiles) : dim3(tiles, (unsigned)n_chans);
+    fir_mac_kernel<UNROLL, BPT, NT, SWAP><<<grid, dim3(threads), 0, s>>>(d_chans, P);
 }
 
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s) {
@@ -497,6 +498,12 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, h
     case 7: launch_mac<2, 2, false>(P, d_chans, n_chans, s); break;
     case 8: launch_mac<2, 4, true>(P, d_chans, n_chans, s); break;
     case 9: launch_mac<4, 1, false>(P, d_chans, n_chans, s); break;
+    case 10: launch_mac<8, 1, true>(P, d_chans, n_chans, s, 64); break;
+    case 11: launch_mac<8, 1, true>(P, d_chans, n_chans, s, 128); break;
+    case 12: launch_mac<8, 1, true>(P, d_chans, n_chans, s, 512); break;
+    case 13: launch_mac<8, 1, true>(P, d_chans, n_chans, s, 1024); break;
+    case 14: launch_mac<8, 1, true, true>(P, d_chans, n_chans, s, 256); break;
+    case 15: launch_mac<8, 1, true, true>(P, d_chans, n_chans, s, 1024); break;
     default: launch_mac<8, 1, true>(P, d_chans, n_chans, s); break;      /* measured best: profiles/mac_variants_r01.txt */
     }
     return hipGetLastError();

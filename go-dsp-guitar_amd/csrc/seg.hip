@@ -33,6 +33,23 @@
 #define SEG_SCR 3328
 #define LX(e) ((e) + ((e) >> 5))
 
+/* the workgroup's LDS, at file scope so that the (non-inlined) unit functions address it as LDS, not through flat pointers */
+__shared__ double s_a[SEG_LBUF];                     /* frame ping */
+__shared__ double s_b[SEG_LBUF];                     /* frame pong */
+__shared__ double s_scr[SEG_SCR];                    /* oversampling / run-list tile */
+__shared__ double s_tmp[2 * 4 * (SEG_T / 64)];       /* scan scratch: (A, B) x up to 4 recurrences x waves */
+
+/* every unit is its own function (own register allocation); `flip` says which LDS frame is the input */
+#define UNIT_FN __device__ __attribute__((noinline)) void
+#define UNIT_ARGS const gdg_seg_unit *U, int flip, int N
+#define UNIT_PROLOGUE                                                                     \
+    double *in = flip ? s_b : s_a;                                                        \
+    double *out = flip ? s_a : s_b;                                                       \
+    double *tmp = s_tmp;                                                                  \
+    double *scr = s_scr;                                                                  \
+    (void)in; (void)out; (void)tmp; (void)scr;
+
+
 #define ATTENUATION_HALF_DECIBEL 0.9440608762859234   /* oversampling/oversampling.go:13 */
 
 __device__ __forceinline__ double clip1(double v) { return v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v); }
@@ -117,12 +134,21 @@ __device__ __forceinline__ void block_scan(const double (&A)[C], const double (&
         /* exclusive value: the inclusive one of the lane below; at a row start that is the rows-below prefix */
         double ae = row_shr<1>(a[c]), be = row_shr<1>(b[c]);
         if ((lane & 15) == 0) { ae = pa[c]; be = pb[c]; }
-        double aw = 1.0, bw = 0.0;                 /* maps of the preceding waves */
-        for (int w = 0; w < wave; w++) {
-            double a2 = tmp[(w * C + c) * 2], b2 = tmp[(w * C + c) * 2 + 1];
-            compose<MAXOP>(a2, b2, aw, bw);
-            aw = a2; bw = b2;
+        /* maps of the preceding waves: lanes 0..15 of every wave scan the 16 wave totals with DPP (no serial
+         * loop over LDS), then everybody reads the entry of wave - 1 through a scalar register */
+        double wa = 1.0, wb = 0.0;
+        if (lane < SEG_WAVES) { wa = tmp[(lane * C + c) * 2]; wb = tmp[(lane * C + c) * 2 + 1]; }
+        {
+            double t[1] = { wa }, u[1] = { wb };
+            scan_row_step<1, MAXOP, 1>(t, u, lane);
+            scan_row_step<1, MAXOP, 2>(t, u, lane);
+            scan_row_step<1, MAXOP, 4>(t, u, lane);
+            scan_row_step<1, MAXOP, 8>(t, u, lane);
+            wa = t[0]; wb = u[0];
         }
+        const int wsel = __builtin_amdgcn_readfirstlane(wave > 0 ? wave - 1 : 0);
+        double aw = read_lane(wa, wsel), bw = read_lane(wb, wsel);
+        if (wave == 0) { aw = 1.0; bw = 0.0; }
         compose<MAXOP>(ae, be, aw, bw);            /* first the preceding waves, then the lanes below */
         Ap[c] = ae; Bp[c] = be;
     }
@@ -211,18 +237,120 @@ __device__ __forceinline__ void envelope_to(const double *in, double *dst, int N
     }
 }
 
+/* ---- register-resident chunks --------------------------------------------------------------------
+ * With 1024 threads a thread owns at most CHK = 8 consecutive samples, so a whole recurrence chain (zero-state
+ * pass, scan, exact replay, next section ...) runs on registers: one LDS read and one LDS write per sample and unit. */
+#define CHK (GDG_MAX_FRAMES / SEG_T)
+static_assert(CHK * SEG_T == GDG_MAX_FRAMES, "chunk size");
+
+struct Chunk { int c0, len; bool last; };
+
+__device__ __forceinline__ Chunk my_chunk(int N) {
+    const int m = (N + SEG_T - 1) / SEG_T;
+    Chunk c;
+    c.c0 = min(N, (int)threadIdx.x * m);
+    c.len = min(N, c.c0 + m) - c.c0;
+    c.last = (c.len > 0) && (c.c0 + c.len == N);
+    return c;
+}
+__device__ __forceinline__ void chunk_load(const double *buf, const Chunk &c, double (&v)[CHK]) {
+#pragma unroll
+    for (int i = 0; i < CHK; i++) v[i] = (i < c.len) ? buf[LX(c.c0 + i)] : 0.0;
+}
+__device__ __forceinline__ void chunk_store(double *buf, const Chunk &c, const double (&v)[CHK]) {
+#pragma unroll
+    for (int i = 0; i < CHK; i++) if (i < c.len) buf[LX(c.c0 + i)] = v[i];
+}
+
+/* one-pole section on a register chunk; s is the section's state before the frame on entry, after it on exit (valid in the `last` thread) */
+enum { OP_DIFF_OLD = 0, OP_OLD = 1, OP_NEW = 2, OP_DIFF_NEW = 3 };    /* what a one-pole section emits, see onepole() below */
+
+template <int MODE>
+__device__ __forceinline__ void onepole_reg(double (&v)[CHK], const Chunk &c, double a, double &s, double *tmp) {
+    double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+    const double keep = 1.0 - a;
+#pragma unroll
+    for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= keep; double diff = v[i] - B[0]; B[0] += diff * a; }
+    block_scan<1, false>(A, B, Ap, Bp, tmp);
+    s = apply_map<false>(Ap[0], Bp[0], s);
+#pragma unroll
+    for (int i = 0; i < CHK; i++) {
+        if (i < c.len) {
+            double x = v[i];
+            double diff = x - s;
+            double s_old = s;
+            s += diff * a;
+            v[i] = (MODE == OP_DIFF_OLD) ? diff : (MODE == OP_OLD) ? s_old : (MODE == OP_NEW) ? s : x - s;
+        }
+    }
+}
+
+/* the same with a per-sample coefficient (auto-wah) */
+template <int MODE>
+__device__ __forceinline__ void onepole_reg_var(double (&v)[CHK], const double (&a)[CHK], const Chunk &c, double &s, double *tmp) {
+    double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+#pragma unroll
+    for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= (1.0 - a[i]); double diff = v[i] - B[0]; B[0] += diff * a[i]; }
+    block_scan<1, false>(A, B, Ap, Bp, tmp);
+    s = apply_map<false>(Ap[0], Bp[0], s);
+#pragma unroll
+    for (int i = 0; i < CHK; i++) {
+        if (i < c.len) {
+            double x = v[i];
+            double diff = x - s;
+            double s_old = s;
+            s += diff * a[i];
+            v[i] = (MODE == OP_DIFF_OLD) ? diff : (MODE == OP_OLD) ? s_old : (MODE == OP_NEW) ? s : x - s;
+        }
+    }
+}
+
+/* follower on a register chunk: x -> e (value after each sample); same conventions as onepole_reg */
+__device__ __forceinline__ void envelope_reg(const double (&x)[CHK], double (&e)[CHK], const Chunk &c, int follow, double d_inv, double d,
+                                             double &s, double *tmp) {
+    double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
+#pragma unroll
+    for (int i = 0; i < CHK; i++) e[i] = 1.0;
+    if (follow == 0) {
+#pragma unroll
+        for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= d_inv; B[0] *= d_inv; double q = fabs(x[i]); if (q > B[0]) B[0] = q; }
+        block_scan<1, true>(A, B, Ap, Bp, tmp);
+        s = apply_map<true>(Ap[0], Bp[0], s);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) if (i < c.len) { s *= d_inv; double q = fabs(x[i]); if (q > s) s = q; e[i] = s; }
+    } else if (follow == 1) {
+#pragma unroll
+        for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= d_inv; double diff = fabs(x[i]) - B[0]; B[0] += diff * d; }
+        block_scan<1, false>(A, B, Ap, Bp, tmp);
+        s = apply_map<false>(Ap[0], Bp[0], s);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) if (i < c.len) { double diff = fabs(x[i]) - s; s += diff * d; e[i] = s; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CHK; i++) e[i] = 1.0;
+        s = 1.0;
+    }
+}
+
 /* ---- compressor: effects/compressor.go:18-84 ---------------------------------------------------
  * ip0 follow; dp0 gain limit factor, dp1 target factor, dp2 exp(-20/sr), dp3 1 - dp2; ds0 envelope */
-__device__ void unit_compressor(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
-    envelope_to(in, out, N, U->ip[0], U->dp[2], U->dp[3], U->ds, tmp);
+UNIT_FN unit_compressor(UNIT_ARGS) {
+    UNIT_PROLOGUE
+    const Chunk c = my_chunk(N);
+    double s = U->ds[0];
+    double x[CHK], e[CHK];
+    chunk_load(in, c, x);
+    __syncthreads();                                /* everybody holds the old state before the last thread rewrites it */
+    envelope_reg(x, e, c, U->ip[0], U->dp[2], U->dp[3], s, tmp);
     const double limit = U->dp[0], target = U->dp[1];
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
-    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
-    for (int i = c0; i < c1; i++) {
-        double gain = target / out[LX(i)];
+#pragma unroll
+    for (int i = 0; i < CHK; i++) {
+        double gain = target / e[i];
         if (gain > limit) gain = limit;
-        out[LX(i)] = clip1(gain * in[LX(i)]);
+        x[i] = clip1(gain * x[i]);
     }
+    chunk_store(out, c, x);
+    if (c.last) U->ds[0] = s;
 }
 
 /* ---- memoryless waveshapers ---------------------------------------------------------------------- */
@@ -264,7 +392,8 @@ __device__ __forceinline__ double shape(const Shaper &S, double sample) {
  * dp0 gain, dp1 drive, dp2 clean, dp3 level; ip[4] valve (overdrive); jp0 factor (1, 2, 4).
  * hist: [0..7] the last 8 inputs, [8 .. 8+TAPS-2] the last TAPS-1 waveshaped oversampled samples.
  */
-__device__ void unit_shaper(const gdg_seg_unit *U, const double *in, double *out, int N, double *scr, const gdg_os_tables &os) {
+UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
+    UNIT_PROLOGUE
     Shaper S;
     S.type = U->type; S.valve = U->ip[4];
     S.gain = U->dp[0]; S.drive = U->dp[1]; S.clean = U->dp[2]; S.level = U->dp[3];
@@ -328,21 +457,25 @@ __device__ void unit_shaper(const gdg_seg_unit *U, const double *in, double *out
 
 /* ---- tone stack: effects/tonestack.go:19-100 ------------------------------------------------------
  * dp0..3 band factors, dp4..7 (1 - exp(-2 pi fA/sr)), dp8..11 (1 - exp(-2 pi fB/sr)); ds0..3 hcv, ds4..7 lcv */
-__device__ void unit_tonestack(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
-    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
+UNIT_FN unit_tonestack(UNIT_ARGS) {
+    UNIT_PROLOGUE
+    const Chunk c = my_chunk(N);
     double fac[4], aH[4], aL[4], h0[4], l0[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { fac[j] = U->dp[j]; aH[j] = U->dp[4 + j]; aL[j] = U->dp[8 + j]; h0[j] = U->ds[j]; l0[j] = U->ds[4 + j]; }
+    double x[CHK];
+    chunk_load(in, c, x);
     __syncthreads();
     double A[4], B[4], Ap[4], Bp[4];
     /* pass 1: chunk maps of the four high-pass capacitors */
 #pragma unroll
     for (int j = 0; j < 4; j++) { A[j] = 1.0; B[j] = 0.0; }
-    for (int i = c0; i < c1; i++) {
-        double x = in[LX(i)];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { A[j] *= (1.0 - aH[j]); double diff = x - B[j]; B[j] += diff * aH[j]; }
+    for (int i = 0; i < CHK; i++) {
+        if (i < c.len) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { A[j] *= (1.0 - aH[j]); double diff = x[i] - B[j]; B[j] += diff * aH[j]; }
+        }
     }
     block_scan<4, false>(A, B, Ap, Bp, tmp);
     double h[4], hs[4];
@@ -351,15 +484,17 @@ __device__ void unit_tonestack(const gdg_seg_unit *U, const double *in, double *
     /* pass 2: exact high-pass, chunk maps of the four low-pass capacitors */
 #pragma unroll
     for (int j = 0; j < 4; j++) { A[j] = 1.0; B[j] = 0.0; }
-    for (int i = c0; i < c1; i++) {
-        double x = in[LX(i)];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            double diff = x - h[j];
-            h[j] += diff * aH[j];
-            A[j] *= (1.0 - aL[j]);
-            diff -= B[j];
-            B[j] += diff * aL[j];
+    for (int i = 0; i < CHK; i++) {
+        if (i < c.len) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                double diff = x[i] - h[j];
+                h[j] += diff * aH[j];
+                A[j] *= (1.0 - aL[j]);
+                diff -= B[j];
+                B[j] += diff * aL[j];
+            }
         }
     }
     block_scan<4, false>(A, B, Ap, Bp, tmp);
@@ -367,53 +502,61 @@ __device__ void unit_tonestack(const gdg_seg_unit *U, const double *in, double *
 #pragma unroll
     for (int j = 0; j < 4; j++) { l[j] = apply_map<false>(Ap[j], Bp[j], l0[j]); h[j] = hs[j]; }
     /* pass 3: the reference's loop body from the exact chunk-start state */
-    for (int i = c0; i < c1; i++) {
-        double x = in[LX(i)];
-        double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            double diff = x - h[j];
-            h[j] += diff * aH[j];
-            diff -= l[j];
-            double pre = l[j];
-            l[j] += diff * aL[j];
-            sum += fac[j] * pre;
+    for (int i = 0; i < CHK; i++) {
+        if (i < c.len) {
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                double diff = x[i] - h[j];
+                h[j] += diff * aH[j];
+                diff -= l[j];
+                double pre = l[j];
+                l[j] += diff * aL[j];
+                sum += fac[j] * pre;
+            }
+            x[i] = clip1(sum);
         }
-        out[LX(i)] = clip1(sum);
     }
-    if (c1 == N && c0 < N) {
+    chunk_store(out, c, x);
+    if (c.last) {
 #pragma unroll
         for (int j = 0; j < 4; j++) { U->ds[j] = h[j]; U->ds[4 + j] = l[j]; }
     }
 }
 
 /* ---- cabinet (IIR): effects/cabinet.go:27-162 -------------------------------------------------------
- * dp0..2 high-pass (1 - exp(-2 pi f/sr)) for 300/120/80 Hz, dp3..6 low-pass for 3/4/5/6 kHz; ds0..2 hcv, ds3..6 lcv */
-__device__ void unit_cabinet(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
-    const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
-    for (int i = c0; i < c1; i++) out[LX(i)] = in[LX(i)];
-    /* stage p: zero-state chunk map from its input sequence (held in `out`), scan, exact replay in place */
-    for (int p = 0; p < 7; p++) {
-        const double ap = U->dp[p];
-        const double s0 = U->ds[p];               /* read by everybody before the scan's barriers, written after them */
-        double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
-        for (int i = c0; i < c1; i++) { A[0] *= (1.0 - ap); double diff = out[LX(i)] - B[0]; B[0] += diff * ap; }
-        block_scan<1, false>(A, B, Ap, Bp, tmp);
-        double s = apply_map<false>(Ap[0], Bp[0], s0);
-        if (p < 3) {
-            for (int i = c0; i < c1; i++) { double diff = out[LX(i)] - s; out[LX(i)] = diff; s += diff * ap; }
-        } else {
-            for (int i = c0; i < c1; i++) { double diff = out[LX(i)] - s; out[LX(i)] = s; s += diff * ap; }
-        }
-        if (c1 == N && c0 < N) U->ds[p] = s;
+ * dp0..2 high-pass (1 - exp(-2 pi f/sr)) for 300/120/80 Hz, dp3..6 low-pass for 3/4/5/6 kHz; ds0..2 hcv, ds3..6 lcv.
+ * Seven one-pole sections in series on a register chunk: per section a zero-state pass, a workgroup scan, an exact replay. */
+UNIT_FN unit_cabinet(UNIT_ARGS) {
+    UNIT_PROLOGUE
+    const Chunk c = my_chunk(N);
+    double a[7], st[7];
+#pragma unroll
+    for (int p = 0; p < 7; p++) { a[p] = U->dp[p]; st[p] = U->ds[p]; }     /* all states fetched in one go */
+    double v[CHK];
+    chunk_load(in, c, v);
+    __syncthreads();
+    onepole_reg<OP_DIFF_OLD>(v, c, a[0], st[0], tmp);
+    onepole_reg<OP_DIFF_OLD>(v, c, a[1], st[1], tmp);
+    onepole_reg<OP_DIFF_OLD>(v, c, a[2], st[2], tmp);
+    onepole_reg<OP_OLD>(v, c, a[3], st[3], tmp);
+    onepole_reg<OP_OLD>(v, c, a[4], st[4], tmp);
+    onepole_reg<OP_OLD>(v, c, a[5], st[5], tmp);
+    onepole_reg<OP_OLD>(v, c, a[6], st[6], tmp);
+#pragma unroll
+    for (int i = 0; i < CHK; i++) v[i] = clip1(v[i]);
+    chunk_store(out, c, v);
+    if (c.last) {
+#pragma unroll
+        for (int p = 0; p < 7; p++) U->ds[p] = st[p];
     }
-    for (int i = c0; i < c1; i++) out[LX(i)] = clip1(out[LX(i)]);
 }
 
 /* ---- chorus: effects/chorus.go:19-131 ------------------------------------------------------------------
  * dp0 depth (0..10), dp1 angular speed, dp2 sample rate; jp0 ring capacity; ds0 previousPhase; is0 ring wp */
-__device__ void unit_chorus(const gdg_seg_unit *U, const double *in, double *out, int N) {
+UNIT_FN unit_chorus(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const double depth = U->dp[0], angular = U->dp[1], sr = U->dp[2];
     const int C = U->jp[0], wp = U->is[0];
     const double prev = U->ds[0];
@@ -447,7 +590,8 @@ __device__ void unit_chorus(const gdg_seg_unit *U, const double *in, double *out
 
 /* ---- flanger / phaser: effects/flanger.go:19-119, effects/phaser.go:19-125 --------------------------------
  * dp0 depth (0..1), dp1 angular speed, dp2 sr, dp3 1/sr, dp4 dry factor, dp5 wet factor; jp0 ring capacity */
-__device__ void unit_flanger(const gdg_seg_unit *U, const double *in, double *out, int N) {
+UNIT_FN unit_flanger(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const double depth = U->dp[0], angular = U->dp[1], sr = U->dp[2], sr_inv = U->dp[3];
     const double mix_dry = U->dp[4], mix_wet = U->dp[5];
     const int C = U->jp[0], wp = U->is[0];
@@ -472,7 +616,8 @@ __device__ void unit_flanger(const gdg_seg_unit *U, const double *in, double *ou
 
 /* ---- delay: effects/delay.go:18-89 ------------------------------------------------------------------------
  * dp0 feedback factor, dp1 level factor; jp0 delay in samples (= ring capacity) */
-__device__ void unit_delay(const gdg_seg_unit *U, const double *in, double *out, int N) {
+UNIT_FN unit_delay(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const double feedback = U->dp[0], level = U->dp[1];
     const int D = U->jp[0], wp = U->is[0];
     const double *ring = U->hist;
@@ -486,7 +631,8 @@ __device__ void unit_delay(const gdg_seg_unit *U, const double *in, double *out,
 }
 
 /* ---- ring modulator: effects/ringmodulator.go:18-45.  dp0 phase increment per sample; ds0 phase ---------- */
-__device__ void unit_ringmod(const gdg_seg_unit *U, const double *in, double *out, int N) {
+UNIT_FN unit_ringmod(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const double fraction = U->dp[0], phase = U->ds[0];
     for (int i = threadIdx.x; i < N; i += SEG_T) {
         double cur = fmod(phase + ((double)i * fraction), GO_MATH_TWO_PI);
@@ -499,7 +645,8 @@ __device__ void unit_ringmod(const gdg_seg_unit *U, const double *in, double *ou
 /* ---- tremolo: effects/tremolo.go:15-65 ----------------------------------------------------------------------
  * dp0 attenuation factor; jp0 samplesUnattenuated, jp1 samplesAttenuated (uint32); is0 attenuated, is1 inStateSince.
  * The counter FSM is data independent: thread 0 walks it in runs (a run ends where the reference flips state). */
-__device__ void unit_tremolo(const gdg_seg_unit *U, const double *in, double *out, int N, double *scr) {
+UNIT_FN unit_tremolo(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const double fac = U->dp[0];
     int *runs = reinterpret_cast<int *>(scr);          /* pairs (start, attenuated), terminated by start = N */
     if (threadIdx.x == 0) {
@@ -538,7 +685,8 @@ __device__ void unit_tremolo(const gdg_seg_unit *U, const double *in, double *ou
 __device__ __forceinline__ unsigned lcg_mulmod(unsigned a, unsigned b) {
     return (unsigned)(((unsigned long long)a * (unsigned long long)b) % 2147483647ull);
 }
-__device__ void unit_siggen(const gdg_seg_unit *U, const double *in, double *out, int N) {
+UNIT_FN unit_siggen(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const int type = U->ip[2];
     const double fac_in = U->dp[0], fac_sig = U->dp[1], inc = U->dp[2], phase = U->ds[0];
     if (type == 4) {                                    /* "noise": random/random.go LCG, seed 1337 */
@@ -584,7 +732,8 @@ __device__ void unit_siggen(const gdg_seg_unit *U, const double *in, double *out
  * Here each ring keeps the last M values of p[n] = in[n] - g p[n - M]; o[n] = g p[n] + p[n - M].
  */
 #define REVERB_QMAX (GDG_MAX_FRAMES / SEG_T)
-__device__ void unit_reverb(const gdg_seg_unit *U, const double *in, double *out, int N) {
+UNIT_FN unit_reverb(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const int tid = threadIdx.x;
     const double dry = U->dp[0], half_wet = U->dp[1];
     const double coeff[4] = { 0.1855, 0.18325, 0.17875, 0.17425 };
@@ -676,8 +825,6 @@ __device__ void unit_reverb(const gdg_seg_unit *U, const double *in, double *out
  * emitted value:  DIFF_OLD v - s_old (high-pass, effects/cabinet.go:114-118)   OLD s_old (low-pass, cabinet.go:135-139)
  *                 NEW s_new (auto-wah low-pass, autowah.go:106-109)            DIFF_NEW v - s_new (coupling capacitor, fuzz.go:92-94)
  * VAR: the coefficient varies per sample and is read from abuf (auto-wah). */
-enum { OP_DIFF_OLD = 0, OP_OLD = 1, OP_NEW = 2, OP_DIFF_NEW = 3 };
-
 template <int MODE, bool VAR>
 __device__ __forceinline__ void onepole(double *buf, const double *abuf, double a_const, double *state, int N, double *tmp) {
     const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
@@ -751,20 +898,39 @@ __device__ __forceinline__ IMap block_scan_imap(IMap mine, IMap identity, Compos
     for (int k = 0; k < 5; k++) e.f[k] = row_shr_i<1>(a.f[k]);
     if ((lane & 15) == 0) e = rowpre;
     IMap w = identity;
-    for (int q = 0; q < wave; q++) {
-        IMap t;
+    if (lane < SEG_WAVES) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) t.f[k] = itmp[q * 5 + k];
-        w = comp(w, t);
+        for (int k = 0; k < 5; k++) w.f[k] = itmp[lane * 5 + k];
     }
-    e = comp(w, e);
+    {
+        IMap o;
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<1>(w.f[k]);
+        if ((lane & 15) >= 1) w = comp(o, w);
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<2>(w.f[k]);
+        if ((lane & 15) >= 2) w = comp(o, w);
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<4>(w.f[k]);
+        if ((lane & 15) >= 4) w = comp(o, w);
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.f[k] = row_shr_i<8>(w.f[k]);
+        if ((lane & 15) >= 8) w = comp(o, w);
+    }
+    const int wsel = __builtin_amdgcn_readfirstlane(wave > 0 ? wave - 1 : 0);
+    IMap wp;
+#pragma unroll
+    for (int k = 0; k < 5; k++) wp.f[k] = __builtin_amdgcn_readlane(w.f[k], wsel);
+    if (wave == 0) wp = identity;
+    e = comp(wp, e);
     __syncthreads();
     return e;
 }
 
 /* ---- fuzz without oversampling: effects/fuzz.go:24-108 ------------------------------------------------------------------------
  * ip0 follow; dp0 bias, dp1 gain, dp2 fuzz, dp3 1 - fuzz, dp4 level, dp5 exp(-20/sr), dp6 1 - dp5; ds0 envelope, ds1 coupling cap */
-__device__ void unit_fuzz(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+UNIT_FN unit_fuzz(UNIT_ARGS) {
+    UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
     const double bias = U->dp[0], gain = U->dp[1], fuzz = U->dp[2], fuzz_inv = U->dp[3], level = U->dp[4];
     const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
@@ -817,7 +983,8 @@ __device__ __forceinline__ void envelope_lin(const double *v, double *e, int cnt
     __syncthreads();
 }
 
-__device__ void unit_fuzz_os(const gdg_seg_unit *U, const double *in, double *out, int N, double *scr, double *tmp, const gdg_os_tables &os) {
+UNIT_FN unit_fuzz_os(UNIT_ARGS, const gdg_os_tables &os) {
+    UNIT_PROLOGUE
     const int tid = threadIdx.x;
     const int f = U->jp[0];
     const int follow = U->ip[0];
@@ -896,7 +1063,8 @@ __device__ void unit_fuzz_os(const gdg_seg_unit *U, const double *in, double *ou
 
 /* ---- auto-yoy: effects/autoyoy.go:19-157 ----------------------------------------------------------------------------------------
  * ip0 follow; dp0 level A, dp1 level B, dp2 depth A, dp3 depth B, dp4 slope, dp5 exp(-20/sr), dp6 1 - dp5, dp7 sr; jp0 ring capacity */
-__device__ void unit_autoyoy(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+UNIT_FN unit_autoyoy(UNIT_ARGS) {
+    UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
     const double la = U->dp[0], lb = U->dp[1], da = U->dp[2], db = U->dp[3], slope = U->dp[4], sr = U->dp[7];
     const int C = U->jp[0], wp = U->is[0];
@@ -921,7 +1089,8 @@ __device__ void unit_autoyoy(const gdg_seg_unit *U, const double *in, double *ou
 /* ---- auto-wah: effects/autowah.go:20-130 -------------------------------------------------------------------------------------------
  * ip0 follow; dp0 level A, dp1 level B, dp2 freq A, dp3 freq B, dp4 slope, dp5 exp(-20/sr), dp6 1 - dp5, dp7 sr;
  * ds0 envelope, ds1..8 hcv, ds9..16 lcv.  CLOBBERS its input buffer (it is free: the next unit overwrites it anyway). */
-__device__ void unit_autowah(const gdg_seg_unit *U, double *in, double *out, int N, double *tmp) {
+UNIT_FN unit_autowah(UNIT_ARGS) {
+    UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
     const double la = U->dp[0], lb = U->dp[1], fa = U->dp[2], fb = U->dp[3], slope = U->dp[4], sr = U->dp[7];
     const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
@@ -945,7 +1114,8 @@ __device__ void unit_autowah(const gdg_seg_unit *U, double *in, double *out, int
 }
 
 /* ---- bandpass: effects/bandpass.go:20-98.  jp0 half order; dp0 high-pass coefficient, dp1 low-pass coefficient; ds0..3 hcv, ds4..7 lcv */
-__device__ void unit_bandpass(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+UNIT_FN unit_bandpass(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     for (int i = c0; i < c1; i++) out[LX(i)] = in[LX(i)];
@@ -961,7 +1131,8 @@ __device__ void unit_bandpass(const gdg_seg_unit *U, const double *in, double *o
  * ip0 follow; dp0 up, dp1 clean, dp2 dist, dp3 down1, dp4 down2, dp5 hysteresis factors, dp6 exp(-20/sr), dp7 1 - dp6;
  * ds0 envelope, ds1 coupling cap; is0 previousPolarity (-1, 0, 1), is1 octaveRegister.
  * The polarity FSM is scanned as a map  pp_in -> (pp_out, register increment):  f = {has, s1, drest, pp_out}. */
-__device__ void unit_octaver(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+UNIT_FN unit_octaver(UNIT_ARGS) {
+    UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[6], U->dp[7], &U->ds[0], tmp);
     const double f_up = U->dp[0], f_clean = U->dp[1], f_dist = U->dp[2], f_d1 = U->dp[3], f_d2 = U->dp[4], f_hyst = U->dp[5];
     const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
@@ -1018,7 +1189,8 @@ __device__ void unit_octaver(const gdg_seg_unit *U, const double *in, double *ou
  *   since_out = has_reset ? off : since_in + off;   open_out = forced ? fv : (open_in && since_in < T)
  * (every sample above the open threshold is also above the close threshold, so before the first reset only closing can happen). */
 #define GATE_INF 0x3fffffff
-__device__ void unit_noisegate(const gdg_seg_unit *U, const double *in, double *out, int N, double *tmp) {
+UNIT_FN unit_noisegate(UNIT_ARGS) {
+    UNIT_PROLOGUE
     const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     if (U->jp[1]) {
@@ -1086,50 +1258,48 @@ __device__ void unit_noisegate(const gdg_seg_unit *U, const double *in, double *
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(SEG_T)
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, gdg_os_tables os, int *d_error) {
-    __shared__ double s_a[SEG_LBUF];
-    __shared__ double s_b[SEG_LBUF];
-    __shared__ double s_scr[SEG_SCR];
-    __shared__ double s_tmp[2 * 4 * SEG_WAVES];      /* scan scratch: (A, B) x up to 4 recurrences x waves */
     const gdg_seg_chan ch = chans[blockIdx.x];
     const int tid = threadIdx.x;
     for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = ch.src[i];
     __syncthreads();
-    double *in = s_a, *out = s_b;
+    int flip = 0;                                   /* 0: s_a holds the current frame, 1: s_b */
     for (int u = 0; u < ch.unit_count; u++) {
+        double *out = flip ? s_a : s_b;
         const gdg_seg_unit *U = units + ch.unit_begin + u;
         switch (U->type) {
-        case GDG_UNIT_COMPRESSOR: unit_compressor(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N); break;
         case GDG_UNIT_OVERDRIVE:
         case GDG_UNIT_DISTORTION:
-        case GDG_UNIT_EXCESS: unit_shaper(U, in, out, N, s_scr, os); break;
-        case GDG_UNIT_TONESTACK: unit_tonestack(U, in, out, N, s_tmp); break;
-        case GDG_UNIT_CABINET: unit_cabinet(U, in, out, N, s_tmp); break;
-        case GDG_UNIT_CHORUS: unit_chorus(U, in, out, N); break;
+        case GDG_UNIT_EXCESS: unit_shaper(U, flip, N, os); break;
+        case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N); break;
+        case GDG_UNIT_CABINET: unit_cabinet(U, flip, N); break;
+        case GDG_UNIT_CHORUS: unit_chorus(U, flip, N); break;
         case GDG_UNIT_FLANGER:
-        case GDG_UNIT_PHASER: unit_flanger(U, in, out, N); break;
-        case GDG_UNIT_DELAY: unit_delay(U, in, out, N); break;
-        case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, in, out, N); break;
-        case GDG_UNIT_TREMOLO: unit_tremolo(U, in, out, N, s_scr); break;
-        case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, in, out, N); break;
-        case GDG_UNIT_REVERB: unit_reverb(U, in, out, N); break;
+        case GDG_UNIT_PHASER: unit_flanger(U, flip, N); break;
+        case GDG_UNIT_DELAY: unit_delay(U, flip, N); break;
+        case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N); break;
+        case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N); break;
+        case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N); break;
+        case GDG_UNIT_REVERB: unit_reverb(U, flip, N); break;
         case GDG_UNIT_FUZZ:
-            if (U->jp[0] > 1) unit_fuzz_os(U, in, out, N, s_scr, s_tmp, os);
-            else unit_fuzz(U, in, out, N, s_tmp);
+            if (U->jp[0] > 1) unit_fuzz_os(U, flip, N, os);
+            else unit_fuzz(U, flip, N);
             break;
-        case GDG_UNIT_AUTOYOY: unit_autoyoy(U, in, out, N, s_tmp); break;
-        case GDG_UNIT_AUTOWAH: unit_autowah(U, in, out, N, s_tmp); break;
-        case GDG_UNIT_BANDPASS: unit_bandpass(U, in, out, N, s_tmp); break;
-        case GDG_UNIT_OCTAVER: unit_octaver(U, in, out, N, s_tmp); break;
-        case GDG_UNIT_NOISEGATE: unit_noisegate(U, in, out, N, s_tmp); break;
+        case GDG_UNIT_AUTOYOY: unit_autoyoy(U, flip, N); break;
+        case GDG_UNIT_AUTOWAH: unit_autowah(U, flip, N); break;
+        case GDG_UNIT_BANDPASS: unit_bandpass(U, flip, N); break;
+        case GDG_UNIT_OCTAVER: unit_octaver(U, flip, N); break;
+        case GDG_UNIT_NOISEGATE: unit_noisegate(U, flip, N); break;
         default:
             if (tid == 0) atomicExch(d_error, 1 + U->type);
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
             break;
         }
         __syncthreads();
-        double *t = in; in = out; out = t;
+        flip ^= 1;
     }
-    for (int i = tid; i < N; i += SEG_T) ch.dst[i] = in[LX(i)];
+    const double *fin = flip ? s_b : s_a;
+    for (int i = tid; i < N; i += SEG_T) ch.dst[i] = fin[LX(i)];
 }
 
 int gdg_seg_supported(int unit_type) {

@@ -42,6 +42,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for v in range(9):
+        for v in ([int(a) for a in sys.argv[1:]] or range(9)):
             env = dict(os.environ, GDG_MAC_VARIANT=str(v))
             subprocess.call([sys.executable, os.path.abspath(__file__), "child"], env=env)
