@@ -37,7 +37,8 @@
 __shared__ double s_a[SEG_LBUF];                     /* frame ping */
 __shared__ double s_b[SEG_LBUF];                     /* frame pong */
 __shared__ double s_scr[SEG_SCR];                    /* oversampling / run-list tile */
-__shared__ double s_tmp[2 * 4 * (SEG_T / 64)];       /* scan scratch: (A, B) x up to 4 recurrences x waves */
+__shared__ double s_tmp[2 * 4 * (SEG_T / 64) + 32];  /* scan scratch: (A, B) x up to 4 recurrences x waves; + 32 state cells */
+#define SEG_STASH (2 * 4 * (SEG_T / 64))          /* first state cell inside s_tmp */
 
 /* every unit is its own function (own register allocation); `flip` says which LDS frame is the input */
 #define UNIT_FN __device__ __attribute__((noinline)) void
@@ -460,9 +461,11 @@ UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
 UNIT_FN unit_tonestack(UNIT_ARGS) {
     UNIT_PROLOGUE
     const Chunk c = my_chunk(N);
-    double fac[4], aH[4], aL[4], h0[4], l0[4];
+    double *st = tmp + SEG_STASH;                    /* the eight capacitor voltages, stashed in LDS (not in live registers) */
+    if (threadIdx.x < 8) st[threadIdx.x] = U->ds[threadIdx.x];
+    double aH[4], aL[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { fac[j] = U->dp[j]; aH[j] = U->dp[4 + j]; aL[j] = U->dp[8 + j]; h0[j] = U->ds[j]; l0[j] = U->ds[4 + j]; }
+    for (int j = 0; j < 4; j++) { aH[j] = U->dp[4 + j]; aL[j] = U->dp[8 + j]; }
     double x[CHK];
     chunk_load(in, c, x);
     __syncthreads();
@@ -480,7 +483,7 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
     block_scan<4, false>(A, B, Ap, Bp, tmp);
     double h[4], hs[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { hs[j] = apply_map<false>(Ap[j], Bp[j], h0[j]); h[j] = hs[j]; }
+    for (int j = 0; j < 4; j++) { hs[j] = apply_map<false>(Ap[j], Bp[j], st[j]); h[j] = hs[j]; }
     /* pass 2: exact high-pass, chunk maps of the four low-pass capacitors */
 #pragma unroll
     for (int j = 0; j < 4; j++) { A[j] = 1.0; B[j] = 0.0; }
@@ -500,8 +503,11 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
     block_scan<4, false>(A, B, Ap, Bp, tmp);
     double l[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { l[j] = apply_map<false>(Ap[j], Bp[j], l0[j]); h[j] = hs[j]; }
+    for (int j = 0; j < 4; j++) { l[j] = apply_map<false>(Ap[j], Bp[j], st[4 + j]); h[j] = hs[j]; }
     /* pass 3: the reference's loop body from the exact chunk-start state */
+    double fac[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) fac[j] = U->dp[j];
 #pragma unroll
     for (int i = 0; i < CHK; i++) {
         if (i < c.len) {
@@ -531,26 +537,22 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
 UNIT_FN unit_cabinet(UNIT_ARGS) {
     UNIT_PROLOGUE
     const Chunk c = my_chunk(N);
-    double a[7], st[7];
-#pragma unroll
-    for (int p = 0; p < 7; p++) { a[p] = U->dp[p]; st[p] = U->ds[p]; }     /* all states fetched in one go */
+    double *st = tmp + SEG_STASH;                    /* the seven capacitor voltages, fetched once, kept in LDS */
+    if (threadIdx.x < 7) st[threadIdx.x] = U->ds[threadIdx.x];
     double v[CHK];
     chunk_load(in, c, v);
     __syncthreads();
-    onepole_reg<OP_DIFF_OLD>(v, c, a[0], st[0], tmp);
-    onepole_reg<OP_DIFF_OLD>(v, c, a[1], st[1], tmp);
-    onepole_reg<OP_DIFF_OLD>(v, c, a[2], st[2], tmp);
-    onepole_reg<OP_OLD>(v, c, a[3], st[3], tmp);
-    onepole_reg<OP_OLD>(v, c, a[4], st[4], tmp);
-    onepole_reg<OP_OLD>(v, c, a[5], st[5], tmp);
-    onepole_reg<OP_OLD>(v, c, a[6], st[6], tmp);
+#pragma unroll 1
+    for (int p = 0; p < 7; p++) {
+        const double a = U->dp[p];
+        double s = st[p];
+        if (p < 3) onepole_reg<OP_DIFF_OLD>(v, c, a, s, tmp);
+        else onepole_reg<OP_OLD>(v, c, a, s, tmp);
+        if (c.last) U->ds[p] = s;
+    }
 #pragma unroll
     for (int i = 0; i < CHK; i++) v[i] = clip1(v[i]);
     chunk_store(out, c, v);
-    if (c.last) {
-#pragma unroll
-        for (int p = 0; p < 7; p++) U->ds[p] = st[p];
-    }
 }
 
 /* ---- chorus: effects/chorus.go:19-131 ------------------------------------------------------------------
@@ -996,7 +998,7 @@ UNIT_FN unit_fuzz_os(UNIT_ARGS, const gdg_os_tables &os) {
     double *hist = U->hist;
     /* scr: [w: TAPS-1 old + f*S_out new | e: f*S_out envelope values]; the two carried states live in tmp[120..121] */
     const int TILE = ((SEG_SCR - TAPS) / 2) / f;
-    double *st = tmp + 120;
+    double *st = tmp + SEG_STASH + 16;
     if (tid == 0) { st[0] = U->ds[0]; st[1] = U->ds[1]; }
     __syncthreads();
     auto s_at = [&](int k) -> double { return k >= 0 ? in[LX(k)] : hist[8 + k]; };
