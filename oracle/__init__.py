@@ -473,3 +473,71 @@ class Spatializer:
         a = _f64(aux) if aux is not None else None
         lib().gdgo_spatializer_process(self._h, ptrs, n_in, n, _ptr(a) if a is not None else None, _ptr(left), _ptr(right))
         return left, right
+
+
+# ---- wave sample codecs / level meter --------------------------------------------------------------
+WAVE_FORMATS = {"lpcm8": 0, "lpcm16": 1, "lpcm24": 2, "lpcm32": 3, "ieee32": 4, "ieee64": 5}
+
+
+class Meter(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("current_value", C.c_double), ("peak_value", C.c_double), ("sample_counter", C.c_uint64)]
+
+
+def _io_lib():
+    L = lib()
+    if not getattr(L, "_io_ready", False):
+        L.gdgo_wave_bytes_per_sample.restype = C.c_int
+        L.gdgo_wave_bytes_per_sample.argtypes = [C.c_int]
+        L.gdgo_wave_encode.restype = C.c_int
+        L.gdgo_wave_encode.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gdgo_wave_decode.restype = C.c_int
+        L.gdgo_wave_decode.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gdgo_meter_init.argtypes = [C.POINTER(Meter)]
+        L.gdgo_meter_set_enabled.argtypes = [C.POINTER(Meter), C.c_int]
+        L.gdgo_meter_process.argtypes = [C.POINTER(Meter), C.c_void_p, C.c_size_t, C.c_uint32]
+        L.gdgo_meter_analyze.argtypes = [C.POINTER(Meter), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L._io_ready = True
+    return L
+
+
+def wave_encode(fmt, samples):
+    L = _io_lib()
+    f = WAVE_FORMATS[fmt] if isinstance(fmt, str) else fmt
+    s = _f64(samples)
+    out = np.zeros(len(s) * L.gdgo_wave_bytes_per_sample(f), dtype=np.uint8)
+    assert L.gdgo_wave_encode(f, _ptr(s), len(s), _ptr(out)) == 0
+    return out
+
+
+def wave_decode(fmt, data):
+    L = _io_lib()
+    f = WAVE_FORMATS[fmt] if isinstance(fmt, str) else fmt
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    n = len(d) // L.gdgo_wave_bytes_per_sample(f)
+    out = np.zeros(n)
+    assert L.gdgo_wave_decode(f, _ptr(d), n, _ptr(out)) == 0
+    return out
+
+
+class ChannelMeter:
+    """level.channelMeterStruct (level/level.go:147-210)"""
+
+    def __init__(self):
+        self._m = Meter()
+        _io_lib().gdgo_meter_init(C.byref(self._m))
+
+    def set_enabled(self, on):
+        _io_lib().gdgo_meter_set_enabled(C.byref(self._m), 1 if on else 0)
+
+    def process(self, buf, sample_rate):
+        b = _f64(buf)
+        _io_lib().gdgo_meter_process(C.byref(self._m), _ptr(b), len(b), sample_rate)
+
+    def analyze(self):
+        lv, pk = C.c_int32(0), C.c_int32(0)
+        _io_lib().gdgo_meter_analyze(C.byref(self._m), C.byref(lv), C.byref(pk))
+        return lv.value, pk.value
+
+    @property
+    def state(self):
+        return self._m.current_value, self._m.peak_value, self._m.sample_counter

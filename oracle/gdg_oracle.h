@@ -154,6 +154,19 @@ void gdgo_spatializer_set_sample_rate(gdgo_spatializer *s, uint32_t rate);
 void gdgo_spatializer_process(gdgo_spatializer *s, const double *const *inputs, int n_in, int n,
                               const double *aux, double *out_left, double *out_right);
 
+/* ---- wave/wave.go sample codecs ------------------------------------------ */
+enum { GDGO_FMT_LPCM8 = 0, GDGO_FMT_LPCM16, GDGO_FMT_LPCM24, GDGO_FMT_LPCM32, GDGO_FMT_IEEE32, GDGO_FMT_IEEE64 };
+int gdgo_wave_bytes_per_sample(int fmt);
+int gdgo_wave_encode(int fmt, const double *samples, size_t n, uint8_t *data);
+int gdgo_wave_decode(int fmt, const uint8_t *data, size_t n, double *samples);
+
+/* ---- level/level.go channel meter ---------------------------------------- */
+typedef struct { int enabled; double current_value, peak_value; uint64_t sample_counter; } gdgo_meter;
+void gdgo_meter_init(gdgo_meter *m);
+void gdgo_meter_set_enabled(gdgo_meter *m, int enabled);
+void gdgo_meter_process(gdgo_meter *m, const double *buffer, size_t n, uint32_t sample_rate);
+void gdgo_meter_analyze(const gdgo_meter *m, int32_t *level, int32_t *peak);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,8 @@ FILES = {
     "resample": "resample/resample_test.go",
     "random": "random/random_test.go",
     "circular": "circular/circular_test.go",
+    "wave": "wave/wave_test.go",
+    "level": "level/level_test.go",
 }
 
 NUM = r"-?(?:0x[0-9a-fA-F]+|\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+)"
@@ -78,7 +80,7 @@ def extract(path):
         f_end = find_matching(src, fm.end() - 1)
         fbody_start = fm.end()
         entry = {}
-        for vm in re.finditer(r"(\w+) := ((?:\[\])+(?:float64|complex128|uint64|int|uint32))\s*\{", src[fbody_start:f_end]):
+        for vm in re.finditer(r"(\w+) := ((?:\[\])+(?:float64|complex128|uint64|int|uint32|byte|int32))\s*\{", src[fbody_start:f_end]):
             var, type_str = vm.group(1), vm.group(2)
             pos = fbody_start + vm.end() - 1
             value, _ = parse_literal(src, pos, type_str)

@@ -153,3 +153,44 @@ def test_ring(oracle, golden):
         assert rc == 0
         np.testing.assert_array_equal(g, w)
     assert r.retrieve(4)[0] != 0
+
+
+# ---- wave/wave_test.go: byte-exact sample codecs ------------------------------------------------
+WAVE_CASES = [("lpcm8", "PCM8", 1), ("lpcm16", "PCM16", 2), ("lpcm24", "PCM24", 3), ("lpcm32", "PCM32", 4), ("ieee32", "IEEE32", 4), ("ieee64", "IEEE64", 8)]
+
+
+@pytest.mark.parametrize("fmt,tag,width", WAVE_CASES)
+def test_wave_export_data_section_is_byte_exact(oracle, golden, fmt, tag, width):
+    t = golden("wave")["tests"]["TestExport%sMono" % tag]       # wave_test.go: samples -> file bytes; the data chunk is the tail
+    samples = t["samples"]["value"]
+    want = np.array(t["expectedOutput"]["value"], dtype=np.uint8)[-len(samples) * width:]
+    np.testing.assert_array_equal(oracle.wave_encode(fmt, samples), want)
+
+
+@pytest.mark.parametrize("fmt,tag,width", WAVE_CASES)
+def test_wave_import_samples(oracle, golden, fmt, tag, width):
+    t = golden("wave")["tests"]["TestImport%sMono" % tag]
+    want = np.array(t["expectedSamples"]["value"])
+    data = np.array(t["buf"]["value"], dtype=np.uint8)[-len(want) * width:]
+    # the reference's own per-format tolerances (wave_test.go:319, :567, :819, :1077, :1335, :1613)
+    tol = {"lpcm8": 0.078125, "lpcm16": 3.0518e-5, "lpcm24": 1.1921e-7, "lpcm32": 4.6567e-10, "ieee32": 1.1921e-7, "ieee64": 1.0e-16}[fmt]
+    got = oracle.wave_decode(fmt, data)
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    if fmt != "lpcm8":      # decode(encode(x)) reproduces the quantised value exactly (8-bit: 127 vs 1/127 scaling is lossy by design)
+        np.testing.assert_array_equal(oracle.wave_decode(fmt, oracle.wave_encode(fmt, got)), got)
+
+
+# ---- level/level_test.go: known meter readings ---------------------------------------------------
+def test_level_meter_known_readings(oracle):
+    sr = 96000                                                    # level_test.go:17-224: one second of a 1 Hz sine
+    a = np.sin(2.0 * np.pi * (np.arange(sr) / float(sr)))
+    for buf, want in ((a, (-3, 0)), (0.5 * a, (-9, -6))):
+        m = oracle.ChannelMeter()
+        m.set_enabled(True)
+        m.process(buf, sr)
+        assert m.analyze() == want
+        m.set_enabled(False)
+        assert m.analyze() == (-200, -200)
+    m = oracle.ChannelMeter()                                     # a disabled meter ignores its input
+    m.process(a, sr)
+    assert m.analyze() == (-200, -200)
