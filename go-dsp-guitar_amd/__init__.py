@@ -26,7 +26,8 @@ UNIT_NAMES = [
 ]
 UNIT = {name: i for i, name in enumerate(UNIT_NAMES)}
 
-K_FIR_FWD, K_FIR_MAC, K_FIR_INV, K_SEGMENT, K_TUNER, K_SPATIALIZER = range(6)
+K_FIR_FWD, K_FIR_MAC, K_FIR_INV, K_SEGMENT, K_TUNER, K_SPATIALIZER, K_WAVE, K_RESAMPLE, K_METER = range(9)
+WAVE_FORMATS = {"lpcm8": 0, "lpcm16": 1, "lpcm24": 2, "lpcm32": 3, "ieee32": 4, "ieee64": 5}     # enum gdg_wave_format
 KERNEL_KINDS = ["fir_fwd", "fir_mac", "fir_inv", "segment", "tuner", "spatializer"]
 
 # every symbol include/gdg.h declares (checked by tests/test_abi.py)
@@ -37,6 +38,9 @@ ABI_SYMBOLS = [
     "gdg_staging_buffers", "gdg_process_staged", "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
     "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_analyze", "gdg_tuner_note_name",
     "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device",
+    "gdg_wave_bytes_per_sample", "gdg_wave_decode", "gdg_wave_decode_device", "gdg_wave_encode", "gdg_wave_encode_device",
+    "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
+    "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
 ]
 
 
@@ -105,6 +109,20 @@ def lib():
             "gdg_spatializer_set_sample_rate": (i32, [vp, u32]),
             "gdg_spatialize": (i32, [vp, vp, vp, vp, i32]),
             "gdg_spatialize_device": (i32, [vp, vp, vp, i32]),
+            "gdg_wave_bytes_per_sample": (i32, [i32]),
+            "gdg_wave_decode": (i32, [vp, i32, vp, C.c_size_t, C.c_uint, vp]),
+            "gdg_wave_decode_device": (i32, [vp, i32, vp, C.c_size_t, C.c_uint, vp]),
+            "gdg_wave_encode": (i32, [vp, i32, vp, C.c_size_t, C.c_uint, vp]),
+            "gdg_wave_encode_device": (i32, [vp, i32, vp, C.c_size_t, C.c_uint, vp]),
+            "gdg_resample_time_length": (i32, [i32, u32, u32]),
+            "gdg_resample_time": (i32, [vp, vp, i32, u32, u32, vp, i32]),
+            "gdg_resample_time_device": (i32, [vp, vp, i32, u32, u32, vp, i32]),
+            "gdg_meter_configure": (i32, [vp, i32]),
+            "gdg_meter_set_enabled": (i32, [vp, i32, i32]),
+            "gdg_meter_process": (i32, [vp, vp, i32, u32]),
+            "gdg_meter_process_device": (i32, [vp, vp, C.c_size_t, i32, u32]),
+            "gdg_meter_analyze": (i32, [vp, vp, vp]),
+            "gdg_meter_state": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_uint64)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -316,3 +334,58 @@ class Context:
         pi = d_x.ptr if isinstance(d_x, DeviceBuffer) else d_x
         po = d_out_lr.ptr if isinstance(d_out_lr, DeviceBuffer) else d_out_lr
         self._check(lib().gdg_spatialize_device(self._h, pi, po, frames))
+
+    # -- data formats either side of the path -------------------------------------------
+    def wave_decode(self, fmt, data, channels=1):
+        """Data section of a WAVE file (interleaved bytes) -> planar float64 [channels][n]."""
+        f = WAVE_FORMATS[fmt] if isinstance(fmt, str) else fmt
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        w = lib().gdg_wave_bytes_per_sample(f)
+        per = data.size // (w * channels) if w else 0
+        out = np.empty((channels, per), dtype=np.float64)
+        self._check(lib().gdg_wave_decode(self._h, f, data.ctypes.data, per, channels, out.ctypes.data))
+        return out[0] if channels == 1 else out
+
+    def wave_encode(self, fmt, samples):
+        """Planar float64 [channels][n] (or [n]) -> interleaved little-endian bytes."""
+        f = WAVE_FORMATS[fmt] if isinstance(fmt, str) else fmt
+        x = _f64(samples)
+        channels, per = (1, x.size) if x.ndim == 1 else x.shape
+        out = np.empty(channels * per * max(lib().gdg_wave_bytes_per_sample(f), 1), dtype=np.uint8)
+        self._check(lib().gdg_wave_encode(self._h, f, x.ctypes.data, per, channels, out.ctypes.data))
+        return out
+
+    def resample_time(self, samples, source_rate, target_rate):
+        x = _f64(samples)
+        n_out = lib().gdg_resample_time_length(x.size, source_rate, target_rate)
+        out = np.empty(max(n_out, 0), dtype=np.float64)
+        self._check(lib().gdg_resample_time(self._h, x.ctypes.data, x.size, source_rate, target_rate, out.ctypes.data, n_out))
+        return out
+
+    def meter_configure(self, n_ports):
+        self._n_ports = n_ports
+        self._check(lib().gdg_meter_configure(self._h, n_ports))
+
+    def meter_set_enabled(self, enabled, port=-1):
+        self._check(lib().gdg_meter_set_enabled(self._h, port, 1 if enabled else 0))
+
+    def meter_process(self, x, sample_rate):
+        x = _f64(x)
+        assert x.ndim == 2 and x.shape[0] == self._n_ports
+        ptrs = (C.c_void_p * self._n_ports)(*[x[p].ctypes.data for p in range(self._n_ports)])
+        self._check(lib().gdg_meter_process(self._h, ptrs, x.shape[1], sample_rate))
+
+    def meter_process_device(self, d_rows, row_stride, frames, sample_rate):
+        p = d_rows.ptr if isinstance(d_rows, DeviceBuffer) else d_rows
+        self._check(lib().gdg_meter_process_device(self._h, p, row_stride, frames, sample_rate))
+
+    def meter_analyze(self):
+        lv = np.empty(self._n_ports, dtype=np.int32)
+        pk = np.empty(self._n_ports, dtype=np.int32)
+        self._check(lib().gdg_meter_analyze(self._h, lv.ctypes.data, pk.ctypes.data))
+        return lv, pk
+
+    def meter_state(self, port):
+        c, p, n = C.c_double(), C.c_double(), C.c_uint64()
+        self._check(lib().gdg_meter_state(self._h, port, C.byref(c), C.byref(p), C.byref(n)))
+        return c.value, p.value, n.value

@@ -114,6 +114,11 @@ struct gdg_ctx {
     gdg_spat_chan *d_sp_chan = nullptr;
     double *d_sp_partial = nullptr, *d_sp_out = nullptr;
     bool sp_dirty = true;
+    /* io (wave codecs, resample.Time, level meters) */
+    void *d_io[2] = { nullptr, nullptr };
+    size_t io_cap[2] = { 0, 0 };
+    gdg_meter_rec *d_meter = nullptr;
+    int n_meter = 0;
 };
 
 static int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {
@@ -220,7 +225,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
     hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
-    hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_partial); hipFree(ctx->d_sp_out);
+    hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_partial); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1218,6 +1223,231 @@ int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, doub
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out_left, ctx->h_stage_out, (size_t)frames * sizeof(double));
     memcpy(out_right, ctx->h_stage_out + frames, (size_t)frames * sizeof(double));
+    return GDG_OK;
+}
+
+/* ================================================================================================
+ * Data formats either side of the path: wave codecs, resample.Time, level meters
+ * ============================================================================================== */
+
+static int ensure_io(gdg_ctx *ctx, int which, size_t bytes) {
+    if (ctx->io_cap[which] >= bytes) return GDG_OK;
+    if (ctx->d_io[which]) { hipStreamSynchronize(ctx->stream); hipFree(ctx->d_io[which]); ctx->d_io[which] = nullptr; ctx->io_cap[which] = 0; }
+    size_t cap = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&ctx->d_io[which], cap) != hipSuccess) return fail(ctx, GDG_ERR_NOMEM, "cannot allocate %zu bytes of io scratch", cap);
+    ctx->io_cap[which] = cap;
+    return GDG_OK;
+}
+
+int gdg_wave_bytes_per_sample(int format) {
+    static const int w[GDG_FMT_COUNT] = { 1, 2, 3, 4, 4, 8 };
+    return (format >= 0 && format < GDG_FMT_COUNT) ? w[format] : 0;
+}
+
+int gdg_wave_decode_device(gdg_ctx *ctx, int format, const void *d_bytes, size_t per, unsigned channels, double *d_samples) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (!gdg_wave_bytes_per_sample(format)) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", format);
+    if (channels == 0) return fail(ctx, GDG_ERR_INVALID, "channel count must be positive");
+    if (per == 0) return GDG_OK;
+    if (!d_bytes || !d_samples) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    ProfScope ps(ctx, GDG_K_WAVE);
+    HIP_TRY(ctx, gdg_launch_wave_decode(format, d_bytes, per, channels, d_samples, ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_wave_encode_device(gdg_ctx *ctx, int format, const double *d_samples, size_t per, unsigned channels, void *d_bytes) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (!gdg_wave_bytes_per_sample(format)) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", format);
+    if (channels == 0) return fail(ctx, GDG_ERR_INVALID, "channel count must be positive");
+    if (per == 0) return GDG_OK;
+    if (!d_bytes || !d_samples) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    ProfScope ps(ctx, GDG_K_WAVE);
+    HIP_TRY(ctx, gdg_launch_wave_encode(format, d_samples, per, channels, d_bytes, ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_wave_decode(gdg_ctx *ctx, int format, const void *bytes, size_t per, unsigned channels, double *samples) {
+    if (!ctx) return GDG_ERR_INVALID;
+    int w = gdg_wave_bytes_per_sample(format);
+    if (!w) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", format);
+    if (channels == 0) return fail(ctx, GDG_ERR_INVALID, "channel count must be positive");
+    size_t n = per * channels;
+    if (n == 0) return GDG_OK;
+    if (!bytes || !samples) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure_io(ctx, 0, n * w);
+    if (rc == GDG_OK) rc = ensure_io(ctx, 1, n * sizeof(double));
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_io[0], bytes, n * w, hipMemcpyHostToDevice, ctx->stream));
+    rc = gdg_wave_decode_device(ctx, format, ctx->d_io[0], per, channels, static_cast<double *>(ctx->d_io[1]));
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(samples, ctx->d_io[1], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_wave_encode(gdg_ctx *ctx, int format, const double *samples, size_t per, unsigned channels, void *bytes) {
+    if (!ctx) return GDG_ERR_INVALID;
+    int w = gdg_wave_bytes_per_sample(format);
+    if (!w) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", format);
+    if (channels == 0) return fail(ctx, GDG_ERR_INVALID, "channel count must be positive");
+    size_t n = per * channels;
+    if (n == 0) return GDG_OK;
+    if (!bytes || !samples) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure_io(ctx, 0, n * w);
+    if (rc == GDG_OK) rc = ensure_io(ctx, 1, n * sizeof(double));
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_io[1], samples, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = gdg_wave_encode_device(ctx, format, static_cast<const double *>(ctx->d_io[1]), per, channels, ctx->d_io[0]);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(bytes, ctx->d_io[0], n * w, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+/* resample/resample.go:72-87 */
+int gdg_resample_time_length(int input_length, uint32_t source_rate, uint32_t target_rate) {
+    if (input_length < 0 || source_rate == 0 || target_rate == 0) return -1;
+    double expansion = (double)target_rate / (double)source_rate;
+    double out_len_f = (double)input_length * expansion;
+    double out_len_floor = floor(out_len_f);
+    int out_len = (int)out_len_floor;
+    if (out_len_floor == out_len_f) out_len--;
+    return out_len < 0 ? 0 : out_len;
+}
+
+int gdg_resample_time_device(gdg_ctx *ctx, const double *d_samples, int n, uint32_t source_rate, uint32_t target_rate, double *d_out, int n_out) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (source_rate == 0 || target_rate == 0 || n < 0) return fail(ctx, GDG_ERR_INVALID, "invalid rates or length");
+    if (n_out != gdg_resample_time_length(n, source_rate, target_rate))
+        return fail(ctx, GDG_ERR_INVALID, "output length %d does not follow the reference's length rule (%d)", n_out,
+                    gdg_resample_time_length(n, source_rate, target_rate));
+    if (n_out == 0) return GDG_OK;
+    if (!d_samples || !d_out) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    double dx = (double)source_rate / (double)target_rate;       /* resample.go:88-90 */
+    ProfScope ps(ctx, GDG_K_RESAMPLE);
+    HIP_TRY(ctx, gdg_launch_resample_time(d_samples, n, dx, d_out, n_out, ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_resample_time(gdg_ctx *ctx, const double *samples, int n, uint32_t source_rate, uint32_t target_rate, double *out, int n_out) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (n_out == 0 && n >= 0 && source_rate && target_rate && gdg_resample_time_length(n, source_rate, target_rate) == 0) return GDG_OK;
+    if (!samples || !out || n <= 0 || n_out < 0) return fail(ctx, GDG_ERR_INVALID, "invalid buffers");
+    hipSetDevice(ctx->device);
+    int rc = ensure_io(ctx, 0, (size_t)n * sizeof(double));
+    if (rc == GDG_OK) rc = ensure_io(ctx, 1, (size_t)(n_out > 0 ? n_out : 1) * sizeof(double));
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_io[0], samples, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = gdg_resample_time_device(ctx, static_cast<const double *>(ctx->d_io[0]), n, source_rate, target_rate, static_cast<double *>(ctx->d_io[1]), n_out);
+    if (rc != GDG_OK) return rc;
+    if (n_out > 0) HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_io[1], (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+/* ---- level meters ----------------------------------------------------------------------------------------- */
+#define METER_PEAK_HOLD_SECONDS 2       /* level/level.go:12 */
+#define METER_TIME_CONSTANT 1.7         /* level/level.go:13 */
+#define METER_MIN_LEVEL (-200.0)        /* level/level.go:14 */
+
+int gdg_meter_configure(gdg_ctx *ctx, int n_ports) {
+    if (!ctx || n_ports < 0) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_meter) { hipFree(ctx->d_meter); ctx->d_meter = nullptr; }
+    ctx->n_meter = 0;
+    if (n_ports == 0) return GDG_OK;
+    if (hipMalloc(&ctx->d_meter, (size_t)n_ports * sizeof(gdg_meter_rec)) != hipSuccess) return fail(ctx, GDG_ERR_NOMEM, "cannot allocate meter state");
+    HIP_TRY(ctx, hipMemset(ctx->d_meter, 0, (size_t)n_ports * sizeof(gdg_meter_rec)));
+    ctx->n_meter = n_ports;
+    return GDG_OK;
+}
+
+int gdg_meter_set_enabled(gdg_ctx *ctx, int port, int enabled) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (port >= ctx->n_meter) return fail(ctx, GDG_ERR_INVALID, "meter port %d out of range (%d configured)", port, ctx->n_meter);
+    if (ctx->n_meter == 0) return GDG_OK;
+    hipSetDevice(ctx->device);
+    std::vector<gdg_meter_rec> st(ctx->n_meter);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(st.data(), ctx->d_meter, st.size() * sizeof(gdg_meter_rec), hipMemcpyDeviceToHost));
+    int lo = port < 0 ? 0 : port, hi = port < 0 ? ctx->n_meter : port + 1;
+    for (int p = lo; p < hi; p++) {
+        if ((enabled != 0) == (st[p].enabled != 0)) continue;           /* level.go:264: only a change acts */
+        if (!enabled) { st[p].current = 0.0; st[p].peak = 0.0; st[p].counter = 0; }
+        st[p].enabled = enabled != 0;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_meter, st.data(), st.size() * sizeof(gdg_meter_rec), hipMemcpyHostToDevice));
+    return GDG_OK;
+}
+
+int gdg_meter_process_device(gdg_ctx *ctx, const double *d_rows, size_t row_stride, int frames, uint32_t sample_rate) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (ctx->n_meter == 0 || frames == 0) return GDG_OK;
+    if (!d_rows || frames < 0 || sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "invalid meter input");
+    hipSetDevice(ctx->device);
+    double sr = (double)sample_rate;                                   /* level.go:166-171 */
+    unsigned long long hold = (unsigned long long)(METER_PEAK_HOLD_SECONDS * sr);
+    double decay = pow(10.0, -1.0 / (METER_TIME_CONSTANT * sr));
+    int seg = GDG_METER_SEG;
+    if ((unsigned long long)seg > hold) seg = (int)hold;             /* the kernel's single-record argument needs n <= hold */
+    ProfScope ps(ctx, GDG_K_METER);
+    for (int off = 0; off < frames; off += seg) {
+        int n = frames - off < seg ? frames - off : seg;
+        HIP_TRY(ctx, gdg_launch_meter(d_rows + off, row_stride, ctx->n_meter, n, ctx->d_meter, decay, hold, ctx->stream));
+    }
+    return GDG_OK;
+}
+
+int gdg_meter_process(gdg_ctx *ctx, const double *const *buffers, int frames, uint32_t sample_rate) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (ctx->n_meter == 0 || frames == 0) return GDG_OK;
+    if (!buffers || frames < 0) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure_io(ctx, 1, (size_t)ctx->n_meter * frames * sizeof(double));
+    if (rc != GDG_OK) return rc;
+    double *d = static_cast<double *>(ctx->d_io[1]);
+    for (int p = 0; p < ctx->n_meter; p++) {
+        if (!buffers[p]) return fail(ctx, GDG_ERR_INVALID, "meter buffer %d is null", p);
+        HIP_TRY(ctx, hipMemcpyAsync(d + (size_t)p * frames, buffers[p], (size_t)frames * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = gdg_meter_process_device(ctx, d, (size_t)frames, frames, sample_rate);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+static int32_t to_decibels_int(double value) {                         /* level.go:100-118 */
+    double level = 20.0 * log10(value);
+    if (std::isnan(level) || level < METER_MIN_LEVEL) level = METER_MIN_LEVEL;
+    return (int32_t)round(level);
+}
+
+int gdg_meter_analyze(gdg_ctx *ctx, int32_t *levels, int32_t *peaks) {
+    if (!ctx || !levels || !peaks) return GDG_ERR_INVALID;
+    if (ctx->n_meter == 0) return GDG_OK;
+    hipSetDevice(ctx->device);
+    std::vector<gdg_meter_rec> st(ctx->n_meter);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(st.data(), ctx->d_meter, st.size() * sizeof(gdg_meter_rec), hipMemcpyDeviceToHost));
+    for (int p = 0; p < ctx->n_meter; p++) { levels[p] = to_decibels_int(st[p].current); peaks[p] = to_decibels_int(st[p].peak); }
+    return GDG_OK;
+}
+
+int gdg_meter_state(gdg_ctx *ctx, int port, double *current, double *peak, uint64_t *counter) {
+    if (!ctx || port < 0 || port >= ctx->n_meter) return GDG_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    gdg_meter_rec st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(&st, ctx->d_meter + port, sizeof(st), hipMemcpyDeviceToHost));
+    if (current) *current = st.current;
+    if (peak) *peak = st.peak;
+    if (counter) *counter = st.counter;
     return GDG_OK;
 }
 

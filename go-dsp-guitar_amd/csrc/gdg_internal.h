@@ -119,4 +119,17 @@ hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, doub
                                     const double2 *d_tw_n, const double2 *d_tw_m, const double2 *d_tw512, const double2 *d_tw256,
                                     const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s);
 
+/* ------------------------------------------------------------------------------------------------
+ * io.hip: the data formats either side of the path: wave sample codecs, resample.Time,
+ * level meters.  Planar float64 [channels][per] on the sample side, interleaved little-endian bytes on
+ * the file side.
+ * ---------------------------------------------------------------------------------------------- */
+#define GDG_METER_SEG 8192
+struct gdg_meter_rec { double current, peak; unsigned long long counter; int enabled, pad; };
+hipError_t gdg_launch_wave_decode(int fmt, const void *d_bytes, size_t per, unsigned channels, double *d_out, hipStream_t s);
+hipError_t gdg_launch_wave_encode(int fmt, const double *d_in, size_t per, unsigned channels, void *d_bytes, hipStream_t s);
+hipError_t gdg_launch_resample_time(const double *d_in, int n, double dx, double *d_out, int n_out, hipStream_t s);
+hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, int n, gdg_meter_rec *d_state,
+                            double decay, unsigned long long hold, hipStream_t s);
+
 #endif

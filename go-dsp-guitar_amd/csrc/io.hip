@@ -5,6 +5,7 @@
  * Both are embarrassingly parallel and HBM bound (1..8 B in + 8 B out per sample for the codecs;
  * ~6 x 8 B gathered (cache hits) + 8 B out for the resampler, which is sin()-bound in FP64).
  */
+#include "../../include/gdg.h"
 #include "gdg_internal.h"
 #include <math.h>
 
@@ -16,38 +17,40 @@ __device__ __forceinline__ double clamp1(double s) { return s < -1.0 ? -1.0 : (s
 
 template <int FMT>
 __global__ void __launch_bounds__(256)
-wave_decode_kernel(const unsigned char *__restrict__ data, size_t n, double *__restrict__ out) {
+wave_decode_kernel(const unsigned char *__restrict__ data, size_t n, double *__restrict__ out, unsigned channels, size_t per) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         double r;
         if (FMT == GDG_FMT_LPCM8) {                              /* wave.go:316-342 */
             short temp = (short)((short)data[i] + (-128));
             r = (1.0 / 127.0) * (double)temp;
             r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
-        } else if (FMT == GDG_FMT_LPCM16) {                      /* wave.go:400-427 */
+        } else if (FMT == GDG_FMT_LPCM16) {                      /* wave.go:400-428 */
             short s = (short)(unsigned short)(data[2 * i] | (data[2 * i + 1] << 8));
             r = (2.0 / 65535.0) * (double)s;
-        } else if (FMT == GDG_FMT_LPCM24) {                      /* wave.go:475-514 */
+        } else if (FMT == GDG_FMT_LPCM24) {                      /* wave.go:483-531 */
             unsigned w = (unsigned)data[3 * i] | ((unsigned)data[3 * i + 1] << 8) | ((unsigned)data[3 * i + 2] << 16);
             int v = (int)w;
             if (w & SIGN_BIT_INT24) v = MIN_INT24 + (v & MAX_INT24);
             r = (2.0 / 16777215.0) * (double)v;
-        } else if (FMT == GDG_FMT_LPCM32) {                      /* wave.go:567-594 */
+        } else if (FMT == GDG_FMT_LPCM32) {                      /* wave.go:589-617 */
             unsigned w = reinterpret_cast<const unsigned *>(data)[i];
             r = (2.0 / 4294967295.0) * (double)(int)w;
-        } else if (FMT == GDG_FMT_IEEE32) {                      /* wave.go:640-669 */
+        } else if (FMT == GDG_FMT_IEEE32) {                      /* wave.go:662-689 */
             r = (double)reinterpret_cast<const float *>(data)[i];
-        } else {                                                 /* wave.go:695-714 */
+        } else {                                                 /* wave.go:714-732 */
             r = reinterpret_cast<const double *>(data)[i];
         }
-        out[i] = r;
+        /* samplesToChannels (wave.go:237-270): interleaved sample i belongs to channel i % C, position i / C */
+        out[channels == 1 ? i : (size_t)(i % channels) * per + i / channels] = r;
     }
 }
 
 template <int FMT>
 __global__ void __launch_bounds__(256)
-wave_encode_kernel(const double *__restrict__ in, size_t n, unsigned char *__restrict__ data) {
+wave_encode_kernel(const double *__restrict__ in, size_t n, unsigned char *__restrict__ data, unsigned channels, size_t per) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        double sample = in[i];
+        /* channelsToSamples (wave.go:173-232) */
+        double sample = in[channels == 1 ? i : (size_t)(i % channels) * per + i / channels];
         if (FMT == GDG_FMT_LPCM8) {                              /* wave.go:275-311 */
             sample = clamp1(sample);
             short temp = (short)(127.0 * sample);
@@ -58,7 +61,7 @@ wave_encode_kernel(const double *__restrict__ in, size_t n, unsigned char *__res
             int tmp = (int)((0.5 * 65535.0) * sample);
             tmp = tmp > 32767 ? 32767 : (tmp < -32768 ? -32768 : tmp);
             reinterpret_cast<short *>(data)[i] = (short)tmp;
-        } else if (FMT == GDG_FMT_LPCM24) {                      /* wave.go:433-470 */
+        } else if (FMT == GDG_FMT_LPCM24) {                      /* wave.go:433-478 */
             sample = clamp1(sample);
             int tmp = (int)((0.5 * 16777215.0) * sample);
             tmp = tmp > MAX_INT24 ? MAX_INT24 : (tmp < MIN_INT24 ? MIN_INT24 : tmp);
@@ -66,14 +69,14 @@ wave_encode_kernel(const double *__restrict__ in, size_t n, unsigned char *__res
             data[3 * i] = (unsigned char)(u & 0xff);
             data[3 * i + 1] = (unsigned char)((u >> 8) & 0xff);
             data[3 * i + 2] = (unsigned char)((u >> 16) & 0xff);
-        } else if (FMT == GDG_FMT_LPCM32) {                      /* wave.go:519-562 */
+        } else if (FMT == GDG_FMT_LPCM32) {                      /* wave.go:536-584 */
             sample = clamp1(sample);
             long long tmp = (long long)((0.5 * 4294967295.0) * sample);
             tmp = tmp > 2147483647LL ? 2147483647LL : (tmp < -2147483648LL ? -2147483648LL : tmp);
             reinterpret_cast<int *>(data)[i] = (int)tmp;
-        } else if (FMT == GDG_FMT_IEEE32) {                      /* wave.go:599-635 */
+        } else if (FMT == GDG_FMT_IEEE32) {                      /* wave.go:622-657 */
             reinterpret_cast<float *>(data)[i] = (float)clamp1(sample);
-        } else {                                                 /* wave.go:674-690: no clipping */
+        } else {                                                 /* wave.go:694-709: no clipping */
             reinterpret_cast<double *>(data)[i] = sample;
         }
     }
@@ -111,39 +114,146 @@ resample_time_kernel(const double *__restrict__ s, int n, double dx, double *__r
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * level/level.go:147-210 channel meter, one workgroup per port, at most GDG_METER_SEG samples per launch.
+ *   current:  c <- max(c * d, |x|)  ==  max(c0 d^n, max_i |x_i| d^(n-1-i))            (weighted max reduction)
+ *   peak/hold: the reference's per-sample state machine (decay once the counter passed `hold`, a sample
+ *   >= peak records and restarts the hold) has, within a segment of n <= hold samples, exactly one
+ *   interesting event: the FIRST record r.  Before it the peak is p0 (hold phase) or p0 d^k (decay phase,
+ *   closed form); after it the peak is the running maximum of |x_r..|, the counter the distance to the LAST
+ *   sample attaining that maximum.  The host guarantees n <= hold (gdg_meter_process splits).
+ * ---------------------------------------------------------------------------------------------- */
+#define METER_T 1024
+#define METER_CHK (GDG_METER_SEG / METER_T)
+
+__device__ __forceinline__ double block_max_d(double v, double *scr) {
+    int tid = threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+    __syncthreads();
+    if ((tid & 63) == 0) scr[tid >> 6] = v;
+    __syncthreads();
+    double r = scr[0];
+    for (int w = 1; w < METER_T / 64; w++) r = fmax(r, scr[w]);
+    return r;
+}
+__device__ __forceinline__ int block_max_i(int v, int *scr) {
+    int tid = threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o));
+    __syncthreads();
+    if ((tid & 63) == 0) scr[tid >> 6] = v;
+    __syncthreads();
+    int r = scr[0];
+    for (int w = 1; w < METER_T / 64; w++) r = max(r, scr[w]);
+    return r;
+}
+
+__global__ void __launch_bounds__(METER_T)
+meter_kernel(const double *__restrict__ rows, size_t stride, int n, gdg_meter_rec *__restrict__ st,
+             double decay, unsigned long long hold) {
+    __shared__ double scr_d[METER_T / 64];
+    __shared__ int scr_i[METER_T / 64];
+    const int tid = threadIdx.x;
+    gdg_meter_rec *m = st + blockIdx.x;
+    if (!m->enabled) return;
+    const double *x = rows + (size_t)blockIdx.x * stride;
+    const double c0 = m->current, p0 = m->peak;
+    const unsigned long long cnt0 = m->counter;
+    const int base = tid * METER_CHK;
+
+    double a[METER_CHK];
+#pragma unroll
+    for (int k = 0; k < METER_CHK; k++) a[k] = (base + k < n) ? fabs(x[base + k]) : -1.0;
+
+    /* current value: zero-state follower over the chunk, then its decay to the end of the segment */
+    double b = 0.0;
+    int len = 0;
+#pragma unroll
+    for (int k = 0; k < METER_CHK; k++)
+        if (base + k < n) { b *= decay; if (a[k] > b) b = a[k]; len++; }
+    double contrib = (len > 0) ? b * pow(decay, (double)(n - base - len)) : 0.0;
+    double cur = fmax(block_max_d(contrib, scr_d), c0 * pow(decay, (double)n));
+
+    /* first record: smallest i with |x_i| >= p_i;  p_i = p0 for i < e, p0 d^(i-e+1) from e on */
+    const long long e = (cnt0 > hold) ? 0 : (long long)(hold - cnt0) + 1;
+    double p = p0;
+    if ((long long)base >= e) p = p0 * pow(decay, (double)((long long)base - e));      /* value before sample `base` decays */
+    int first = n;
+#pragma unroll
+    for (int k = 0; k < METER_CHK; k++) {
+        int i = base + k;
+        if (i < n) {
+            if ((long long)i >= e) p *= decay;
+            if (first == n && a[k] >= p) first = i;
+        }
+    }
+    const int r = n - block_max_i(n - first, scr_i);        /* min over the block */
+
+    double peak;
+    unsigned long long counter;
+    if (r >= n) {       /* no record in this segment */
+        long long dec = (long long)n - e;
+        peak = (dec > 0) ? p0 * pow(decay, (double)dec) : p0;
+        counter = (cnt0 > hold) ? cnt0 : ((cnt0 + (unsigned long long)n < hold + 1) ? cnt0 + (unsigned long long)n : hold + 1);
+    } else {
+        double mx = -1.0;
+#pragma unroll
+        for (int k = 0; k < METER_CHK; k++)
+            if (base + k >= r && a[k] > mx) mx = a[k];
+        peak = block_max_d(mx, scr_d);
+        int last = -1;
+#pragma unroll
+        for (int k = 0; k < METER_CHK; k++)
+            if (base + k >= r && base + k < n && a[k] == peak) last = base + k;
+        last = block_max_i(last, scr_i);
+        counter = (unsigned long long)(n - 1 - last);
+    }
+    __syncthreads();
+    if (tid == 0) { m->current = cur; m->peak = peak; m->counter = counter; }
+}
+
+hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, int n, gdg_meter_rec *d_state,
+                            double decay, unsigned long long hold, hipStream_t s) {
+    if (n_ports <= 0 || n <= 0) return hipSuccess;
+    if (n > GDG_METER_SEG) return hipErrorInvalidValue;
+    meter_kernel<<<n_ports, METER_T, 0, s>>>(d_rows, stride, n, d_state, decay, hold);
+    return hipGetLastError();
+}
+
 static int grid_for(size_t n) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     return (int)(blocks ? blocks : 1);
 }
 
-hipError_t gdg_launch_wave_decode(int fmt, const void *d_bytes, size_t n, double *d_out, hipStream_t s) {
+hipError_t gdg_launch_wave_decode(int fmt, const void *d_bytes, size_t per, unsigned channels, double *d_out, hipStream_t s) {
+    size_t n = per * channels;
     if (n == 0) return hipSuccess;
     const unsigned char *p = static_cast<const unsigned char *>(d_bytes);
     int g = grid_for(n);
     switch (fmt) {
-    case GDG_FMT_LPCM8: wave_decode_kernel<GDG_FMT_LPCM8><<<g, 256, 0, s>>>(p, n, d_out); break;
-    case GDG_FMT_LPCM16: wave_decode_kernel<GDG_FMT_LPCM16><<<g, 256, 0, s>>>(p, n, d_out); break;
-    case GDG_FMT_LPCM24: wave_decode_kernel<GDG_FMT_LPCM24><<<g, 256, 0, s>>>(p, n, d_out); break;
-    case GDG_FMT_LPCM32: wave_decode_kernel<GDG_FMT_LPCM32><<<g, 256, 0, s>>>(p, n, d_out); break;
-    case GDG_FMT_IEEE32: wave_decode_kernel<GDG_FMT_IEEE32><<<g, 256, 0, s>>>(p, n, d_out); break;
-    case GDG_FMT_IEEE64: wave_decode_kernel<GDG_FMT_IEEE64><<<g, 256, 0, s>>>(p, n, d_out); break;
+    case GDG_FMT_LPCM8: wave_decode_kernel<GDG_FMT_LPCM8><<<g, 256, 0, s>>>(p, n, d_out, channels, per); break;
+    case GDG_FMT_LPCM16: wave_decode_kernel<GDG_FMT_LPCM16><<<g, 256, 0, s>>>(p, n, d_out, channels, per); break;
+    case GDG_FMT_LPCM24: wave_decode_kernel<GDG_FMT_LPCM24><<<g, 256, 0, s>>>(p, n, d_out, channels, per); break;
+    case GDG_FMT_LPCM32: wave_decode_kernel<GDG_FMT_LPCM32><<<g, 256, 0, s>>>(p, n, d_out, channels, per); break;
+    case GDG_FMT_IEEE32: wave_decode_kernel<GDG_FMT_IEEE32><<<g, 256, 0, s>>>(p, n, d_out, channels, per); break;
+    case GDG_FMT_IEEE64: wave_decode_kernel<GDG_FMT_IEEE64><<<g, 256, 0, s>>>(p, n, d_out, channels, per); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t gdg_launch_wave_encode(int fmt, const double *d_in, size_t n, void *d_bytes, hipStream_t s) {
+hipError_t gdg_launch_wave_encode(int fmt, const double *d_in, size_t per, unsigned channels, void *d_bytes, hipStream_t s) {
+    size_t n = per * channels;
     if (n == 0) return hipSuccess;
     unsigned char *p = static_cast<unsigned char *>(d_bytes);
     int g = grid_for(n);
     switch (fmt) {
-    case GDG_FMT_LPCM8: wave_encode_kernel<GDG_FMT_LPCM8><<<g, 256, 0, s>>>(d_in, n, p); break;
-    case GDG_FMT_LPCM16: wave_encode_kernel<GDG_FMT_LPCM16><<<g, 256, 0, s>>>(d_in, n, p); break;
-    case GDG_FMT_LPCM24: wave_encode_kernel<GDG_FMT_LPCM24><<<g, 256, 0, s>>>(d_in, n, p); break;
-    case GDG_FMT_LPCM32: wave_encode_kernel<GDG_FMT_LPCM32><<<g, 256, 0, s>>>(d_in, n, p); break;
-    case GDG_FMT_IEEE32: wave_encode_kernel<GDG_FMT_IEEE32><<<g, 256, 0, s>>>(d_in, n, p); break;
-    case GDG_FMT_IEEE64: wave_encode_kernel<GDG_FMT_IEEE64><<<g, 256, 0, s>>>(d_in, n, p); break;
+    case GDG_FMT_LPCM8: wave_encode_kernel<GDG_FMT_LPCM8><<<g, 256, 0, s>>>(d_in, n, p, channels, per); break;
+    case GDG_FMT_LPCM16: wave_encode_kernel<GDG_FMT_LPCM16><<<g, 256, 0, s>>>(d_in, n, p, channels, per); break;
+    case GDG_FMT_LPCM24: wave_encode_kernel<GDG_FMT_LPCM24><<<g, 256, 0, s>>>(d_in, n, p, channels, per); break;
+    case GDG_FMT_LPCM32: wave_encode_kernel<GDG_FMT_LPCM32><<<g, 256, 0, s>>>(d_in, n, p, channels, per); break;
+    case GDG_FMT_IEEE32: wave_encode_kernel<GDG_FMT_IEEE32><<<g, 256, 0, s>>>(d_in, n, p, channels, per); break;
+    case GDG_FMT_IEEE64: wave_encode_kernel<GDG_FMT_IEEE64><<<g, 256, 0, s>>>(d_in, n, p, channels, per); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -148,6 +148,9 @@ enum gdg_kernel_kind {
     GDG_K_SEGMENT,       /* fused per-sample units between FIR units */
     GDG_K_TUNER,
     GDG_K_SPATIALIZER,
+    GDG_K_WAVE,          /* wave sample codecs */
+    GDG_K_RESAMPLE,      /* resample.Time */
+    GDG_K_METER,         /* level meters */
     GDG_K_COUNT
 };
 /* enable != 0: bracket every kernel launch with a HIP event pair from now on (costs a little). */
@@ -182,7 +185,43 @@ int gdg_spatializer_set_sample_rate(gdg_ctx *ctx, uint32_t rate);
 int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, double *out_right, int frames);
 int gdg_spatialize_device(gdg_ctx *ctx, const double *d_in, double *d_out_lr, int frames);
 
+/* ---- data formats either side of the path ---------------------------------------- */
+
+/* wave/wave.go:51-60 sample formats x bit depths the reference reads and writes */
+enum gdg_wave_format { GDG_FMT_LPCM8 = 0, GDG_FMT_LPCM16, GDG_FMT_LPCM24, GDG_FMT_LPCM32, GDG_FMT_IEEE32, GDG_FMT_IEEE64, GDG_FMT_COUNT };
+int gdg_wave_bytes_per_sample(int format);      /* 0 for an unknown format */
+/*
+ * bytesToSamples + samplesToChannels (wave/wave.go:790-838, :237-270): the data section of a RIFF/WAVE file
+ * (interleaved, little endian, `channels` x `samples_per_channel` samples) -> planar float64
+ * [channels][samples_per_channel].  Bit exact with the reference.  Header parsing stays with the host.
+ */
+int gdg_wave_decode(gdg_ctx *ctx, int format, const void *bytes, size_t samples_per_channel, unsigned channels, double *samples);
+int gdg_wave_decode_device(gdg_ctx *ctx, int format, const void *d_bytes, size_t samples_per_channel, unsigned channels, double *d_samples);
+/* channelsToSamples + samplesToBytes (wave/wave.go:173-232, :737-785): the inverse, including the clipping rules. */
+int gdg_wave_encode(gdg_ctx *ctx, int format, const double *samples, size_t samples_per_channel, unsigned channels, void *bytes);
+int gdg_wave_encode_device(gdg_ctx *ctx, int format, const double *d_samples, size_t samples_per_channel, unsigned channels, void *d_bytes);
+
+/* resample.Time (resample/resample.go:72-103): Lanczos-3 rate conversion; the length rule is :72-87. */
+int gdg_resample_time_length(int input_length, uint32_t source_rate, uint32_t target_rate);
+int gdg_resample_time(gdg_ctx *ctx, const double *samples, int n, uint32_t source_rate, uint32_t target_rate, double *out, int n_out);
+int gdg_resample_time_device(gdg_ctx *ctx, const double *d_samples, int n, uint32_t source_rate, uint32_t target_rate, double *d_out, int n_out);
+
+/*
+ * level.Meter (level/level.go): n_ports independent channel meters (the reference runs 2N+3 of them:
+ * inputs, outputs, master L/R, metronome).  gdg_meter_configure (re)creates them disabled and cleared;
+ * process = level.go:147-210 for every enabled port over one buffer each; analyze = level.go:100-145
+ * (integer dB, -200 floor).
+ */
+int gdg_meter_configure(gdg_ctx *ctx, int n_ports);
+int gdg_meter_set_enabled(gdg_ctx *ctx, int port, int enabled);        /* port < 0: all ports (level.go:260-279) */
+int gdg_meter_process(gdg_ctx *ctx, const double *const *buffers, int frames, uint32_t sample_rate);
+int gdg_meter_process_device(gdg_ctx *ctx, const double *d_rows, size_t row_stride, int frames, uint32_t sample_rate);
+int gdg_meter_analyze(gdg_ctx *ctx, int32_t *levels, int32_t *peaks);
+/* raw meter state of one port (current value, held peak, hold counter) for parity tests */
+int gdg_meter_state(gdg_ctx *ctx, int port, double *current, double *peak, uint64_t *counter);
+
 #ifdef __cplusplus
+
 }
 #endif
 #endif
