@@ -234,3 +234,30 @@ def test_level_meter_device_rows(pkg, oracle):
             r.process(x[p], sr)
         assert (lv[p], pk[p]) == r.analyze()
         assert ctx.meter_state(p)[2] == r.state[2]
+
+
+def test_wave_device_entry_unaligned_buffers(pkg, ctx, oracle):
+    """The four-samples-per-thread fast path needs aligned buffers; odd device offsets take the scalar kernel."""
+    n = 5003
+    x = awkward_samples(n, 99)
+    d_x = ctx.alloc(1, n + 2)
+    d_b = ctx.alloc(1, n + 2)
+    for fmt, f in pkg.WAVE_FORMATS.items():
+        w = pkg.lib().gdg_wave_bytes_per_sample(f)
+        for off_s, off_b in ((0, 0), (8, 1), (8, 2), (0, 3), (8, 4)):
+            if fmt in ("lpcm32", "ieee32") and off_b % 4:
+                continue                                           # 32-bit containers stay naturally aligned
+            if fmt == "lpcm16" and off_b % 2:
+                continue
+            if fmt == "ieee64" and off_b:
+                continue
+            buf = np.zeros(n + 2)
+            buf.view(np.uint8)[off_s:off_s + 8 * n] = x.view(np.uint8)
+            d_x.upload(buf)
+            ctx._check(pkg.lib().gdg_wave_encode_device(ctx._h, f, d_x.ptr + off_s, n, 1, d_b.ptr + off_b))
+            got = d_b.download().view(np.uint8).reshape(-1)[off_b:off_b + n * w]
+            want = oracle.wave_encode(fmt, x)
+            np.testing.assert_array_equal(got, want)
+            ctx._check(pkg.lib().gdg_wave_decode_device(ctx._h, f, d_b.ptr + off_b, n, 1, d_x.ptr + off_s))
+            back = d_x.download().view(np.uint8).reshape(-1)[off_s:off_s + 8 * n].view(np.float64)
+            np.testing.assert_array_equal(back.view(np.uint64), oracle.wave_decode(fmt, want).view(np.uint64))
