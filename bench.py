@@ -154,7 +154,9 @@ def main():
     for _ in range(max(args.warmup, 1)):      # the first step also builds the plan and the IR spectra
         step()
     ctx.synchronize()
-    ctx.profile_enable(True)
+    # timed region: HIP events around the DOMINANT kernel only (the roofline's kernel; ~0.5 us per event record).
+    # Bracketing all eight launches of a step costs ~7% of the step, so the other kernels are timed in an untimed pass below.
+    ctx.profile_enable(kinds=[pkg.K_FIR_MAC])
     from go_dsp_guitar_amd import shard
 
     def synchronize():
@@ -165,9 +167,19 @@ def main():
     elapsed = shard.timed_steps(step, args.steps, synchronize, dist if distributed else None, dev)
     ctx.profile_enable(False)
     kernels = {}
+    ms, n = ctx.profile_read(pkg.K_FIR_MAC)
+    kernels["fir_mac"] = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None, "pass": "timed region"}
+    ctx.profile_enable(True)                      # untimed pass: the same steps again with every launch bracketed
+    for _ in range(args.steps):
+        step()
+    synchronize()
+    ctx.profile_enable(False)
     for kind, name in enumerate(pkg.KERNEL_KINDS[:4]):
         ms, n = ctx.profile_read(kind)
-        kernels[name] = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None}
+        if name == "fir_mac":
+            kernels["fir_mac"]["avg_ms_untimed_pass"] = (ms / n) if n else None
+            continue
+        kernels[name] = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None, "pass": "untimed, all launches bracketed"}
     finite = bool(torch.isfinite(y).all().item())
 
     if rank == 0:
@@ -176,11 +188,13 @@ def main():
         samples_per_step = nch * frames
         mac = kernels["fir_mac"]
         # algorithmic bytes of the MAC launch: K delay-line spectra + K IR spectra per channel (d = 1);
-        # its own write of Y is NOT counted (it would vanish in a fused kernel)
-        mac_bytes = nch * 2.0 * K * spec_bytes
+        # its own write of Y is NOT counted (it would vanish in a fused kernel).  With channel groups a step issues
+        # several smaller launches per FIR unit: bytes per launch = bytes per step / launches per step.
+        fir_per_chain = sum(1 for _, p in CHAIN if isinstance(p, str))
+        mac_bytes = nch * 2.0 * K * spec_bytes * fir_per_chain * args.steps / max(mac["launches"], 1)
         mac_gbs = mac_bytes / (mac["avg_ms"] * 1e-3) / 1e9 if mac["avg_ms"] else None
-        fir_ms = sum(kernels[k]["ms_total"] for k in ("fir_fwd", "fir_mac", "fir_inv"))
         fir_units = mac["launches"]
+        fir_ms = sum(kernels[k]["avg_ms"] * fir_units for k in ("fir_fwd", "fir_mac", "fir_inv"))
         fir_bytes_per_sample = 16.0 + 16.0 * (1 + 2 * K)              # SURVEY 8d B_conv with (P+1)/P -> 1 (packed bin 0)
         fir_gbs = fir_units * samples_per_step * fir_bytes_per_sample / (fir_ms * 1e-3) / 1e9 if fir_ms else None
         seg = kernels["segment"]

@@ -290,8 +290,10 @@ class Context:
         return lib().gdg_ctx_stream(self._h)
 
     # -- profiling ------------------------------------------------------------------------------------
-    def profile_enable(self, on=True):
-        self._check(lib().gdg_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, on=True, kinds=None):
+        """on: every kernel launch; kinds: only the listed kernel kinds (cheaper inside a timed region)."""
+        mask = sum(1 << (k + 1) for k in kinds) if kinds else (1 if on else 0)
+        self._check(lib().gdg_profile_enable(self._h, mask))
 
     def profile_read(self, kind):
         ms, n = C.c_double(0.0), C.c_int(0)

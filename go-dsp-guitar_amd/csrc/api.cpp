@@ -97,7 +97,7 @@ struct gdg_ctx {
     double *d_os = nullptr;
     gdg_os_tables os;
     /* profiling */
-    bool profiling = false;
+    unsigned profiling = 0;                  /* bit 0: everything; bit k+1: kernel kind k */
     std::vector<ProfEvent> prof;
     std::vector<hipEvent_t> event_pool;
     /* tuner / spatializer */
@@ -824,18 +824,19 @@ static hipEvent_t take_event(gdg_ctx *ctx) {
 }
 
 struct ProfScope {
-    gdg_ctx *ctx; int kind; hipEvent_t a = nullptr, b = nullptr;
+    gdg_ctx *ctx; int kind; hipEvent_t a = nullptr, b = nullptr; bool on = false;
     ProfScope(gdg_ctx *c, int k) : ctx(c), kind(k) {
-        if (ctx->profiling) { a = take_event(ctx); b = take_event(ctx); hipEventRecord(a, ctx->stream); }
+        on = (ctx->profiling & 1u) || (ctx->profiling & (1u << (k + 1)));
+        if (on) { a = take_event(ctx); b = take_event(ctx); hipEventRecord(a, ctx->stream); }
     }
     ~ProfScope() {
-        if (ctx->profiling) { hipEventRecord(b, ctx->stream); ctx->prof.push_back(ProfEvent{ kind, a, b }); }
+        if (on) { hipEventRecord(b, ctx->stream); ctx->prof.push_back(ProfEvent{ kind, a, b }); }
     }
 };
 
 int gdg_profile_enable(gdg_ctx *ctx, int enable) {
     if (!ctx) return GDG_ERR_INVALID;
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable < 0 ? 0u : (unsigned)enable;
     return GDG_OK;
 }
 

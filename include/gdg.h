@@ -153,7 +153,8 @@ enum gdg_kernel_kind {
     GDG_K_METER,         /* level meters */
     GDG_K_COUNT
 };
-/* enable != 0: bracket every kernel launch with a HIP event pair from now on (costs a little). */
+/* enable == 1: bracket every kernel launch with a HIP event pair from now on (costs a few microseconds per launch);
+ * enable == 1 << (kind + 1) (or-able): only the launches of those kernel kinds; 0: off. */
 int gdg_profile_enable(gdg_ctx *ctx, int enable);
 /* Drain the recorded pairs: total milliseconds and launch count of one kernel kind; resets it. */
 int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches);
