@@ -463,71 +463,72 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
     const Chunk c = my_chunk(N);
     double *st = tmp + SEG_STASH;                    /* the eight capacitor voltages, stashed in LDS (not in live registers) */
     if (threadIdx.x < 8) st[threadIdx.x] = U->ds[threadIdx.x];
-    double aH[4], aL[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { aH[j] = U->dp[4 + j]; aL[j] = U->dp[8 + j]; }
     double x[CHK];
     chunk_load(in, c, x);
     __syncthreads();
-    double A[4], B[4], Ap[4], Bp[4];
-    /* pass 1: chunk maps of the four high-pass capacitors */
+    /* two bands at a time (all four at once do not fit 128 VGPRs and spill); the band sum keeps the reference's
+     * order j = 0..3 because the partial sum is carried across the two rounds (in the thread's own cells of `out`) */
+#pragma unroll 1
+    for (int pair = 0; pair < 2; pair++) {
+        double aH[2], aL[2], fac[2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { A[j] = 1.0; B[j] = 0.0; }
+        for (int j = 0; j < 2; j++) { aH[j] = U->dp[4 + 2 * pair + j]; aL[j] = U->dp[8 + 2 * pair + j]; fac[j] = U->dp[2 * pair + j]; }
+        double A[2], B[2], Ap[2], Bp[2];
+        /* pass 1: chunk maps of the high-pass capacitors */
 #pragma unroll
-    for (int i = 0; i < CHK; i++) {
-        if (i < c.len) {
+        for (int j = 0; j < 2; j++) { A[j] = 1.0; B[j] = 0.0; }
 #pragma unroll
-            for (int j = 0; j < 4; j++) { A[j] *= (1.0 - aH[j]); double diff = x[i] - B[j]; B[j] += diff * aH[j]; }
-        }
-    }
-    block_scan<4, false>(A, B, Ap, Bp, tmp);
-    double h[4], hs[4];
+        for (int i = 0; i < CHK; i++) {
+            if (i < c.len) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) { hs[j] = apply_map<false>(Ap[j], Bp[j], st[j]); h[j] = hs[j]; }
-    /* pass 2: exact high-pass, chunk maps of the four low-pass capacitors */
-#pragma unroll
-    for (int j = 0; j < 4; j++) { A[j] = 1.0; B[j] = 0.0; }
-#pragma unroll
-    for (int i = 0; i < CHK; i++) {
-        if (i < c.len) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                double diff = x[i] - h[j];
-                h[j] += diff * aH[j];
-                A[j] *= (1.0 - aL[j]);
-                diff -= B[j];
-                B[j] += diff * aL[j];
+                for (int j = 0; j < 2; j++) { A[j] *= (1.0 - aH[j]); double diff = x[i] - B[j]; B[j] += diff * aH[j]; }
             }
         }
-    }
-    block_scan<4, false>(A, B, Ap, Bp, tmp);
-    double l[4];
+        block_scan<2, false>(A, B, Ap, Bp, tmp);
+        double h[2], hs[2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { l[j] = apply_map<false>(Ap[j], Bp[j], st[4 + j]); h[j] = hs[j]; }
-    /* pass 3: the reference's loop body from the exact chunk-start state */
-    double fac[4];
+        for (int j = 0; j < 2; j++) { hs[j] = apply_map<false>(Ap[j], Bp[j], st[2 * pair + j]); h[j] = hs[j]; }
+        /* pass 2: exact high-pass, chunk maps of the low-pass capacitors */
 #pragma unroll
-    for (int j = 0; j < 4; j++) fac[j] = U->dp[j];
+        for (int j = 0; j < 2; j++) { A[j] = 1.0; B[j] = 0.0; }
 #pragma unroll
-    for (int i = 0; i < CHK; i++) {
-        if (i < c.len) {
-            double sum = 0.0;
+        for (int i = 0; i < CHK; i++) {
+            if (i < c.len) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                double diff = x[i] - h[j];
-                h[j] += diff * aH[j];
-                diff -= l[j];
-                double pre = l[j];
-                l[j] += diff * aL[j];
-                sum += fac[j] * pre;
+                for (int j = 0; j < 2; j++) {
+                    double diff = x[i] - h[j];
+                    h[j] += diff * aH[j];
+                    A[j] *= (1.0 - aL[j]);
+                    diff -= B[j];
+                    B[j] += diff * aL[j];
+                }
             }
-            x[i] = clip1(sum);
         }
-    }
-    chunk_store(out, c, x);
-    if (c.last) {
+        block_scan<2, false>(A, B, Ap, Bp, tmp);
+        double l[2];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { U->ds[j] = h[j]; U->ds[4 + j] = l[j]; }
+        for (int j = 0; j < 2; j++) { l[j] = apply_map<false>(Ap[j], Bp[j], st[4 + 2 * pair + j]); h[j] = hs[j]; }
+        /* pass 3: the reference's loop body from the exact chunk-start state */
+#pragma unroll
+        for (int i = 0; i < CHK; i++) {
+            if (i < c.len) {
+                double sum = (pair == 0) ? 0.0 : out[LX(c.c0 + i)];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    double diff = x[i] - h[j];
+                    h[j] += diff * aH[j];
+                    diff -= l[j];
+                    double pre = l[j];
+                    l[j] += diff * aL[j];
+                    sum += fac[j] * pre;
+                }
+                out[LX(c.c0 + i)] = (pair == 0) ? sum : clip1(sum);
+            }
+        }
+        if (c.last) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) { U->ds[2 * pair + j] = h[j]; U->ds[4 + 2 * pair + j] = l[j]; }
+        }
     }
 }
 
@@ -734,18 +735,77 @@ UNIT_FN unit_siggen(UNIT_ARGS) {
  * Here each ring keeps the last M values of p[n] = in[n] - g p[n - M]; o[n] = g p[n] + p[n - M].
  */
 #define REVERB_QMAX (GDG_MAX_FRAMES / SEG_T)
+#define REVERB_G 0.7                                  /* reverb.go:34 */
+
+/* One Schroeder all-pass over the frame in `buf`, in place.  The recurrence p[n] = x[n] - g p[n - M] only couples samples
+ * M apart, so sample chains r, r + M, r + 2M, ... are independent: a thread walks its chains in the reference's operation
+ * order (no tiles, no barriers inside), starting from the ring value p[r - M] it fetched into `pm0` at the top of the unit
+ * (one exposed HBM latency for the whole unit), and leaves the last p of every chain in the ring. */
+template <int Q>
+__device__ __forceinline__ void allpass_fetch(const double *ring, int M, int rp, int N, double (&pm0)[Q]) {
+    const int cnt = min(M, N);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        int r = (int)threadIdx.x + q * SEG_T;
+        pm0[q] = (r < cnt) ? ring[(rp + r) % M] : 0.0;
+    }
+}
+template <int Q>
+__device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M, int rp, int N, const double (&pm0)[Q], int *rp_out) {
+    const int cnt = min(M, N);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        int r = (int)threadIdx.x + q * SEG_T;
+        if (r < cnt) {
+            double pm = pm0[q], p;
+            int n = r;
+            do {
+                p = buf[LX(n)] - (REVERB_G * pm);           /* reverb.go:51-58: write in - g * delayed, emit g * written + delayed */
+                buf[LX(n)] = (REVERB_G * p) + pm;
+                pm = p;
+                n += M;
+            } while (n < N);
+            if (N >= M) ring[n - N] = p;                    /* the last M values of p, oldest first (n - M is this chain's last index) */
+            else ring[(rp + r) % M] = p;
+        }
+    }
+    if (threadIdx.x == 0) *rp_out = (N >= M) ? 0 : (rp + N) % M;
+    __syncthreads();
+}
+/* any ring size: fetch at use (exposes the latency; only sample rates far above 192 kHz come here) */
+__device__ __attribute__((noinline)) void allpass_generic(double *buf, double *ring, int M, int rp, int N, int *rp_out) {
+    double pm0[REVERB_QMAX];
+    allpass_fetch<REVERB_QMAX>(ring, M, rp, N, pm0);
+    __syncthreads();                                        /* every old ring value is in a register before anyone overwrites the ring */
+    allpass_chains<REVERB_QMAX>(buf, ring, M, rp, N, pm0, rp_out);
+}
+
 UNIT_FN unit_reverb(UNIT_ARGS) {
     UNIT_PROLOGUE
     const int tid = threadIdx.x;
     const double dry = U->dp[0], half_wet = U->dp[1];
     const double coeff[4] = { 0.1855, 0.18325, 0.17875, 0.17425 };
-    const double g = 0.7;
     int taps[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) taps[j] = U->jp[j];
     const int DL = U->jp[4];
     double *dl_ring = U->hist;
     const int dl_wp = U->is[0];
+    int M[3], rp[3];
+    double *ring[3];
+    {
+        double *r = dl_ring + DL;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { M[k] = U->jp[5 + k] - 1; rp[k] = U->is[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
+    }
+    /* ring heads of the three all-passes first (in-order return: they are home before the tap loads below are consumed) */
+    const bool fast = min(M[1], N) <= 3 * SEG_T && min(M[2], N) <= SEG_T;
+    double pm_a[REVERB_QMAX], pm_b[3], pm_c[1];
+    if (M[0] >= 1) allpass_fetch<REVERB_QMAX>(ring[0], M[0], rp[0], N, pm_a);
+    if (fast) {
+        if (M[1] >= 1) allpass_fetch<3>(ring[1], M[1], rp[1], N, pm_b);
+        if (M[2] >= 1) allpass_fetch<1>(ring[2], M[2], rp[2], N, pm_c);
+    }
     double dlr[REVERB_QMAX];
     /* tapped delay line over the input history (reverb.go:65-116) */
 #pragma unroll
@@ -765,50 +825,17 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         }
         dlr[q] = pre;
     }
+    /* every old ring value must have arrived before any thread overwrites the rings below: vmcnt(0) (the tap loads were
+     * needed here anyway), then the barrier */
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    double *ring = dl_ring + DL;
-    for (int k = 0; k < 3; k++) {
-        const int D = U->jp[5 + k];
-        const int M = D - 1;
-        const int rp = U->is[1 + k];                   /* position of the oldest value p[-M] */
-        if (M >= 1) {
-            /* recurrence in place, tile by tile: inside a tile of M samples nothing depends on the tile itself */
-            for (int n0 = 0; n0 < N; n0 += M) {
-                int n1 = min(N, n0 + M);
-                for (int n = n0 + tid; n < n1; n += SEG_T) {
-                    double pm = (n >= M) ? out[LX(n - M)] : ring[(rp + n) % M];
-                    out[LX(n)] = out[LX(n)] - (g * pm);
-                }
-                __syncthreads();
-            }
-            /* o[n] into registers (needs the OLD ring), then refresh the ring, then overwrite p by o */
-            double o[REVERB_QMAX];
-#pragma unroll
-            for (int q = 0; q < REVERB_QMAX; q++) {
-                int n = tid + q * SEG_T;
-                o[q] = 0.0;
-                if (n < N) {
-                    double pm = (n >= M) ? out[LX(n - M)] : ring[(rp + n) % M];
-                    o[q] = (g * out[LX(n)]) + pm;
-                }
-            }
-            __syncthreads();
-            if (N >= M) {
-                for (int i = tid; i < M; i += SEG_T) ring[i] = out[LX(N - M + i)];
-                if (tid == 0) U->is[1 + k] = 0;
-            } else {
-                for (int n = tid; n < N; n += SEG_T) ring[(rp + n) % M] = out[LX(n)];
-                if (tid == 0) U->is[1 + k] = (rp + N) % M;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < REVERB_QMAX; q++) {
-                int n = tid + q * SEG_T;
-                if (n < N) out[LX(n)] = o[q];
-            }
-            __syncthreads();
-        }
-        ring += (M > 0 ? M : 0);
+    if (M[0] >= 1) allpass_chains<REVERB_QMAX>(out, ring[0], M[0], rp[0], N, pm_a, &U->is[1]);
+    if (fast) {
+        if (M[1] >= 1) allpass_chains<3>(out, ring[1], M[1], rp[1], N, pm_b, &U->is[2]);
+        if (M[2] >= 1) allpass_chains<1>(out, ring[2], M[2], rp[2], N, pm_c, &U->is[3]);
+    } else {
+        if (M[1] >= 1) allpass_generic(out, ring[1], M[1], rp[1], N, &U->is[2]);
+        if (M[2] >= 1) allpass_generic(out, ring[2], M[2], rp[2], N, &U->is[3]);
     }
 #pragma unroll
     for (int q = 0; q < REVERB_QMAX; q++) {
