@@ -267,11 +267,11 @@ class Context:
         self._check(lib().gdg_staging_buffers(self._h, C.byref(pin), C.byref(pout), C.byref(stride)))
         slab_in = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_double)), shape=(self.n_channels, stride.value))
         slab_out = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_double)), shape=(self.n_channels, stride.value))
-        for i, c in enumerate(channels):
-            slab_in[c, :frames] = x[i]
+        idx = np.asarray(channels, dtype=np.intp)
+        slab_in[idx, :frames] = x
         chans = (C.c_int * n)(*channels)
         self._check(lib().gdg_process_staged(self._h, chans, n, frames, sample_rate))
-        return np.stack([slab_out[c, :frames].copy() for c in channels])
+        return slab_out[idx, :frames].copy()
 
     def process_device(self, d_in, d_out, frames, sample_rate):
         """Device-resident block; d_in / d_out are plain device pointers (ints) or DeviceBuffers."""

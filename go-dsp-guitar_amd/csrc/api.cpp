@@ -990,12 +990,23 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
     const size_t stride = (size_t)ctx->max_frames;
-    for (int c : active)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in + (size_t)c * stride, ctx->h_stage_in + (size_t)c * stride, (size_t)frames * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    /* one strided copy per run of consecutive channels (512 single-row copies cost ~10 us each) */
+    auto copy_runs = [&](double *dst, const double *src, hipMemcpyKind kind) -> hipError_t {
+        for (size_t i = 0; i < active.size();) {
+            size_t j = i + 1;
+            while (j < active.size() && active[j] == active[j - 1] + 1) j++;
+            size_t off = (size_t)active[i] * stride;
+            hipError_t e = hipMemcpy2DAsync(dst + off, stride * sizeof(double), src + off, stride * sizeof(double),
+                                            (size_t)frames * sizeof(double), j - i, kind, ctx->stream);
+            if (e != hipSuccess) return e;
+            i = j;
+        }
+        return hipSuccess;
+    };
+    HIP_TRY(ctx, copy_runs(ctx->d_stage_in, ctx->h_stage_in, hipMemcpyHostToDevice));
     rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true);
     if (rc != GDG_OK) return rc;
-    for (int c : active)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage_out + (size_t)c * stride, ctx->d_stage_out + (size_t)c * stride, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, copy_runs(ctx->h_stage_out, ctx->d_stage_out, hipMemcpyDeviceToHost));
     return check_device_error(ctx);
 }
 
