@@ -1,0 +1,169 @@
+"""BASELINE.json's configurations at their FULL sizes on one GPU.  The oracle is too slow to follow 512 channels of
+65536-tap convolution for long, so the full-size runs are checked through size-independent properties:
+  * channel independence: channels that carry the same chain and the same input give bit-identical output whatever
+    their index (first / last workgroup, different XCDs), and differ from their neighbours;
+  * determinism: a second context fed the same stream reproduces the output bit for bit (checksum of checksums);
+  * linearity of the convolution stage: FIR(a x + b y) = a FIR(x) + b FIR(y) to rounding;
+  * a sample of channels is followed by the oracle at the 1e-9 RMS bar.
+Configs 3 and 5 are small enough for the oracle to follow every channel.  Run with `pytest -m gpu`."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import TOL_RMS, ChainPair, package, rms, synth_ir, synth_signal
+from test_gpu_parity import full_chain
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = package()
+    assert p.device_count() > 0
+    return p
+
+
+def checksum_of_checksums(y):
+    rows = [hashlib.sha256(np.ascontiguousarray(r).tobytes()).digest() for r in y]
+    return hashlib.sha256(b"".join(rows)).hexdigest()
+
+
+def build_config4(pkg, oracle, nch, frames, taps, n_distinct, followed):
+    """512-channel full chain with two 65536-tap IRs; channel c uses parameter/IR set c % n_distinct."""
+    ctx = pkg.Context(nch, frames)
+    cab = [synth_ir(taps, seed=4242 + i) for i in range(n_distinct)]
+    rev = [synth_ir(taps, seed=5242 + i) for i in range(n_distinct)]
+    pairs = {}
+    for c in range(nch):
+        k = c % n_distinct
+        if c in followed:
+            p = ChainPair(ctx, c, oracle)
+            full_chain(p, 0, cab[k], rev[k])
+            pairs[c] = p
+        else:
+            ctx.append_unit(c, "compressor", params=[1, 30, -20])
+            ctx.append_unit(c, "overdrive", params=[0, 20, 100, 0, 1, 0])
+            ctx.append_unit(c, "tone_stack")
+            ctx.append_unit(c, "chorus")
+            ctx.append_unit(c, "power_amp", fir=cab[k])
+            ctx.append_unit(c, "power_amp", fir=rev[k])
+            ctx.append_unit(c, "cabinet")
+            ctx.append_unit(c, "reverb", params=[50])
+    return ctx, pairs
+
+
+def test_config4_512_channels_192k_two_64k_irs(pkg, oracle):
+    nch, frames, sr, taps, blocks, n_distinct = 512, 8192, 192000, 65536, 3, 8
+    followed = {0, 257, 511}
+    ctx, pairs = build_config4(pkg, oracle, nch, frames, taps, n_distinct, followed)
+    ctx2, _ = build_config4(pkg, oracle, nch, frames, taps, n_distinct, set())
+    # input: channel c carries signal (c % 16): channels c and c + 16 k * ... with equal c % 16 AND equal c % 8 are twins
+    sig = np.stack([synth_signal(s, frames * blocks, sr) for s in range(16)])
+    x = sig[np.arange(nch) % 16]
+    got = np.empty_like(x)
+    sums = []
+    for b in range(blocks):
+        blk = np.ascontiguousarray(x[:, b * frames:(b + 1) * frames])
+        got[:, b * frames:(b + 1) * frames] = ctx.process(blk, sr)
+        sums.append(checksum_of_checksums(ctx2.process(blk, sr)))
+    assert np.isfinite(got).all()
+    # determinism across contexts
+    for b in range(blocks):
+        assert checksum_of_checksums(got[:, b * frames:(b + 1) * frames]) == sums[b]
+    # channel independence: twins (same signal, same parameter set) are bit identical, neighbours are not
+    for c in range(16, nch):
+        np.testing.assert_array_equal(got[c], got[c % 16])
+    assert not np.array_equal(got[0], got[1])
+    # the oracle follows three channels (first, middle, last workgroup)
+    for c, p in pairs.items():
+        want = np.concatenate([p.ref.process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+        assert rms(got[c] - want) <= TOL_RMS, c
+    ctx.close()
+    ctx2.close()
+
+
+def test_config4_convolution_is_linear_at_full_size(pkg):
+    nch, frames, sr, taps, blocks = 512, 8192, 192000, 65536, 10            # 10 blocks: the whole 8-partition delay line is live
+    irs = [synth_ir(taps, seed=777 + i) * 0.05 for i in range(4)]           # small gain: the output clip stays inactive
+    ctxs = []
+    for _ in range(3):
+        ctx = pkg.Context(nch, frames)
+        for c in range(nch):
+            ctx.append_unit(c, "power_amp", fir=irs[c % 4])
+        ctxs.append(ctx)
+    rng = np.random.default_rng(5)
+    a, b = 0.75, -0.4
+    worst = 0.0
+    for _ in range(blocks):
+        xa = rng.uniform(-0.5, 0.5, (nch, frames))
+        xb = rng.uniform(-0.5, 0.5, (nch, frames))
+        ya = ctxs[0].process(xa, sr)
+        yb = ctxs[1].process(xb, sr)
+        yc = ctxs[2].process(a * xa + b * xb, sr)
+        assert np.abs(yc).max() < 1.0
+        worst = max(worst, rms(yc - (a * ya + b * yb)) / max(rms(yc), 1e-30))
+    assert worst <= 1e-13, worst
+    for ctx in ctxs:
+        ctx.close()
+
+
+def test_config3_64_channels_96k_4x_oversampling_32k_ir(pkg, oracle):
+    nch, frames, sr, taps, blocks = 64, 8192, 96000, 32768, 2
+    ctx = pkg.Context(nch, frames)
+    pairs = []
+    for c in range(nch):
+        p = ChainPair(ctx, c, oracle)
+        full_chain(p, 2, synth_ir(taps, seed=4242 + c % 4))
+        pairs.append(p)
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(nch)])
+    for b in range(blocks):
+        blk = np.ascontiguousarray(x[:, b * frames:(b + 1) * frames])
+        got = ctx.process(blk, sr)
+        for c, p in enumerate(pairs):
+            assert rms(got[c] - p.ref.process(blk[c], sr)) <= TOL_RMS, (b, c)
+    ctx.close()
+
+
+def test_config2_single_channel_8k_ir_1024_frame_buffers(pkg, oracle):
+    frames, sr, taps, blocks = 1024, 48000, 8192, 24                          # 24 blocks: three full turns of the delay line
+    ctx = pkg.Context(1, frames)
+    p = ChainPair(ctx, 0, oracle)
+    full_chain(p, 0, synth_ir(taps))
+    x = synth_signal(0, frames * blocks, sr)[None, :]
+    got = np.concatenate([ctx.process(x[:, b * frames:(b + 1) * frames], sr)[0] for b in range(blocks)])
+    want = np.concatenate([p.ref.process(x[0, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+    assert rms(got - want) <= TOL_RMS
+    ctx.close()
+
+
+def test_config5_256_tuners_and_spatializer_192k(pkg, oracle):
+    nch, frames, sr = 256, 8192, 192000
+    total = 96000 + 2 * frames
+    notes = [73.4162, 110.0, 146.8324, 195.9978, 246.9417, 329.6276]
+    t = np.arange(total) / float(sr)
+    x = np.stack([sum(a * np.sin(2 * np.pi * notes[c % 6] * 2.0 ** (((c % 7) - 3) / 1200.0) * h * t + 0.1 * c)
+                      for h, a in ((1, 0.5), (2, 0.25), (3, 0.12))) for c in range(nch)])
+    ctx = pkg.Context(nch, frames)
+    sp = oracle.Spatializer(nch)
+    sp.set_sample_rate(sr)
+    ctx.spatializer_set_sample_rate(sr)
+    for c in range(nch):
+        az, dist, lv = -90.0 + 180.0 * c / (nch - 1), 0.5 + 0.05 * (c % 40), 0.2 + 0.003 * c
+        ctx.spatializer_set_position(c, az, dist, lv)
+        sp.set_azimuth(c, az); sp.set_distance(c, dist); sp.set_level(c, lv)
+    tuners = [oracle.Tuner() for _ in range(nch)]
+    for b in range(0, total - frames + 1, frames):
+        blk = np.ascontiguousarray(x[:, b:b + frames])
+        ctx.tuner_enqueue(blk, sr)
+        left, right = ctx.spatialize(blk)
+        wl, wr = sp.process(blk)
+        assert rms(left - wl) <= TOL_RMS and rms(right - wr) <= TOL_RMS
+        for c in range(nch):
+            tuners[c].process(blk[c], sr)
+    got = ctx.tuner_analyze()
+    for c in range(nch):
+        want = tuners[c].analyze()
+        assert got[c]["note_index"] == want["note_index"] and got[c]["cents"] == want["cents"], c
+        assert abs(got[c]["frequency"] - want["frequency"]) <= 1e-9 * want["frequency"], c
+    ctx.close()
