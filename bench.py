@@ -241,7 +241,7 @@ def main():
                                    "achieved": (seg["launches"] * samples_per_step * 16.0 / (seg["ms_total"] * 1e-3) / 1e9) if seg["ms_total"] else None},
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: it is a property of the host, not of the GPU count
             out["cpu_baseline"] = cpu_baseline(sr, frames, taps)
         print(json.dumps(out))
     ctx.close()
