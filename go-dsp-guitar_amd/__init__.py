@@ -34,7 +34,7 @@ KERNEL_KINDS = ["fir_fwd", "fir_mac", "fir_inv", "segment", "tuner", "spatialize
 ABI_SYMBOLS = [
     "gdg_version", "gdg_device_count", "gdg_ctx_create", "gdg_ctx_destroy", "gdg_last_error", "gdg_ctx_channels",
     "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
-    "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_subset", "gdg_process_device",
+    "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_compile_fir", "gdg_unit_get_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_subset", "gdg_process_device",
     "gdg_staging_buffers", "gdg_process_staged", "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
     "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_analyze", "gdg_tuner_note_name",
     "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device",
@@ -89,6 +89,8 @@ def lib():
             "gdg_unit_get_param": (i32, [vp, i32, i32, C.POINTER(C.c_int32)]),
             "gdg_unit_set_fir": (i32, [vp, i32, vp, i32]),
             "gdg_unit_reset": (i32, [vp, i32]),
+            "gdg_unit_compile_fir": (i32, [vp, i32, i32, vp, vp, vp, vp, u32]),
+            "gdg_unit_get_fir": (i32, [vp, i32, vp, i32, C.POINTER(i32)]),
             "gdg_chain_set": (i32, [vp, i32, vp, vp, i32]),
             "gdg_process": (i32, [vp, vp, vp, i32, u32]),
             "gdg_process_subset": (i32, [vp, vp, i32, vp, vp, i32, u32]),
@@ -211,6 +213,24 @@ class Context:
     def unit_set_fir(self, handle, taps):
         t = _f64(taps)
         self._check(lib().gdg_unit_set_fir(self._h, handle, t.ctypes.data if t.size else None, t.size))
+
+    def unit_compile_fir(self, handle, filters, target_order=0):
+        """filters: list of (taps or None, gain_compensation_factor, level_db) per slot (gdg_unit_compile_fir)."""
+        n = len(filters)
+        arrs = [(_f64(t) if t is not None else None) for t, _, _ in filters]
+        ptrs = (C.c_void_p * n)(*[(a.ctypes.data if a is not None and a.size else None) for a in arrs])
+        lens = (C.c_int * n)(*[(a.size if a is not None else 0) for a in arrs])
+        comp = (C.c_double * n)(*[float(f[1]) for f in filters])
+        lev = (C.c_int32 * n)(*[int(f[2]) for f in filters])
+        self._check(lib().gdg_unit_compile_fir(self._h, handle, n, ptrs, lens, comp, lev, target_order))
+
+    def unit_get_fir(self, handle):
+        n = C.c_int(0)
+        self._check(lib().gdg_unit_get_fir(self._h, handle, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float64)
+        if n.value:
+            self._check(lib().gdg_unit_get_fir(self._h, handle, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def unit_reset(self, handle):
         self._check(lib().gdg_unit_reset(self._h, handle))

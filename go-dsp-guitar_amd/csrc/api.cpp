@@ -1463,4 +1463,77 @@ int gdg_meter_state(gdg_ctx *ctx, int port, double *current, double *peak, uint6
     return GDG_OK;
 }
 
+/* ---- power-amp filter compilation on the device (effects/poweramp.go:25-127) ----------------------------------------------- */
+
+int gdg_unit_compile_fir(gdg_ctx *ctx, int handle, int n_filters, const double *const *taps, const int *lengths, const double *gain_compensation,
+                         const int32_t *levels_db, uint32_t target_order) {
+    Unit *u = get_unit(ctx, handle);
+    if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
+    if (u->type != GDG_UNIT_POWERAMP) return fail(ctx, GDG_ERR_INVALID, "unit %d is not a power amp", handle);
+    if (n_filters < 0 || (n_filters > 0 && (!taps || !lengths || !gain_compensation || !levels_db))) return fail(ctx, GDG_ERR_INVALID, "bad filter list");
+    hipSetDevice(ctx->device);
+    /* lengths after Reduce, composite length = the longest (filter.go:167-236 Add pads with zeros) */
+    size_t max_in = 0, max_out = 0, work_points = 0, pos_points = 0;
+    for (int i = 0; i < n_filters; i++) {
+        if (!taps[i] || lengths[i] <= 0) continue;                  /* "- NONE -" slot (poweramp.go:78) */
+        size_t n = (size_t)lengths[i];
+        size_t out = (target_order > 0 && n > (size_t)target_order) ? (size_t)target_order : n;
+        if (out != n) {
+            size_t w, p;
+            gdg_filter_reduce_sizes(lengths[i], target_order, &w, &p);
+            if (w > work_points) work_points = w;
+            if (p > pos_points) pos_points = p;
+        }
+        if (n > max_in) max_in = n;
+        if (out > max_out) max_out = out;
+    }
+    std::vector<double> composite(max_out, 0.0);
+    if (max_out > 0) {
+        double *d_in = nullptr, *d_red = nullptr, *d_comp = nullptr, *d_partial = nullptr;
+        double2 *d_wa = nullptr, *d_wb = nullptr, *d_wp = nullptr;
+        bool ok = hipMalloc((void **)&d_in, max_in * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&d_red, max_out * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&d_comp, max_out * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&d_partial, 257 * sizeof(double)) == hipSuccess;
+        if (work_points) {
+            ok = ok && hipMalloc((void **)&d_wa, work_points * sizeof(double2)) == hipSuccess;
+            ok = ok && hipMalloc((void **)&d_wb, work_points * sizeof(double2)) == hipSuccess;
+            ok = ok && hipMalloc((void **)&d_wp, pos_points * sizeof(double2)) == hipSuccess;
+        }
+        hipError_t e = ok ? hipMemsetAsync(d_comp, 0, max_out * sizeof(double), ctx->stream) : hipErrorOutOfMemory;
+        for (int i = 0; e == hipSuccess && i < n_filters; i++) {
+            if (!taps[i] || lengths[i] <= 0) continue;
+            const int n = lengths[i];
+            e = hipMemcpyAsync(d_in, taps[i], (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+            const double *d_cur = d_in;
+            int n_cur = n;
+            if (e == hipSuccess && target_order > 0 && (size_t)n > (size_t)target_order) {        /* poweramp.go:88-90 */
+                e = gdg_launch_filter_reduce(d_in, n, target_order, d_wa, d_wb, d_wp, d_red, ctx->stream);
+                d_cur = d_red;
+                n_cur = (int)target_order;
+            }
+            /* Normalize, Multiply(level), Add (poweramp.go:92-94, :108-118) */
+            if (e == hipSuccess)
+                e = gdg_launch_normalize_scale_add(d_cur, n_cur, gain_compensation[i], decibels_to_factor(levels_db[i]), d_partial, d_comp, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     /* taps[i] is pageable host memory reused by the next upload */
+        }
+        if (e == hipSuccess) e = hipMemcpy(composite.data(), d_comp, max_out * sizeof(double), hipMemcpyDeviceToHost);
+        hipFree(d_in); hipFree(d_red); hipFree(d_comp); hipFree(d_partial); hipFree(d_wa); hipFree(d_wb); hipFree(d_wp);
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? GDG_ERR_NOMEM : GDG_ERR_HIP, "filter compilation failed: %s", hipGetErrorString(e));
+    }
+    return gdg_unit_set_fir(ctx, handle, composite.data(), (int)composite.size());
+}
+
+int gdg_unit_get_fir(gdg_ctx *ctx, int handle, double *taps, int capacity, int *n_taps) {
+    Unit *u = get_unit(ctx, handle);
+    if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
+    if (u->type != GDG_UNIT_POWERAMP) return fail(ctx, GDG_ERR_INVALID, "unit %d is not a power amp", handle);
+    if (n_taps) *n_taps = (int)u->taps.size();
+    if (taps) {
+        if (capacity < (int)u->taps.size()) return fail(ctx, GDG_ERR_INVALID, "buffer too small for %zu taps", u->taps.size());
+        if (!u->taps.empty()) memcpy(taps, u->taps.data(), u->taps.size() * sizeof(double));
+    }
+    return GDG_OK;
+}
+
 }  /* extern "C" */

@@ -132,4 +132,12 @@ hipError_t gdg_launch_resample_time(const double *d_in, int n, double dx, double
 hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, int n, gdg_meter_rec *d_state,
                             double decay, unsigned long long hold, hipStream_t s);
 
+/* compile.hip: power-amp filter compilation */
+hipError_t gdg_launch_filter_reduce(const double *d_taps, int n, unsigned order, double2 *work_a, double2 *work_b, double2 *work_pos, double *d_out,
+                                    hipStream_t s);
+void gdg_filter_reduce_sizes(int n, unsigned order, size_t *work_points, size_t *pos_points);
+/* d_partial: 257 doubles of scratch */
+hipError_t gdg_launch_normalize_scale_add(const double *d_src, int n, double compensation, double level, double *d_partial, double *d_composite,
+                                          hipStream_t s);
+
 #endif

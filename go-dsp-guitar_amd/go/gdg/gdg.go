@@ -9,6 +9,8 @@ package gdg
 
 /*
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "gdg.h"
 */
 import "C"
@@ -76,6 +78,36 @@ func (this *Context) UnitSetFir(handle int, taps []float64) error {
 		p = (*C.double)(unsafe.Pointer(&taps[0])) // a []float64 holds no Go pointers: legal for the duration of the call
 	}
 	return this.err(C.gdg_unit_set_fir(this.ctx, C.int(handle), p, C.int(len(taps))))
+}
+
+// UnitCompileFir runs poweramp.compile() on the device (effects/poweramp.go:25-127): slot i = taps of impulse response i at the
+// current rate (nil = "- NONE -"), its gain compensation factor and its level in dB.  An array of Go slices would be a
+// pointer to Go pointers, which cgo forbids, so every slot is copied into C memory for the duration of the call.
+func (this *Context) UnitCompileFir(handle int, taps [][]float64, compensation []float64, levelsDb []int32, targetOrder uint32) error {
+	n := len(taps)
+	if n == 0 {
+		return this.err(C.gdg_unit_compile_fir(this.ctx, C.int(handle), 0, nil, nil, nil, nil, C.uint32_t(targetOrder)))
+	}
+	ptrSize := C.size_t(unsafe.Sizeof(uintptr(0)))
+	ptrs := (*[1 << 20]*C.double)(C.calloc(C.size_t(n), ptrSize))
+	defer C.free(unsafe.Pointer(ptrs))
+	lens := make([]C.int, n)
+	comp := make([]C.double, n)
+	lev := make([]C.int32_t, n)
+	for i := 0; i < n; i++ {
+		comp[i] = C.double(compensation[i])
+		lev[i] = C.int32_t(levelsDb[i])
+		if len(taps[i]) == 0 {
+			continue
+		}
+		bytes := C.size_t(len(taps[i])) * 8
+		mem := C.malloc(bytes)
+		defer C.free(mem)
+		C.memcpy(mem, unsafe.Pointer(&taps[i][0]), bytes)
+		ptrs[i] = (*C.double)(mem)
+		lens[i] = C.int(len(taps[i]))
+	}
+	return this.err(C.gdg_unit_compile_fir(this.ctx, C.int(handle), C.int(n), (**C.double)(unsafe.Pointer(ptrs)), &lens[0], &comp[0], &lev[0], C.uint32_t(targetOrder)))
 }
 
 func (this *Context) ChainSet(channel int, handles []int, bypass []bool) error {

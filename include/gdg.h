@@ -93,6 +93,18 @@ int gdg_unit_set_fir(gdg_ctx *ctx, int handle, const double *taps, int n_taps);
 int gdg_unit_reset(gdg_ctx *ctx, int handle);
 
 /*
+ * poweramp.compile on the device (effects/poweramp.go:25-127).  Slot i of the power amp holds the taps of
+ * impulse response i at the current sample rate (filter.ImpulseResponses.CreateFilter(...).Coefficients(); NULL or length 0 =
+ * "- NONE -"), its gain compensation FACTOR (filter/filter.go:127-138) and its `level_i` parameter in dB.  Per slot:
+ * Reduce(target_order) when target_order > 0 and the slot is longer (filter.go:520-604), Normalize, Multiply(level); the
+ * slots are then added in order (filter.go:167-236) and the composite becomes the unit's FIR exactly as gdg_unit_set_fir
+ * would set it (including the state reset).  gdg_unit_get_fir reads the composite back (taps may be NULL to query n_taps).
+ */
+int gdg_unit_compile_fir(gdg_ctx *ctx, int handle, int n_filters, const double *const *taps, const int *lengths,
+                         const double *gain_compensation, const int32_t *levels_db, uint32_t target_order);
+int gdg_unit_get_fir(gdg_ctx *ctx, int handle, double *taps, int capacity, int *n_taps);
+
+/*
  * signal.Chain slot list of one channel (signal/signal.go:52-157): handles in processing
  * order with their bypass flags.  Bypassed slots are skipped and do not advance their state
  * (signal.go:390-401).  State stays with the unit handle, not with the slot index.
