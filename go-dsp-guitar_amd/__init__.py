@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "gdg_wave_bytes_per_sample", "gdg_wave_decode", "gdg_wave_decode_device", "gdg_wave_encode", "gdg_wave_encode_device",
     "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
+    "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
 ]
 
 
@@ -125,6 +126,11 @@ def lib():
             "gdg_meter_process_device": (i32, [vp, vp, C.c_size_t, i32, u32]),
             "gdg_meter_analyze": (i32, [vp, vp, vp]),
             "gdg_meter_state": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_uint64)]),
+            "gdg_metronome_set_tick": (i32, [vp, vp, i32]),
+            "gdg_metronome_set_tock": (i32, [vp, vp, i32]),
+            "gdg_metronome_configure": (i32, [vp, u32, u32, u32]),
+            "gdg_metronome_process": (i32, [vp, vp, i32]),
+            "gdg_metronome_process_device": (i32, [vp, vp, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -411,3 +417,19 @@ class Context:
         c, p, n = C.c_double(), C.c_double(), C.c_uint64()
         self._check(lib().gdg_meter_state(self._h, port, C.byref(c), C.byref(p), C.byref(n)))
         return c.value, p.value, n.value
+
+    def metronome_set_sounds(self, tick, tock):
+        for fn, a in ((lib().gdg_metronome_set_tick, tick), (lib().gdg_metronome_set_tock, tock)):
+            if a is None:
+                self._check(fn(self._h, None, 0))
+            else:
+                a = _f64(a)
+                self._check(fn(self._h, a.ctypes.data if a.size else C.cast(C.create_string_buffer(8), C.c_void_p), a.size))
+
+    def metronome_configure(self, beats_per_period, bpm_speed, sample_rate):
+        self._check(lib().gdg_metronome_configure(self._h, beats_per_period, bpm_speed, sample_rate))
+
+    def metronome_process(self, frames):
+        out = np.empty(frames, dtype=np.float64)
+        self._check(lib().gdg_metronome_process(self._h, out.ctypes.data, frames))
+        return out

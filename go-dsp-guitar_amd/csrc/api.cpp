@@ -119,6 +119,10 @@ struct gdg_ctx {
     size_t io_cap[2] = { 0, 0 };
     gdg_meter_rec *d_meter = nullptr;
     int n_meter = 0;
+    /* metronome (metronome/metronome.go): sounds in HBM, the two counters on the host */
+    double *d_tick = nullptr, *d_tock = nullptr;
+    uint32_t n_tick = 0, n_tock = 0;
+    uint32_t met_sample_counter = 0, met_tick_counter = 0, met_beats = 4, met_bpm = 120, met_sr = 96000;
 };
 
 static int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {
@@ -225,7 +229,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
     hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
-    hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_partial); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter);
+    hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_partial); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter); hipFree(ctx->d_tick); hipFree(ctx->d_tock);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1533,6 +1537,76 @@ int gdg_unit_get_fir(gdg_ctx *ctx, int handle, double *taps, int capacity, int *
         if (capacity < (int)u->taps.size()) return fail(ctx, GDG_ERR_INVALID, "buffer too small for %zu taps", u->taps.size());
         if (!u->taps.empty()) memcpy(taps, u->taps.data(), u->taps.size() * sizeof(double));
     }
+    return GDG_OK;
+}
+
+/* ---- metronome (metronome/metronome.go) ------------------------------------------------------------------------------------ */
+
+static int set_sound(gdg_ctx *ctx, double **d_buf, uint32_t *n_buf, const double *coeffs, int n) {
+    if (n < 0) return fail(ctx, GDG_ERR_INVALID, "bad sound length");
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*d_buf) { hipFree(*d_buf); *d_buf = nullptr; }
+    *n_buf = 0;
+    if (!coeffs) return GDG_OK;                                    /* SetTick(name, nil): no sound */
+    /* a non-nil empty slice is an allocated sound of length 0: keep a one-element allocation so the pointer stays non-null */
+    if (hipMalloc((void **)d_buf, (size_t)(n > 0 ? n : 1) * sizeof(double)) != hipSuccess) return fail(ctx, GDG_ERR_NOMEM, "cannot allocate the metronome sound");
+    if (n > 0) HIP_TRY(ctx, hipMemcpy(*d_buf, coeffs, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    *n_buf = (uint32_t)n;
+    return GDG_OK;
+}
+
+int gdg_metronome_set_tick(gdg_ctx *ctx, const double *coefficients, int n) {
+    if (!ctx) return GDG_ERR_INVALID;
+    return set_sound(ctx, &ctx->d_tick, &ctx->n_tick, coefficients, n);
+}
+
+int gdg_metronome_set_tock(gdg_ctx *ctx, const double *coefficients, int n) {
+    if (!ctx) return GDG_ERR_INVALID;
+    return set_sound(ctx, &ctx->d_tock, &ctx->n_tock, coefficients, n);
+}
+
+int gdg_metronome_configure(gdg_ctx *ctx, uint32_t beats_per_period, uint32_t bpm_speed, uint32_t sample_rate) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (bpm_speed == 0) return fail(ctx, GDG_ERR_INVALID, "metronome speed must be positive");     /* the reference would divide by zero */
+    ctx->met_beats = beats_per_period;
+    ctx->met_bpm = bpm_speed;
+    ctx->met_sr = sample_rate;
+    return GDG_OK;
+}
+
+int gdg_metronome_process_device(gdg_ctx *ctx, double *d_out, int frames) {
+    if (!ctx || (frames > 0 && !d_out) || frames < 0) return GDG_ERR_INVALID;
+    if (frames == 0) return GDG_OK;
+    hipSetDevice(ctx->device);
+    const uint32_t sc0 = ctx->met_sample_counter, tc0 = ctx->met_tick_counter;
+    const uint32_t spb = (60u * ctx->met_sr) / ctx->met_bpm;                    /* metronome.go:79, uint32 arithmetic */
+    const uint32_t beats = ctx->met_beats == 0 ? 1u : ctx->met_beats;           /* :84-86 */
+    /* sample j0 is the first whose increment reaches samples_per_beat (:122-125) */
+    const uint32_t j0 = (sc0 + 1u >= spb) ? 0u : (spb - 1u - sc0);
+    HIP_TRY(ctx, gdg_launch_metronome(ctx->d_tick, ctx->n_tick, ctx->d_tock, ctx->n_tock, d_out, frames, sc0, tc0, spb, beats, j0, ctx->stream));
+    /* counters after the buffer */
+    const uint32_t n = (uint32_t)frames;
+    if (n - 1u < j0) { ctx->met_sample_counter = sc0 + n; }
+    else {
+        uint32_t m = n - j0 - 1u;                                               /* samples after the first reset */
+        uint32_t resets = 1u + (spb ? m / spb : m);
+        ctx->met_sample_counter = spb ? m % spb : 0u;
+        ctx->met_tick_counter = ((tc0 + 1u) % beats + (resets - 1u) % beats) % beats;
+    }
+    return GDG_OK;
+}
+
+int gdg_metronome_process(gdg_ctx *ctx, double *out, int frames) {
+    if (!ctx || (frames > 0 && !out) || frames < 0) return GDG_ERR_INVALID;
+    if (frames == 0) return GDG_OK;
+    hipSetDevice(ctx->device);
+    int rc = ensure_io(ctx, 1, (size_t)frames * sizeof(double));
+    if (rc != GDG_OK) return rc;
+    rc = gdg_metronome_process_device(ctx, static_cast<double *>(ctx->d_io[1]), frames);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_io[1], (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GDG_OK;
 }
 

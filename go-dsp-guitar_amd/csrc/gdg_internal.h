@@ -132,6 +132,9 @@ hipError_t gdg_launch_resample_time(const double *d_in, int n, double dx, double
 hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, int n, gdg_meter_rec *d_state,
                             double decay, unsigned long long hold, hipStream_t s);
 
+hipError_t gdg_launch_metronome(const double *d_tick, unsigned n_tick, const double *d_tock, unsigned n_tock, double *d_out, int n,
+                                unsigned sc0, unsigned tc0, unsigned spb, unsigned beats, unsigned j0, hipStream_t s);
+
 /* compile.hip: power-amp filter compilation */
 hipError_t gdg_launch_filter_reduce(const double *d_taps, int n, unsigned order, double2 *work_a, double2 *work_b, double2 *work_pos, double *d_out,
                                     hipStream_t s);

@@ -220,6 +220,37 @@ hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, in
     return hipGetLastError();
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * metronome/metronome.go:63-131.  The two counters have closed forms inside a buffer: up to and including sample j0 (the
+ * last one before the first beat boundary) the sample counter is sc0 + i; after it sample i lies m = i - j0 - 1 samples
+ * into a run of whole beats: counter = m mod spb, resets so far = 1 + m div spb.  The host keeps the two counters.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+metronome_kernel(const double *__restrict__ tick, unsigned n_tick, const double *__restrict__ tock, unsigned n_tock, double *__restrict__ out, int n,
+                 unsigned sc0, unsigned tc0, unsigned spb, unsigned beats, unsigned j0) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        unsigned sc, tc;
+        if ((unsigned)i <= j0) { sc = sc0 + (unsigned)i; tc = tc0; }
+        else {
+            unsigned m = (unsigned)i - j0 - 1u;
+            unsigned resets = 1u + (spb ? m / spb : m);
+            sc = spb ? m % spb : 0u;
+            tc = ((tc0 + 1u) % beats + (resets - 1u) % beats) % beats;
+        }
+        double sample = 0.0;
+        if (tc == 0) { if (tick && sc < n_tick) sample = tick[sc]; }
+        else { if (tock && sc < n_tock) sample = tock[sc]; }
+        out[i] = sample;
+    }
+}
+
+hipError_t gdg_launch_metronome(const double *d_tick, unsigned n_tick, const double *d_tock, unsigned n_tock, double *d_out, int n,
+                                unsigned sc0, unsigned tc0, unsigned spb, unsigned beats, unsigned j0, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    metronome_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_tick, n_tick, d_tock, n_tock, d_out, n, sc0, tc0, spb, beats, j0);
+    return hipGetLastError();
+}
+
 static int grid_for(size_t n) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;

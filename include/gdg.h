@@ -233,7 +233,18 @@ int gdg_meter_analyze(gdg_ctx *ctx, int32_t *levels, int32_t *peaks);
 /* raw meter state of one port (current value, held peak, hold counter) for parity tests */
 int gdg_meter_state(gdg_ctx *ctx, int port, double *current, double *peak, uint64_t *counter);
 
+/*
+ * metronome.Metronome (metronome/metronome.go): SetTick / SetTock (NULL = no sound), SetBeatsPerPeriod / SetSpeed /
+ * SetSampleRate (none of them touches the counters, as in the reference), Process (:63-131) into one output buffer.
+ */
+int gdg_metronome_set_tick(gdg_ctx *ctx, const double *coefficients, int n);
+int gdg_metronome_set_tock(gdg_ctx *ctx, const double *coefficients, int n);
+int gdg_metronome_configure(gdg_ctx *ctx, uint32_t beats_per_period, uint32_t bpm_speed, uint32_t sample_rate);
+int gdg_metronome_process(gdg_ctx *ctx, double *out, int frames);
+int gdg_metronome_process_device(gdg_ctx *ctx, double *d_out, int frames);
+
 #ifdef __cplusplus
+
 
 }
 #endif

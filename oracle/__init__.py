@@ -496,6 +496,8 @@ def _io_lib():
         L.gdgo_meter_set_enabled.argtypes = [C.POINTER(Meter), C.c_int]
         L.gdgo_meter_process.argtypes = [C.POINTER(Meter), C.c_void_p, C.c_size_t, C.c_uint32]
         L.gdgo_meter_analyze.argtypes = [C.POINTER(Meter), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gdgo_metronome_init.argtypes = [C.c_void_p]
+        L.gdgo_metronome_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L._io_ready = True
     return L
 
@@ -541,3 +543,25 @@ class ChannelMeter:
     @property
     def state(self):
         return self._m.current_value, self._m.peak_value, self._m.sample_counter
+
+
+class MetronomeState(C.Structure):
+    _fields_ = [("sample_counter", C.c_uint32), ("tick_counter", C.c_uint32), ("beats_per_period", C.c_uint32),
+                ("bpm_speed", C.c_uint32), ("sample_rate", C.c_uint32)]
+
+
+class Metronome:
+    """metronome.metronomeStruct (metronome/metronome.go:63-131)"""
+
+    def __init__(self):
+        self.s = MetronomeState()
+        _io_lib().gdgo_metronome_init(C.byref(self.s))
+        self.tick = self.tock = None
+
+    def process(self, n):
+        out = np.zeros(n)
+        t = _f64(self.tick) if self.tick is not None else None
+        k = _f64(self.tock) if self.tock is not None else None
+        _io_lib().gdgo_metronome_process(C.byref(self.s), _ptr(t) if t is not None else None, len(t) if t is not None else 0,
+                                         _ptr(k) if k is not None else None, len(k) if k is not None else 0, _ptr(out), n)
+        return out

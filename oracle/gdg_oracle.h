@@ -167,6 +167,11 @@ void gdgo_meter_set_enabled(gdgo_meter *m, int enabled);
 void gdgo_meter_process(gdgo_meter *m, const double *buffer, size_t n, uint32_t sample_rate);
 void gdgo_meter_analyze(const gdgo_meter *m, int32_t *level, int32_t *peak);
 
+/* ---- metronome/metronome.go ------------------------------------------------ */
+typedef struct { uint32_t sample_counter, tick_counter, beats_per_period, bpm_speed, sample_rate; } gdgo_metronome;
+void gdgo_metronome_init(gdgo_metronome *m);
+void gdgo_metronome_process(gdgo_metronome *m, const double *tick, int n_tick, const double *tock, int n_tock, double *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

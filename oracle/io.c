@@ -171,3 +171,30 @@ void gdgo_meter_analyze(const gdgo_meter *m, int32_t *level, int32_t *peak) {
     *level = to_decibels_int(m->current_value);
     *peak = to_decibels_int(m->peak_value);
 }
+
+/* ---- metronome/metronome.go:63-131: tick/tock generator.  The reference has no test for it: unpinned,
+ * cross-checked against a closed form in tests/test_oracle_independent.py ------------------------------------------------ */
+void gdgo_metronome_init(gdgo_metronome *m) {
+    memset(m, 0, sizeof(*m));
+    m->beats_per_period = 4; m->bpm_speed = 120; m->sample_rate = 96000;      /* metronome.go:12-14, Create() */
+}
+
+void gdgo_metronome_process(gdgo_metronome *m, const double *tick, int n_tick, const double *tock, int n_tock, double *out, int n) {
+    uint32_t sample_counter = m->sample_counter, tick_counter = m->tick_counter;
+    uint32_t beats = m->beats_per_period;
+    uint32_t samples_per_beat = (60u * m->sample_rate) / m->bpm_speed;
+    if (beats == 0) beats = 1;
+    for (int i = 0; i < n; i++) {
+        double sample = 0.0;
+        if (tick_counter == 0) {
+            if (tick != NULL && sample_counter < (uint32_t)n_tick) sample = tick[sample_counter];
+        } else {
+            if (tock != NULL && sample_counter < (uint32_t)n_tock) sample = tock[sample_counter];
+        }
+        out[i] = sample;
+        sample_counter++;
+        if (sample_counter >= samples_per_beat) { sample_counter = 0; tick_counter = (tick_counter + 1) % beats; }
+    }
+    m->sample_counter = sample_counter;
+    m->tick_counter = tick_counter;
+}

@@ -261,3 +261,39 @@ def test_wave_device_entry_unaligned_buffers(pkg, ctx, oracle):
             ctx._check(pkg.lib().gdg_wave_decode_device(ctx._h, f, d_b.ptr + off_b, n, 1, d_x.ptr + off_s))
             back = d_x.download().view(np.uint8).reshape(-1)[off_s:off_s + 8 * n].view(np.float64)
             np.testing.assert_array_equal(back.view(np.uint64), oracle.wave_decode(fmt, want).view(np.uint64))
+
+
+# ---- metronome -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sr,bpm,beats,frames", [(192000, 120, 4, 8192), (48000, 208, 3, 1024), (44100, 60, 0, 5000), (96000, 30, 7, 8192),
+                                                  (1000, 60001, 2, 64), (8000, 480, 1, 1000)])
+def test_metronome_matches_oracle(pkg, oracle, sr, bpm, beats, frames):
+    rng = np.random.default_rng(bpm)
+    tick, tock = rng.uniform(-1, 1, 1500), rng.uniform(-1, 1, 900)
+    ctx = pkg.Context(1, 8192)
+    ref = oracle.Metronome()
+    blocks = 40
+    for b in range(blocks):
+        if b == 0:
+            ctx.metronome_set_sounds(tick, tock)
+            ref.tick, ref.tock = tick, tock
+            ctx.metronome_configure(beats, bpm, sr)
+            ref.s.beats_per_period, ref.s.bpm_speed, ref.s.sample_rate = beats, bpm, sr
+        if b == 17:                                   # a speed change mid-stream leaves the counters where they are
+            ctx.metronome_configure(beats, bpm * 3, sr)
+            ref.s.bpm_speed = bpm * 3
+        if b == 25:                                   # fewer beats per period than the current tick counter, and no tock sound
+            nb = 2 if beats != 2 else 1
+            ctx.metronome_configure(nb, bpm * 3, sr)
+            ref.s.beats_per_period = nb
+            ctx.metronome_set_sounds(tick, None)
+            ref.tock = None
+        np.testing.assert_array_equal(ctx.metronome_process(frames), ref.process(frames), err_msg="block %d" % b)
+    ctx.close()
+
+
+def test_metronome_defaults_and_errors(pkg, oracle):
+    ctx = pkg.Context(1, 1024)
+    np.testing.assert_array_equal(ctx.metronome_process(1024), np.zeros(1024))       # no sounds set: silence (metronome.go:98, :108)
+    with pytest.raises(pkg.GdgError):
+        ctx.metronome_configure(4, 0, 48000)
+    ctx.close()

@@ -370,3 +370,20 @@ def test_tuner_autocorrelation_against_numpy(oracle):
     shift = np.clip(0.5 * (r[k + 1] - r[k - 1]) / (2 * r[k] - (r[k + 1] + r[k - 1])), -0.5, 0.5)
     assert res["note"] == "A2" and abs(res["cents"]) <= 5
     assert abs(res["frequency"] - sr / (k + shift)) / res["frequency"] < 1e-9
+
+
+# ---- metronome (metronome/metronome.go:63-131): no reference test exists; second formulation = beat arithmetic ------------------
+def test_metronome_against_beat_arithmetic(oracle):
+    rng = np.random.default_rng(12)
+    tick, tock = rng.uniform(-1, 1, 700), rng.uniform(-1, 1, 300)
+    for sr, bpm, beats, n in ((48000, 120, 4, 8192), (96000, 200, 3, 8192), (1000, 90, 1, 500), (44100, 60, 0, 10000)):
+        m = oracle.Metronome()
+        m.tick, m.tock = tick, tock
+        m.s.sample_rate, m.s.bpm_speed, m.s.beats_per_period = sr, bpm, beats
+        got = np.concatenate([m.process(n) for _ in range(12)])
+        spb = (60 * sr) // bpm
+        g = np.arange(got.size)
+        sc, beat = g % spb, (g // spb) % max(beats, 1)
+        want = np.where(beat == 0, np.where(sc < tick.size, tick[np.minimum(sc, tick.size - 1)], 0.0),
+                        np.where(sc < tock.size, tock[np.minimum(sc, tock.size - 1)], 0.0))
+        np.testing.assert_array_equal(got, want)
