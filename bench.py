@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8192)
     ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct-irs", type=int, default=0,
+                    help="number of distinct IR tap sets (0 = one per channel = the metric's d = 1; fewer lets power amps share spectra)")
     args = ap.parse_args()
 
     import torch  # first: libgdg.so then binds to the same HIP runtime (same SONAME)
@@ -137,7 +139,8 @@ def main():
 
     nch, frames, sr, taps = args.channels, args.frames, args.sample_rate, args.taps
     ctx = pkg.Context(nch, frames, local_rank)
-    n_distinct = 8          # distinct tap sets; every channel still owns its spectra in HBM (d = 1)
+    # every channel has its OWN impulse responses (d = 1): identical filters would share one copy of the spectra
+    n_distinct = args.distinct_irs if args.distinct_irs > 0 else nch
     irs = {"cab": [synth_ir(taps, 4242 + i) for i in range(n_distinct)], "rev": [synth_ir(taps, 5242 + i) for i in range(n_distinct)]}
     for c in range(nch):
         for name, p in CHAIN:
@@ -191,7 +194,8 @@ def main():
         # its own write of Y is NOT counted (it would vanish in a fused kernel).  With channel groups a step issues
         # several smaller launches per FIR unit: bytes per launch = bytes per step / launches per step.
         fir_per_chain = sum(1 for _, p in CHAIN if isinstance(p, str))
-        mac_bytes = nch * 2.0 * K * spec_bytes * fir_per_chain * args.steps / max(mac["launches"], 1)
+        d_share = min(n_distinct, nch) / float(nch)                       # d = 1 with per-channel IRs
+        mac_bytes = nch * (1.0 + d_share) * K * spec_bytes * fir_per_chain * args.steps / max(mac["launches"], 1)
         mac_gbs = mac_bytes / (mac["avg_ms"] * 1e-3) / 1e9 if mac["avg_ms"] else None
         fir_units = mac["launches"]
         fir_ms = sum(kernels[k]["avg_ms"] * fir_units for k in ("fir_fwd", "fir_mac", "fir_inv"))
@@ -204,7 +208,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_fir_mac.json")) as f:
                 pmc = json.load(f)
-            if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps):
+            if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps) and n_distinct >= nch:
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
@@ -222,8 +226,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%d channels/GPU @ %d Hz, %d-frame blocks, full chain: compressor>overdrive>tone_stack>chorus>power_amp(%d-tap cab IR)>power_amp(%d-tap reverb IR)>cabinet>reverb; per-channel IR spectra; input resident in HBM"
-                            % (nch, sr, frames, taps, taps),
+                "workload": "%d channels/GPU @ %d Hz, %d-frame blocks, full chain: compressor>overdrive>tone_stack>chorus>power_amp(%d-tap cab IR)>power_amp(%d-tap reverb IR)>cabinet>reverb; %s; input resident in HBM"
+                            % (nch, sr, frames, taps, taps, "per-channel IRs (d = 1)" if n_distinct >= nch else "%d distinct IR sets shared by the channels" % n_distinct),
                 "channels_per_gpu": nch, "sample_rate": sr, "frames": frames, "ir_taps": taps, "partitions": K,
                 "realtime_factor": world * samples_per_step * args.steps / elapsed / (world * nch * sr),
                 "output_finite": finite,

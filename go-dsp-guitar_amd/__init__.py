@@ -33,7 +33,7 @@ KERNEL_KINDS = ["fir_fwd", "fir_mac", "fir_inv", "segment", "tuner", "spatialize
 # every symbol include/gdg.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gdg_version", "gdg_device_count", "gdg_ctx_create", "gdg_ctx_destroy", "gdg_last_error", "gdg_ctx_channels",
-    "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
+    "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_ctx_share_ir_spectra", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
     "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_compile_fir", "gdg_unit_get_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_subset", "gdg_process_device",
     "gdg_staging_buffers", "gdg_process_staged", "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
     "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_analyze", "gdg_tuner_note_name",
@@ -82,6 +82,7 @@ def lib():
             "gdg_ctx_destroy": (i32, [vp]),
             "gdg_last_error": (C.c_char_p, [vp]),
             "gdg_ctx_channels": (i32, [vp]),
+            "gdg_ctx_share_ir_spectra": (i32, [vp, i32]),
             "gdg_ctx_stream": (vp, [vp]),
             "gdg_ctx_synchronize": (i32, [vp]),
             "gdg_unit_create": (i32, [vp, i32, i32, C.POINTER(i32)]),
@@ -192,6 +193,9 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def share_ir_spectra(self, enable):
+        self._check(lib().gdg_ctx_share_ir_spectra(self._h, 1 if enable else 0))
 
     def _check(self, rc):
         if rc != GDG_OK:

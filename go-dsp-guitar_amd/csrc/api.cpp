@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <map>
 #include <string>
 #include <vector>
@@ -32,6 +33,15 @@ static const int32_t g_param_default[GDG_UNIT_COUNT][GDG_MAX_PARAMS] = {
     { 1, -40, -10, 100 }, { 1, 30, -20 }, { 1, -20, -20, -20, -20, -20, -20 }, { 0, 0, 0 },
     { 1, 50, 0, 0, 100, 0, 0 }, { 0, 0, 100, 0, 1, 0 }, { 0, 0, 0, 0 }, { 0, -2, -5, -5 },
     { 100, 30 }, { 100, 10 }, { 100, 10, 45 }, { 100, 50, -10 }, { 100 }, { 200, -5, -5 }, { 50 }, { 14 }, { 0 },
+};
+
+/* IR spectra of one (taps, partition size) pair; power amps with identical composite filters share one copy in HBM
+ * (the MAC then streams it from L2 / MALL for all but the first channel: SURVEY.md 8d, d < 1) */
+struct SharedSpectra {
+    std::vector<double> taps;
+    int P = 0, K = 0;
+    double2 *d_H = nullptr;
+    ~SharedSpectra() { if (d_H) hipFree(d_H); }
 };
 
 struct Unit {
@@ -53,7 +63,8 @@ struct Unit {
     int fir_P = 0, fir_K = 0;
     uint32_t fir_sr = 0;
     double *d_prev = nullptr;
-    double2 *d_fdl = nullptr, *d_H = nullptr, *d_Y = nullptr;
+    double2 *d_fdl = nullptr, *d_Y = nullptr;
+    std::shared_ptr<SharedSpectra> H;
     int *d_pos = nullptr;
 };
 
@@ -63,6 +74,7 @@ struct StepDesc {
     bool is_fir;
     int n;
     size_t offset;                    /* byte offset of its descriptor array inside the plan blob */
+    bool shared_spectra = false;      /* FIR step: some channels read the same IR spectra */
 };
 
 struct ProfEvent { int kind; hipEvent_t a, b; };
@@ -94,6 +106,8 @@ struct gdg_ctx {
     int *d_error = nullptr;
     /* tables */
     std::map<int, std::pair<double2 *, double2 *>> fir_tables;
+    std::multimap<uint64_t, std::weak_ptr<SharedSpectra>> spectra;     /* content hash -> live IR spectra */
+    bool share_spectra = true;
     double *d_os = nullptr;
     gdg_os_tables os;
     /* profiling */
@@ -183,6 +197,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ctx->max_frames = max_frames;
     ctx->device = device;
     ctx->chains.resize((size_t)n_channels);
+    { const char *e = getenv("GDG_SHARE_IR_SPECTRA"); if (e) ctx->share_spectra = atoi(e) != 0; }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -213,8 +228,8 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
 
 static void free_unit(Unit &u) {
     hipFree(u.d_ds); hipFree(u.d_is); hipFree(u.d_hist);
-    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_H); hipFree(u.d_Y); hipFree(u.d_pos);
-    u = Unit();
+    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_Y); hipFree(u.d_pos);
+    u = Unit();                     /* drops the unit's reference to its (possibly shared) IR spectra */
 }
 
 int gdg_ctx_destroy(gdg_ctx *ctx) {
@@ -239,6 +254,12 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
 
 const char *gdg_last_error(const gdg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int gdg_ctx_channels(const gdg_ctx *ctx) { return ctx ? ctx->nch : 0; }
+
+int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable) {
+    if (!ctx) return GDG_ERR_INVALID;
+    ctx->share_spectra = enable != 0;       /* affects power amps prepared from now on */
+    return GDG_OK;
+}
 void *gdg_ctx_stream(const gdg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 /* ---- units ------------------------------------------------------------------------------------- */
@@ -652,37 +673,63 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
     int K = (L + P - 1) / P;
     if (K < 1) K = 1;                 /* filter.Empty: one all-zero partition => zeros out */
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_H); hipFree(u.d_Y); hipFree(u.d_pos);
-    u.d_prev = nullptr; u.d_fdl = nullptr; u.d_H = nullptr; u.d_Y = nullptr; u.d_pos = nullptr;
+    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_Y); hipFree(u.d_pos);
+    u.d_prev = nullptr; u.d_fdl = nullptr; u.d_Y = nullptr; u.d_pos = nullptr;
+    u.H.reset();
     size_t spec = (size_t)K * (size_t)P * sizeof(double2);
     HIP_TRY(ctx, hipMalloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void **)&u.d_fdl, spec));
-    HIP_TRY(ctx, hipMalloc((void **)&u.d_H, spec));
     HIP_TRY(ctx, hipMalloc((void **)&u.d_Y, (size_t)P * sizeof(double2)));
     HIP_TRY(ctx, hipMalloc((void **)&u.d_pos, sizeof(int)));
     HIP_TRY(ctx, hipMemsetAsync(u.d_prev, 0, 2 * (size_t)P * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(u.d_fdl, 0, spec, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(u.d_H, 0, spec, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(u.d_pos, 0, sizeof(int), ctx->stream));
-    if (L > 0) {
-        double2 *tw, *tw2;
-        int rc = fir_tables(ctx, P, &tw, &tw2);
-        if (rc != GDG_OK) return rc;
-        std::vector<double> padded((size_t)K * (size_t)P, 0.0);
-        memcpy(padded.data(), u.taps.data(), (size_t)L * sizeof(double));
-        double *d_taps = nullptr;
-        gdg_fir_irjob *d_jobs = nullptr;
-        std::vector<gdg_fir_irjob> jobs((size_t)K);
-        HIP_TRY(ctx, hipMalloc((void **)&d_taps, padded.size() * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc((void **)&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
-        for (int k = 0; k < K; k++) { jobs[(size_t)k].a = d_taps + (size_t)k * P; jobs[(size_t)k].out = u.d_H + (size_t)k * P; }
-        HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
-        /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
-        HIP_TRY(ctx, gdg_launch_fir_ir(P, d_jobs, K, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        hipFree(d_taps);
-        hipFree(d_jobs);
+    /* IR spectra: reuse a live copy of the same taps at the same partition size, else build one */
+    uint64_t key = 1469598103934665603ull;                              /* FNV-1a over the tap bytes, P and L */
+    {
+        const unsigned char *b = reinterpret_cast<const unsigned char *>(u.taps.data());
+        for (size_t i = 0; i < u.taps.size() * sizeof(double); i++) { key ^= b[i]; key *= 1099511628211ull; }
+        key ^= (uint64_t)P; key *= 1099511628211ull;
+        key ^= (uint64_t)L; key *= 1099511628211ull;
+    }
+    if (ctx->share_spectra) {
+        auto range = ctx->spectra.equal_range(key);
+        for (auto it = range.first; it != range.second;) {
+            std::shared_ptr<SharedSpectra> sp = it->second.lock();
+            if (!sp) { it = ctx->spectra.erase(it); continue; }
+            if (sp->P == P && sp->taps == u.taps) { u.H = sp; break; }      /* compared in full: a hash match alone is not trusted */
+            ++it;
+        }
+    }
+    if (!u.H) {
+        auto sp = std::make_shared<SharedSpectra>();
+        sp->taps = u.taps;
+        sp->P = P;
+        sp->K = K;
+        HIP_TRY(ctx, hipMalloc((void **)&sp->d_H, spec));
+        HIP_TRY(ctx, hipMemsetAsync(sp->d_H, 0, spec, ctx->stream));
+        if (L > 0) {
+            double2 *tw, *tw2;
+            int rc = fir_tables(ctx, P, &tw, &tw2);
+            if (rc != GDG_OK) return rc;
+            std::vector<double> padded((size_t)K * (size_t)P, 0.0);
+            memcpy(padded.data(), u.taps.data(), (size_t)L * sizeof(double));
+            double *d_taps = nullptr;
+            gdg_fir_irjob *d_jobs = nullptr;
+            std::vector<gdg_fir_irjob> jobs((size_t)K);
+            HIP_TRY(ctx, hipMalloc((void **)&d_taps, padded.size() * sizeof(double)));
+            HIP_TRY(ctx, hipMalloc((void **)&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
+            for (int k = 0; k < K; k++) { jobs[(size_t)k].a = d_taps + (size_t)k * P; jobs[(size_t)k].out = sp->d_H + (size_t)k * P; }
+            HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
+            /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
+            HIP_TRY(ctx, gdg_launch_fir_ir(P, d_jobs, K, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(d_taps);
+            hipFree(d_jobs);
+        }
+        u.H = sp;
+        if (ctx->share_spectra) ctx->spectra.emplace(key, sp);
     }
     u.fir_P = P;
     u.fir_K = K;
@@ -755,7 +802,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 if (rc != GDG_OK) return rc;
                 gdg_fir_chan f;
                 memset(&f, 0, sizeof(f));
-                f.src = cur[(size_t)c]; f.dst = dst; f.prev = u.d_prev; f.fdl = u.d_fdl; f.H = u.d_H; f.Y = u.d_Y;
+                f.src = cur[(size_t)c]; f.dst = dst; f.prev = u.d_prev; f.fdl = u.d_fdl; f.H = u.H->d_H; f.Y = u.d_Y;
                 f.pos = u.d_pos; f.K = u.fir_K;
                 fd.push_back(f);
                 u.fir_live = true;
@@ -781,6 +828,12 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         st.is_fir = is_fir;
         st.n = is_fir ? (int)fd.size() : (int)sd.size();
         st.offset = 0;
+        if (is_fir) {
+            std::vector<const void *> hp;
+            for (auto &f : fd) hp.push_back(f.H);
+            std::sort(hp.begin(), hp.end());
+            st.shared_spectra = std::adjacent_find(hp.begin(), hp.end()) != hp.end();
+        }
         ctx->steps.push_back(st);
         seg_descs.push_back(sd);
         fir_descs.push_back(fd);
@@ -893,7 +946,7 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             int rc = fir_tables(ctx, frames, &tw, &tw2);
             if (rc != GDG_OK) return rc;
             { ProfScope ps(ctx, GDG_K_FIR_FWD); HIP_TRY(ctx, gdg_launch_fir_fwd(frames, d, st.n, tw, tw2, ctx->stream)); }
-            { ProfScope ps(ctx, GDG_K_FIR_MAC); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, st.n, ctx->stream)); }
+            { ProfScope ps(ctx, GDG_K_FIR_MAC); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, st.n, st.shared_spectra ? 1 : 0, ctx->stream)); }
             { ProfScope ps(ctx, GDG_K_FIR_INV); HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, st.n, tw, tw2, ctx->stream)); }
         } else {
             const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset);

@@ -288,7 +288,7 @@ __device__ __forceinline__ cplx mac_load(const cplx *p) {
     }
 }
 
-template <int UNROLL, int BPT, bool NT, bool SWAP = false>
+template <int UNROLL, int BPT, bool NT, bool SWAP = false, bool HNT = NT>
 __global__ void __launch_bounds__(1024)
 fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     gdg_fir_chan ch = chans[SWAP ? blockIdx.x : blockIdx.y];
@@ -311,7 +311,7 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
 #pragma unroll
             for (int q = 0; q < BPT; q++) {
                 x[u][q] = mac_load<NT>(fdl + (size_t)slot * P + q);
-                h[u][q] = mac_load<NT>(H + (size_t)(k + u) * P + q);
+                h[u][q] = mac_load<HNT>(H + (size_t)(k + u) * P + q);
             }
         }
 #pragma unroll
@@ -473,18 +473,20 @@ hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, dou
     return hipGetLastError();
 }
 
-template <int UNROLL, int BPT, bool NT, bool SWAP = false>
+template <int UNROLL, int BPT, bool NT, bool SWAP = false, bool HNT = NT>
 static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s, int block = 256) {
     int per_block = block * BPT;
     int threads = P < per_block ? (P / BPT) : block;
     if (threads < 1) threads = 1;
     unsigned tiles = (unsigned)((P + threads * BPT - 1) / (threads * BPT));
     dim3 grid = SWAP ? dim3((unsigned)n_chans, tiles) : dim3(tiles, (unsigned)n_chans);
-    fir_mac_kernel<UNROLL, BPT, NT, SWAP><<<grid, dim3(threads), 0, s>>>(d_chans, P);
+    fir_mac_kernel<UNROLL, BPT, NT, SWAP, HNT><<<grid, dim3(threads), 0, s>>>(d_chans, P);
 }
 
-hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s) {
+hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
+    /* IR spectra shared between channels are worth caching; private ones are read once: non-temporal like the delay line */
+    if (shared_spectra) { launch_mac<8, 1, true, false, false>(P, d_chans, n_chans, s); return hipGetLastError(); }
     /* GDG_MAC_VARIANT: tuning knob for profiles/mac_variants.py; the default is the measured best */
     static int variant = -1;
     if (variant < 0) { const char *e = getenv("GDG_MAC_VARIANT"); variant = e ? atoi(e) : 0; }

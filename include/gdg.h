@@ -69,6 +69,13 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out);
 int gdg_ctx_destroy(gdg_ctx *ctx);
 const char *gdg_last_error(const gdg_ctx *ctx);
 int gdg_ctx_channels(const gdg_ctx *ctx);
+/*
+ * Power amps whose composite filters are identical (same taps, same partition size) share ONE copy of the IR spectra in
+ * HBM; the spectrum multiply-accumulate then streams it from L2 / MALL for all but the first channel (d < 1).
+ * On by default (env GDG_SHARE_IR_SPECTRA=0 or enable = 0 turns it off for power amps prepared afterwards).  Results are
+ * bit-identical either way.
+ */
+int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
 /* The hipStream_t all of this context's work is enqueued on (as void*), for event timing. */
 void *gdg_ctx_stream(const gdg_ctx *ctx);
 /* Block until everything enqueued so far has finished. */

@@ -86,3 +86,33 @@ def test_frame_size_change_with_live_fir_state_fails_loudly(pkg):
     ctx.unit_reset(h)
     ctx.process(np.zeros((1, 512)), 48000)                      # after a reset the new partition size is accepted
     ctx.close()
+
+
+def test_identical_filters_share_spectra_without_changing_results(pkg, oracle):
+    """Power amps with identical taps share one copy of the IR spectra (gdg_ctx_share_ir_spectra): same bits as private
+    copies; replacing or destroying one sharer leaves the others alone."""
+    sr, frames, nch = 48000, 1024, 6
+    ir_a, ir_b = synth_ir(5000, seed=1), synth_ir(5000, seed=2)
+    x = np.stack([synth_signal(c, frames * 4, sr) for c in range(nch)])
+
+    def run(share):
+        ctx = pkg.Context(nch, frames)
+        ctx.share_ir_spectra(share)
+        hs = [ctx.append_unit(c, "power_amp", fir=ir_a if c % 2 == 0 else ir_b) for c in range(nch)]
+        outs = [ctx.process(x[:, :frames], sr)]
+        ctx.unit_set_fir(hs[2], ir_b)                            # channel 2 leaves the ir_a group (fresh state, like the reference)
+        outs.append(ctx.process(x[:, frames:2 * frames], sr))
+        ctx.chain_set(4, [])                                     # channel 4: power amp removed and destroyed
+        ctx.unit_destroy(hs[4])
+        outs.append(ctx.process(x[:, 2 * frames:3 * frames], sr))
+        outs.append(ctx.process(x[:, 3 * frames:], sr))
+        ctx.close()
+        return np.concatenate(outs, axis=1)
+
+    shared, private = run(True), run(False)
+    np.testing.assert_array_equal(shared, private)
+    # and both follow the oracle on a channel that kept its filter throughout
+    ref = oracle.Chain()
+    ref.append_unit("power_amp", fir=ir_a)
+    want = np.concatenate([ref.process(x[0, b * frames:(b + 1) * frames], sr) for b in range(4)])
+    assert rms(shared[0] - want) <= TOL_RMS
