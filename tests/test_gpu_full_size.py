@@ -167,3 +167,29 @@ def test_config5_256_tuners_and_spatializer_192k(pkg, oracle):
         assert got[c]["note_index"] == want["note_index"] and got[c]["cents"] == want["cents"], c
         assert abs(got[c]["frequency"] - want["frequency"]) <= 1e-9 * want["frequency"], c
     ctx.close()
+
+
+@pytest.mark.parametrize("sr,taps,os_index,two_irs", [(192000, 65536, 0, True), (96000, 32768, 2, False)])
+def test_long_stream_64_blocks_does_not_drift(pkg, oracle, sr, taps, os_index, two_irs):
+    """the synthetic stream is 64 blocks of 8192 frames; RMS over the WHOLE stream stays under the bar (scan-carried
+    states, LFO phases, ring positions and the partition delay line all wrap many times)."""
+    frames, blocks, nch = 8192, 64, 2
+    ctx = pkg.Context(nch, frames)
+    pairs = []
+    for c in range(nch):
+        p = ChainPair(ctx, c, oracle)
+        full_chain(p, os_index, synth_ir(taps, seed=4242 + c), synth_ir(taps, seed=4243 + c) if two_irs else None)
+        pairs.append(p)
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(nch)])
+    got, want = np.empty_like(x), np.empty_like(x)
+    for b in range(blocks):
+        blk = np.ascontiguousarray(x[:, b * frames:(b + 1) * frames])
+        got[:, b * frames:(b + 1) * frames] = ctx.process(blk, sr)
+        for c, p in enumerate(pairs):
+            want[c, b * frames:(b + 1) * frames] = p.ref.process(blk[c], sr)
+    for c in range(nch):
+        assert rms(got[c] - want[c]) <= TOL_RMS, (c, rms(got[c] - want[c]))
+        last = slice((blocks - 1) * frames, blocks * frames)
+        assert rms(got[c, last] - want[c, last]) <= TOL_RMS, ("last block", c)
+    print("max abs error over %d samples: %.3e" % (x.size, np.abs(got - want).max()))
+    ctx.close()
