@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <map>
 #include <string>
@@ -75,6 +76,7 @@ struct StepDesc {
     int n;
     size_t offset;                    /* byte offset of its descriptor array inside the plan blob */
     bool shared_spectra = false;      /* FIR step: some channels read the same IR spectra */
+    std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
 
 struct ProfEvent { int kind; hipEvent_t a, b; };
@@ -133,6 +135,12 @@ struct gdg_ctx {
     size_t io_cap[2] = { 0, 0 };
     gdg_meter_rec *d_meter = nullptr;
     int n_meter = 0;
+    /* channel groups of the host-buffer paths: group g's upload, kernels and download run on stream g, so one group's
+     * PCIe transfers overlap the other groups' kernels (channels are independent) */
+    int plan_groups = 1;
+    std::vector<hipStream_t> gstreams;
+    std::vector<hipEvent_t> gjoin;
+    hipEvent_t gfork = nullptr;
     /* metronome (metronome/metronome.go): sounds in HBM, the two counters on the host */
     double *d_tick = nullptr, *d_tock = nullptr;
     uint32_t n_tick = 0, n_tock = 0;
@@ -245,6 +253,9 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
     hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
     hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_partial); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter); hipFree(ctx->d_tick); hipFree(ctx->d_tock);
+    for (auto st : ctx->gstreams) hipStreamDestroy(st);
+    for (auto e : ctx->gjoin) hipEventDestroy(e);
+    if (ctx->gfork) hipEventDestroy(ctx->gfork);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -742,8 +753,12 @@ struct Op { bool is_fir; std::vector<int> handles; };
 
 /* `active`: the channels taking part in this call; row i of d_in / d_out belongs to channel active[i] */
 static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
-                      int stride, bool rows_by_channel) {
+                      int stride, bool rows_by_channel, int G) {
     const int nch = ctx->nch;
+    /* channel groups: group of the i-th active channel = floor(i G / |active|), i.e. contiguous runs of `active` */
+    std::vector<int> group_of((size_t)nch, 0);
+    for (size_t i = 0; i < active.size(); i++) group_of[(size_t)active[i]] = (int)(i * (size_t)G / active.size());
+    ctx->plan_groups = G;
     /* per channel: ops placed on a common grid of slots: 2k = segment k, 2k+1 = FIR k */
     std::map<int, std::vector<std::pair<int, Op>>> by_slot;           /* slot -> (channel, op) */
     std::vector<int> n_ops((size_t)nch, 0);
@@ -828,6 +843,17 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         st.is_fir = is_fir;
         st.n = is_fir ? (int)fd.size() : (int)sd.size();
         st.offset = 0;
+        /* descriptors are in `active` order, so every channel group owns one contiguous run of them */
+        st.group_range.assign((size_t)G, std::make_pair(0, 0));
+        {
+            int pos = 0;
+            for (auto &entry : kv.second) {
+                auto &r = st.group_range[(size_t)group_of[(size_t)entry.first]];
+                if (r.second == 0) r.first = pos;
+                r.second++;
+                pos++;
+            }
+        }
         if (is_fir) {
             std::vector<const void *> hp;
             for (auto &f : fd) hp.push_back(f.H);
@@ -881,13 +907,13 @@ static hipEvent_t take_event(gdg_ctx *ctx) {
 }
 
 struct ProfScope {
-    gdg_ctx *ctx; int kind; hipEvent_t a = nullptr, b = nullptr; bool on = false;
-    ProfScope(gdg_ctx *c, int k) : ctx(c), kind(k) {
+    gdg_ctx *ctx; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on = false;
+    ProfScope(gdg_ctx *c, int k, hipStream_t s = nullptr) : ctx(c), kind(k), st(s ? s : c->stream) {
         on = (ctx->profiling & 1u) || (ctx->profiling & (1u << (k + 1)));
-        if (on) { a = take_event(ctx); b = take_event(ctx); hipEventRecord(a, ctx->stream); }
+        if (on) { a = take_event(ctx); b = take_event(ctx); hipEventRecord(a, st); }
     }
     ~ProfScope() {
-        if (on) { hipEventRecord(b, ctx->stream); ctx->prof.push_back(ProfEvent{ kind, a, b }); }
+        if (on) { hipEventRecord(b, st); ctx->prof.push_back(ProfEvent{ kind, a, b }); }
     }
 };
 
@@ -922,39 +948,75 @@ int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
 static int ensure_staging(gdg_ctx *ctx);
 static int check_device_error(gdg_ctx *ctx);
 
+/* what a host-buffer entry point does around group g's kernels, on group g's stream (upload before, download after) */
+typedef std::function<hipError_t(int g, hipStream_t s)> GroupHook;
+
 static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
-                        int stride = 0, bool rows_by_channel = false) {
+                        int stride = 0, bool rows_by_channel = false, int groups = 1, const GroupHook *before = nullptr, const GroupHook *after = nullptr) {
     if (stride == 0) stride = frames;
     if (d_in == d_out) return fail(ctx, GDG_ERR_INVALID, "in-place processing is not supported");
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
     if (sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     hipSetDevice(ctx->device);
+    const int G = groups < 1 ? 1 : groups;
     if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate || ctx->plan_in != d_in || ctx->plan_out != d_out ||
-        ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_by_channel != rows_by_channel) {
-        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, rows_by_channel);
+        ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_by_channel != rows_by_channel || ctx->plan_groups != G) {
+        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, rows_by_channel, G);
         ctx->plan_stride = stride;
         ctx->plan_by_channel = rows_by_channel;
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }
         ctx->plan_active = active;
     }
     const gdg_seg_unit *d_units = reinterpret_cast<const gdg_seg_unit *>(ctx->d_blob + ctx->units_offset);
-    for (auto &st : ctx->steps) {
-        if (st.n == 0) continue;
-        if (st.is_fir) {
-            const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset);
-            double2 *tw, *tw2;
-            int rc = fir_tables(ctx, frames, &tw, &tw2);
-            if (rc != GDG_OK) return rc;
-            { ProfScope ps(ctx, GDG_K_FIR_FWD); HIP_TRY(ctx, gdg_launch_fir_fwd(frames, d, st.n, tw, tw2, ctx->stream)); }
-            { ProfScope ps(ctx, GDG_K_FIR_MAC); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, st.n, st.shared_spectra ? 1 : 0, ctx->stream)); }
-            { ProfScope ps(ctx, GDG_K_FIR_INV); HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, st.n, tw, tw2, ctx->stream)); }
-        } else {
-            const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset);
-            ProfScope ps(ctx, GDG_K_SEGMENT);
-            HIP_TRY(ctx, gdg_launch_seg(d, st.n, d_units, frames, ctx->os, ctx->d_error, ctx->stream));
+    double2 *tw = nullptr, *tw2 = nullptr;
+    for (auto &st : ctx->steps)
+        if (st.is_fir && st.n) { int rc = fir_tables(ctx, frames, &tw, &tw2); if (rc != GDG_OK) return rc; break; }
+    if (G > 1) {
+        while ((int)ctx->gstreams.size() < G) {
+            hipStream_t s = nullptr;
+            hipEvent_t e = nullptr;
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->gstreams.push_back(s);
+            ctx->gjoin.push_back(e);
+        }
+        if (!ctx->gfork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->gfork, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->gfork, ctx->stream));            /* the plan upload and earlier work on the main stream */
+    }
+    for (int g = 0; g < G; g++) {
+        hipStream_t s = G > 1 ? ctx->gstreams[(size_t)g] : ctx->stream;
+        if (G > 1) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->gfork, 0));
+        if (before) HIP_TRY(ctx, (*before)(g, s));
+        for (auto &st : ctx->steps) {
+            int first = st.group_range[(size_t)g].first, n = st.group_range[(size_t)g].second;
+            if (n == 0) continue;
+            if (st.is_fir) {
+                const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset) + first;
+                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(frames, d, n, tw, tw2, s)); }
+                { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, n, st.shared_spectra ? 1 : 0, s)); }
+                { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, n, tw, tw2, s)); }
+            } else {
+                const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
+                ProfScope ps(ctx, GDG_K_SEGMENT, s);
+                HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, ctx->os, ctx->d_error, s));
+            }
+        }
+        if (after) HIP_TRY(ctx, (*after)(g, s));
+        if (G > 1) {
+            HIP_TRY(ctx, hipEventRecord(ctx->gjoin[(size_t)g], s));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->gjoin[(size_t)g], 0));
         }
     }
     return GDG_OK;
+}
+
+/* how many channel groups a host-buffer call over n channels is split into (env GDG_PCIE_GROUPS overrides) */
+static int pcie_groups(int n) {
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("GDG_PCIE_GROUPS"); forced = e ? atoi(e) : 0; }
+    int g = forced > 0 ? forced : (n >= 128 ? 2 : 1);        /* measured: profiles/host_path_rate_r01.txt */
+    if (g > n) g = n;
+    return g < 1 ? 1 : (g > 16 ? 16 : g);
 }
 
 int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
@@ -1003,16 +1065,31 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     hipSetDevice(ctx->device);
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
-    size_t bytes = (size_t)n * (size_t)frames * sizeof(double);
-    for (int i = 0; i < n; i++) memcpy(ctx->h_stage_in + (size_t)i * frames, in[i], (size_t)frames * sizeof(double));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, ctx->h_stage_in, bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate);
+    /* rows travel compactly ([i][frames]); G channel groups: group g's rows are staged and uploaded on stream g while the
+     * earlier groups already compute, and copied back to the caller while the later groups still run */
+    const int G = pcie_groups(n);
+    const size_t row = (size_t)frames;
+    auto lo = [&](int g) { return (size_t)(((size_t)g * (size_t)n + (size_t)G - 1) / (size_t)G); };     /* first i with floor(i G / n) == g */
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           /* the staging slabs may still be in use */
+    GroupHook before = [&](int g, hipStream_t s) -> hipError_t {
+        size_t a = lo(g), b = lo(g + 1);
+        for (size_t i = a; i < b; i++) memcpy(ctx->h_stage_in + i * row, in[i], row * sizeof(double));
+        if (b == a) return hipSuccess;
+        return hipMemcpyAsync(ctx->d_stage_in + a * row, ctx->h_stage_in + a * row, (b - a) * row * sizeof(double), hipMemcpyHostToDevice, s);
+    };
+    GroupHook after = [&](int g, hipStream_t s) -> hipError_t {
+        size_t a = lo(g), b = lo(g + 1);
+        if (b == a) return hipSuccess;
+        return hipMemcpyAsync(ctx->h_stage_out + a * row, ctx->d_stage_out + a * row, (b - a) * row * sizeof(double), hipMemcpyDeviceToHost, s);
+    };
+    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, 0, false, G, &before, &after);
     if (rc != GDG_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage_out, ctx->d_stage_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    rc = check_device_error(ctx);
-    if (rc != GDG_OK) return rc;
-    for (int i = 0; i < n; i++) memcpy(out[i], ctx->h_stage_out + (size_t)i * frames, (size_t)frames * sizeof(double));
-    return GDG_OK;
+    for (int g = 0; g < G; g++) {
+        if (G > 1) HIP_TRY(ctx, hipStreamSynchronize(ctx->gstreams[(size_t)g]));
+        else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = lo(g); i < lo(g + 1); i++) memcpy(out[i], ctx->h_stage_out + i * row, row * sizeof(double));
+    }
+    return check_device_error(ctx);
 }
 
 int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int frames, uint32_t sample_rate) {
@@ -1047,23 +1124,26 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
     const size_t stride = (size_t)ctx->max_frames;
-    /* one strided copy per run of consecutive channels (512 single-row copies cost ~10 us each) */
-    auto copy_runs = [&](double *dst, const double *src, hipMemcpyKind kind) -> hipError_t {
-        for (size_t i = 0; i < active.size();) {
+    /* G channel groups on their own streams: uploads, kernels and downloads of different groups overlap.  One strided copy
+     * per run of consecutive channels inside a group (512 single-row copies would cost ~10 us each). */
+    const int G = pcie_groups(n);
+    auto lo = [&](int g) { return (size_t)(((size_t)g * (size_t)n + (size_t)G - 1) / (size_t)G); };
+    auto copy_runs = [&](int g, double *dst, const double *src, hipMemcpyKind kind, hipStream_t s) -> hipError_t {
+        for (size_t i = lo(g); i < lo(g + 1);) {
             size_t j = i + 1;
-            while (j < active.size() && active[j] == active[j - 1] + 1) j++;
+            while (j < lo(g + 1) && active[j] == active[j - 1] + 1) j++;
             size_t off = (size_t)active[i] * stride;
             hipError_t e = hipMemcpy2DAsync(dst + off, stride * sizeof(double), src + off, stride * sizeof(double),
-                                            (size_t)frames * sizeof(double), j - i, kind, ctx->stream);
+                                            (size_t)frames * sizeof(double), j - i, kind, s);
             if (e != hipSuccess) return e;
             i = j;
         }
         return hipSuccess;
     };
-    HIP_TRY(ctx, copy_runs(ctx->d_stage_in, ctx->h_stage_in, hipMemcpyHostToDevice));
-    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true);
+    GroupHook before = [&](int g, hipStream_t s) { return copy_runs(g, ctx->d_stage_in, ctx->h_stage_in, hipMemcpyHostToDevice, s); };
+    GroupHook after = [&](int g, hipStream_t s) { return copy_runs(g, ctx->h_stage_out, ctx->d_stage_out, hipMemcpyDeviceToHost, s); };
+    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true, G, &before, &after);
     if (rc != GDG_OK) return rc;
-    HIP_TRY(ctx, copy_runs(ctx->h_stage_out, ctx->d_stage_out, hipMemcpyDeviceToHost));
     return check_device_error(ctx);
 }
 
