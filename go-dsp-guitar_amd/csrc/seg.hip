@@ -568,11 +568,16 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
      * differs from the reference's sin(fmod(zero_phase + j 2pi/5, 2pi)) by ~1e-16, i.e. ~1e-13 samples of delay */
     const double cj[5] = { 1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410, 0.30901699437494742410 };
     const double sj[5] = { 0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917, -0.95105651629515357212 };
-    for (int i = threadIdx.x; i < N; i += SEG_T) {
-        double time = (double)i / sr;
+    /* one sincos per thread: a thread's samples are SEG_T apart, so its LFO phase advances by a fixed angle from one to the
+     * next and (sin, cos) follow by rotation (error ~1e-16 per step, eight steps) */
+    double s0, c0, sd, cd;
+    {
+        double time = (double)threadIdx.x / sr;
         double zero_phase = fmod_2pi(prev + (angular * time));
-        double s0, c0;
         sincos(zero_phase, &s0, &c0);
+        sincos(angular * ((double)SEG_T / sr), &sd, &cd);
+    }
+    for (int i = threadIdx.x; i < N; i += SEG_T) {
         double effected = 0.0;
 #pragma unroll
         for (int j = 0; j < 5; j++) {
@@ -582,6 +587,10 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
             effected += 0.2 * frac_delay(in, ring, C, wp, i, delay_samples);
         }
         out[LX(i)] = (0.5 * in[LX(i)]) + (0.5 * effected);
+        {
+            double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
+            s0 = sn; c0 = cn;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -600,14 +609,21 @@ UNIT_FN unit_flanger(UNIT_ARGS) {
     const int C = U->jp[0], wp = U->is[0];
     const double prev = U->ds[0];
     const double *ring = U->hist;
+    /* one sincos per thread, then rotation by the fixed phase step between a thread's samples (as in the chorus) */
+    double s0, c0, sd, cd;
+    {
+        double time = (double)threadIdx.x * sr_inv;
+        sincos(fmod_2pi(prev + (angular * time)), &s0, &c0);
+        sincos(angular * ((double)SEG_T * sr_inv), &sd, &cd);
+    }
     for (int i = threadIdx.x; i < N; i += SEG_T) {
-        double time = (double)i * sr_inv;
-        double phase = fmod_2pi(prev + (angular * time));
-        double offset = depth * sin(phase);
+        double offset = depth * s0;
         double delay_time = 0.001 * (depth + offset);
         double delay_samples = delay_time * sr;
         double delayed = frac_delay(in, ring, C, wp, i, delay_samples);
         out[LX(i)] = (mix_dry * in[LX(i)]) + (mix_wet * delayed);
+        double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
+        s0 = sn; c0 = cn;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
