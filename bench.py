@@ -191,14 +191,16 @@ def main():
         samples_per_step = nch * frames
         mac = kernels["fir_mac"]
         # algorithmic bytes of the MAC launch: K delay-line spectra + K IR spectra per channel (d = 1);
-        # its own write of Y is NOT counted (it would vanish in a fused kernel).  With channel groups a step issues
+        # the split variant's write of Y is NOT counted (it vanishes in the fused kernel).  With channel groups a step issues
         # several smaller launches per FIR unit: bytes per launch = bytes per step / launches per step.
         fir_per_chain = sum(1 for _, p in CHAIN if isinstance(p, str))
         d_share = min(n_distinct, nch) / float(nch)                       # d = 1 with per-channel IRs
-        mac_bytes = nch * (1.0 + d_share) * K * spec_bytes * fir_per_chain * args.steps / max(mac["launches"], 1)
+        fused = not kernels["fir_inv"]["launches"]        # the library's default: MAC fused into the inverse transform's kernel
+        out_bytes = 8.0 * frames if fused else 0.0         # the fused kernel also emits the output frame (8 B y out)
+        mac_bytes = nch * ((1.0 + d_share) * K * spec_bytes + out_bytes) * fir_per_chain * args.steps / max(mac["launches"], 1)
         mac_gbs = mac_bytes / (mac["avg_ms"] * 1e-3) / 1e9 if mac["avg_ms"] else None
         fir_units = mac["launches"]
-        fir_ms = sum(kernels[k]["avg_ms"] * fir_units for k in ("fir_fwd", "fir_mac", "fir_inv"))
+        fir_ms = sum((kernels[k]["avg_ms"] or 0.0) * fir_units for k in ("fir_fwd", "fir_mac", "fir_inv"))
         fir_bytes_per_sample = 16.0 + 16.0 * (1 + 2 * K)              # SURVEY 8d B_conv with (P+1)/P -> 1 (packed bin 0)
         fir_gbs = fir_units * samples_per_step * fir_bytes_per_sample / (fir_ms * 1e-3) / 1e9 if fir_ms else None
         seg = kernels["segment"]
@@ -208,7 +210,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_fir_mac.json")) as f:
                 pmc = json.load(f)
-            if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps) and n_distinct >= nch:
+            if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps) and n_distinct >= nch and bool(pmc.get("fused")) == fused:
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
@@ -233,7 +235,8 @@ def main():
                 "output_finite": finite,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "fir_mac_kernel",
+                "bound": "hbm",
+                "kernel": "fir_inv_kernel<13, 1> (spectrum multiply-accumulate fused into the inverse FFT)" if fused else "fir_mac_kernel",
                 "achieved": mac_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (mac_gbs / HBM_PEAK_GBS) if mac_gbs else None,
                 "traffic": traffic,

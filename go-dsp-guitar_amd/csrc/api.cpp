@@ -110,6 +110,7 @@ struct gdg_ctx {
     std::map<int, std::pair<double2 *, double2 *>> fir_tables;
     std::multimap<uint64_t, std::weak_ptr<SharedSpectra>> spectra;     /* content hash -> live IR spectra */
     bool share_spectra = true;
+    bool fir_fused = true;            /* GDG_FIR_FUSED=0: separate MAC and inverse launches (A/B measurements) */
     double *d_os = nullptr;
     gdg_os_tables os;
     /* profiling */
@@ -206,6 +207,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ctx->device = device;
     ctx->chains.resize((size_t)n_channels);
     { const char *e = getenv("GDG_SHARE_IR_SPECTRA"); if (e) ctx->share_spectra = atoi(e) != 0; }
+    { const char *e = getenv("GDG_FIR_FUSED"); if (e) ctx->fir_fused = atoi(e) != 0; }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -993,8 +995,14 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             if (st.is_fir) {
                 const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset) + first;
                 { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(frames, d, n, tw, tw2, s)); }
-                { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, n, st.shared_spectra ? 1 : 0, s)); }
-                { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, n, tw, tw2, s)); }
+                if (ctx->fir_fused) {
+                    /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel) */
+                    ProfScope ps(ctx, GDG_K_FIR_MAC, s);
+                    HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, n, tw, tw2, st.shared_spectra ? 2 : 1, s));
+                } else {
+                    { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, n, st.shared_spectra ? 1 : 0, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, n, tw, tw2, 0, s)); }
+                }
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);

@@ -340,8 +340,58 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     for (int q = 0; q < BPT; q++) ch.Y[b0 + q] = (b0 + q == 0) ? make_double2(br, bi) : make_double2(ar[q], ai[q]);
 }
 
+/* The spectrum multiply-accumulate for the bin pair (k, n) of one channel, all K partitions:
+ *   y = sum_u FDL[(cur - u) mod K][bin] * H[u][bin];  bin 0 carries (DC, Nyquist) as two reals and is summed component-wise.
+ * UNROLL partitions x 2 bins x 2 arrays = 4 UNROLL 16-byte loads are issued before the first one is used. */
+template <int UNROLL, bool HNT>
+__device__ __forceinline__ void mac_pair(const gdg_fir_chan &ch, int P, int cur, int k, int n, cplx &yk, cplx &yn) {
+    const int K = ch.K;
+    const cplx *__restrict__ fdl = ch.fdl;
+    const cplx *__restrict__ H = ch.H;
+    double kr = 0.0, ki = 0.0, nr = 0.0, ni = 0.0, br = 0.0, bi = 0.0;
+    int u0 = 0;
+    for (; u0 + UNROLL <= K; u0 += UNROLL) {
+        cplx xk[UNROLL], hk[UNROLL], xn[UNROLL], hn[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            int slot = cur - (u0 + u);
+            if (slot < 0) slot += K;
+            xk[u] = mac_load<true>(fdl + (size_t)slot * P + k);
+            hk[u] = mac_load<HNT>(H + (size_t)(u0 + u) * P + k);
+            xn[u] = mac_load<true>(fdl + (size_t)slot * P + n);
+            hn[u] = mac_load<HNT>(H + (size_t)(u0 + u) * P + n);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            kr += xk[u].x * hk[u].x - xk[u].y * hk[u].y;
+            ki += xk[u].x * hk[u].y + xk[u].y * hk[u].x;
+            nr += xn[u].x * hn[u].x - xn[u].y * hn[u].y;
+            ni += xn[u].x * hn[u].y + xn[u].y * hn[u].x;
+            br += xk[u].x * hk[u].x;
+            bi += xk[u].y * hk[u].y;
+        }
+    }
+    for (; u0 < K; u0++) {
+        int slot = cur - u0;
+        if (slot < 0) slot += K;
+        cplx xk = fdl[(size_t)slot * P + k], hk = H[(size_t)u0 * P + k];
+        cplx xn = fdl[(size_t)slot * P + n], hn = H[(size_t)u0 * P + n];
+        kr += xk.x * hk.x - xk.y * hk.y;
+        ki += xk.x * hk.y + xk.y * hk.x;
+        nr += xn.x * hn.x - xn.y * hn.y;
+        ni += xn.x * hn.y + xn.y * hn.x;
+        br += xk.x * hk.x;
+        bi += xk.y * hk.y;
+    }
+    yk = (k == 0) ? make_double2(br, bi) : make_double2(kr, ki);
+    yn = make_double2(nr, ni);
+}
+
 /* Inverse: packed half spectrum Y -> second half of the 2N-point real sequence -> clip -> dst */
-template <int LOGN>
+/* FUSED 0: Y comes from fir_mac_kernel.  FUSED 1 / 2: the multiply-accumulate runs here, straight into the inverse's
+ * first stage (no Y round trip through HBM: the 6 % of extra bytes cost the separate MAC 20 % of its time, see
+ * profiles/probes/); 2 = the IR spectra are shared between channels and read with cacheable loads. */
+template <int LOGN, int FUSED>
 __global__ void __launch_bounds__(FftCfg<LOGN>::T)
 fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
@@ -350,21 +400,29 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
     const int tid = threadIdx.x;
     gdg_fir_chan ch = chans[blockIdx.x];
     const cplx *__restrict__ Y = ch.Y;
+    int cur = 0;
+    if constexpr (FUSED != 0) cur = (*ch.pos) % ch.K;
 
     constexpr int ITER = (N / 2) / T;
 #pragma unroll
     for (int i = 0; i < ITER; i++) {
         int k = tid + T * i;
+        cplx yk, yn;
+        {
+            const int n = (k == 0) ? N / 2 : N - k;
+            if constexpr (FUSED == 0) { yk = Y[k]; yn = Y[n]; }
+            else if constexpr (FUSED == 1) mac_pair<(N >= 1024 ? 8 : 4), true>(ch, N, cur, k, n, yk, yn);
+            else mac_pair<(N >= 1024 ? 8 : 4), false>(ch, N, cur, k, n, yk, yn);
+        }
         if (k == 0) {
-            cplx y = Y[0];
+            cplx y = yk;
             sre[0] = y.x + y.y;
             sim[0] = y.x - y.y;
-            cplx h = Y[N / 2];
+            cplx h = yn;
             sre[GDG_PAD(N / 2)] = 2.0 * h.x;
             sim[GDG_PAD(N / 2)] = -2.0 * h.y;
         } else {
             int n = N - k;
-            cplx yk = Y[k], yn = Y[n];
             cplx A = make_double2(yk.x + yn.x, yk.y - yn.y);
             cplx Bv = make_double2(yk.x - yn.x, yk.y + yn.y);
             cplx w = tw2[k];
@@ -455,8 +513,10 @@ template <int LG> static void launch_fwd(const gdg_fir_chan *d_chans, int n, con
 template <int LG> static void launch_ir(const gdg_fir_irjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
     fir_fwd_kernel<LG, true><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(nullptr, d_jobs, scale, tw, tw2);
 }
-template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, hipStream_t s) {
-    fir_inv_kernel<LG><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
+template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, hipStream_t s) {
+    if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
+    else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
+    else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
 }
 
 hipError_t gdg_launch_fir_fwd(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
@@ -511,10 +571,11 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, i
     return hipGetLastError();
 }
 
-hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
+/* fused: 0 = inverse only (Y from gdg_launch_fir_mac), 1 = MAC + inverse, 2 = MAC + inverse with shared (cacheable) IR spectra */
+hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, int fused, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
     int L = ilog2_exact(P);
-    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, s));
+    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, s));
     return hipGetLastError();
 }
 
