@@ -73,6 +73,15 @@ __global__ void __launch_bounds__(256) mac_like_kernel(const Desc *__restrict__ 
     else if (ar == 123.456) out[0] = ai;
 }
 
+__global__ void fill_kernel(double *p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long x = (i + seed) * 6364136223846793005ull + 1442695040888963407ull;
+        x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 32;
+        p[i] = (double)(long long)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+static void fill(void *p, size_t bytes, unsigned seed) { fill_kernel<<<4096, 256>>>((double *)p, bytes / 8, seed); }
+
 template <typename F> static float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -83,7 +92,7 @@ template <typename F> static float timeit(F f) {
 int main() {
     const size_t bytes = (size_t)1 << 30, n = bytes / 16;
     v2d *d; double *o;
-    hipMalloc(&d, bytes); hipMalloc(&o, 8); hipMemset(d, 0, bytes);
+    hipMalloc(&d, bytes); hipMalloc(&o, 8); fill(d, bytes, 1);   /* random bits (zero-filled buffers give the same numbers) */
     auto rep = [&](const char *name, float ms) { printf("%-44s %8.1f us  %7.0f GB/s  %.3f of 8 TB/s\n", name, ms * 1e3, bytes / ms / 1e6, bytes / ms / 1e6 / 8000); };
     rep("16 streams x 4 KiB per block, NT", timeit([&] { read_kernel<16, true><<<n / 256 / 16, 256>>>(d, n, o); }));
     rep("16 streams x 4 KiB per block", timeit([&] { read_kernel<16, false><<<n / 256 / 16, 256>>>(d, n, o); }));
@@ -100,7 +109,7 @@ int main() {
     {
         // 1024 separate 1 MiB allocations vs the same 1024 pieces carved from the one slab
         std::vector<v2d *> sep(1024), slab(1024);
-        for (int i = 0; i < 1024; i++) { hipMalloc(&sep[i], 1 << 20); hipMemset(sep[i], 0, 1 << 20); slab[i] = d + (size_t)i * 65536; }
+        for (int i = 0; i < 1024; i++) { hipMalloc(&sep[i], 1 << 20); fill(sep[i], 1 << 20, 100 + i); slab[i] = d + (size_t)i * 65536; }
         const v2d **d_sep, **d_slab;
         hipMalloc(&d_sep, 1024 * sizeof(void *)); hipMalloc(&d_slab, 1024 * sizeof(void *));
         hipMemcpy(d_sep, sep.data(), 1024 * sizeof(void *), hipMemcpyHostToDevice);
@@ -116,7 +125,7 @@ int main() {
         for (int i = 0; i < 512; i++) {
             v2d *a, *b, *y;
             hipMalloc(&a, 1 << 20); hipMalloc(&b, 1 << 20); hipMalloc(&y, 1 << 17);
-            hipMemset(a, 0, 1 << 20); hipMemset(b, 0, 1 << 20);
+            fill(a, 1 << 20, 7 * i); fill(b, 1 << 20, 7 * i + 3);
             h[i] = Desc{ a, b, y, d_pos + i, 8, 0 };
         }
         Desc *dd; hipMalloc(&dd, 512 * sizeof(Desc)); hipMemcpy(dd, h.data(), 512 * sizeof(Desc), hipMemcpyHostToDevice);
