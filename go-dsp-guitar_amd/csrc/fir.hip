@@ -340,54 +340,73 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     for (int q = 0; q < BPT; q++) ch.Y[b0 + q] = (b0 + q == 0) ? make_double2(br, bi) : make_double2(ar[q], ai[q]);
 }
 
-/* The spectrum multiply-accumulate for the bin pair (k, n) of one channel, all K partitions:
- *   y = sum_u FDL[(cur - u) mod K][bin] * H[u][bin];  bin 0 carries (DC, Nyquist) as two reals and is summed component-wise.
- * UNROLL partitions x 2 bins x 2 arrays = 4 UNROLL 16-byte loads are issued before the first one is used. */
-template <int UNROLL, bool HNT>
-__device__ __forceinline__ void mac_pair(const gdg_fir_chan &ch, int P, int cur, int k, int n, cplx &yk, cplx &yn) {
-    const int K = ch.K;
-    const cplx *__restrict__ fdl = ch.fdl;
-    const cplx *__restrict__ H = ch.H;
-    double kr = 0.0, ki = 0.0, nr = 0.0, ni = 0.0, br = 0.0, bi = 0.0;
-    int u0 = 0;
-    for (; u0 + UNROLL <= K; u0 += UNROLL) {
-        cplx xk[UNROLL], hk[UNROLL], xn[UNROLL], hn[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            int slot = cur - (u0 + u);
-            if (slot < 0) slot += K;
-            xk[u] = mac_load<true>(fdl + (size_t)slot * P + k);
-            hk[u] = mac_load<HNT>(H + (size_t)(u0 + u) * P + k);
-            xn[u] = mac_load<true>(fdl + (size_t)slot * P + n);
-            hn[u] = mac_load<HNT>(H + (size_t)(u0 + u) * P + n);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            kr += xk[u].x * hk[u].x - xk[u].y * hk[u].y;
-            ki += xk[u].x * hk[u].y + xk[u].y * hk[u].x;
-            nr += xn[u].x * hn[u].x - xn[u].y * hn[u].y;
-            ni += xn[u].x * hn[u].y + xn[u].y * hn[u].x;
-            br += xk[u].x * hk[u].x;
-            bi += xk[u].y * hk[u].y;
-        }
+/* Inverse: packed half spectrum Y -> second half of the 2N-point real sequence -> clip -> dst */
+/* first stage of the packed-real inverse: the spectrum pair (Y[k], Y[n]) -> Z[k], Z[n] in LDS (k = 0: n = N/2) */
+template <int LOGN>
+__device__ __forceinline__ void inv_head_store(int k, cplx yk, cplx yn, double *sre, double *sim, const cplx *__restrict__ tw2) {
+    constexpr int N = FftCfg<LOGN>::N;
+    if (k == 0) {
+        sre[0] = yk.x + yk.y;
+        sim[0] = yk.x - yk.y;
+        sre[GDG_PAD(N / 2)] = 2.0 * yn.x;
+        sim[GDG_PAD(N / 2)] = -2.0 * yn.y;
+    } else {
+        int n = N - k;
+        cplx A = make_double2(yk.x + yn.x, yk.y - yn.y);
+        cplx Bv = make_double2(yk.x - yn.x, yk.y + yn.y);
+        cplx w = tw2[k];
+        w.y = -w.y;
+        cplx O = cmul(Bv, w);
+        sre[GDG_PAD(k)] = A.x - O.y;
+        sim[GDG_PAD(k)] = A.y + O.x;
+        sre[GDG_PAD(n)] = A.x + O.y;
+        sim[GDG_PAD(n)] = -A.y + O.x;
     }
-    for (; u0 < K; u0++) {
-        int slot = cur - u0;
-        if (slot < 0) slot += K;
-        cplx xk = fdl[(size_t)slot * P + k], hk = H[(size_t)u0 * P + k];
-        cplx xn = fdl[(size_t)slot * P + n], hn = H[(size_t)u0 * P + n];
-        kr += xk.x * hk.x - xk.y * hk.y;
-        ki += xk.x * hk.y + xk.y * hk.x;
-        nr += xn.x * hn.x - xn.y * hn.y;
-        ni += xn.x * hn.y + xn.y * hn.x;
-        br += xk.x * hk.x;
-        bi += xk.y * hk.y;
-    }
-    yk = (k == 0) ? make_double2(br, bi) : make_double2(kr, ki);
-    yn = make_double2(nr, ni);
 }
 
-/* Inverse: packed half spectrum Y -> second half of the 2N-point real sequence -> clip -> dst */
+/* The fused head: the workgroup walks ONE partition at a time through all its bins (partition-major), accumulating the
+ * thread's eight bin pairs in registers.  Per partition it reads the delay-line slot and the IR partition front to back
+ * (k ascending from 0, n descending from N - 1): two long sequential streams per workgroup.  The bin-major order (all K
+ * partitions of one bin pair at once) had 32 interleaved streams per workgroup, 8192 on the chip, and lost 25 % of the
+ * bandwidth to DRAM page conflicts (profiles/experiments/README.md). */
+template <int LOGN, bool HNT>
+__device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int tid, double *sre, double *sim, const cplx *__restrict__ tw2) {
+    constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
+    const int K = ch.K;
+    double kr[ITER], ki[ITER], nr[ITER], ni[ITER], br = 0.0, bi = 0.0;
+#pragma unroll
+    for (int i = 0; i < ITER; i++) { kr[i] = 0.0; ki[i] = 0.0; nr[i] = 0.0; ni[i] = 0.0; }
+    for (int u = 0; u < K; u++) {
+        int slot = cur - u;
+        if (slot < 0) slot += K;
+        const cplx *__restrict__ x = ch.fdl + (size_t)slot * N;
+        const cplx *__restrict__ h = ch.H + (size_t)u * N;
+        cplx xk[ITER], hk[ITER], xn[ITER], hn[ITER];
+#pragma unroll
+        for (int i = 0; i < ITER; i++) {
+            const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+            xk[i] = mac_load<true>(x + k);
+            hk[i] = mac_load<HNT>(h + k);
+            xn[i] = mac_load<true>(x + n);
+            hn[i] = mac_load<HNT>(h + n);
+        }
+#pragma unroll
+        for (int i = 0; i < ITER; i++) {
+            kr[i] += xk[i].x * hk[i].x - xk[i].y * hk[i].y;
+            ki[i] += xk[i].x * hk[i].y + xk[i].y * hk[i].x;
+            nr[i] += xn[i].x * hn[i].x - xn[i].y * hn[i].y;
+            ni[i] += xn[i].x * hn[i].y + xn[i].y * hn[i].x;
+        }
+        br += xk[0].x * hk[0].x;                       /* bin 0 = (DC, Nyquist) as two reals: component-wise */
+        bi += xk[0].y * hk[0].y;
+    }
+#pragma unroll
+    for (int i = 0; i < ITER; i++) {
+        const int k = tid + T * i;
+        inv_head_store<LOGN>(k, (k == 0) ? make_double2(br, bi) : make_double2(kr[i], ki[i]), make_double2(nr[i], ni[i]), sre, sim, tw2);
+    }
+}
+
 /* FUSED 0: Y comes from fir_mac_kernel.  FUSED 1 / 2: the multiply-accumulate runs here, straight into the inverse's
  * first stage (no Y round trip through HBM: the 6 % of extra bytes cost the separate MAC 20 % of its time, see
  * profiles/probes/); 2 = the IR spectra are shared between channels and read with cacheable loads. */
@@ -403,35 +422,14 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
     int cur = 0;
     if constexpr (FUSED != 0) cur = (*ch.pos) % ch.K;
 
-    constexpr int ITER = (N / 2) / T;
+    if constexpr (FUSED == 1) mac_head<LOGN, true>(ch, cur, tid, sre, sim, tw2);
+    else if constexpr (FUSED == 2) mac_head<LOGN, false>(ch, cur, tid, sre, sim, tw2);
+    else {
+        constexpr int ITER = (N / 2) / T;
 #pragma unroll
-    for (int i = 0; i < ITER; i++) {
-        int k = tid + T * i;
-        cplx yk, yn;
-        {
-            const int n = (k == 0) ? N / 2 : N - k;
-            if constexpr (FUSED == 0) { yk = Y[k]; yn = Y[n]; }
-            else if constexpr (FUSED == 1) mac_pair<(N >= 1024 ? 8 : 4), true>(ch, N, cur, k, n, yk, yn);
-            else mac_pair<(N >= 1024 ? 8 : 4), false>(ch, N, cur, k, n, yk, yn);
-        }
-        if (k == 0) {
-            cplx y = yk;
-            sre[0] = y.x + y.y;
-            sim[0] = y.x - y.y;
-            cplx h = yn;
-            sre[GDG_PAD(N / 2)] = 2.0 * h.x;
-            sim[GDG_PAD(N / 2)] = -2.0 * h.y;
-        } else {
-            int n = N - k;
-            cplx A = make_double2(yk.x + yn.x, yk.y - yn.y);
-            cplx Bv = make_double2(yk.x - yn.x, yk.y + yn.y);
-            cplx w = tw2[k];
-            w.y = -w.y;
-            cplx O = cmul(Bv, w);
-            sre[GDG_PAD(k)] = A.x - O.y;
-            sim[GDG_PAD(k)] = A.y + O.x;
-            sre[GDG_PAD(n)] = A.x + O.y;
-            sim[GDG_PAD(n)] = -A.y + O.x;
+        for (int i = 0; i < ITER; i++) {
+            const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+            inv_head_store<LOGN>(k, Y[k], Y[n], sre, sim, tw2);
         }
     }
     __syncthreads();
