@@ -166,10 +166,18 @@ __device__ __forceinline__ double apply_map(double A, double B, double s) {
  * A ring of capacity C holds the last C inputs of a unit: oldest at wp, newest at wp - 1.
  * Sample with frame-relative index idx (-C <= idx < 0) is ring[(wp + idx) mod C].
  */
+/* Rings, unit states and frames live in HBM, but their pointers reach the unit functions through structs in memory, so the
+ * compiler only knows "generic" and emits FLAT loads (which also count as LDS operations and stall on both counters).  The
+ * accessors below restore the global address space. */
+#define GDG_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ const GDG_GLOBAL double *as_global(const double *p) { return (const GDG_GLOBAL double *)p; }
+__device__ __forceinline__ GDG_GLOBAL double *as_global(double *p) { return (GDG_GLOBAL double *)p; }
+__device__ __forceinline__ GDG_GLOBAL int *as_global(int *p) { return (GDG_GLOBAL int *)p; }
+
 __device__ __forceinline__ double ring_read(const double *ring, int C, int wp, int idx) {
     int p = wp + idx;
     if (p < 0) p += C;
-    return ring[p];
+    return as_global(ring)[p];
 }
 
 /* append the frame held in LDS buffer `in` to the ring (all threads), then thread 0 advances wp */
@@ -179,10 +187,10 @@ __device__ __forceinline__ void ring_append(double *ring, int C, int *wp_ptr, co
     int first = N > C ? N - C : 0;
     for (int i = first + (int)threadIdx.x; i < N; i += SEG_T) {
         int p = (wp + i) % C;
-        ring[p] = in[LX(i)];
+        as_global(ring)[p] = in[LX(i)];
     }
     __syncthreads();
-    if (threadIdx.x == 0) *wp_ptr = (wp + N) % C;
+    if (threadIdx.x == 0) *as_global(wp_ptr) = (wp + N) % C;
 }
 
 /* the reference's fractional delay read (e.g. effects/flanger.go:63-90): both weights are 1 when the delay is integral */
@@ -763,7 +771,7 @@ __device__ __forceinline__ void allpass_fetch(const double *ring, int M, int rp,
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         int r = (int)threadIdx.x + q * SEG_T;
-        pm0[q] = (r < cnt) ? ring[(rp + r) % M] : 0.0;
+        pm0[q] = (r < cnt) ? as_global(ring)[(rp + r) % M] : 0.0;
     }
 }
 template <int Q>
@@ -781,8 +789,8 @@ __device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M,
                 pm = p;
                 n += M;
             } while (n < N);
-            if (N >= M) ring[n - N] = p;                    /* the last M values of p, oldest first (n - M is this chain's last index) */
-            else ring[(rp + r) % M] = p;
+            if (N >= M) as_global(ring)[n - N] = p;         /* the last M values of p, oldest first (n - M is this chain's last index) */
+            else as_global(ring)[(rp + r) % M] = p;
         }
     }
     if (threadIdx.x == 0) *rp_out = (N >= M) ? 0 : (rp + N) % M;
@@ -824,22 +832,24 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     }
     double dlr[REVERB_QMAX];
     /* tapped delay line over the input history (reverb.go:65-116) */
+    {
 #pragma unroll
-    for (int q = 0; q < REVERB_QMAX; q++) {
-        int i = tid + q * SEG_T;
-        double pre = 0.0;
-        if (i < N) {
+        for (int q = 0; q < REVERB_QMAX; q++) {
+            int i = tid + q * SEG_T;
+            double pre = 0.0;
+            if (i < N) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int idx = i - taps[j];
-                double cur = 0.0;
-                if (idx >= 0) cur = in[LX(idx)];
-                else if (idx >= -DL) cur = ring_read(dl_ring, DL, dl_wp, idx);
-                pre += coeff[j] * cur;
+                for (int j = 0; j < 4; j++) {
+                    int idx = i - taps[j];
+                    double cur = 0.0;
+                    if (idx >= 0) cur = in[LX(idx)];
+                    else if (idx >= -DL) cur = ring_read(dl_ring, DL, dl_wp, idx);
+                    pre += coeff[j] * cur;
+                }
+                out[LX(i)] = pre;
             }
-            out[LX(i)] = pre;
+            dlr[q] = pre;
         }
-        dlr[q] = pre;
     }
     /* every old ring value must have arrived before any thread overwrites the rings below: vmcnt(0) (the tap loads were
      * needed here anyway), then the barrier */
@@ -1305,7 +1315,7 @@ __global__ void __launch_bounds__(SEG_T)
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, gdg_os_tables os, int *d_error) {
     const gdg_seg_chan ch = chans[blockIdx.x];
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = ch.src[i];
+    for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = as_global(ch.src)[i];
     __syncthreads();
     int flip = 0;                                   /* 0: s_a holds the current frame, 1: s_b */
     for (int u = 0; u < ch.unit_count; u++) {
@@ -1344,7 +1354,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         flip ^= 1;
     }
     const double *fin = flip ? s_b : s_a;
-    for (int i = tid; i < N; i += SEG_T) ch.dst[i] = fin[LX(i)];
+    for (int i = tid; i < N; i += SEG_T) as_global(ch.dst)[i] = fin[LX(i)];
 }
 
 int gdg_seg_supported(int unit_type) {
