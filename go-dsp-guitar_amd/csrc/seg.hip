@@ -170,6 +170,7 @@ __device__ __forceinline__ double apply_map(double A, double B, double s) {
  * compiler only knows "generic" and emits FLAT loads (which also count as LDS operations and stall on both counters).  The
  * accessors below restore the global address space. */
 #define GDG_GLOBAL __attribute__((address_space(1)))
+typedef double seg_v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ const GDG_GLOBAL double *as_global(const double *p) { return (const GDG_GLOBAL double *)p; }
 __device__ __forceinline__ GDG_GLOBAL double *as_global(double *p) { return (GDG_GLOBAL double *)p; }
 __device__ __forceinline__ GDG_GLOBAL int *as_global(int *p) { return (GDG_GLOBAL int *)p; }
@@ -1315,7 +1316,13 @@ __global__ void __launch_bounds__(SEG_T)
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, gdg_os_tables os, int *d_error) {
     const gdg_seg_chan ch = chans[blockIdx.x];
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = as_global(ch.src)[i];
+    if (((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0) {
+        /* 16 bytes per lane: half the load instructions, 1 KiB per wave access */
+        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)ch.src;
+        for (int i = tid; i < N / 2; i += SEG_T) { seg_v2d v = s2[i]; s_a[LX(2 * i)] = v.x; s_a[LX(2 * i + 1)] = v.y; }
+    } else {
+        for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = as_global(ch.src)[i];
+    }
     __syncthreads();
     int flip = 0;                                   /* 0: s_a holds the current frame, 1: s_b */
     for (int u = 0; u < ch.unit_count; u++) {
@@ -1354,7 +1361,12 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         flip ^= 1;
     }
     const double *fin = flip ? s_b : s_a;
-    for (int i = tid; i < N; i += SEG_T) as_global(ch.dst)[i] = fin[LX(i)];
+    if (((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0) {
+        GDG_GLOBAL seg_v2d *d2 = (GDG_GLOBAL seg_v2d *)ch.dst;
+        for (int i = tid; i < N / 2; i += SEG_T) { seg_v2d v = { fin[LX(2 * i)], fin[LX(2 * i + 1)] }; d2[i] = v; }
+    } else {
+        for (int i = tid; i < N; i += SEG_T) as_global(ch.dst)[i] = fin[LX(i)];
+    }
 }
 
 int gdg_seg_supported(int unit_type) {
