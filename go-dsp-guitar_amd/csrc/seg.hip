@@ -402,59 +402,82 @@ __device__ __forceinline__ double shape(const Shaper &S, double sample) {
  * dp0 gain, dp1 drive, dp2 clean, dp3 level; ip[4] valve (overdrive); jp0 factor (1, 2, 4).
  * hist: [0..7] the last 8 inputs, [8 .. 8+TAPS-2] the last TAPS-1 waveshaped oversampled samples.
  */
-UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
-    UNIT_PROLOGUE
-    Shaper S;
-    S.type = U->type; S.valve = U->ip[4];
-    S.gain = U->dp[0]; S.drive = U->dp[1]; S.clean = U->dp[2]; S.level = U->dp[3];
+/* Oversampled shaping (oversampling/oversampling.go:160-236 + the unit's curve), F = 2 or 4, in tiles through LDS:
+ *   stage 1: one thread per INPUT sample: the six-sample Lanczos window is read once and gives all F phases
+ *            (resample.go:148-176: phase 0 is the input sample itself), each shaped and stored in a POLYPHASE layout
+ *            (sample m at [m mod F][m div F]), so that stage 2's lanes walk consecutive LDS words;
+ *   stage 2: one thread per OUTPUT sample: y = clip(sum_k h[k] w[F o - k]) * 0.944 (filter.Process semantics), k ascending as
+ *            in the reference; the taps come through the scalar cache (uniform index, constant address space), the samples
+ *            from LDS without bank conflicts.  (The first version read taps per lane from global memory and walked LDS with
+ *            a stride of F doubles: 8-way conflicts at 4x.)
+ * hist: [8 inputs | TAPS - 1 oversampled samples of the previous call]. */
+#define GDG_CONST __attribute__((address_space(4)))
+__device__ __forceinline__ const double *uniform_ptr(const double *p) {
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const double *)(((unsigned long long)hi << 32) | lo);
+}
+template <int F>
+__device__ __forceinline__ void shaper_oversampled(const Shaper &S, const double *in, double *out, double *scr, double *hist_generic,
+                                                   const double *taps_generic, const double *lw_generic, int N) {
+    constexpr int TAPS = (F == 2) ? 77 : 155;
+    constexpr int PH = SEG_SCR / F;                           /* capacity of one phase array */
+    constexpr int BACK = (TAPS - 1 + F - 1) / F;              /* input samples reached back by the filter: ceil((TAPS-1)/F) */
+    constexpr int TILE = PH - BACK - 1;                       /* output samples per tile */
+    /* wave-uniform table pointers in SGPRs + constant address space: the taps arrive through scalar loads */
+    const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);
+    const GDG_CONST double *lw = (const GDG_CONST double *)uniform_ptr(lw_generic);
+    GDG_GLOBAL double *hist = as_global(hist_generic);
     const int tid = threadIdx.x;
-    const int f = U->jp[0];
-    if (f <= 1) {
-        for (int i = tid; i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
-        return;
-    }
-    const int TAPS = (f == 2) ? 77 : 155;
-    const double *taps = (f == 2) ? os.taps2 : os.taps4;
-    const double *lw = (f == 2) ? os.lanczos2 : os.lanczos4;
-    double *hist = U->hist;
-    const int TILE = (SEG_SCR - TAPS) / f;          /* output samples per tile */
     /* stream sample s[k]: k < 0 from the 8-sample history, else the frame */
     auto s_at = [&](int k) -> double { return k >= 0 ? in[LX(k)] : hist[8 + k]; };
     for (int o0 = 0; o0 < N; o0 += TILE) {
         const int S_out = min(TILE, N - o0);
-        const int m0 = f * o0 - (TAPS - 1);         /* first oversampled index needed */
-        const int cnt = f * S_out + (TAPS - 1);
-        for (int q = tid; q < cnt; q += SEG_T) {
-            int m = m0 + q;
-            double w;
-            if (m < 0) {
-                w = hist[8 + (TAPS - 1) + m];       /* tail of the previous call */
-            } else {
-                int i = m / f, r = m - i * f;
-                double up;
-                if (r == 0) {
-                    up = s_at(i - 4);               /* resample.go:160-164: exact input sample */
-                } else {
-                    const double *wq = lw + (r - 1) * 6;
-                    up = 0.0;
+        const int I0 = o0 - BACK;                             /* input index held at slot 0 of every phase array */
+        const int slots = S_out + BACK;                       /* slots I0 .. o0 + S_out - 1 */
+        for (int idx = tid; idx < slots; idx += SEG_T) {
+            const int i = I0 + idx;
+            if (i < 0) {
+                /* oversampled samples of the previous call (m = F i + r < 0); older than the stored tail: never read */
 #pragma unroll
-                    for (int t = 0; t < 6; t++) up += s_at(i - 6 + t) * wq[t];
+                for (int r = 0; r < F; r++) {
+                    const int m = F * i + r;
+                    scr[r * PH + idx] = (m >= -(TAPS - 1)) ? hist[8 + (TAPS - 1) + m] : 0.0;
                 }
-                w = shape(S, up);
+            } else {
+                double w6[6];
+#pragma unroll
+                for (int t = 0; t < 6; t++) w6[t] = s_at(i - 6 + t);
+                scr[idx] = shape(S, w6[2]);                   /* phase 0: s[i - 4], resample.go:160-164 */
+#pragma unroll
+                for (int r = 1; r < F; r++) {
+                    double up = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 6; t++) up += w6[t] * lw[(r - 1) * 6 + t];
+                    scr[r * PH + idx] = shape(S, up);
+                }
             }
-            scr[q] = w;
         }
         __syncthreads();
         for (int o = tid; o < S_out; o += SEG_T) {
-            /* filter.Process semantics: clip(sum_k h[k] w[n-k]) at the oversampled rate, keep every f-th */
-            int q = f * o + (TAPS - 1);
+            /* w[F (o0 + o) - k] lives in phase (-k mod F) at slot o + BACK - ceil(k / F) */
+            const double *base = scr + o + BACK;
             double acc = 0.0;
-            for (int k = 0; k < TAPS; k++) acc += taps[k] * scr[q - k];
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) {
+                const int r = (F - (k % F)) % F, back = (k + F - 1) / F;
+                acc += taps[k] * base[r * PH - back];
+            }
             out[LX(o0 + o)] = ATTENUATION_HALF_DECIBEL * clip1(acc);
         }
         if (o0 + TILE >= N) {
-            /* keep the last TAPS-1 oversampled samples; needs cnt >= TAPS-1 which always holds */
-            for (int q = tid; q < TAPS - 1; q += SEG_T) hist[8 + q] = scr[cnt - (TAPS - 1) + q];
+            /* keep the last TAPS - 1 oversampled samples m = F N - (TAPS - 1) .. F N - 1 */
+            for (int q = tid; q < TAPS - 1; q += SEG_T) {
+                const int m = F * N - (TAPS - 1) + q;
+                const int i = (m >= 0) ? m / F : -((-m + F - 1) / F);
+                const int r = m - i * F;
+                hist[8 + q] = scr[r * PH + (i - I0)];          /* i >= I0 always: F * BACK >= TAPS - 1 */
+            }
         }
         __syncthreads();
     }
@@ -463,6 +486,20 @@ UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
     if (tid < 8) keep = s_at(N - 8 + tid);
     __syncthreads();
     if (tid < 8) hist[tid] = keep;
+}
+
+UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
+    UNIT_PROLOGUE
+    Shaper S;
+    S.type = U->type; S.valve = U->ip[4];
+    S.gain = U->dp[0]; S.drive = U->dp[1]; S.clean = U->dp[2]; S.level = U->dp[3];
+    const int f = U->jp[0];
+    if (f <= 1) {
+        for (int i = threadIdx.x; i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
+        return;
+    }
+    if (f == 2) shaper_oversampled<2>(S, in, out, scr, U->hist, os.taps2, os.lanczos2, N);
+    else shaper_oversampled<4>(S, in, out, scr, U->hist, os.taps4, os.lanczos4, N);
 }
 
 /* ---- tone stack: effects/tonestack.go:19-100 ------------------------------------------------------
