@@ -1076,6 +1076,21 @@ __device__ __forceinline__ void envelope_lin(const double *v, double *e, int cnt
     __syncthreads();
 }
 
+/* decimating FIR over a LINEAR tile (the fuzz needs the oversampled stream in time order for its scans): taps through the
+ * scalar cache, k ascending as in the reference */
+template <int F>
+__device__ __forceinline__ void fir_decimate_linear(const double *scr, const double *taps_generic, double *out, int o0, int S_out) {
+    constexpr int TAPS = (F == 2) ? 77 : 155;
+    const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);
+    for (int o = threadIdx.x; o < S_out; o += SEG_T) {
+        const double *base = scr + F * o + (TAPS - 1);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) acc += taps[k] * base[-k];
+        out[LX(o0 + o)] = ATTENUATION_HALF_DECIBEL * clip1(acc);
+    }
+}
+
 UNIT_FN unit_fuzz_os(UNIT_ARGS, const gdg_os_tables &os) {
     UNIT_PROLOGUE
     const int tid = threadIdx.x;
@@ -1132,12 +1147,8 @@ UNIT_FN unit_fuzz_os(UNIT_ARGS, const gdg_os_tables &os) {
             if (c1 == cnt && c0 < cnt) st[1] = s;
         }
         __syncthreads();
-        for (int o = tid; o < S_out; o += SEG_T) {
-            int q = f * o + (TAPS - 1);
-            double acc = 0.0;
-            for (int k = 0; k < TAPS; k++) acc += taps[k] * scr[q - k];
-            out[LX(o0 + o)] = ATTENUATION_HALF_DECIBEL * clip1(acc);
-        }
+        if (f == 2) fir_decimate_linear<2>(scr, taps, out, o0, S_out);
+        else fir_decimate_linear<4>(scr, taps, out, o0, S_out);
         __syncthreads();
         /* slide: the last TAPS-1 shaped samples become the head of the next tile (and of the next call) */
         double keep = 0.0;

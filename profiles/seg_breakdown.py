@@ -31,6 +31,7 @@ CASES = [
     ("octaver", [("octaver", None)]),
     ("auto_wah", [("auto_wah", None)]),
     ("fuzz", [("fuzz", None)]),
+    ("fuzz 4x", [("fuzz", [1, 50, 0, 20, 100, 0, 2])]),
     ("bandpass 8", [("bandpass", [3, 300, 3000])]),
     ("seg0 of bench", [("compressor", None), ("overdrive", [0, 20, 100, 0, 1, 0]), ("tone_stack", None), ("chorus", None)]),
     ("seg1 of bench", [("cabinet", None), ("reverb", None)]),
@@ -44,7 +45,7 @@ def main():
     x = np.stack([synth_signal(c, frames, sr) for c in range(nch)])
     print("%-16s %10s %12s %12s" % ("chain", "avg_us", "Msamples/s", "GB/s@16B"))
     for name, chain in CASES:
-        if only and name.split()[0] not in only:
+        if only and name.split()[0] not in only and name not in only:
             continue
         ctx = pkg.Context(nch, frames)
         for c in range(nch):
