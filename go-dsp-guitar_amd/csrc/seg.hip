@@ -253,7 +253,15 @@ __device__ __forceinline__ void envelope_to(const double *in, double *dst, int N
 #define CHK (GDG_MAX_FRAMES / SEG_T)
 static_assert(CHK * SEG_T == GDG_MAX_FRAMES, "chunk size");
 
-struct Chunk { int c0, len; bool last; };
+/* A thread's chunk of the frame.  FULL = the frame is exactly CHK * SEG_T samples (the batch block size): every chunk is complete
+ * and the per-sample "inside the chunk?" guards -- a v_cndmask pair and an exec-mask update per sample and per section, 3/4
+ * of the instructions of the cabinet -- fold away at compile time. */
+template <bool FULL> struct ChunkT {
+    int c0, len; bool last;
+    static constexpr bool full = FULL;
+    __device__ __forceinline__ bool has(int i) const { return FULL || i < len; }
+};
+typedef ChunkT<false> Chunk;
 
 __device__ __forceinline__ Chunk my_chunk(int N) {
     const int m = (N + SEG_T - 1) / SEG_T;
@@ -263,29 +271,38 @@ __device__ __forceinline__ Chunk my_chunk(int N) {
     c.last = (c.len > 0) && (c.c0 + c.len == N);
     return c;
 }
-__device__ __forceinline__ void chunk_load(const double *buf, const Chunk &c, double (&v)[CHK]) {
-#pragma unroll
-    for (int i = 0; i < CHK; i++) v[i] = (i < c.len) ? buf[LX(c.c0 + i)] : 0.0;
+__device__ __forceinline__ ChunkT<true> full_chunk() {
+    ChunkT<true> c;
+    c.c0 = (int)threadIdx.x * CHK;
+    c.len = CHK;
+    c.last = threadIdx.x == SEG_T - 1;
+    return c;
 }
-__device__ __forceinline__ void chunk_store(double *buf, const Chunk &c, const double (&v)[CHK]) {
+template <class C>
+__device__ __forceinline__ void chunk_load(const double *buf, const C &c, double (&v)[CHK]) {
 #pragma unroll
-    for (int i = 0; i < CHK; i++) if (i < c.len) buf[LX(c.c0 + i)] = v[i];
+    for (int i = 0; i < CHK; i++) v[i] = c.has(i) ? buf[LX(c.c0 + i)] : 0.0;
+}
+template <class C>
+__device__ __forceinline__ void chunk_store(double *buf, const C &c, const double (&v)[CHK]) {
+#pragma unroll
+    for (int i = 0; i < CHK; i++) if (c.has(i)) buf[LX(c.c0 + i)] = v[i];
 }
 
 /* one-pole section on a register chunk; s is the section's state before the frame on entry, after it on exit (valid in the `last` thread) */
 enum { OP_DIFF_OLD = 0, OP_OLD = 1, OP_NEW = 2, OP_DIFF_NEW = 3 };    /* what a one-pole section emits, see onepole() below */
 
-template <int MODE>
-__device__ __forceinline__ void onepole_reg(double (&v)[CHK], const Chunk &c, double a, double &s, double *tmp) {
+template <int MODE, class C>
+__device__ __forceinline__ void onepole_reg(double (&v)[CHK], const C &c, double a, double &s, double *tmp) {
     double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
     const double keep = 1.0 - a;
 #pragma unroll
-    for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= keep; double diff = v[i] - B[0]; B[0] += diff * a; }
+    for (int i = 0; i < CHK; i++) if (c.has(i)) { A[0] *= keep; double diff = v[i] - B[0]; B[0] += diff * a; }
     block_scan<1, false>(A, B, Ap, Bp, tmp);
     s = apply_map<false>(Ap[0], Bp[0], s);
 #pragma unroll
     for (int i = 0; i < CHK; i++) {
-        if (i < c.len) {
+        if (c.has(i)) {
             double x = v[i];
             double diff = x - s;
             double s_old = s;
@@ -296,16 +313,16 @@ __device__ __forceinline__ void onepole_reg(double (&v)[CHK], const Chunk &c, do
 }
 
 /* the same with a per-sample coefficient (auto-wah) */
-template <int MODE>
-__device__ __forceinline__ void onepole_reg_var(double (&v)[CHK], const double (&a)[CHK], const Chunk &c, double &s, double *tmp) {
+template <int MODE, class C>
+__device__ __forceinline__ void onepole_reg_var(double (&v)[CHK], const double (&a)[CHK], const C &c, double &s, double *tmp) {
     double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
 #pragma unroll
-    for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= (1.0 - a[i]); double diff = v[i] - B[0]; B[0] += diff * a[i]; }
+    for (int i = 0; i < CHK; i++) if (c.has(i)) { A[0] *= (1.0 - a[i]); double diff = v[i] - B[0]; B[0] += diff * a[i]; }
     block_scan<1, false>(A, B, Ap, Bp, tmp);
     s = apply_map<false>(Ap[0], Bp[0], s);
 #pragma unroll
     for (int i = 0; i < CHK; i++) {
-        if (i < c.len) {
+        if (c.has(i)) {
             double x = v[i];
             double diff = x - s;
             double s_old = s;
@@ -316,25 +333,26 @@ __device__ __forceinline__ void onepole_reg_var(double (&v)[CHK], const double (
 }
 
 /* follower on a register chunk: x -> e (value after each sample); same conventions as onepole_reg */
-__device__ __forceinline__ void envelope_reg(const double (&x)[CHK], double (&e)[CHK], const Chunk &c, int follow, double d_inv, double d,
+template <class C>
+__device__ __forceinline__ void envelope_reg(const double (&x)[CHK], double (&e)[CHK], const C &c, int follow, double d_inv, double d,
                                              double &s, double *tmp) {
     double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
 #pragma unroll
     for (int i = 0; i < CHK; i++) e[i] = 1.0;
     if (follow == 0) {
 #pragma unroll
-        for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= d_inv; B[0] *= d_inv; double q = fabs(x[i]); if (q > B[0]) B[0] = q; }
+        for (int i = 0; i < CHK; i++) if (c.has(i)) { A[0] *= d_inv; B[0] *= d_inv; double q = fabs(x[i]); if (q > B[0]) B[0] = q; }
         block_scan<1, true>(A, B, Ap, Bp, tmp);
         s = apply_map<true>(Ap[0], Bp[0], s);
 #pragma unroll
-        for (int i = 0; i < CHK; i++) if (i < c.len) { s *= d_inv; double q = fabs(x[i]); if (q > s) s = q; e[i] = s; }
+        for (int i = 0; i < CHK; i++) if (c.has(i)) { s *= d_inv; double q = fabs(x[i]); if (q > s) s = q; e[i] = s; }
     } else if (follow == 1) {
 #pragma unroll
-        for (int i = 0; i < CHK; i++) if (i < c.len) { A[0] *= d_inv; double diff = fabs(x[i]) - B[0]; B[0] += diff * d; }
+        for (int i = 0; i < CHK; i++) if (c.has(i)) { A[0] *= d_inv; double diff = fabs(x[i]) - B[0]; B[0] += diff * d; }
         block_scan<1, false>(A, B, Ap, Bp, tmp);
         s = apply_map<false>(Ap[0], Bp[0], s);
 #pragma unroll
-        for (int i = 0; i < CHK; i++) if (i < c.len) { double diff = fabs(x[i]) - s; s += diff * d; e[i] = s; }
+        for (int i = 0; i < CHK; i++) if (c.has(i)) { double diff = fabs(x[i]) - s; s += diff * d; e[i] = s; }
     } else {
 #pragma unroll
         for (int i = 0; i < CHK; i++) e[i] = 1.0;
@@ -344,9 +362,9 @@ __device__ __forceinline__ void envelope_reg(const double (&x)[CHK], double (&e)
 
 /* ---- compressor: effects/compressor.go:18-84 ---------------------------------------------------
  * ip0 follow; dp0 gain limit factor, dp1 target factor, dp2 exp(-20/sr), dp3 1 - dp2; ds0 envelope */
-UNIT_FN unit_compressor(UNIT_ARGS) {
+template <class C>
+__device__ __forceinline__ void compressor_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
     UNIT_PROLOGUE
-    const Chunk c = my_chunk(N);
     double s = U->ds[0];
     double x[CHK], e[CHK];
     chunk_load(in, c, x);
@@ -361,6 +379,10 @@ UNIT_FN unit_compressor(UNIT_ARGS) {
     }
     chunk_store(out, c, x);
     if (c.last) U->ds[0] = s;
+}
+UNIT_FN unit_compressor(UNIT_ARGS) {
+    if (N == CHK * SEG_T) compressor_body(U, flip, N, full_chunk());       /* the batch block size: guard-free chunks */
+    else compressor_body(U, flip, N, my_chunk(N));
 }
 
 /* ---- memoryless waveshapers ---------------------------------------------------------------------- */
@@ -504,9 +526,9 @@ UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
 
 /* ---- tone stack: effects/tonestack.go:19-100 ------------------------------------------------------
  * dp0..3 band factors, dp4..7 (1 - exp(-2 pi fA/sr)), dp8..11 (1 - exp(-2 pi fB/sr)); ds0..3 hcv, ds4..7 lcv */
-UNIT_FN unit_tonestack(UNIT_ARGS) {
+template <class C>
+__device__ __forceinline__ void tonestack_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
     UNIT_PROLOGUE
-    const Chunk c = my_chunk(N);
     double *st = tmp + SEG_STASH;                    /* the eight capacitor voltages, stashed in LDS (not in live registers) */
     if (threadIdx.x < 8) st[threadIdx.x] = U->ds[threadIdx.x];
     double x[CHK];
@@ -525,7 +547,7 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
         for (int j = 0; j < 2; j++) { A[j] = 1.0; B[j] = 0.0; }
 #pragma unroll
         for (int i = 0; i < CHK; i++) {
-            if (i < c.len) {
+            if (c.has(i)) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) { A[j] *= (1.0 - aH[j]); double diff = x[i] - B[j]; B[j] += diff * aH[j]; }
             }
@@ -539,7 +561,7 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
         for (int j = 0; j < 2; j++) { A[j] = 1.0; B[j] = 0.0; }
 #pragma unroll
         for (int i = 0; i < CHK; i++) {
-            if (i < c.len) {
+            if (c.has(i)) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     double diff = x[i] - h[j];
@@ -557,7 +579,7 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
         /* pass 3: the reference's loop body from the exact chunk-start state */
 #pragma unroll
         for (int i = 0; i < CHK; i++) {
-            if (i < c.len) {
+            if (c.has(i)) {
                 double sum = (pair == 0) ? 0.0 : out[LX(c.c0 + i)];
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
@@ -577,13 +599,17 @@ UNIT_FN unit_tonestack(UNIT_ARGS) {
         }
     }
 }
+UNIT_FN unit_tonestack(UNIT_ARGS) {
+    if (N == CHK * SEG_T) tonestack_body(U, flip, N, full_chunk());       /* the batch block size: guard-free chunks */
+    else tonestack_body(U, flip, N, my_chunk(N));
+}
 
 /* ---- cabinet (IIR): effects/cabinet.go:27-162 -------------------------------------------------------
  * dp0..2 high-pass (1 - exp(-2 pi f/sr)) for 300/120/80 Hz, dp3..6 low-pass for 3/4/5/6 kHz; ds0..2 hcv, ds3..6 lcv.
  * Seven one-pole sections in series on a register chunk: per section a zero-state pass, a workgroup scan, an exact replay. */
-UNIT_FN unit_cabinet(UNIT_ARGS) {
+template <class C>
+__device__ __forceinline__ void cabinet_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
     UNIT_PROLOGUE
-    const Chunk c = my_chunk(N);
     double *st = tmp + SEG_STASH;                    /* the seven capacitor voltages, fetched once, kept in LDS */
     if (threadIdx.x < 7) st[threadIdx.x] = U->ds[threadIdx.x];
     double v[CHK];
@@ -600,6 +626,10 @@ UNIT_FN unit_cabinet(UNIT_ARGS) {
 #pragma unroll
     for (int i = 0; i < CHK; i++) v[i] = clip1(v[i]);
     chunk_store(out, c, v);
+}
+UNIT_FN unit_cabinet(UNIT_ARGS) {
+    if (N == CHK * SEG_T) cabinet_body(U, flip, N, full_chunk());       /* the batch block size: guard-free chunks */
+    else cabinet_body(U, flip, N, my_chunk(N));
 }
 
 /* ---- chorus: effects/chorus.go:19-131 ------------------------------------------------------------------
