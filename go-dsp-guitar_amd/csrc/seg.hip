@@ -653,7 +653,7 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
         sincos(zero_phase, &s0, &c0);
         sincos(angular * ((double)SEG_T / sr), &sd, &cd);
     }
-    for (int i = threadIdx.x; i < N; i += SEG_T) {
+    auto sample = [&](int i) {
         double effected = 0.0;
 #pragma unroll
         for (int j = 0; j < 5; j++) {
@@ -663,10 +663,14 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
             effected += 0.2 * frac_delay(in, ring, C, wp, i, delay_samples);
         }
         out[LX(i)] = (0.5 * in[LX(i)]) + (0.5 * effected);
-        {
-            double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
-            s0 = sn; c0 = cn;
-        }
+        double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
+        s0 = sn; c0 = cn;
+    };
+    if (N == CHK * SEG_T) {
+#pragma unroll
+        for (int q = 0; q < CHK; q++) sample((int)threadIdx.x + q * SEG_T);     /* the batch block size: a fixed trip count */
+    } else {
+        for (int i = threadIdx.x; i < N; i += SEG_T) sample(i);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
