@@ -139,3 +139,111 @@ func (this *Context) ProcessStaged(channels []int, frames int, sampleRate uint32
 	}
 	return this.err(C.gdg_process_staged(this.ctx, &cs[0], C.int(len(cs)), C.int(frames), C.uint32_t(sampleRate)))
 }
+
+// ---- the data formats either side of the chain (optional; include/gdg.h "data formats" section) ----------------
+
+// WaveDecode: bytesToSamples + samplesToChannels (wave/wave.go:237-270, :790-838).  data = the data chunk of a RIFF/WAVE file
+// (a []byte holds no Go pointers: legal for the duration of the call); returns planar samples, one slice per channel.
+func (this *Context) WaveDecode(format int, data []byte, channels int) ([][]float64, error) {
+	width := int(C.gdg_wave_bytes_per_sample(C.int(format)))
+	if width == 0 || channels <= 0 {
+		return nil, fmt.Errorf("gdg: unknown sample format %d or bad channel count %d", format, channels)
+	}
+	per := len(data) / (width * channels)
+	flat := make([]float64, per*channels)
+	if per > 0 {
+		rc := C.gdg_wave_decode(this.ctx, C.int(format), unsafe.Pointer(&data[0]), C.size_t(per), C.uint(channels), (*C.double)(unsafe.Pointer(&flat[0])))
+		if err := this.err(rc); err != nil {
+			return nil, err
+		}
+	}
+	out := make([][]float64, channels)
+	for c := range out {
+		out[c] = flat[c*per : (c+1)*per]
+	}
+	return out, nil
+}
+
+// WaveEncode: channelsToSamples + samplesToBytes (wave/wave.go:173-232, :737-785) of equally long channels.
+func (this *Context) WaveEncode(format int, channels [][]float64) ([]byte, error) {
+	width := int(C.gdg_wave_bytes_per_sample(C.int(format)))
+	if width == 0 || len(channels) == 0 {
+		return nil, fmt.Errorf("gdg: unknown sample format %d or no channels", format)
+	}
+	per := len(channels[0])
+	flat := make([]float64, 0, per*len(channels))
+	for _, ch := range channels {
+		flat = append(flat, ch[:per]...)
+	}
+	data := make([]byte, per*len(channels)*width)
+	if per == 0 {
+		return data, nil
+	}
+	rc := C.gdg_wave_encode(this.ctx, C.int(format), (*C.double)(unsafe.Pointer(&flat[0])), C.size_t(per), C.uint(len(channels)), unsafe.Pointer(&data[0]))
+	return data, this.err(rc)
+}
+
+// ResampleTime: resample.Time (resample/resample.go:72-103).
+func (this *Context) ResampleTime(samples []float64, sourceRate uint32, targetRate uint32) ([]float64, error) {
+	n := C.gdg_resample_time_length(C.int(len(samples)), C.uint32_t(sourceRate), C.uint32_t(targetRate))
+	if n <= 0 || len(samples) == 0 {
+		return []float64{}, nil
+	}
+	out := make([]float64, int(n))
+	rc := C.gdg_resample_time(this.ctx, (*C.double)(unsafe.Pointer(&samples[0])), C.int(len(samples)), C.uint32_t(sourceRate), C.uint32_t(targetRate),
+		(*C.double)(unsafe.Pointer(&out[0])), n)
+	return out, this.err(rc)
+}
+
+// MetersConfigure / MetersSetEnabled / MetersAnalyze: level.Meter over n ports (level/level.go:100-279).  Buffers reach the meters
+// through MetersProcessDevice on rows already resident on the device (the staging slab's device twin) or through
+// gdg_meter_process with C-allocated rows; Go slices of slices cannot cross cgo.
+func (this *Context) MetersConfigure(ports int) error { return this.err(C.gdg_meter_configure(this.ctx, C.int(ports))) }
+func (this *Context) MetersSetEnabled(port int, enabled bool) error {
+	e := C.int(0)
+	if enabled {
+		e = 1
+	}
+	return this.err(C.gdg_meter_set_enabled(this.ctx, C.int(port), e))
+}
+func (this *Context) MetersAnalyze(ports int) (levels []int32, peaks []int32, err error) {
+	levels, peaks = make([]int32, ports), make([]int32, ports)
+	if ports == 0 {
+		return levels, peaks, nil
+	}
+	err = this.err(C.gdg_meter_analyze(this.ctx, (*C.int32_t)(unsafe.Pointer(&levels[0])), (*C.int32_t)(unsafe.Pointer(&peaks[0]))))
+	return levels, peaks, err
+}
+
+// Metronome: metronome.Metronome (metronome/metronome.go:63-131).
+func (this *Context) MetronomeSetTick(coefficients []float64) error {
+	if coefficients == nil {
+		return this.err(C.gdg_metronome_set_tick(this.ctx, nil, 0))
+	}
+	var dummy C.double
+	p := &dummy
+	if len(coefficients) > 0 {
+		p = (*C.double)(unsafe.Pointer(&coefficients[0]))
+	}
+	return this.err(C.gdg_metronome_set_tick(this.ctx, p, C.int(len(coefficients))))
+}
+func (this *Context) MetronomeSetTock(coefficients []float64) error {
+	if coefficients == nil {
+		return this.err(C.gdg_metronome_set_tock(this.ctx, nil, 0))
+	}
+	var dummy C.double
+	p := &dummy
+	if len(coefficients) > 0 {
+		p = (*C.double)(unsafe.Pointer(&coefficients[0]))
+	}
+	return this.err(C.gdg_metronome_set_tock(this.ctx, p, C.int(len(coefficients))))
+}
+func (this *Context) MetronomeConfigure(beatsPerPeriod uint32, bpmSpeed uint32, sampleRate uint32) error {
+	return this.err(C.gdg_metronome_configure(this.ctx, C.uint32_t(beatsPerPeriod), C.uint32_t(bpmSpeed), C.uint32_t(sampleRate)))
+}
+func (this *Context) MetronomeProcess(out []float64) error {
+	if len(out) == 0 {
+		return nil
+	}
+	return this.err(C.gdg_metronome_process(this.ctx, (*C.double)(unsafe.Pointer(&out[0])), C.int(len(out))))
+}
