@@ -148,12 +148,18 @@ __device__ __forceinline__ void pass_compute(cplx (&v)[16], const cplx *__restri
         if constexpr (NS > 1) {
             int kk = j & (NS - 1);
             constexpr int stepm = N / (NS * R);
+            /* the R - 1 twiddles w^t of this butterfly from ONE table load: w, w^2, w^4, w^8 by squaring, the others as
+             * products of two of them (depth <= 4 multiplications, error ~4 ulp) instead of R - 1 scattered 16-byte loads */
+            cplx wp[R];
+            wp[1] = tw[kk * stepm];
+            if constexpr (INV) wp[1].y = -wp[1].y;
 #pragma unroll
-            for (int t = 1; t < R; t++) {
-                cplx w = tw[kk * t * stepm];
-                if constexpr (INV) w.y = -w.y;
-                u[t] = cmul(u[t], w);
+            for (int t = 2; t < R; t++) {
+                const int hi = 1 << (31 - __builtin_clz(t)), lo = t - hi;       /* t = hi + lo, hi a power of two */
+                wp[t] = (lo == 0) ? cmul(wp[t / 2], wp[t / 2]) : cmul(wp[hi], wp[lo]);
             }
+#pragma unroll
+            for (int t = 1; t < R; t++) u[t] = cmul(u[t], wp[t]);
         }
         Dft<R, INV>::run(u);
 #pragma unroll
