@@ -28,6 +28,21 @@ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x +
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+/* Frames and spectra live in HBM, but their pointers come out of the channel descriptors in memory, so the compiler only knows
+ * "generic" and would emit FLAT loads / stores -- which also count as LDS operations, so every wait for an LDS read would
+ * wait for the outstanding HBM accesses too.  These accessors restore the global address space. */
+#define GDG_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ cplx gload(const cplx *p) {
+    v2d v = *reinterpret_cast<const GDG_GLOBAL v2d *>((const GDG_GLOBAL void *)p);
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void gstore(cplx *p, cplx c) {
+    v2d v = { c.x, c.y };
+    *reinterpret_cast<GDG_GLOBAL v2d *>((GDG_GLOBAL void *)p) = v;
+}
+
+
 #define GDG_C1 0.92387953251128673848      /* cos(pi/8) */
 #define GDG_S1 0.38268343236508978178      /* sin(pi/8) */
 #define GDG_RH 0.70710678118654752440      /* sqrt(1/2) */
@@ -239,12 +254,12 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
             int e = j + t * (N / R0);
             cplx val;
             if (e < N / 2) {
-                val = *reinterpret_cast<const cplx *>(a + 2 * e);
+                val = gload(reinterpret_cast<const cplx *>(a + 2 * e));
             } else {
                 if constexpr (IRJOB) val = make_double2(0.0, 0.0);
                 else {
-                    val = *reinterpret_cast<const cplx *>(bsrc + 2 * (e - N / 2));
-                    *reinterpret_cast<cplx *>(prev_out + 2 * (e - N / 2)) = val;
+                    val = gload(reinterpret_cast<const cplx *>(bsrc + 2 * (e - N / 2)));
+                    gstore(reinterpret_cast<cplx *>(prev_out + 2 * (e - N / 2)), val);
                 }
             }
             v[b * R0 + t] = val;
@@ -262,9 +277,9 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
         int k = tid + T * i;
         if (k == 0) {
             double zx = sre[0], zy = sim[0];
-            out[0] = make_double2((zx + zy) * scale, (zx - zy) * scale);
+            gstore(out, make_double2((zx + zy) * scale, (zx - zy) * scale));
             double hx = sre[GDG_PAD(N / 2)], hy = sim[GDG_PAD(N / 2)];
-            out[N / 2] = make_double2(hx * scale, -hy * scale);
+            gstore(out + N / 2, make_double2(hx * scale, -hy * scale));
         } else {
             int n = N - k;
             cplx zk = make_double2(sre[GDG_PAD(k)], sim[GDG_PAD(k)]);
@@ -273,8 +288,8 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
             cplx Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
             cplx cw = cmul(tw2[k], Bv);
             double hs = 0.5 * scale;
-            out[k] = make_double2((A.x + cw.y) * hs, (A.y - cw.x) * hs);
-            out[n] = make_double2((A.x - cw.y) * hs, (-A.y - cw.x) * hs);
+            gstore(out + k, make_double2((A.x + cw.y) * hs, (A.y - cw.x) * hs));
+            gstore(out + n, make_double2((A.x - cw.y) * hs, (-A.y - cw.x) * hs));
         }
     }
 }
@@ -282,15 +297,14 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
 /* Y[b] = sum_k FDL[(pos - k) mod K][b] * H[k][b]; bin 0 is the (DC, Nyquist) pair of reals.
  * UNROLL partitions are loaded before any is used (2 * UNROLL * BPT 16-byte loads in flight per lane);
  * BPT adjacent bins per lane; NT: non-temporal loads (each spectrum is read exactly once per launch). */
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 template <bool NT>
 __device__ __forceinline__ cplx mac_load(const cplx *p) {
     if constexpr (NT) {
-        v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+        v2d v = __builtin_nontemporal_load(reinterpret_cast<const GDG_GLOBAL v2d *>((const GDG_GLOBAL void *)p));
         return make_double2(v.x, v.y);
     } else {
-        return *p;
+        return gload(p);
     }
 }
 
@@ -336,14 +350,14 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
         if (slot < 0) slot += K;
 #pragma unroll
         for (int q = 0; q < BPT; q++) {
-            cplx x = fdl[(size_t)slot * P + q], h = H[(size_t)k * P + q];
+            cplx x = gload(fdl + (size_t)slot * P + q), h = gload(H + (size_t)k * P + q);
             ar[q] += x.x * h.x - x.y * h.y;
             ai[q] += x.x * h.y + x.y * h.x;
             if (q == 0) { br += x.x * h.x; bi += x.y * h.y; }
         }
     }
 #pragma unroll
-    for (int q = 0; q < BPT; q++) ch.Y[b0 + q] = (b0 + q == 0) ? make_double2(br, bi) : make_double2(ar[q], ai[q]);
+    for (int q = 0; q < BPT; q++) gstore(ch.Y + b0 + q, (b0 + q == 0) ? make_double2(br, bi) : make_double2(ar[q], ai[q]));
 }
 
 /* Inverse: packed half spectrum Y -> second half of the 2N-point real sequence -> clip -> dst */
@@ -435,7 +449,7 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
 #pragma unroll
         for (int i = 0; i < ITER; i++) {
             const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
-            inv_head_store<LOGN>(k, Y[k], Y[n], sre, sim, tw2);
+            inv_head_store<LOGN>(k, gload(Y + k), gload(Y + n), sre, sim, tw2);
         }
     }
     __syncthreads();
@@ -459,7 +473,7 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
             /* filter/filter.go:487-493: the emitted samples are clipped to [-1, 1] */
             z.x = fmin(1.0, fmax(-1.0, z.x));
             z.y = fmin(1.0, fmax(-1.0, z.y));
-            *reinterpret_cast<cplx *>(dst + 2 * (n - N / 2)) = z;
+            gstore(reinterpret_cast<cplx *>(dst + 2 * (n - N / 2)), z);
         }
     }
     if (tid == 0) {
