@@ -2,23 +2,27 @@
  * seg.hip -- the serial per-sample stage: every effects.Unit.Process() that is not the FIR power
  * amp, fused per channel into ONE launch per chain segment (the units between two FIR units).
  *
- * Design (gfx950): one workgroup of 256 threads (4 wavefronts) per channel; the frame (<= 8192
+ * Design (gfx950): one workgroup of 1024 threads (16 wavefronts, 4 per SIMD) per channel; the frame (<= 8192
  * float64) is loaded once from HBM into LDS, ping-pongs between two LDS buffers from unit to
  * unit and is written once (16 B per sample of frame traffic, plus each unit's own state).
  * The 160 KiB LDS of CDNA4 is what lets two 8192-sample FP64 frames plus a 26 KiB tile live
- * on-chip.  Recurrences are not run sample by sample by one lane:
+ * on-chip.  Every unit is a non-inlined device function over the file-scope LDS arrays (all 21 inlined
+ * into one kernel spilled hundreds of bytes per lane).  Recurrences are not run sample by sample by one lane:
  *   - one-pole sections and the "level" follower are affine maps, the peak follower is a
- *     max-affine map; both compose associatively, so every thread reduces its 32-sample chunk
- *     to one map, the 256 maps are scanned across the workgroup (DPP/shuffle inside a wave, LDS
- *     across the four waves) and every thread then replays its chunk from the exact incoming
- *     state IN THE REFERENCE'S OPERATION ORDER (so only the chunk-start state carries scan
- *     rounding, ~1e-16 relative);
+ *     max-affine map; both compose associatively, so every thread reduces its 8-sample chunk
+ *     to one map, the 1024 maps are scanned across the workgroup (DPP row shifts inside 16-lane rows,
+ *     readlane across rows, a 16-lane DPP scan of the wave totals through LDS) and every thread then
+ *     replays its chunk from the exact incoming state IN THE REFERENCE'S OPERATION ORDER (so only the
+ *     chunk-start state carries scan rounding, ~1e-16 relative);
+ *   - the noise gate and the octaver's polarity logic are finite-state machines: scans of small
+ *     function tables;
  *   - feed-forward delays (chorus, flanger, phaser, delay, reverb taps) read the unit's INPUT
  *     history and are embarrassingly parallel; history lives in an HBM ring per unit;
- *   - the reverb all-passes are true feedback loops of length M >= 99 samples: processed in
- *     tiles of M samples, all lanes busy inside a tile;
+ *   - the reverb all-passes are true feedback loops of length M >= 99 samples that only couple samples
+ *     M apart: the chains n, n + M, n + 2M, ... are walked independently, in place;
  *   - 2x/4x oversampling never leaves the CU: Lanczos-3 up-sampling (precomputed 6-tap polyphase
- *     weights), the waveshaper and the 77/155-tap decimator run tile by tile through LDS.
+ *     weights), the waveshaper and the 77/155-tap decimator run tile by tile through LDS (polyphase
+ *     layout, taps through the scalar cache).
  *
  * Compiled with -ffp-contract=off: Go never fuses multiply-add.
  */
