@@ -10,9 +10,13 @@
  *             Stockham FFT held entirely in registers + LDS (P = 8192: 16 points per thread,
  *             512 threads, 139 KiB of LDS -- only possible with CDNA4's 160 KiB) -> half spectrum
  *             written to slot pos % K of the channel's frequency-domain delay line (FDL) in HBM.
- *   fir_mac   Y[b] = sum_k FDL[(pos - k) % K][b] * H[k][b]: pure streaming, 16 B per lane per
- *             load, 2K loads in flight per lane.  This is the HBM-bound kernel (the roofline one).
- *   fir_inv   one workgroup per channel: Y -> packed inverse FFT -> second half -> clip -> out.
+ *   fir_inv   one workgroup per channel.  Default (FUSED): the spectrum multiply-accumulate
+ *             Y[b] = sum_k FDL[(pos - k) % K][b] * H[k][b] runs HERE, partition by partition through all bins
+ *             (two long sequential streams per workgroup, 32 sixteen-byte loads per lane in flight), and lands
+ *             directly in the inverse transform's first stage in LDS -> packed inverse FFT -> second half ->
+ *             clip -> out.  This is the HBM-bound kernel (the roofline one).
+ *   fir_mac   the same multiply-accumulate as a kernel of its own writing Y (GDG_FIR_FUSED=0, kept for A/B runs:
+ *             the Y store alone costs it 20 % of its time, profiles/probes/).
  *
  * FP64 throughout; no MFMA (there is no dense contraction here).  Spectra are stored as P
  * complex128 per slot: bin 0 carries (Re X[0], Re X[P]) since both are real.
