@@ -40,7 +40,7 @@ static const int32_t g_param_default[GDG_UNIT_COUNT][GDG_MAX_PARAMS] = {
  * (the MAC then streams it from L2 / MALL for all but the first channel: SURVEY.md 8d, d < 1) */
 struct SharedSpectra {
     std::vector<double> taps;
-    int P = 0, K = 0;
+    int P = 0, K = 0, hop = 0;
     double2 *d_H = nullptr;
     ~SharedSpectra() { if (d_H) hipFree(d_H); }
 };
@@ -61,7 +61,7 @@ struct Unit {
     std::vector<double> taps;
     bool fir_dirty = true;
     bool fir_live = false;
-    int fir_P = 0, fir_K = 0;
+    int fir_P = 0, fir_K = 0, fir_hop = 0;     /* transform half size (power of two), partitions, samples per frame */
     uint32_t fir_sr = 0;
     double *d_prev = nullptr;
     double2 *d_fdl = nullptr, *d_Y = nullptr;
@@ -671,19 +671,28 @@ static int fir_tables(gdg_ctx *ctx, int P, double2 **tw, double2 **tw2) {
     return GDG_OK;
 }
 
-/* (Re)build the partitioned spectra and zero the convolution state of one power amp for partition P. */
-static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
+/* transform half size for a frame of `frames` samples: the next power of two, at least GDG_MIN_FIR_FRAMES */
+static int fir_transform_size(int frames) {
+    int P = GDG_MIN_FIR_FRAMES;
+    while (P < frames) P <<= 1;
+    return P;
+}
+
+/* (Re)build the partitioned spectra and zero the convolution state of one power amp: frames of `hop` samples, IR partitions
+ * of `hop` taps, transforms of 2 P points with P = fir_transform_size(hop) (hop == P for the power-of-two frame sizes). */
+static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
+    const int P = fir_transform_size(hop);
     if (u.fir_sr != sample_rate) {
         /* poweramp.go:191-203: a sample-rate change recompiles the filter, i.e. fresh state */
         u.fir_sr = sample_rate;
         u.fir_dirty = true;
         u.fir_live = false;
     }
-    if (!u.fir_dirty && u.fir_P == P) return GDG_OK;
-    if (!u.fir_dirty && u.fir_P != P && u.fir_live)
-        return fail(ctx, GDG_ERR_UNSUPPORTED, "frame size changed from %d to %d while a power amp holds convolution state; reset the unit first", u.fir_P, P);
+    if (!u.fir_dirty && u.fir_hop == hop) return GDG_OK;
+    if (!u.fir_dirty && u.fir_hop != hop && u.fir_live)
+        return fail(ctx, GDG_ERR_UNSUPPORTED, "frame size changed from %d to %d while a power amp holds convolution state; reset the unit first", u.fir_hop, hop);
     int L = (int)u.taps.size();
-    int K = (L + P - 1) / P;
+    int K = (L + hop - 1) / hop;
     if (K < 1) K = 1;                 /* filter.Empty: one all-zero partition => zeros out */
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_Y); hipFree(u.d_pos);
@@ -703,6 +712,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
         const unsigned char *b = reinterpret_cast<const unsigned char *>(u.taps.data());
         for (size_t i = 0; i < u.taps.size() * sizeof(double); i++) { key ^= b[i]; key *= 1099511628211ull; }
         key ^= (uint64_t)P; key *= 1099511628211ull;
+        key ^= (uint64_t)hop; key *= 1099511628211ull;
         key ^= (uint64_t)L; key *= 1099511628211ull;
     }
     if (ctx->share_spectra) {
@@ -710,7 +720,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
         for (auto it = range.first; it != range.second;) {
             std::shared_ptr<SharedSpectra> sp = it->second.lock();
             if (!sp) { it = ctx->spectra.erase(it); continue; }
-            if (sp->P == P && sp->taps == u.taps) { u.H = sp; break; }      /* compared in full: a hash match alone is not trusted */
+            if (sp->P == P && sp->hop == hop && sp->taps == u.taps) { u.H = sp; break; }      /* compared in full: a hash match alone is not trusted */
             ++it;
         }
     }
@@ -719,14 +729,19 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
         sp->taps = u.taps;
         sp->P = P;
         sp->K = K;
+        sp->hop = hop;
         HIP_TRY(ctx, hipMalloc((void **)&sp->d_H, spec));
         HIP_TRY(ctx, hipMemsetAsync(sp->d_H, 0, spec, ctx->stream));
         if (L > 0) {
             double2 *tw, *tw2;
             int rc = fir_tables(ctx, P, &tw, &tw2);
             if (rc != GDG_OK) return rc;
+            /* partition k = taps [k hop, (k + 1) hop), zero-padded to the transform half */
             std::vector<double> padded((size_t)K * (size_t)P, 0.0);
-            memcpy(padded.data(), u.taps.data(), (size_t)L * sizeof(double));
+            for (int k = 0; k < K; k++) {
+                int n = std::min(hop, L - k * hop);
+                memcpy(padded.data() + (size_t)k * P, u.taps.data() + (size_t)k * hop, (size_t)n * sizeof(double));
+            }
             double *d_taps = nullptr;
             gdg_fir_irjob *d_jobs = nullptr;
             std::vector<gdg_fir_irjob> jobs((size_t)K);
@@ -746,6 +761,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int P, uint32_t sample_rate) {
     }
     u.fir_P = P;
     u.fir_K = K;
+    u.fir_hop = hop;
     u.fir_dirty = false;
     u.fir_live = false;
     return GDG_OK;
@@ -788,12 +804,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         if (count == 0) { by_slot[0].push_back({ c, Op{ false, {} } }); count = 1; }     /* empty chain: copy */
         n_ops[(size_t)c] = count;
     }
-    if (any_fir) {
-        int l = 0;
-        while ((1 << l) < frames) l++;
-        if ((1 << l) != frames || frames < GDG_MIN_FIR_FRAMES)
-            return fail(ctx, GDG_ERR_UNSUPPORTED, "a chain with a power amp needs a power-of-two frame size in [%d, %d], got %d", GDG_MIN_FIR_FRAMES, GDG_MAX_FRAMES, frames);
-    }
+    (void)any_fir;
     /* blob layout: [step 0 descs][step 1 descs]...[seg units] */
     std::vector<gdg_seg_unit> seg_units;
     std::vector<std::vector<gdg_seg_chan>> seg_descs;
@@ -820,7 +831,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 gdg_fir_chan f;
                 memset(&f, 0, sizeof(f));
                 f.src = cur[(size_t)c]; f.dst = dst; f.prev = u.d_prev; f.fdl = u.d_fdl; f.H = u.H->d_H; f.Y = u.d_Y;
-                f.pos = u.d_pos; f.K = u.fir_K;
+                f.pos = u.d_pos; f.K = u.fir_K; f.hop = frames;
                 fd.push_back(f);
                 u.fir_live = true;
             } else {
@@ -961,6 +972,7 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     if (sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     hipSetDevice(ctx->device);
     const int G = groups < 1 ? 1 : groups;
+    const int P2 = fir_transform_size(frames);
     if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate || ctx->plan_in != d_in || ctx->plan_out != d_out ||
         ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_by_channel != rows_by_channel || ctx->plan_groups != G) {
         int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, rows_by_channel, G);
@@ -972,7 +984,7 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     const gdg_seg_unit *d_units = reinterpret_cast<const gdg_seg_unit *>(ctx->d_blob + ctx->units_offset);
     double2 *tw = nullptr, *tw2 = nullptr;
     for (auto &st : ctx->steps)
-        if (st.is_fir && st.n) { int rc = fir_tables(ctx, frames, &tw, &tw2); if (rc != GDG_OK) return rc; break; }
+        if (st.is_fir && st.n) { int rc = fir_tables(ctx, fir_transform_size(frames), &tw, &tw2); if (rc != GDG_OK) return rc; break; }
     if (G > 1) {
         while ((int)ctx->gstreams.size() < G) {
             hipStream_t s = nullptr;
@@ -994,14 +1006,14 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             if (n == 0) continue;
             if (st.is_fir) {
                 const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset) + first;
-                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(frames, d, n, tw, tw2, s)); }
+                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, d, n, tw, tw2, s)); }
                 if (ctx->fir_fused) {
                     /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel) */
                     ProfScope ps(ctx, GDG_K_FIR_MAC, s);
-                    HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, n, tw, tw2, st.shared_spectra ? 2 : 1, s));
+                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, s));
                 } else {
-                    { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(frames, d, n, st.shared_spectra ? 1 : 0, s)); }
-                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(frames, d, n, tw, tw2, 0, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(P2, d, n, st.shared_spectra ? 1 : 0, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, s)); }
                 }
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;

@@ -45,6 +45,8 @@ __device__ __forceinline__ void gstore(cplx *p, cplx c) {
     v2d v = { c.x, c.y };
     *reinterpret_cast<GDG_GLOBAL v2d *>((GDG_GLOBAL void *)p) = v;
 }
+__device__ __forceinline__ double gload1(const double *p) { return *(const GDG_GLOBAL double *)p; }
+__device__ __forceinline__ void gstore1(double *p, double x) { *(GDG_GLOBAL double *)p = x; }
 
 
 #define GDG_C1 0.92387953251128673848      /* cos(pi/8) */
@@ -233,6 +235,7 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
     const double *a, *bsrc;
     double *prev_out = nullptr;
     cplx *out;
+    int hop = N;
     if constexpr (IRJOB) {
         gdg_fir_irjob jb = jobs[blockIdx.x];
         a = jb.a;
@@ -245,6 +248,7 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
         prev_out = ch.prev + (size_t)(pos & 1) * N;       /* where this frame is kept for the next call */
         bsrc = ch.src;
         out = ch.fdl + (size_t)(pos % ch.K) * N;
+        hop = ch.hop;
     }
 
     /* pass 0 straight from global memory: packed element e = (r[2e], r[2e+1]) */
@@ -257,7 +261,19 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
         for (int t = 0; t < R0; t++) {
             int e = j + t * (N / R0);
             cplx val;
-            if (e < N / 2) {
+            if (!IRJOB && hop != N) {
+                /* frame shorter than the transform half: r = [previous (hop) | current (hop) | zeros], any parity of hop */
+                double r2[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int i = 2 * e + h;
+                    double x = 0.0;
+                    if (i < hop) x = gload1(a + i);
+                    else if (i < 2 * hop) { x = gload1(bsrc + (i - hop)); gstore1(prev_out + (i - hop), x); }
+                    r2[h] = x;
+                }
+                val = make_double2(r2[0], r2[1]);
+            } else if (e < N / 2) {
                 val = gload(reinterpret_cast<const cplx *>(a + 2 * e));
             } else {
                 if constexpr (IRJOB) val = make_double2(0.0, 0.0);
@@ -467,17 +483,34 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
     pass_load<LOGN, LR>(v, sre, sim, tid);
     pass_compute<LOGN, LR, LNS, true>(v, tw, tid);
     double *__restrict__ dst = ch.dst;
+    const int hop = ch.hop;
+    if (hop == N) {
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-        int j = tid + T * b;
+        for (int b = 0; b < B; b++) {
+            int j = tid + T * b;
 #pragma unroll
-        for (int t = R / 2; t < R; t++) {
-            int n = j + t * (N / R);
-            cplx z = v[b * R + t];
-            /* filter/filter.go:487-493: the emitted samples are clipped to [-1, 1] */
-            z.x = fmin(1.0, fmax(-1.0, z.x));
-            z.y = fmin(1.0, fmax(-1.0, z.y));
-            gstore(reinterpret_cast<cplx *>(dst + 2 * (n - N / 2)), z);
+            for (int t = R / 2; t < R; t++) {
+                int n = j + t * (N / R);
+                cplx z = v[b * R + t];
+                /* filter/filter.go:487-493: the emitted samples are clipped to [-1, 1] */
+                z.x = fmin(1.0, fmax(-1.0, z.x));
+                z.y = fmin(1.0, fmax(-1.0, z.y));
+                gstore(reinterpret_cast<cplx *>(dst + 2 * (n - N / 2)), z);
+            }
+        }
+    } else {
+        /* frame shorter than the transform half: the valid outputs are the real samples [hop, 2 hop) */
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            int j = tid + T * b;
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+                int n = j + t * (N / R);
+                cplx z = v[b * R + t];
+                int i0 = 2 * n - hop;
+                if (i0 >= 0 && i0 < hop) gstore1(dst + i0, fmin(1.0, fmax(-1.0, z.x)));
+                if (i0 + 1 >= 0 && i0 + 1 < hop) gstore1(dst + i0 + 1, fmin(1.0, fmax(-1.0, z.y)));
+            }
         }
     }
     if (tid == 0) {

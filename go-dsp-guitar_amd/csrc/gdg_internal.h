@@ -23,15 +23,16 @@
  *   pos   int            frame counter; slot of the current frame = pos % K
  * ---------------------------------------------------------------------------------------------- */
 struct gdg_fir_chan {
-    const double *src;       /* current frame, P samples */
-    double *dst;             /* output frame, P samples */
-    double *prev;
+    const double *src;       /* current frame, `hop` samples */
+    double *dst;             /* output frame, `hop` samples */
+    double *prev;            /* [2][P]: the previous frame, ping-pong by frame parity */
     double2 *fdl;
     const double2 *H;
     double2 *Y;
     int *pos;
     int K;
-    int pad;
+    int hop;                 /* samples per frame; == P for power-of-two frames, < P otherwise (the transform of
+                              * [previous | current | zeros] still has 2P points, P = nextpow2(hop)) */
 };
 
 /* one forward transform job used to build the IR spectra: [a | zeros] -> out */

@@ -25,7 +25,9 @@ def check(got, want, tol=TOL_RMS):
 
 # ---- FIR (power amp): filter.Process semantics y = clip(x * h) ------------------------------------------
 @pytest.mark.parametrize("frames,taps", [(64, 1), (64, 200), (256, 77), (1024, 1024), (1024, 1025), (1024, 5000),
-                                          (4096, 9600), (8192, 511), (8192, 8192), (8192, 20000)])
+                                          (4096, 9600), (8192, 511), (8192, 8192), (8192, 20000),
+                                          # frame sizes that are not a power of two (e.g. 480-frame periods): hop < transform half
+                                          (1000, 3000), (480, 2000), (37, 100), (100, 77), (1, 5), (8000, 20000), (4097, 4097), (63, 64)])
 def test_fir_stream_matches_oracle_and_direct_convolution(pkg, oracle, frames, taps):
     sr, blocks = 48000, 5
     ctx = pkg.Context(2, frames)
@@ -69,12 +71,18 @@ def test_fir_set_fir_resets_state(pkg, oracle):
     ctx.close()
 
 
-def test_fir_requires_power_of_two_frames(pkg):
-    ctx = pkg.Context(1, 1000)
-    ctx.append_unit(0, "power_amp", fir=synth_ir(100))
-    with pytest.raises(pkg.GdgError) as e:
-        ctx.process(np.zeros((1, 1000)), 48000)
-    assert e.value.code == pkg.GDG_ERR_UNSUPPORTED
+def test_fir_frame_size_changes_need_a_reset_and_odd_sizes_work_in_chains(pkg, oracle):
+    """Any frame size up to 8192 runs (the reference's filter.Process takes any block length); a full chain at 1000 frames."""
+    sr, frames = 44100, 1000
+    ctx = pkg.Context(2, frames)
+    pairs = []
+    for c in range(2):
+        p = ChainPair(ctx, c, oracle)
+        full_chain(p, c, synth_ir(5000, seed=c), synth_ir(2500, seed=10 + c))
+        pairs.append(p)
+    x = np.stack([synth_signal(c, frames * 6, sr) for c in range(2)])
+    got, want = run_pairs(ctx, pairs, x, frames, sr)
+    check(got, want)
     ctx.close()
 
 
