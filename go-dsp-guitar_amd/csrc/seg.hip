@@ -908,7 +908,37 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     }
     double dlr[REVERB_QMAX];
     /* tapped delay line over the input history (reverb.go:65-116) */
-    {
+    const bool pairs = N == CHK * SEG_T && taps[0] >= N && taps[1] >= N && taps[2] >= N && taps[3] >= N;
+    if (pairs) {
+        /* the usual case (taps 192..232 ms back, frames <= 43 ms, the batch block size): every tap lies in the HBM ring.  A thread
+         * takes sample PAIRS (2p, 2p + 1), p = tid + q * SEG_T: one 16-byte load per tap and pair (8-byte aligned; the ring's
+         * wrap between the two samples of a pair falls back to two loads), half the load instructions of the sample-wise walk.
+         * dlr[2q], dlr[2q + 1] hold the pair; the final mix below uses the same mapping. */
+        const GDG_GLOBAL double *g = as_global((const double *)dl_ring);
+#pragma unroll
+        for (int q = 0; q < REVERB_QMAX / 2; q++) {
+            const int i0 = 2 * (tid + q * SEG_T);
+            double pre0 = 0.0, pre1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int p = dl_wp + (i0 - taps[j]);
+                if (p < 0) p += DL;
+                double c0, c1;
+                if (p + 1 < DL) {
+                    seg_v2d v = *(const GDG_GLOBAL seg_v2d *)(g + p);
+                    c0 = v.x; c1 = v.y;
+                } else {
+                    c0 = g[p]; c1 = g[0];
+                }
+                pre0 += coeff[j] * c0;
+                pre1 += coeff[j] * c1;
+            }
+            out[LX(i0)] = pre0;
+            out[LX(i0 + 1)] = pre1;
+            dlr[2 * q] = pre0;
+            dlr[2 * q + 1] = pre1;
+        }
+    } else {
 #pragma unroll
         for (int q = 0; q < REVERB_QMAX; q++) {
             int i = tid + q * SEG_T;
@@ -941,7 +971,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     }
 #pragma unroll
     for (int q = 0; q < REVERB_QMAX; q++) {
-        int i = tid + q * SEG_T;
+        int i = pairs ? 2 * (tid + (q >> 1) * SEG_T) + (q & 1) : tid + q * SEG_T;
         if (i < N) {
             double sum = dlr[q] + out[LX(i)];
             out[LX(i)] = clip1((dry * in[LX(i)]) + (half_wet * sum));
