@@ -190,20 +190,39 @@ __device__ __forceinline__ void ring_append(double *ring, int C, int *wp_ptr, co
     if (C <= 0) return;
     const int wp = *wp_ptr;
     int first = N > C ? N - C : 0;
-    for (int i = first + (int)threadIdx.x; i < N; i += SEG_T) {
-        int p = (wp + i) % C;
-        as_global(ring)[p] = in[LX(i)];
+    if (((N - first) & 1) == 0) {
+        /* sample pairs: one 16-byte store per pair (two stores where the ring wraps inside the pair) */
+        GDG_GLOBAL double *g = as_global(ring);
+        for (int i = first + 2 * (int)threadIdx.x; i < N; i += 2 * SEG_T) {
+            int p = (wp + i) % C;
+            const double a = in[LX(i)], b = in[LX(i + 1)];
+            if (p + 1 < C) { seg_v2d v = { a, b }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
+            else { g[p] = a; g[0] = b; }
+        }
+    } else {
+        for (int i = first + (int)threadIdx.x; i < N; i += SEG_T) {
+            int p = (wp + i) % C;
+            as_global(ring)[p] = in[LX(i)];
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) *as_global(wp_ptr) = (wp + N) % C;
 }
-
 /* the reference's fractional delay read (e.g. effects/flanger.go:63-90): both weights are 1 when the delay is integral */
 __device__ __forceinline__ double frac_delay(const double *in, const double *ring, int C, int wp, int i, double delay_samples) {
     double early = floor(delay_samples), late = ceil(delay_samples);
     int ie = i - (int)early, il = i - (int)late;
-    double se = (ie >= 0) ? in[LX(ie)] : ring_read(ring, C, wp, ie);
-    double sl = (il >= 0) ? in[LX(il)] : ring_read(ring, C, wp, il);
+    double se, sl;
+    int pl = wp + il;
+    if (pl < 0) pl += C;
+    if (ie < 0 && il == ie - 1 && pl + 1 < C) {
+        /* the two neighbours lie side by side in the HBM ring: one 16-byte load */
+        seg_v2d v = *(const GDG_GLOBAL seg_v2d *)(as_global(ring) + pl);
+        sl = v.x; se = v.y;
+    } else {
+        se = (ie >= 0) ? in[LX(ie)] : ring_read(ring, C, wp, ie);
+        sl = (il >= 0) ? in[LX(il)] : ring_read(ring, C, wp, il);
+    }
     double we = 1.0 - (delay_samples - early);
     double wl = 1.0 - (late - delay_samples);
     return (we * se) + (wl * sl);
