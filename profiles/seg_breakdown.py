@@ -41,9 +41,13 @@ CASES = [
 def main():
     pkg = entry.load_package()
     nch, frames, sr, steps = 512, 8192, 192000, 10
-    only = set(sys.argv[1:])
+    args = [a for a in sys.argv[1:] if a != "--cold"]
+    cold = "--cold" in sys.argv[1:]          # evict L2 / MALL between launches (as after the 1 GB MAC stream in the bench)
+    only = set(args)
     x = np.stack([synth_signal(c, frames, sr) for c in range(nch)])
-    print("%-16s %10s %12s %12s" % ("chain", "avg_us", "Msamples/s", "GB/s@16B"))
+    print("%-16s %10s %12s %12s%s" % ("chain", "avg_us", "Msamples/s", "GB/s@16B", "   (cold caches)" if cold else ""))
+    ctx_flush = pkg.Context(1, 64) if cold else None
+    flush = None
     for name, chain in CASES:
         if only and name.split()[0] not in only and name not in only:
             continue
@@ -56,8 +60,15 @@ def main():
         for _ in range(2):
             ctx.process_device(d_in, d_out, frames, sr)
         ctx.synchronize()
+        if cold and flush is None:
+            n_flush = 1 << 27
+            flush = (ctx_flush.alloc(1, n_flush), ctx_flush.alloc(1, n_flush), n_flush)
         ctx.profile_enable(True)
         for _ in range(steps):
+            if cold:
+                ctx.synchronize()
+                ctx_flush._check(pkg.lib().gdg_wave_decode_device(ctx_flush._h, 5, flush[0].ptr, flush[2], 1, flush[1].ptr))
+                ctx_flush.synchronize()
             ctx.process_device(d_in, d_out, frames, sr)
         ctx.synchronize()
         ms, n = ctx.profile_read(pkg.K_SEGMENT)
