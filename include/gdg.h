@@ -13,7 +13,10 @@
  *
  * Conventions
  *   - every function returns GDG_OK (0) or a negative GDG_ERR_* code; gdg_last_error() gives
- *     a message for the calling thread's last failure on that context;
+ *     a message for the last failure on that context;
+ *   - a context is NOT internally synchronised: one call at a time per context (the reference's N worker goroutines meet in a
+ *     rendezvous above the ABI -- go-dsp-guitar_amd/go/signal, host/gdg_host.cpp -- and the last arrival makes the one call;
+ *     control-plane setters take the same lock).  Different contexts (different GPUs) are independent;
  *   - there is NO CPU fallback: without a usable HIP device gdg_ctx_create fails with
  *     GDG_ERR_NO_DEVICE, and a chain that contains something the HIP path cannot run fails
  *     with GDG_ERR_UNSUPPORTED instead of silently computing elsewhere;
