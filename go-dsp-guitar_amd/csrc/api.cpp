@@ -1006,7 +1006,7 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             if (n == 0) continue;
             if (st.is_fir) {
                 const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset) + first;
-                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, d, n, tw, tw2, s)); }
+                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, s)); }
                 if (ctx->fir_fused) {
                     /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel) */
                     ProfScope ps(ctx, GDG_K_FIR_MAC, s);

@@ -157,7 +157,7 @@ __device__ __forceinline__ void pass_load(cplx (&v)[16], const double *sre, cons
 }
 
 /* twiddle + radix-R DFT on the registers */
-template <int LOGN, int LOGR, int LOGNS, bool INV>
+template <int LOGN, int LOGR, int LOGNS, bool INV, int TWS = 1>
 __device__ __forceinline__ void pass_compute(cplx (&v)[16], const cplx *__restrict__ tw, int tid) {
     constexpr int N = 1 << LOGN, T = N / 16, R = 1 << LOGR, B = 16 / R, NS = 1 << LOGNS;
 #pragma unroll
@@ -172,7 +172,7 @@ __device__ __forceinline__ void pass_compute(cplx (&v)[16], const cplx *__restri
             /* the R - 1 twiddles w^t of this butterfly from ONE table load: w, w^2, w^4, w^8 by squaring, the others as
              * products of two of them (depth <= 4 multiplications, error ~4 ulp) instead of R - 1 scattered 16-byte loads */
             cplx wp[R];
-            wp[1] = tw[kk * stepm];
+            wp[1] = tw[kk * stepm * TWS];            /* TWS: the table belongs to a transform TWS times as long */
             if constexpr (INV) wp[1].y = -wp[1].y;
 #pragma unroll
             for (int t = 2; t < R; t++) {
@@ -310,6 +310,114 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
             double hs = 0.5 * scale;
             gstore(out + k, make_double2((A.x + cw.y) * hs, (A.y - cw.x) * hs));
             gstore(out + n, make_double2((A.x - cw.y) * hs, (-A.y - cw.x) * hs));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 8192-point transforms as 8 x 1024 (decimation in frequency): one radix-8 step across the workgroup, then every WAVE runs a
+ * 1024-point Stockham transform on its own LDS region with wave-local exchanges only -- the eight waves stop meeting at a
+ * barrier after every pass (2 workgroup barriers per forward transform instead of 8).
+ *   X[8 k1 + k2] = sum_n1 [ W_N^(n1 k2) * ( sum_n2 x[n1 + 1024 n2] W_8^(n2 k2) ) ] W_1024^(n1 k1)
+ * Region r = k2 holds y[.][k2] (1024 points, padded); RL mod 32 = 4 keeps the k-order reads of the un-packing conflict free.
+ * ---------------------------------------------------------------------------------------------- */
+#define GDG_W_RL 1124
+#define GDG_W_LDS (8 * GDG_W_RL)
+
+/* 1024-point transform of one region by one wave: passes [16, 8, 8]; results stay in v (natural order:
+ * v[b * 8 + t] = X[(lane + 64 b) + 128 t]) */
+template <bool INV>
+__device__ __forceinline__ void wave_fft1024(cplx (&v)[16], double *rre, double *rim, const cplx *__restrict__ tw, int lane) {
+    constexpr int L = 10;
+    static_assert(sched_lr(L, 0) == 4 && sched_lr(L, 1) == 3 && sched_lr(L, 2) == 3 && sched_npass(L) == 3, "1024 = 16 x 8 x 8");
+    pass_load<L, 4>(v, rre, rim, lane);
+    __builtin_amdgcn_wave_barrier();
+    pass_compute<L, 4, 0, INV, 8>(v, tw, lane);
+    pass_store<L, 4, 0>(v, rre, rim, lane);
+    __builtin_amdgcn_wave_barrier();
+    pass_load<L, 3>(v, rre, rim, lane);
+    __builtin_amdgcn_wave_barrier();
+    pass_compute<L, 3, 4, INV, 8>(v, tw, lane);
+    pass_store<L, 3, 4>(v, rre, rim, lane);
+    __builtin_amdgcn_wave_barrier();
+    pass_load<L, 3>(v, rre, rim, lane);
+    __builtin_amdgcn_wave_barrier();
+    pass_compute<L, 3, 7, INV, 8>(v, tw, lane);
+}
+
+/* y[k2] *= w^k2, k2 = 1..7, from w alone (w^2, w^4 by squaring, the rest as products) */
+__device__ __forceinline__ void twiddle_powers8(cplx (&u)[8], cplx w) {
+    cplx w2 = cmul(w, w), w4 = cmul(w2, w2), w3 = cmul(w2, w), w5 = cmul(w4, w), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+    u[1] = cmul(u[1], w); u[2] = cmul(u[2], w2); u[3] = cmul(u[3], w3); u[4] = cmul(u[4], w4);
+    u[5] = cmul(u[5], w5); u[6] = cmul(u[6], w6); u[7] = cmul(u[7], w7);
+}
+
+__global__ void __launch_bounds__(512)
+fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int N = 8192, T = 512;
+    __shared__ double sre[GDG_W_LDS];
+    __shared__ double sim[GDG_W_LDS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    gdg_fir_chan ch = chans[blockIdx.x];
+    const int pos = *ch.pos;
+    const double *a = ch.prev + (size_t)((pos + 1) & 1) * N;       /* previous frame */
+    double *prev_out = ch.prev + (size_t)(pos & 1) * N;            /* where this frame is kept for the next call */
+    const double *bsrc = ch.src;
+    cplx *out = ch.fdl + (size_t)(pos % ch.K) * N;
+
+    /* step A: radix-8 across the workgroup, straight from global memory (element e = n1 + 1024 n2: e < N/2 is the previous frame) */
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int n1 = tid + T * b;
+        cplx u[8];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; n2++) {
+            const int e = n1 + 1024 * n2;
+            if (n2 < 4) u[n2] = gload(reinterpret_cast<const cplx *>(a + 2 * e));
+            else {
+                u[n2] = gload(reinterpret_cast<const cplx *>(bsrc + 2 * (e - N / 2)));
+                gstore(reinterpret_cast<cplx *>(prev_out + 2 * (e - N / 2)), u[n2]);
+            }
+        }
+        Dft<8, false>::run(u);
+        twiddle_powers8(u, tw[n1]);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) { sre[k2 * GDG_W_RL + GDG_PAD(n1)] = u[k2].x; sim[k2 * GDG_W_RL + GDG_PAD(n1)] = u[k2].y; }
+    }
+    __syncthreads();
+    /* step B: wave w transforms region w; X[8 k1 + w] back into the region in natural k1 order */
+    {
+        double *rre = sre + wave * GDG_W_RL, *rim = sim + wave * GDG_W_RL;
+        cplx v[16];
+        wave_fft1024<false>(v, rre, rim, tw, lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int k1 = (lane + 64 * b) + 128 * t;
+                rre[GDG_PAD(k1)] = v[b * 8 + t].x;
+                rim[GDG_PAD(k1)] = v[b * 8 + t].y;
+            }
+    }
+    __syncthreads();
+    /* un-pack: X[k] and X[N-k] from Z[k], Z[N-k]; Z[k] = region[k & 7][k >> 3] */
+    auto Z = [&](int k) { return make_double2(sre[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)], sim[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)]); };
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = tid + T * i;
+        if (k == 0) {
+            cplx z0 = Z(0), zh = Z(N / 2);
+            gstore(out, make_double2(z0.x + z0.y, z0.x - z0.y));
+            gstore(out + N / 2, make_double2(zh.x, -zh.y));
+        } else {
+            const int n = N - k;
+            cplx zk = Z(k), zn = Z(n);
+            cplx A = make_double2(zk.x + zn.x, zk.y - zn.y);
+            cplx Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+            cplx cw = cmul(tw2[k], Bv);
+            gstore(out + k, make_double2((A.x + cw.y) * 0.5, (A.y - cw.x) * 0.5));
+            gstore(out + n, make_double2((A.x - cw.y) * 0.5, (-A.y - cw.x) * 0.5));
         }
     }
 }
@@ -574,8 +682,14 @@ template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, con
     else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
 }
 
-hipError_t gdg_launch_fir_fwd(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
+hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
+    static int wave_fft = -1;
+    if (wave_fft < 0) { const char *e = getenv("GDG_WAVE_FFT"); wave_fft = e ? atoi(e) : 1; }
+    if (P == 8192 && hop == P && (wave_fft & 1)) {
+        fir_fwd13w_kernel<<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, d_tw, d_tw2);
+        return hipGetLastError();
+    }
     int L = ilog2_exact(P);
     GDG_DISPATCH_LOGN(L, launch_fwd<LG>(d_chans, n_chans, d_tw, d_tw2, s));
     return hipGetLastError();

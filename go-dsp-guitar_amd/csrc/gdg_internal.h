@@ -43,7 +43,7 @@ struct gdg_fir_irjob {
 
 /* launchers implemented in fir.hip; all return hipError_t */
 hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
-hipError_t gdg_launch_fir_fwd(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
+hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s);
 hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, hipStream_t s);
 hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
