@@ -82,6 +82,28 @@ __global__ void fill_kernel(double *p, size_t n, unsigned seed) {
 }
 static void fill(void *p, size_t bytes, unsigned seed) { fill_kernel<<<4096, 256>>>((double *)p, bytes / 8, seed); }
 
+// the fused kernel's shape: ONE 512-thread workgroup per channel walks partition by partition through all bins, k ascending
+// and n = N - k descending (REV), 32 loads per lane per partition
+template <bool REV>
+__global__ void __launch_bounds__(512) fused_shape_kernel(const Desc *__restrict__ descs, double *__restrict__ out) {
+    Desc ch = descs[blockIdx.x];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int u = 0; u < 8; u++) {
+        const v2d *x = ch.a + (size_t)u * 8192, *h = ch.b + (size_t)u * 8192;
+        v2d xk[8], hk[8], xn[8], hn[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = tid + 512 * i, n = REV ? 8191 - k : 4096 + k;
+            xk[i] = __builtin_nontemporal_load(x + k); hk[i] = __builtin_nontemporal_load(h + k);
+            xn[i] = __builtin_nontemporal_load(x + n); hn[i] = __builtin_nontemporal_load(h + n);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc += xk[i].x * hk[i].y + xn[i].x * hn[i].y;
+    }
+    if (acc == 123.456) out[0] = acc;
+}
+
 template <typename F> static float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -129,6 +151,8 @@ int main() {
             h[i] = Desc{ a, b, y, d_pos + i, 8, 0 };
         }
         Desc *dd; hipMalloc(&dd, 512 * sizeof(Desc)); hipMemcpy(dd, h.data(), 512 * sizeof(Desc), hipMemcpyHostToDevice);
+        rep("fused shape: 512-thread block per channel, k asc + n desc", timeit([&] { fused_shape_kernel<true><<<512, 512>>>(dd, o); }));
+        rep("fused shape: 512-thread block per channel, both ascending", timeit([&] { fused_shape_kernel<false><<<512, 512>>>(dd, o); }));
         rep("MAC-like, descriptors only, NT", timeit([&] { mac_like_kernel<true, false, 0><<<dim3(32, 512), 256>>>(dd, o); }));
         rep("MAC-like, + *pos chase, NT", timeit([&] { mac_like_kernel<true, true, 0><<<dim3(32, 512), 256>>>(dd, o); }));
         rep("MAC-like, + *pos chase + Y store, NT", timeit([&] { mac_like_kernel<true, true, 1><<<dim3(32, 512), 256>>>(dd, o); }));
