@@ -6,13 +6,24 @@
 One "step" = one pass of the full effects chain over one 8192-frame block of every channel
 (what controller.process() does per BLOCK_SIZE block, controller/controller.go:3076-3107), with
 the input block already resident in HBM.  Workload (BASELINE.json metric config): 512 channels
-@ 192 kHz per GPU, chain = compressor -> overdrive -> tone_stack -> chorus -> power_amp (64k-tap
-cabinet IR) -> power_amp (64k-tap reverb IR) -> cabinet (IIR) -> reverb, every channel with its
-own IR spectra in HBM.  Channels are independent: N GPUs = N shards, no
-collective on the data path; per-GPU work is fixed (weak scaling).
+@ 192 kHz, chain = compressor -> overdrive -> tone_stack -> chorus -> power_amp (64k-tap cabinet
+IR) -> power_amp (64k-tap reverb IR) -> cabinet (IIR) -> reverb, every channel with its own IR
+spectra in HBM (d = 1).  Channels are independent: N GPUs = N shards, no
+collective on the data path, no RCCL (the barrier and the max-over-ranks of the elapsed time go
+through a gloo group).
+
+Two ways to spread the job over N GPUs, both reported:
+  * default ("scaling": "weak"): 512 channels on EVERY GPU -- the headline line;
+  * --total-channels T ("scaling": "strong"): the reference's `-channels T` is a fixed job
+    (controller.go:3262-3269, :3333-3341); rank r takes the contiguous block
+    shard.channel_shard(T, N, r) and IRs / inputs are seeded by GLOBAL channel number.
+    A default run with N > 1 also times this split for T = 512 ("strong_split" in the JSON);
+    a default run with N = 1 times the per-GPU legs of that split (64 / 128 / 256 channels on
+    the one GPU: "strong_split_legs").
 
 Prints ONE JSON line (rank 0) with the metric, the roofline of the dominant kernel measured with
-HIP events over the timed region, and a CPU baseline (the oracle "port") timed on the host cores.
+HIP events over the timed region, the PCIe-inclusive host-buffer rates ("end_to_end"), the other
+BASELINE configs' rates ("configs") and a CPU baseline (the oracle "port") timed on the host cores.
 """
 import argparse
 import json
@@ -39,6 +50,7 @@ CHAIN = [
     ("cabinet", None),
     ("reverb", [50]),
 ]
+IR_SEED = {"cab": 4242, "rev": 5242}
 
 
 def synth_ir(n_taps, seed):
@@ -58,13 +70,44 @@ def synth_block(n_channels, frames, sample_rate, channel0=0):
     return x
 
 
-def cpu_baseline(sample_rate, frames, taps, target_seconds=20.0):
-    """The oracle ("port": structure-preserving C restatement of the Go path) on the host cores,
-    one thread per channel like the reference's goroutine-per-channel (controller.go:3339-3341)."""
+def make_context(pkg, nch, frames, device, taps, channel0=0, n_distinct=0, chain=CHAIN, second_amp=True):
+    """One shard: `nch` channels carrying GLOBAL channel numbers channel0 .. channel0 + nch - 1 (IR seeds follow the global
+    number, so a channel sounds the same whichever GPU it lands on)."""
+    ctx = pkg.Context(nch, frames, device)
+    cache = {}
+    for c in range(nch):
+        g = channel0 + c
+        for name, p in chain:
+            if isinstance(p, str):
+                if p == "rev" and not second_amp:
+                    continue
+                key = (p, g % n_distinct if n_distinct > 0 else g)
+                if n_distinct > 0:
+                    if key not in cache:
+                        cache[key] = synth_ir(taps, IR_SEED[p] + key[1])
+                    ir = cache[key]
+                else:
+                    ir = synth_ir(taps, IR_SEED[p] + key[1])
+                ctx.append_unit(c, name, fir=ir)
+            else:
+                ctx.append_unit(c, name, params=p)
+    return ctx
+
+
+# ---- CPU baseline ---------------------------------------------------------------------------------------------------------
+
+def cpu_baseline(sample_rate, frames, taps, target_seconds=12.0):
+    """The oracle ("port": structure-preserving C restatement of the Go path: unpartitioned 2 * nextpow2(L)-point radix-2 FFT
+    pair per block and power amp, 8 exp per sample in the tone stack ...) on the host cores THIS process may use
+    (sched_getaffinity), one thread per channel like the reference's goroutine per channel (controller.go:3339-3341).
+    Reports the single-thread rate, the all-core rate and the parallel efficiency between them."""
     import __graft_entry__ as entry
     orc = entry.load_oracle()
     orc.build()
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     irs = {"cab": synth_ir(taps, 4242), "rev": synth_ir(taps, 4243)}
 
     def make_chain():
@@ -76,46 +119,165 @@ def cpu_baseline(sample_rate, frames, taps, target_seconds=20.0):
                 ch.append_unit(name, params=p)
         return ch
 
-    probe = make_chain()
     x = synth_block(cores, frames, sample_rate)
-    probe.process(x[0], sample_rate)
+    probe = make_chain()
+    probe.process(x[0], sample_rate)                      # builds H, the FFT tables, the buffers
+    n1 = 0
     t0 = time.perf_counter()
-    probe.process(x[0], sample_rate)
-    t_block = max(time.perf_counter() - t0, 1e-4)
-    blocks = int(max(4, min(400, target_seconds / (cores * t_block))))
+    while n1 < 3 or time.perf_counter() - t0 < 1.0:
+        probe.process(x[0], sample_rate)
+        n1 += 1
+    t_block = (time.perf_counter() - t0) / n1
+    single = frames / t_block / 1e6
+
+    def run(n_threads, blocks, chains):
+        def work(c):
+            for _ in range(blocks):
+                chains[c].process(x[c], sample_rate)
+        threads = [threading.Thread(target=work, args=(c,)) for c in range(n_threads)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        return time.perf_counter() - t0
+
     chains = [make_chain() for _ in range(cores)]
-
-    def work(c):
-        for _ in range(blocks):
-            chains[c].process(x[c], sample_rate)
-
-    threads = [threading.Thread(target=work, args=(c,)) for c in range(cores)]
-    t0 = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    dt = time.perf_counter() - t0
+    run(cores, 1, chains)                                 # first block of every chain: allocations, H
+    dt = run(cores, 2, chains)                            # calibration
+    blocks = int(max(2, min(2000, target_seconds / (dt / 2.0))))
+    dt = run(cores, blocks, chains)
+    all_core = cores * blocks * frames / dt / 1e6
+    scaling = {}
+    for n in sorted({max(1, cores // 16), max(1, cores // 8), max(1, cores // 4), max(1, cores // 2)}):
+        if n >= cores:
+            continue
+        b = max(2, blocks // 2)
+        scaling[str(n)] = n * b * frames / run(n, b, chains) / 1e6
+    scaling[str(cores)] = all_core
+    best_threads = max(scaling, key=lambda k: scaling[k])
     return {
-        "value": cores * blocks * frames / dt / 1e6,
+        # the most favourable thread count for the CPU, not the reference's own (one goroutine per channel on every logical CPU)
+        "value": scaling[best_threads],
         "unit": "Msamples/s",
-        "cores": cores,
+        "cores": int(best_threads),
         "kind": "port",
-        "sample": "%d channels x %d blocks of %d frames, same chain and IR lengths, one thread per channel; single-thread block time %.1f ms"
-                  % (cores, blocks, frames, t_block * 1e3),
+        "logical_cpus": cores,
+        "single_thread": single,
+        "all_core": all_core,
+        "parallel_efficiency_all_core": all_core / (cores * single),
+        "threads_to_msamples": scaling,
+        "sample": "%d channels x %d blocks of %d frames, same chain and IR lengths, one thread per channel on the %d logical CPUs of "
+                  "this process's affinity mask (%.1f s wall); single thread: %d blocks, %.1f ms per block.  Per block and channel the "
+                  "port streams ~340 MiB (2 power amps x 2 transforms of 131072 points x 17 radix-2 passes over data + twiddle table; "
+                  "working set ~10 MB per channel): with few threads each has a whole CCD's L3 and scales, with one thread per logical CPU the working "
+                  "sets evict each other and the run is DRAM-bound -- more threads give LESS throughput (threads_to_msamples); `value` is the best "
+                  "thread count, `all_core` what the reference's goroutine-per-channel scheduling would get"
+                  % (cores, blocks, frames, cores, dt, n1, t_block * 1e3),
     }
 
+
+# ---- helpers for the extra legs ------------------------------------------------------------------------------------------------
+
+def time_ctx_steps(ctx, d_in, d_out, frames, sr, steps, warmup=3):
+    for _ in range(max(warmup, 1)):
+        ctx.process_device(d_in, d_out, frames, sr)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.process_device(d_in, d_out, frames, sr)
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, channel0=0, chain=CHAIN, second_amp=True):
+    ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0, chain=chain, second_amp=second_amp)
+    d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
+    d_in.upload(synth_block(nch, frames, sr, channel0=channel0))
+    dt = time_ctx_steps(ctx, d_in, d_out, frames, sr, steps)
+    ctx.close()
+    return dt
+
+
+def end_to_end(pkg, ctx, nch, frames, sr, steps=6):
+    """The boundary's host-buffer entry points on the SAME context (PCIe both ways inside the call; never the headline)."""
+    import ctypes as C
+    lib = pkg.lib()
+    x = synth_block(nch, frames, sr)
+    out = np.empty_like(x)
+    ins = (C.c_void_p * nch)(*[x[c].ctypes.data for c in range(nch)])
+    outs = (C.c_void_p * nch)(*[out[c].ctypes.data for c in range(nch)])
+    carr = (C.c_int * nch)(*range(nch))
+    ctx.process_staged(list(range(nch)), x, sr)            # fills the pinned slab once (the Go workers write it in parallel)
+    res = {}
+    for key, fn in (("staged", lambda: ctx._check(lib.gdg_process_staged(ctx._h, carr, nch, frames, sr))),
+                    ("pageable", lambda: ctx._check(lib.gdg_process(ctx._h, ins, outs, frames, sr)))):
+        for _ in range(2):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        dt = (time.perf_counter() - t0) / steps
+        res[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "ms_per_block": dt * 1e3,
+                    "pcie_gbs_in_plus_out": 2 * nch * frames * 8 / dt / 1e9}
+    res["what"] = ("gdg_process_staged: frames already in the pinned slab (what the Go workers fill), H2D + chain + D2H inside the call; "
+                   "gdg_process: caller's pageable rows staged through the pinned slab by the library's copy threads")
+    return res
+
+
+def other_configs(pkg, device):
+    """BASELINE.json configs 2, 3 and 5 on one GPU, device-resident frames (config 1 is the CPU oracle by definition)."""
+    out = {}
+    chain3 = [(n, ([0, 20, 100, 0, 1, 2] if n == "overdrive" else p)) for n, p in CHAIN]        # 4x oversampling
+    for key, nch, frames, sr, taps, chain, steps in (("config2_1ch_48k_8ktaps_1024frames", 1, 1024, 48000, 8192, CHAIN, 200),
+                                                    ("config2_1ch_48k_8ktaps_8192frames", 1, 8192, 48000, 8192, CHAIN, 100),
+                                                    ("config3_64ch_96k_4xOS_32ktaps", 64, 8192, 96000, 32768, chain3, 30)):
+        dt = leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, chain=chain, second_amp=False)
+        out[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "us_per_block": dt * 1e6, "realtime_factor": frames / sr / dt}
+    # config 5: 256 tuners (96000-sample windows, 262144-point autocorrelation each) + spatializer 256 -> 2 at 192 kHz
+    nch, frames, sr = 256, 8192, 192000
+    ctx = pkg.Context(nch, frames, device)
+    d_x = ctx.alloc(nch, frames)
+    d_x.upload(synth_block(nch, frames, sr))
+    d_lr = ctx.alloc(2, frames)
+    ctx.spatializer_set_sample_rate(sr)
+    for c in range(nch):
+        ctx.spatializer_set_position(c, -90.0 + 180.0 * c / (nch - 1), 0.5 + 0.01 * c, 0.5)
+    for _ in range(13):
+        ctx.tuner_enqueue_device(d_x, frames, sr)
+    ctx.spatialize_device(d_x, d_lr, frames)
+    ctx.tuner_analyze()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ctx.spatialize_device(d_x, d_lr, frames)
+    ctx.synchronize()
+    t_sp = (time.perf_counter() - t0) / 20
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.tuner_analyze()
+    t_an = (time.perf_counter() - t0) / 5
+    ctx.close()
+    out["config5_256_tuners"] = {"value": nch / t_an, "unit": "analyses/s", "ms_per_256_analyses": t_an * 1e3}
+    out["config5_spatializer_256_to_2"] = {"value": nch * frames / t_sp / 1e6, "unit": "Msamples/s", "us_per_block": t_sp * 1e6}
+    return out
+
+
+# ---- main ----------------------------------------------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=512, help="channels per GPU")
+    ap.add_argument("--channels", type=int, default=512, help="channels per GPU (weak scaling, the default)")
+    ap.add_argument("--total-channels", type=int, default=0,
+                    help="strong scaling: this many channels in total, split over the GPUs in contiguous blocks (0 = weak mode)")
     ap.add_argument("--sample-rate", type=int, default=192000)
     ap.add_argument("--frames", type=int, default=8192)
     ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (no end_to_end / configs / split legs)")
     ap.add_argument("--distinct-irs", type=int, default=0,
                     help="number of distinct IR tap sets (0 = one per channel = the metric's d = 1; fewer lets power amps share spectra)")
     args = ap.parse_args()
@@ -123,32 +285,33 @@ def main():
     import torch  # first: libgdg.so then binds to the same HIP runtime (same SONAME)
     import __graft_entry__ as entry
     pkg = entry.load_package()
+    from go_dsp_guitar_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        # control plane only (barrier + max of one scalar): gloo, so that NO RCCL / xGMI traffic exists anywhere in this job
+        dist.init_process_group("gloo")
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    nch, frames, sr, taps = args.channels, args.frames, args.sample_rate, args.taps
-    ctx = pkg.Context(nch, frames, local_rank)
+    frames, sr, taps = args.frames, args.sample_rate, args.taps
+    strong = args.total_channels > 0
+    if strong:
+        channel0, nch = shard.channel_shard(args.total_channels, world, rank)
+        total_channels = args.total_channels
+    else:
+        channel0, nch = rank * args.channels, args.channels
+        total_channels = world * args.channels
     # every channel has its OWN impulse responses (d = 1): identical filters would share one copy of the spectra
-    n_distinct = args.distinct_irs if args.distinct_irs > 0 else nch
-    irs = {"cab": [synth_ir(taps, 4242 + i) for i in range(n_distinct)], "rev": [synth_ir(taps, 5242 + i) for i in range(n_distinct)]}
-    for c in range(nch):
-        for name, p in CHAIN:
-            if isinstance(p, str):
-                ctx.append_unit(c, name, fir=irs[p][c % n_distinct])
-            else:
-                ctx.append_unit(c, name, params=p)
-    x = torch.from_numpy(synth_block(nch, frames, sr, channel0=rank * nch)).to(dev)
+    n_distinct = args.distinct_irs
+    ctx = make_context(pkg, nch, frames, local_rank, taps, channel0=channel0, n_distinct=n_distinct)
+    x = torch.from_numpy(synth_block(nch, frames, sr, channel0=channel0)).to(dev)
     y = torch.empty_like(x)
 
     def step():
@@ -160,14 +323,13 @@ def main():
     # timed region: HIP events around the DOMINANT kernel only (the roofline's kernel; ~0.5 us per event record).
     # Bracketing all eight launches of a step costs ~7% of the step, so the other kernels are timed in an untimed pass below.
     ctx.profile_enable(kinds=[pkg.K_FIR_MAC])
-    from go_dsp_guitar_amd import shard
 
     def synchronize():
         ctx.synchronize()
         torch.cuda.synchronize()
 
     # barrier + synchronize | exactly K steps | synchronize; MAX over ranks (tested on CPU with gloo)
-    elapsed = shard.timed_steps(step, args.steps, synchronize, dist if distributed else None, dev)
+    elapsed = shard.timed_steps(step, args.steps, synchronize, dist if distributed else None, None)
     ctx.profile_enable(False)
     kernels = {}
     ms, n = ctx.profile_read(pkg.K_FIR_MAC)
@@ -185,6 +347,50 @@ def main():
         kernels[name] = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None, "pass": "untimed, all launches bracketed"}
     finite = bool(torch.isfinite(y).all().item())
 
+    extras = {}
+    if not args.no_extras and not strong:
+        if world == 1:
+            extras["end_to_end"] = end_to_end(pkg, ctx, nch, frames, sr)
+    ctx.close()
+    del x, y
+    if not args.no_extras and not strong:
+        if world > 1:
+            # the strong split of the same 512-channel job over these N GPUs (BASELINE config 4: 64 channels per GPU at N = 8)
+            T = args.channels
+            c0, n_loc = shard.channel_shard(T, world, rank)
+            sctx = make_context(pkg, n_loc, frames, local_rank, taps, channel0=c0)
+            sx = torch.from_numpy(synth_block(n_loc, frames, sr, channel0=c0)).to(dev)
+            sy = torch.empty_like(sx)
+
+            def sstep():
+                sctx.process_device(sx.data_ptr(), sy.data_ptr(), frames, sr)
+
+            def ssync():
+                sctx.synchronize()
+                torch.cuda.synchronize()
+
+            for _ in range(max(args.warmup, 1)):
+                sstep()
+            s_elapsed = shard.timed_steps(sstep, args.steps, ssync, dist, None)
+            sctx.close()
+            extras["strong_split"] = {
+                "scaling": "strong", "total_channels": T, "channels_per_gpu": n_loc, "n_gpus": world,
+                "value": T * frames * args.steps / s_elapsed / 1e6, "unit": "Msamples/s",
+                "ms_per_step": s_elapsed / args.steps * 1e3, "realtime_factor": frames * args.steps / s_elapsed / sr,
+            }
+        elif rank == 0:
+            legs = {}
+            for n_loc in (64, 128, 256):
+                dt = leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank, 30)
+                legs[str(n_loc)] = {"n_gpus_of_the_split": args.channels // n_loc, "us_per_step": dt * 1e6,
+                                    "value_this_gpu": n_loc * frames / dt / 1e6,
+                                    "predicted_job_value": args.channels * frames / dt / 1e6, "unit": "Msamples/s",
+                                    "predicted_realtime_factor": frames / sr / dt}
+            extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
+                                                   "(channels are independent: the job's step time is the slowest shard's step time)",
+                                           "legs": legs}
+            extras["configs"] = other_configs(pkg, local_rank)
+
     if rank == 0:
         K = (taps + frames - 1) // frames
         spec_bytes = 16.0 * frames                       # one packed half spectrum (P complex128)
@@ -194,8 +400,8 @@ def main():
         # the split variant's write of Y is NOT counted (it vanishes in the fused kernel).  With channel groups a step issues
         # several smaller launches per FIR unit: bytes per launch = bytes per step / launches per step.
         fir_per_chain = sum(1 for _, p in CHAIN if isinstance(p, str))
-        d_share = min(n_distinct, nch) / float(nch)                       # d = 1 with per-channel IRs
-        fused = not kernels["fir_inv"]["launches"]        # the library's default: MAC fused into the inverse transform's kernel
+        d_share = (min(n_distinct, nch) / float(nch)) if n_distinct > 0 else 1.0       # d = 1 with per-channel IRs
+        fused = not kernels["fir_inv"]["launches"]        # >= 128 channels per launch: MAC fused into the inverse transform's kernel
         out_bytes = 8.0 * frames if fused else 0.0         # the fused kernel also emits the output frame (8 B y out)
         mac_bytes = nch * ((1.0 + d_share) * K * spec_bytes + out_bytes) * fir_per_chain * args.steps / max(mac["launches"], 1)
         mac_gbs = mac_bytes / (mac["avg_ms"] * 1e-3) / 1e9 if mac["avg_ms"] else None
@@ -210,29 +416,33 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_fir_mac.json")) as f:
                 pmc = json.load(f)
-            if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps) and n_distinct >= nch and bool(pmc.get("fused")) == fused:
+            if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps) and n_distinct == 0 and bool(pmc.get("fused")) == fused:
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
+        value = total_channels * frames * args.steps / elapsed / 1e6
         out = {
             "metric": "Msamples/s through full chain incl. 64k-tap cab IR, 512ch@192kHz; %HBM roofline",
-            "value": world * samples_per_step * args.steps / elapsed / 1e6,
+            "value": value,
             "unit": "Msamples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%d channels/GPU @ %d Hz, %d-frame blocks, full chain: compressor>overdrive>tone_stack>chorus>power_amp(%d-tap cab IR)>power_amp(%d-tap reverb IR)>cabinet>reverb; %s; input resident in HBM"
-                            % (nch, sr, frames, taps, taps, "per-channel IRs (d = 1)" if n_distinct >= nch else "%d distinct IR sets shared by the channels" % n_distinct),
-                "channels_per_gpu": nch, "sample_rate": sr, "frames": frames, "ir_taps": taps, "partitions": K,
-                "realtime_factor": world * samples_per_step * args.steps / elapsed / (world * nch * sr),
+                "workload": "%s @ %d Hz, %d-frame blocks, full chain: compressor>overdrive>tone_stack>chorus>power_amp(%d-tap cab IR)>power_amp(%d-tap reverb IR)>cabinet>reverb; %s; input resident in HBM"
+                            % (("%d channels in total, split over %d GPU(s) in contiguous blocks" % (total_channels, world)) if strong
+                               else ("%d channels/GPU" % nch), sr, frames, taps, taps,
+                               "per-channel IRs (d = 1)" if n_distinct == 0 else "%d distinct IR sets shared by the channels" % n_distinct),
+                "channels_per_gpu": nch, "total_channels": total_channels, "sample_rate": sr, "frames": frames, "ir_taps": taps, "partitions": K,
+                "realtime_factor": value * 1e6 / (total_channels * sr),
                 "output_finite": finite,
+                "control_plane": "gloo barrier + max of one scalar; no RCCL, no data-path collective",
             },
             "roofline": {
                 "bound": "hbm",
@@ -248,11 +458,12 @@ def main():
                                    "achieved": (seg["launches"] * samples_per_step * 16.0 / (seg["ms_total"] * 1e-3) / 1e9) if seg["ms_total"] else None},
             },
         }
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: it is a property of the host, not of the GPU count
             out["cpu_baseline"] = cpu_baseline(sr, frames, taps)
         print(json.dumps(out))
-    ctx.close()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

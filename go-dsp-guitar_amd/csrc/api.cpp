@@ -23,6 +23,7 @@
 #include <memory>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define NUM_FILTERS 8
@@ -110,7 +111,12 @@ struct gdg_ctx {
     std::map<int, std::pair<double2 *, double2 *>> fir_tables;
     std::multimap<uint64_t, std::weak_ptr<SharedSpectra>> spectra;     /* content hash -> live IR spectra */
     bool share_spectra = true;
-    bool fir_fused = true;            /* GDG_FIR_FUSED=0: separate MAC and inverse launches (A/B measurements) */
+    /* FIR launch shape.  -1 (default): by channel count -- the fused kernel (one workgroup per channel: multiply-accumulate
+     * straight into the inverse transform) needs >= ~128 channels to fill the 256 CUs; below that the multiply-accumulate runs
+     * as its own bin-tiled kernel (32 workgroups per channel) followed by the inverse (profiles/channels_sweep_r02.txt).
+     * GDG_FIR_FUSED=0 / 1 forces one shape (A/B measurements). */
+    int fir_fused = -1;
+    int fir_split_max = 96;           /* GDG_FIR_SPLIT_MAX: largest launch (channels) that takes the split shape */
     double *d_os = nullptr;
     gdg_os_tables os;
     /* profiling */
@@ -207,7 +213,8 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ctx->device = device;
     ctx->chains.resize((size_t)n_channels);
     { const char *e = getenv("GDG_SHARE_IR_SPECTRA"); if (e) ctx->share_spectra = atoi(e) != 0; }
-    { const char *e = getenv("GDG_FIR_FUSED"); if (e) ctx->fir_fused = atoi(e) != 0; }
+    { const char *e = getenv("GDG_FIR_FUSED"); if (e) ctx->fir_fused = atoi(e) != 0 ? 1 : 0; }
+    { const char *e = getenv("GDG_FIR_SPLIT_MAX"); if (e) ctx->fir_split_max = atoi(e); }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -1007,7 +1014,8 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             if (st.is_fir) {
                 const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset) + first;
                 { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, s)); }
-                if (ctx->fir_fused) {
+                const bool fused = ctx->fir_fused < 0 ? (n > ctx->fir_split_max) : (ctx->fir_fused != 0);
+                if (fused) {
                     /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel) */
                     ProfScope ps(ctx, GDG_K_FIR_MAC, s);
                     HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, s));
@@ -1072,6 +1080,27 @@ static int ensure_staging(gdg_ctx *ctx) {
     return GDG_OK;
 }
 
+/* rows [a, b) of a host-side staging copy, spread over a few threads: one core moves pageable memory at ~10 GB/s, which made
+ * the 2 x 32 MiB of a 512-channel block cost 3 ms -- more than the whole chain (env GDG_COPY_THREADS, default 8) */
+static void copy_rows_parallel(size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes) {
+    static int threads = -1;
+    if (threads < 0) {
+        const char *e = getenv("GDG_COPY_THREADS");
+        threads = e ? atoi(e) : 8;
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw > 0 && threads > (int)hw) threads = (int)hw;
+        if (threads < 1) threads = 1;
+    }
+    size_t n = b > a ? b - a : 0;
+    size_t T = std::min((size_t)threads, n * row_bytes / (1u << 20) + 1);      /* at least ~1 MiB per thread */
+    if (T <= 1 || n < 2) { for (size_t i = a; i < b; i++) copy_row(i); return; }
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < T; t++)
+        pool.emplace_back([=, &copy_row]() { for (size_t i = a + n * t / T; i < a + n * (t + 1) / T; i++) copy_row(i); });
+    for (size_t i = a; i < a + n / T; i++) copy_row(i);
+    for (auto &th : pool) th.join();
+}
+
 int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *const *in, double *const *out, int frames, uint32_t sample_rate) {
     if (!ctx || !in || !out || !channels) return GDG_ERR_INVALID;
     if (n <= 0 || n > ctx->nch) return fail(ctx, GDG_ERR_INVALID, "bad channel count %d", n);
@@ -1093,7 +1122,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           /* the staging slabs may still be in use */
     GroupHook before = [&](int g, hipStream_t s) -> hipError_t {
         size_t a = lo(g), b = lo(g + 1);
-        for (size_t i = a; i < b; i++) memcpy(ctx->h_stage_in + i * row, in[i], row * sizeof(double));
+        copy_rows_parallel(a, b, [&](size_t i) { memcpy(ctx->h_stage_in + i * row, in[i], row * sizeof(double)); }, row * sizeof(double));
         if (b == a) return hipSuccess;
         return hipMemcpyAsync(ctx->d_stage_in + a * row, ctx->h_stage_in + a * row, (b - a) * row * sizeof(double), hipMemcpyHostToDevice, s);
     };
@@ -1107,7 +1136,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     for (int g = 0; g < G; g++) {
         if (G > 1) HIP_TRY(ctx, hipStreamSynchronize(ctx->gstreams[(size_t)g]));
         else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t i = lo(g); i < lo(g + 1); i++) memcpy(out[i], ctx->h_stage_out + i * row, row * sizeof(double));
+        copy_rows_parallel(lo(g), lo(g + 1), [&](size_t i) { memcpy(out[i], ctx->h_stage_out + i * row, row * sizeof(double)); }, row * sizeof(double));
     }
     return check_device_error(ctx);
 }
