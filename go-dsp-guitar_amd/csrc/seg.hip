@@ -36,6 +36,8 @@
 #define SEG_LBUF (8192 + 256 + 8)
 #define SEG_SCR 3328
 #define LX(e) ((e) + ((e) >> 5))
+#define CHK (GDG_MAX_FRAMES / SEG_T)     /* samples per thread at the batch block size */
+static_assert(CHK * SEG_T == GDG_MAX_FRAMES, "chunk size");
 
 /* the workgroup's LDS, at file scope so that the (non-inlined) unit functions address it as LDS, not through flat pointers */
 __shared__ double s_a[SEG_LBUF];                     /* frame ping */
@@ -166,6 +168,162 @@ __device__ __forceinline__ double apply_map(double A, double B, double s) {
     return MAXOP ? fmax(v, B) : v + B;
 }
 
+/* ---- constant-coefficient recurrences on the batch block (8192 = 1024 threads x 8 samples) ---------------------------
+ * A one-pole section (or follower) with a FIXED coefficient maps a thread's chunk start state s to  A s + B  (max(A s, B)
+ * for the peak follower) with the SAME A = keep^8 for every thread.  The general block_scan above carries (A, B) pairs
+ * through every step (4 DPP moves + 3 flops + a select, ~130 instructions per wave and scan: 70 % of the cabinet's
+ * instruction stream, and these units are VALU-issue bound).  With A constant only B travels:
+ *   - the chunk's zero-state result B is a dot product with precomputed weights a keep^(7-i)   (8 fma instead of 32 flops);
+ *   - a scan step is  B += A^d * shifted(B): two DPP moves with zero fill (bound_ctrl) + one fma, no select;
+ *   - rows are joined with row_bcast:15 / row_bcast:31 and per-lane powers A^(q+1), A^(lane-31) from a small LDS table;
+ *   - the 16 wave totals are scanned by lanes 0..15 of every wave with the A^64 ladder, seeded with the state before the
+ *     frame in lane 0, so lane w holds the state entering wave w;
+ *   - start state of the thread's chunk = exclusive in-wave value (wave_shr:1) + A^lane * (state entering the wave).
+ * One workgroup barrier per scan (the exchange slots alternate).  The tables are built once per unit call by one wave per
+ * section (binary exponentiation, ~100 instructions).  The exact replay from the start state is unchanged, so only that
+ * start state carries the scan's rounding (~1e-16 relative), as before.
+ * 2 x 2 variant (tone stack band = high-pass feeding a low-pass): the pair (h, l) evolves linearly with the constant
+ * lower-triangular matrix [[1-aH, 0], [-aL, 1-aL]] per sample, so ONE scan of vectors replaces two scans and one of the
+ * three passes. */
+#define LT_W 0                    /* [8]  dot weights */
+#define LT_ST 8                   /* [10] A^(2^k), k = 0..9 */
+#define LT_PA 18                  /* [16] A^(q + 1), q = lane & 15 */
+#define LT_PB 34                  /* [32] A^(lane - 31), lane = 32..63, at index lane - 32 */
+#define LT_PC 66                  /* [64] A^lane */
+#define LT_SIZE 130
+#define LX_SLOT 17                /* exchange slot: [state before the frame | 16 wave totals] */
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp0(double v) {       /* DPP move, lanes without a source (and rows outside ROWMASK) read 0 */
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_ROW_SHR(d) (0x110 | (d))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_WAVE_SHR1 0x138
+
+__device__ __forceinline__ double pow_u(double A, int e) {     /* A^e, 0 <= e < 1024 */
+    double r = 1.0, b = A;
+#pragma unroll
+    for (int k = 0; k < 10; k++) { if (e & (1 << k)) r *= b; b *= b; }
+    return r;
+}
+
+/* built by ONE wave (all 64 lanes call it); a = per-sample coefficient, keep = 1 - a (the follower passes its own pair) */
+template <bool MAXOP>
+__device__ __forceinline__ void lin_tab_build(double *tab, double a, double keep) {
+    const int lane = threadIdx.x & 63;
+    const double k2 = keep * keep, k4 = k2 * k2, A = k4 * k4;
+    tab[LT_PC + lane] = pow_u(A, lane);
+    if (lane < 16) tab[LT_PA + lane] = pow_u(A, lane + 1);
+    if (lane >= 32) tab[LT_PB + lane - 32] = pow_u(A, lane - 31);
+    if (lane < 10) tab[LT_ST + lane] = pow_u(A, 1 << lane);
+    if (lane < CHK) tab[LT_W + lane] = (MAXOP ? 1.0 : a) * pow_u(keep, CHK - 1 - lane);
+}
+
+template <bool MAXOP>
+__device__ __forceinline__ double lin_comb(double acc, double f, double v) { return MAXOP ? fmax(acc, f * v) : fma(f, v, acc); }
+
+/* zero-state result of this thread's chunk */
+template <bool MAXOP, bool ABS = MAXOP>
+__device__ __forceinline__ double lin_chunk_map(const double (&x)[CHK], const double *tab) {
+    double B = 0.0;
+#pragma unroll
+    for (int i = 0; i < CHK; i++) B = lin_comb<MAXOP>(B, tab[LT_W + i], ABS ? fabs(x[i]) : x[i]);
+    return B;
+}
+
+/* B = zero-state chunk result of this thread; *s0 (LDS) = state before the frame; returns the state at this thread's chunk start */
+template <bool MAXOP>
+__device__ __forceinline__ double lin_scan(double B, const double *tab, const double *s0, double *xch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double I = B;
+    I = lin_comb<MAXOP>(I, tab[LT_ST + 0], dpp0<DPP_ROW_SHR(1), 0xf>(I));
+    I = lin_comb<MAXOP>(I, tab[LT_ST + 1], dpp0<DPP_ROW_SHR(2), 0xf>(I));
+    I = lin_comb<MAXOP>(I, tab[LT_ST + 2], dpp0<DPP_ROW_SHR(4), 0xf>(I));
+    I = lin_comb<MAXOP>(I, tab[LT_ST + 3], dpp0<DPP_ROW_SHR(8), 0xf>(I));
+    I = lin_comb<MAXOP>(I, tab[LT_PA + (lane & 15)], dpp0<DPP_ROW_BCAST15, 0xa>(I));     /* rows 1, 3 <- totals of rows 0, 2 */
+    I = lin_comb<MAXOP>(I, tab[LT_PB + (lane & 31)], dpp0<DPP_ROW_BCAST31, 0xc>(I));     /* rows 2, 3 <- total of rows 0..1 */
+    if (lane == 63) xch[1 + wave] = I;
+    __syncthreads();
+    const double E = dpp0<DPP_WAVE_SHR1, 0xf>(I);                 /* exclusive inside the wave */
+    double T = (lane == 0) ? *s0 : xch[lane & 15];                /* lanes 0..15: [s0, total of wave 0, ..., of wave 14] */
+    T = lin_comb<MAXOP>(T, tab[LT_ST + 6], dpp0<DPP_ROW_SHR(1), 0xf>(T));
+    T = lin_comb<MAXOP>(T, tab[LT_ST + 7], dpp0<DPP_ROW_SHR(2), 0xf>(T));
+    T = lin_comb<MAXOP>(T, tab[LT_ST + 8], dpp0<DPP_ROW_SHR(4), 0xf>(T));
+    T = lin_comb<MAXOP>(T, tab[LT_ST + 9], dpp0<DPP_ROW_SHR(8), 0xf>(T));
+    const double V = read_lane(T, __builtin_amdgcn_readfirstlane(wave));     /* state entering this wave */
+    return lin_comb<MAXOP>(E, tab[LT_PC + lane], V);
+}
+
+/* ---- 2 x 2: lower-triangular matrices (m00, m10, m11) --------------------------------------------------------------- */
+struct Tri { double a, b, c; };                                /* [[a, 0], [b, c]] */
+__device__ __forceinline__ Tri tri_mul(const Tri &x, const Tri &y) { Tri r = { x.a * y.a, (x.b * y.a) + (x.c * y.b), x.c * y.c }; return r; }
+__device__ __forceinline__ Tri tri_pow(Tri M, int e) {
+    Tri r = { 1.0, 0.0, 1.0 };
+#pragma unroll
+    for (int k = 0; k < 10; k++) { if (e & (1 << k)) r = tri_mul(r, M); M = tri_mul(M, M); }
+    return r;
+}
+#define L2_W 0                    /* [8][2]  dot weights (gH_i, gL_i) */
+#define L2_ST 16                  /* [10][3] P^(2^k) */
+#define L2_PA 46                  /* [16][3] */
+#define L2_PB 94                  /* [32][3] */
+#define L2_PC 190                 /* [64][3] */
+#define L2_SIZE 382
+__device__ __forceinline__ void tri_store(double *p, const Tri &t) { p[0] = t.a; p[1] = t.b; p[2] = t.c; }
+
+/* one wave builds the tables of one band: per sample (h, l) <- M (h, l) + (aH, aL) x, M = [[1-aH, 0], [-aL, 1-aL]] */
+__device__ __forceinline__ void lin2_tab_build(double *tab, double aH, double aL) {
+    const int lane = threadIdx.x & 63;
+    const Tri M = { 1.0 - aH, -aL, 1.0 - aL };
+    const Tri P = tri_pow(M, CHK);
+    tri_store(tab + L2_PC + 3 * lane, tri_pow(P, lane));
+    if (lane < 16) tri_store(tab + L2_PA + 3 * lane, tri_pow(P, lane + 1));
+    if (lane >= 32) tri_store(tab + L2_PB + 3 * (lane - 32), tri_pow(P, lane - 31));
+    if (lane < 10) tri_store(tab + L2_ST + 3 * lane, tri_pow(P, 1 << lane));
+    if (lane < CHK) {
+        Tri G = tri_pow(M, CHK - 1 - lane);
+        tab[L2_W + 2 * lane] = G.a * aH;
+        tab[L2_W + 2 * lane + 1] = (G.b * aH) + (G.c * aL);
+    }
+}
+__device__ __forceinline__ void lin2_comb(double &h, double &l, const double *m, double sh, double sl) {
+    h = fma(m[0], sh, h);
+    l = fma(m[2], sl, fma(m[1], sh, l));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void lin2_step(double &h, double &l, const double *m) {
+    const double sh = dpp0<CTRL, ROWMASK>(h), sl = dpp0<CTRL, ROWMASK>(l);
+    lin2_comb(h, l, m, sh, sl);
+}
+/* (ch, cl): zero-state chunk result; s0h / s0l (LDS): state before the frame; returns the chunk start state in (ch, cl) */
+__device__ __forceinline__ void lin2_scan(double &ch, double &cl, const double *tab, const double *s0h, const double *s0l, double *xch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double h = ch, l = cl;
+    lin2_step<DPP_ROW_SHR(1), 0xf>(h, l, tab + L2_ST + 0);
+    lin2_step<DPP_ROW_SHR(2), 0xf>(h, l, tab + L2_ST + 3);
+    lin2_step<DPP_ROW_SHR(4), 0xf>(h, l, tab + L2_ST + 6);
+    lin2_step<DPP_ROW_SHR(8), 0xf>(h, l, tab + L2_ST + 9);
+    lin2_step<DPP_ROW_BCAST15, 0xa>(h, l, tab + L2_PA + 3 * (lane & 15));
+    lin2_step<DPP_ROW_BCAST31, 0xc>(h, l, tab + L2_PB + 3 * (lane & 31));
+    if (lane == 63) { xch[1 + wave] = h; xch[LX_SLOT + 1 + wave] = l; }
+    __syncthreads();
+    const double eh = dpp0<DPP_WAVE_SHR1, 0xf>(h), el = dpp0<DPP_WAVE_SHR1, 0xf>(l);
+    double th = (lane == 0) ? *s0h : xch[lane & 15];
+    double tl = (lane == 0) ? *s0l : xch[LX_SLOT + (lane & 15)];
+    lin2_step<DPP_ROW_SHR(1), 0xf>(th, tl, tab + L2_ST + 18);
+    lin2_step<DPP_ROW_SHR(2), 0xf>(th, tl, tab + L2_ST + 21);
+    lin2_step<DPP_ROW_SHR(4), 0xf>(th, tl, tab + L2_ST + 24);
+    lin2_step<DPP_ROW_SHR(8), 0xf>(th, tl, tab + L2_ST + 27);
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    const double vh = read_lane(th, w), vl = read_lane(tl, w);
+    ch = eh; cl = el;
+    lin2_comb(ch, cl, tab + L2_PC + 3 * lane, vh, vl);
+}
+
 /* ---- history rings in HBM --------------------------------------------------------------------
  * A ring of capacity C holds the last C inputs of a unit: oldest at wp, newest at wp - 1.
  * Sample with frame-relative index idx (-C <= idx < 0) is ring[(wp + idx) mod C].
@@ -273,8 +431,6 @@ __device__ __forceinline__ void envelope_to(const double *in, double *dst, int N
 /* ---- register-resident chunks --------------------------------------------------------------------
  * With 1024 threads a thread owns at most CHK = 8 consecutive samples, so a whole recurrence chain (zero-state
  * pass, scan, exact replay, next section ...) runs on registers: one LDS read and one LDS write per sample and unit. */
-#define CHK (GDG_MAX_FRAMES / SEG_T)
-static_assert(CHK * SEG_T == GDG_MAX_FRAMES, "chunk size");
 
 /* A thread's chunk of the frame.  FULL = the frame is exactly CHK * SEG_T samples (the batch block size): every chunk is complete
  * and the per-sample "inside the chunk?" guards -- a v_cndmask pair and an exec-mask update per sample and per section, 3/4
@@ -383,6 +539,15 @@ __device__ __forceinline__ void envelope_reg(const double (&x)[CHK], double (&e)
     }
 }
 
+/* The unit descriptor is the same for the whole workgroup and never written by the kernel: read it through scalar loads
+ * (wave-uniform pointer in SGPRs, constant address space) instead of FLAT vector loads from the generic pointer. */
+#define GDG_CONST __attribute__((address_space(4)))
+__device__ __forceinline__ const GDG_CONST gdg_seg_unit *uniform_unit(const gdg_seg_unit *p) {
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const GDG_CONST gdg_seg_unit *)(((unsigned long long)hi << 32) | lo);
+}
+
 /* ---- compressor: effects/compressor.go:18-84 ---------------------------------------------------
  * ip0 follow; dp0 gain limit factor, dp1 target factor, dp2 exp(-20/sr), dp3 1 - dp2; ds0 envelope */
 template <class C>
@@ -403,8 +568,45 @@ __device__ __forceinline__ void compressor_body(const gdg_seg_unit *U, int flip,
     chunk_store(out, c, x);
     if (c.last) U->ds[0] = s;
 }
+/* the batch block size: constant-coefficient scan (see lin_scan) */
+__device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
+    double *st = tmp + SEG_STASH;
+    const int tid = threadIdx.x;
+    const int follow = U->ip[0];
+    const double d_inv = U->dp[2], d = U->dp[3], limit = U->dp[0], target = U->dp[1];
+    GDG_GLOBAL double *ds = as_global(U->ds);
+    if (tid == 0) st[0] = ds[0];
+    if (tid < 64) { if (follow == 0) lin_tab_build<true>(scr, 0.0, d_inv); else lin_tab_build<false>(scr, d, d_inv); }
+    const ChunkT<true> c = full_chunk();
+    double x[CHK], e[CHK];
+    chunk_load(in, c, x);
+    __syncthreads();
+    double s = 1.0;
+    if (follow == 0) {
+        s = lin_scan<true>(lin_chunk_map<true>(x, scr), scr, &st[0], tmp);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) { s *= d_inv; double q = fabs(x[i]); if (q > s) s = q; e[i] = s; }
+    } else if (follow == 1) {
+        s = lin_scan<false>(lin_chunk_map<false, true>(x, scr), scr, &st[0], tmp);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) { double diff = fabs(x[i]) - s; s += diff * d; e[i] = s; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CHK; i++) e[i] = 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < CHK; i++) {
+        double gain = target / e[i];
+        if (gain > limit) gain = limit;
+        x[i] = clip1(gain * x[i]);
+    }
+    chunk_store(out, c, x);
+    if (c.last) ds[0] = s;
+}
 UNIT_FN unit_compressor(UNIT_ARGS) {
-    if (N == CHK * SEG_T) compressor_body(U, flip, N, full_chunk());       /* the batch block size: guard-free chunks */
+    if (N == CHK * SEG_T) compressor_full(U, flip);
     else compressor_body(U, flip, N, my_chunk(N));
 }
 
@@ -456,7 +658,6 @@ __device__ __forceinline__ double shape(const Shaper &S, double sample) {
  *            from LDS without bank conflicts.  (The first version read taps per lane from global memory and walked LDS with
  *            a stride of F doubles: 8-way conflicts at 4x.)
  * hist: [8 inputs | TAPS - 1 oversampled samples of the previous call]. */
-#define GDG_CONST __attribute__((address_space(4)))
 __device__ __forceinline__ const double *uniform_ptr(const double *p) {
     unsigned long long v = (unsigned long long)p;
     unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -622,8 +823,48 @@ __device__ __forceinline__ void tonestack_body(const gdg_seg_unit *U, int flip, 
         }
     }
 }
+/* the batch block size: per band ONE scan of the (high-pass, low-pass) state pair with the constant 2 x 2 chunk matrix, then the
+ * reference's loop body from the scanned chunk-start state; the band sum stays in registers (j = 0..3 as in the reference) */
+__device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
+    double *st = tmp + SEG_STASH;                    /* [0..7] the capacitor voltages, [16..27] factors and coefficients */
+    const int tid = threadIdx.x, wave = tid >> 6;
+    GDG_GLOBAL double *ds = as_global(U->ds);
+    if (tid < 8) st[tid] = ds[tid];
+    if (tid < 12) st[16 + tid] = U->dp[tid];
+    if (wave < 4) lin2_tab_build(scr + wave * L2_SIZE, U->dp[4 + wave], U->dp[8 + wave]);
+    const ChunkT<true> c = full_chunk();
+    double x[CHK], sum[CHK];
+    chunk_load(in, c, x);
+#pragma unroll
+    for (int i = 0; i < CHK; i++) sum[i] = 0.0;
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+        const double *tab = scr + j * L2_SIZE;
+        const double fac = st[16 + j], aH = st[20 + j], aL = st[24 + j];
+        double h = 0.0, l = 0.0;
+#pragma unroll
+        for (int i = 0; i < CHK; i++) { h = fma(tab[L2_W + 2 * i], x[i], h); l = fma(tab[L2_W + 2 * i + 1], x[i], l); }
+        lin2_scan(h, l, tab, &st[j], &st[4 + j], tmp + (j & 1) * 2 * LX_SLOT);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) {
+            double diff = x[i] - h;
+            h += diff * aH;
+            diff -= l;
+            double pre = l;
+            l += diff * aL;
+            sum[i] += fac * pre;
+        }
+        if (c.last) { ds[j] = h; ds[4 + j] = l; }
+    }
+#pragma unroll
+    for (int i = 0; i < CHK; i++) sum[i] = clip1(sum[i]);
+    chunk_store(out, c, sum);
+}
 UNIT_FN unit_tonestack(UNIT_ARGS) {
-    if (N == CHK * SEG_T) tonestack_body(U, flip, N, full_chunk());       /* the batch block size: guard-free chunks */
+    if (N == CHK * SEG_T) tonestack_full(U, flip);
     else tonestack_body(U, flip, N, my_chunk(N));
 }
 
@@ -650,8 +891,39 @@ __device__ __forceinline__ void cabinet_body(const gdg_seg_unit *U, int flip, in
     for (int i = 0; i < CHK; i++) v[i] = clip1(v[i]);
     chunk_store(out, c, v);
 }
+/* the batch block size: per section a dot product, a constant-coefficient scan (lin_scan) and the exact replay */
+__device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
+    double *st = tmp + SEG_STASH;                    /* [0..6] the capacitor voltages, [16..22] the coefficients */
+    const int tid = threadIdx.x, wave = tid >> 6;
+    GDG_GLOBAL double *ds = as_global(U->ds);
+    if (tid < 7) { st[tid] = ds[tid]; st[16 + tid] = U->dp[tid]; }
+    if (wave < 7) { const double a = U->dp[wave]; lin_tab_build<false>(scr + wave * LT_SIZE, a, 1.0 - a); }
+    const ChunkT<true> c = full_chunk();
+    double v[CHK];
+    chunk_load(in, c, v);
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < 7; p++) {
+        const double *tab = scr + p * LT_SIZE;
+        const double a = st[16 + p];
+        double s = lin_scan<false>(lin_chunk_map<false>(v, tab), tab, &st[p], tmp + (p & 1) * 2 * LX_SLOT);
+        if (p < 3) {
+#pragma unroll
+            for (int i = 0; i < CHK; i++) { double diff = v[i] - s; s += diff * a; v[i] = diff; }          /* cabinet.go:114-118 */
+        } else {
+#pragma unroll
+            for (int i = 0; i < CHK; i++) { double diff = v[i] - s; v[i] = s; s += diff * a; }             /* cabinet.go:135-139 */
+        }
+        if (c.last) ds[p] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < CHK; i++) v[i] = clip1(v[i]);
+    chunk_store(out, c, v);
+}
 UNIT_FN unit_cabinet(UNIT_ARGS) {
-    if (N == CHK * SEG_T) cabinet_body(U, flip, N, full_chunk());       /* the batch block size: guard-free chunks */
+    if (N == CHK * SEG_T) cabinet_full(U, flip);
     else cabinet_body(U, flip, N, my_chunk(N));
 }
 
