@@ -303,10 +303,14 @@ int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle) {
     u.type = unit_type;
     u.channel = channel;
     memcpy(u.params, g_param_default[unit_type], sizeof(u.params));
-    HIP_TRY(ctx, hipMalloc((void **)&u.d_ds, GDG_DS_LEN * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void **)&u.d_is, GDG_IS_LEN * sizeof(int)));
-    HIP_TRY(ctx, hipMemsetAsync(u.d_ds, 0, GDG_DS_LEN * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(u.d_is, 0, GDG_IS_LEN * sizeof(int), ctx->stream));
+    hipError_t e = hipMalloc((void **)&u.d_ds, GDG_DS_LEN * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&u.d_is, GDG_IS_LEN * sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(u.d_ds, 0, GDG_DS_LEN * sizeof(double), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(u.d_is, 0, GDG_IS_LEN * sizeof(int), ctx->stream);
+    if (e != hipSuccess) {
+        free_unit(u);               /* the slot goes back to "not alive"; nothing leaks */
+        return fail(ctx, GDG_ERR_HIP, "gdg_unit_create: %s", hipGetErrorString(e));
+    }
     *handle = (int)h;
     return GDG_OK;
 }
@@ -685,35 +689,22 @@ static int fir_transform_size(int frames) {
     return P;
 }
 
-/* (Re)build the partitioned spectra and zero the convolution state of one power amp: frames of `hop` samples, IR partitions
- * of `hop` taps, transforms of 2 P points with P = fir_transform_size(hop) (hop == P for the power-of-two frame sizes). */
-static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
-    const int P = fir_transform_size(hop);
-    if (u.fir_sr != sample_rate) {
-        /* poweramp.go:191-203: a sample-rate change recompiles the filter, i.e. fresh state */
-        u.fir_sr = sample_rate;
-        u.fir_dirty = true;
-        u.fir_live = false;
-    }
-    if (!u.fir_dirty && u.fir_hop == hop) return GDG_OK;
-    if (!u.fir_dirty && u.fir_hop != hop && u.fir_live)
-        return fail(ctx, GDG_ERR_UNSUPPORTED, "frame size changed from %d to %d while a power amp holds convolution state; reset the unit first", u.fir_hop, hop);
-    int L = (int)u.taps.size();
-    int K = (L + hop - 1) / hop;
-    if (K < 1) K = 1;                 /* filter.Empty: one all-zero partition => zeros out */
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_Y); hipFree(u.d_pos);
-    u.d_prev = nullptr; u.d_fdl = nullptr; u.d_Y = nullptr; u.d_pos = nullptr;
-    u.H.reset();
+/* filter.Process walks the frame in blocks of nextpow2(L) samples but counts them on nextpow2(N): when N is not a power of two a
+ * block can start beyond the frame and the reference panics on the slice bounds (filter/filter.go:370-382, :443-453).  Such a
+ * (frame size, filter length) pair is rejected instead of replicated. */
+static bool reference_panics(int frames, int taps) {
+    if (taps <= 0 || frames <= 0) return false;
+    uint64_t n_power = 1, block = 1;
+    while (n_power < (uint64_t)frames) n_power <<= 1;
+    while (block < (uint64_t)taps) block <<= 1;
+    uint64_t blocks = n_power / block + ((n_power % block) ? 1 : 0);
+    return blocks > 0 && (blocks - 1) * block > (uint64_t)frames;
+}
+
+/* IR spectra of `taps` for frames of `hop` samples: reuse a live copy of the same taps at the same partition size, else build one */
+static int fir_spectra(gdg_ctx *ctx, Unit &u, int hop, int P, int K) {
+    const int L = (int)u.taps.size();
     size_t spec = (size_t)K * (size_t)P * sizeof(double2);
-    HIP_TRY(ctx, hipMalloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void **)&u.d_fdl, spec));
-    HIP_TRY(ctx, hipMalloc((void **)&u.d_Y, (size_t)P * sizeof(double2)));
-    HIP_TRY(ctx, hipMalloc((void **)&u.d_pos, sizeof(int)));
-    HIP_TRY(ctx, hipMemsetAsync(u.d_prev, 0, 2 * (size_t)P * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(u.d_fdl, 0, spec, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(u.d_pos, 0, sizeof(int), ctx->stream));
-    /* IR spectra: reuse a live copy of the same taps at the same partition size, else build one */
     uint64_t key = 1469598103934665603ull;                              /* FNV-1a over the tap bytes, P and L */
     {
         const unsigned char *b = reinterpret_cast<const unsigned char *>(u.taps.data());
@@ -722,6 +713,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
         key ^= (uint64_t)hop; key *= 1099511628211ull;
         key ^= (uint64_t)L; key *= 1099511628211ull;
     }
+    u.H.reset();
     if (ctx->share_spectra) {
         auto range = ctx->spectra.equal_range(key);
         for (auto it = range.first; it != range.second;) {
@@ -731,46 +723,151 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
             ++it;
         }
     }
-    if (!u.H) {
-        auto sp = std::make_shared<SharedSpectra>();
-        sp->taps = u.taps;
-        sp->P = P;
-        sp->K = K;
-        sp->hop = hop;
-        HIP_TRY(ctx, hipMalloc((void **)&sp->d_H, spec));
-        HIP_TRY(ctx, hipMemsetAsync(sp->d_H, 0, spec, ctx->stream));
-        if (L > 0) {
-            double2 *tw, *tw2;
-            int rc = fir_tables(ctx, P, &tw, &tw2);
-            if (rc != GDG_OK) return rc;
-            /* partition k = taps [k hop, (k + 1) hop), zero-padded to the transform half */
-            std::vector<double> padded((size_t)K * (size_t)P, 0.0);
-            for (int k = 0; k < K; k++) {
-                int n = std::min(hop, L - k * hop);
-                memcpy(padded.data() + (size_t)k * P, u.taps.data() + (size_t)k * hop, (size_t)n * sizeof(double));
-            }
-            double *d_taps = nullptr;
-            gdg_fir_irjob *d_jobs = nullptr;
-            std::vector<gdg_fir_irjob> jobs((size_t)K);
-            HIP_TRY(ctx, hipMalloc((void **)&d_taps, padded.size() * sizeof(double)));
-            HIP_TRY(ctx, hipMalloc((void **)&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
-            for (int k = 0; k < K; k++) { jobs[(size_t)k].a = d_taps + (size_t)k * P; jobs[(size_t)k].out = sp->d_H + (size_t)k * P; }
-            HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
-            /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
-            HIP_TRY(ctx, gdg_launch_fir_ir(P, d_jobs, K, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            hipFree(d_taps);
-            hipFree(d_jobs);
+    if (u.H) return GDG_OK;
+    auto sp = std::make_shared<SharedSpectra>();
+    sp->taps = u.taps;
+    sp->P = P;
+    sp->K = K;
+    sp->hop = hop;
+    HIP_TRY(ctx, hipMalloc((void **)&sp->d_H, spec));
+    HIP_TRY(ctx, hipMemsetAsync(sp->d_H, 0, spec, ctx->stream));
+    if (L > 0) {
+        double2 *tw, *tw2;
+        int rc = fir_tables(ctx, P, &tw, &tw2);
+        if (rc != GDG_OK) return rc;
+        /* partition k = taps [k hop, (k + 1) hop), zero-padded to the transform half */
+        std::vector<double> padded((size_t)K * (size_t)P, 0.0);
+        for (int k = 0; k < K; k++) {
+            int n = std::min(hop, L - k * hop);
+            memcpy(padded.data() + (size_t)k * P, u.taps.data() + (size_t)k * hop, (size_t)n * sizeof(double));
         }
-        u.H = sp;
-        if (ctx->share_spectra) ctx->spectra.emplace(key, sp);
+        double *d_taps = nullptr;
+        gdg_fir_irjob *d_jobs = nullptr;
+        std::vector<gdg_fir_irjob> jobs((size_t)K);
+        HIP_TRY(ctx, hipMalloc((void **)&d_taps, padded.size() * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
+        for (int k = 0; k < K; k++) { jobs[(size_t)k].a = d_taps + (size_t)k * P; jobs[(size_t)k].out = sp->d_H + (size_t)k * P; }
+        HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
+        /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
+        HIP_TRY(ctx, gdg_launch_fir_ir(P, d_jobs, K, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(d_taps);
+        hipFree(d_jobs);
     }
+    u.H = sp;
+    if (ctx->share_spectra) ctx->spectra.emplace(key, sp);
+    return GDG_OK;
+}
+
+/* (Re)build the partitioned spectra of one power amp for frames of `hop` samples: IR partitions of `hop` taps, transforms of 2 P
+ * points with P = fir_transform_size(hop) (hop == P for the power-of-two frame sizes).
+ *   - new filter / new sample rate / reset: the convolution state starts from zero (poweramp.go:131-203);
+ *   - frame size changed while the filter is live: the reference's tail and transform sizes depend on L only, so any sequence of
+ *     frame sizes is one continuous convolution (filter.go:370-428).  Here the partition size follows the frame, so the delay
+ *     line is RE-PARTITIONED: its slots are transformed back to the last (K + 1) hop input samples (raw inverse, ~1e-16), which
+ *     are re-cut into frames of the new size and transformed into the new delay line.  Samples older than that only ever meet
+ *     zero-padded taps, so the continuation is exact.  Happens once per change, never in the steady state. */
+static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
+    const int P = fir_transform_size(hop);
+    if (u.fir_sr != sample_rate) {
+        /* poweramp.go:191-203: a sample-rate change recompiles the filter, i.e. fresh state */
+        u.fir_sr = sample_rate;
+        u.fir_dirty = true;
+        u.fir_live = false;
+    }
+    if (!u.fir_dirty && u.fir_hop == hop) return GDG_OK;
+    int L = (int)u.taps.size();
+    if (reference_panics(hop, L))
+        return fail(ctx, GDG_ERR_UNSUPPORTED, "frame size %d with a %d-tap filter: the reference panics on this pair (filter/filter.go:443-453: a block of "
+                    "nextpow2(L) samples starts beyond the frame); rejected, not replicated", hop, L);
+    int K = (L + hop - 1) / hop;
+    if (K < 1) K = 1;                 /* filter.Empty: one all-zero partition => zeros out */
+    const bool carry = !u.fir_dirty && u.fir_live && u.fir_hop != hop && L > 0 && u.d_fdl && u.d_pos;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    /* the old state, kept until the new delay line is built */
+    double *o_prev = u.d_prev; double2 *o_fdl = u.d_fdl, *o_Y = u.d_Y; int *o_pos = u.d_pos;
+    const int K1 = u.fir_K, P1 = u.fir_P, hop1 = u.fir_hop;
+    auto free_old = [&]() { hipFree(o_prev); hipFree(o_fdl); hipFree(o_Y); hipFree(o_pos); };
+    u.d_prev = nullptr; u.d_fdl = nullptr; u.d_Y = nullptr; u.d_pos = nullptr;
+    double *d_old_hist = nullptr, *d_new_hist = nullptr;
+    void *d_jobs = nullptr;
+    size_t old_len = 0;
+    int rc = GDG_OK;
+    auto body = [&]() -> int {
+        double2 *tw, *tw2;
+        if (carry) {
+            /* 1. the last (K1 + 1) hop1 input samples out of the old delay line, oldest first */
+            int pos = 0;
+            HIP_TRY(ctx, hipMemcpy(&pos, o_pos, sizeof(int), hipMemcpyDeviceToHost));
+            old_len = (size_t)(K1 + 1) * (size_t)hop1;
+            HIP_TRY(ctx, hipMalloc((void **)&d_old_hist, old_len * sizeof(double)));
+            std::vector<gdg_fir_rawjob> jobs((size_t)K1);
+            for (int j = 0; j < K1; j++) {
+                int m = K1 - 1 - j;                                   /* frame t - m, t = the latest one, sits in slot (pos - 1 - m) mod K1 */
+                int slot = (((pos - 1 - m) % K1) + K1) % K1;
+                jobs[(size_t)j].Y = o_fdl + (size_t)slot * P1;
+                jobs[(size_t)j].first = (j == 0) ? d_old_hist : nullptr;
+                jobs[(size_t)j].second = d_old_hist + (size_t)(j + 1) * hop1;
+                jobs[(size_t)j].hop = hop1;
+            }
+            HIP_TRY(ctx, hipMalloc(&d_jobs, jobs.size() * sizeof(gdg_fir_rawjob)));
+            HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_rawjob), hipMemcpyHostToDevice, ctx->stream));
+            int r = fir_tables(ctx, P1, &tw, &tw2);
+            if (r != GDG_OK) return r;
+            HIP_TRY(ctx, gdg_launch_fir_raw_inv(P1, (const gdg_fir_rawjob *)d_jobs, K1, 1.0 / (2.0 * (double)P1), tw, tw2, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(d_jobs); d_jobs = nullptr;
+        }
+        size_t spec = (size_t)K * (size_t)P * sizeof(double2);
+        HIP_TRY(ctx, hipMalloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&u.d_fdl, spec));
+        HIP_TRY(ctx, hipMalloc((void **)&u.d_Y, (size_t)P * sizeof(double2)));
+        HIP_TRY(ctx, hipMalloc((void **)&u.d_pos, sizeof(int)));
+        HIP_TRY(ctx, hipMemsetAsync(u.d_prev, 0, 2 * (size_t)P * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(u.d_fdl, 0, spec, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(u.d_pos, 0, sizeof(int), ctx->stream));
+        int r = fir_spectra(ctx, u, hop, P, K);
+        if (r != GDG_OK) return r;
+        if (carry) {
+            /* 2. the newest K hop samples, re-cut into K frames of the new size (zeros where the old line does not reach) */
+            size_t new_len = (size_t)K * (size_t)hop;
+            HIP_TRY(ctx, hipMalloc((void **)&d_new_hist, new_len * sizeof(double)));
+            HIP_TRY(ctx, hipMemsetAsync(d_new_hist, 0, new_len * sizeof(double), ctx->stream));
+            size_t n = std::min(old_len, new_len);
+            HIP_TRY(ctx, hipMemcpyAsync(d_new_hist + (new_len - n), d_old_hist + (old_len - n), n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            /* 3. slot f = spectrum of [frame f - 1 | frame f], f = 1 .. K - 1; the next frame goes to slot K mod K = 0 */
+            if (K > 1) {
+                std::vector<gdg_fir_irjob> jobs((size_t)(K - 1));
+                for (int f = 1; f < K; f++) {
+                    jobs[(size_t)(f - 1)].a = d_new_hist + (size_t)(f - 1) * hop;
+                    jobs[(size_t)(f - 1)].b = d_new_hist + (size_t)f * hop;
+                    jobs[(size_t)(f - 1)].hop = hop;
+                    jobs[(size_t)(f - 1)].out = u.d_fdl + (size_t)f * P;
+                }
+                HIP_TRY(ctx, hipMalloc(&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
+                HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
+                r = fir_tables(ctx, P, &tw, &tw2);
+                if (r != GDG_OK) return r;
+                HIP_TRY(ctx, gdg_launch_fir_ir(P, (const gdg_fir_irjob *)d_jobs, K - 1, 1.0, tw, tw2, ctx->stream));
+            }
+            /* 4. the overlap-save history = the newest frame, where the forward transform of frame counter K looks for it */
+            HIP_TRY(ctx, hipMemcpyAsync(u.d_prev + (size_t)((K + 1) & 1) * P, d_new_hist + (size_t)(K - 1) * hop, (size_t)hop * sizeof(double),
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(u.d_pos, &K, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return GDG_OK;
+    };
+    rc = body();
+    hipFree(d_old_hist); hipFree(d_new_hist); hipFree(d_jobs);
+    free_old();
+    if (rc != GDG_OK) { u.fir_dirty = true; u.fir_live = false; return rc; }
     u.fir_P = P;
     u.fir_K = K;
     u.fir_hop = hop;
     u.fir_dirty = false;
-    u.fir_live = false;
+    u.fir_live = carry;
     return GDG_OK;
 }
 

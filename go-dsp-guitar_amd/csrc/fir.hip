@@ -239,8 +239,10 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
     if constexpr (IRJOB) {
         gdg_fir_irjob jb = jobs[blockIdx.x];
         a = jb.a;
-        bsrc = nullptr;
+        bsrc = jb.b;
         out = jb.out;
+        if (jb.hop > 0) hop = jb.hop;                    /* [a (hop) | b (hop) | zeros]; hop == 0: [a (N) | zeros] */
+        else bsrc = nullptr;
     } else {
         gdg_fir_chan ch = chans[blockIdx.x];
         int pos = *ch.pos;
@@ -261,15 +263,16 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
         for (int t = 0; t < R0; t++) {
             int e = j + t * (N / R0);
             cplx val;
-            if (!IRJOB && hop != N) {
-                /* frame shorter than the transform half: r = [previous (hop) | current (hop) | zeros], any parity of hop */
+            if ((!IRJOB && hop != N) || (IRJOB && bsrc != nullptr)) {
+                /* frame shorter than the transform half: r = [previous (hop) | current (hop) | zeros], any parity of hop
+                 * (also the re-partitioning jobs, whatever their hop: their frames need not be 16-byte aligned) */
                 double r2[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int i = 2 * e + h;
                     double x = 0.0;
                     if (i < hop) x = gload1(a + i);
-                    else if (i < 2 * hop) { x = gload1(bsrc + (i - hop)); gstore1(prev_out + (i - hop), x); }
+                    else if (i < 2 * hop) { x = gload1(bsrc + (i - hop)); if constexpr (!IRJOB) gstore1(prev_out + (i - hop), x); }
                     r2[h] = x;
                 }
                 val = make_double2(r2[0], r2[1]);
@@ -628,6 +631,49 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
     }
 }
 
+/* Raw inverse (frame size change with live convolution state): one delay-line slot -- the packed half spectrum of
+ * [x_{t-1} | x_t | zeros] -- back to its two frames, unclipped.  The forward transform is unscaled and this inverse is too, so
+ * scale = 1 / (2N) restores the samples. */
+template <int LOGN>
+__global__ void __launch_bounds__(FftCfg<LOGN>::T)
+fir_raw_inv_kernel(const gdg_fir_rawjob *__restrict__ jobs, double scale, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
+    __shared__ double sre[FftCfg<LOGN>::LDS];
+    __shared__ double sim[FftCfg<LOGN>::LDS];
+    const int tid = threadIdx.x;
+    const gdg_fir_rawjob jb = jobs[blockIdx.x];
+    constexpr int ITER = (N / 2) / T;
+#pragma unroll
+    for (int i = 0; i < ITER; i++) {
+        const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+        inv_head_store<LOGN>(k, gload(jb.Y + k), gload(jb.Y + n), sre, sim, tw2);
+    }
+    __syncthreads();
+    cplx v[16];
+    constexpr int NP = sched_npass(LOGN);
+    run_lds_passes<LOGN, 0, NP - 1, true>(v, sre, sim, tw, tid);
+    constexpr int LR = sched_lr(LOGN, NP - 1), LNS = sched_lns(LOGN, NP - 1), R = 1 << LR, B = 16 / R;
+    pass_load<LOGN, LR>(v, sre, sim, tid);
+    pass_compute<LOGN, LR, LNS, true>(v, tw, tid);
+    const int hop = jb.hop;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const int j = tid + T * b;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const int n = j + t * (N / R);
+            const cplx z = v[b * R + t];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = 2 * n + h;                    /* real sample i of [first (hop) | second (hop) | zeros] */
+                const double x = (h ? z.y : z.x) * scale;
+                if (i < hop) { if (jb.first) gstore1(jb.first + i, x); }
+                else if (i < 2 * hop) gstore1(jb.second + (i - hop), x);
+            }
+        }
+    }
+}
+
 /* ---- host side ------------------------------------------------------------------------------- */
 
 static int ilog2_exact(int P) {
@@ -676,6 +722,9 @@ template <int LG> static void launch_fwd(const gdg_fir_chan *d_chans, int n, con
 template <int LG> static void launch_ir(const gdg_fir_irjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
     fir_fwd_kernel<LG, true><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(nullptr, d_jobs, scale, tw, tw2);
 }
+template <int LG> static void launch_raw_inv(const gdg_fir_rawjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
+    fir_raw_inv_kernel<LG><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_jobs, scale, tw, tw2);
+}
 template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, hipStream_t s) {
     if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
     else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
@@ -699,6 +748,13 @@ hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, dou
     if (n_jobs <= 0) return hipSuccess;
     int L = ilog2_exact(P);
     GDG_DISPATCH_LOGN(L, launch_ir<LG>(d_jobs, n_jobs, scale, d_tw, d_tw2, s));
+    return hipGetLastError();
+}
+
+hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_jobs, double scale, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
+    if (n_jobs <= 0) return hipSuccess;
+    int L = ilog2_exact(P);
+    GDG_DISPATCH_LOGN(L, launch_raw_inv<LG>(d_jobs, n_jobs, scale, d_tw, d_tw2, s));
     return hipGetLastError();
 }
 

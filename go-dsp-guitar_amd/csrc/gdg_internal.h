@@ -35,10 +35,22 @@ struct gdg_fir_chan {
                               * [previous | current | zeros] still has 2P points, P = nextpow2(hop)) */
 };
 
-/* one forward transform job used to build the IR spectra: [a | zeros] -> out */
+/* one forward transform job: [a | b | zeros] -> out.  IR spectra: a = one partition zero padded to P samples, b = NULL (zeros),
+ * hop = 0.  Re-partitioning of a live delay line (frame size change): a, b = two consecutive frames of `hop` samples. */
 struct gdg_fir_irjob {
-    const double *a;         /* P samples (zero padded on the host) */
+    const double *a;
     double2 *out;            /* P complex */
+    const double *b;
+    int hop;                 /* 0: a holds P samples, b is not read */
+    int pad;
+};
+
+/* one raw inverse transform job (frame size change): packed half spectrum Y of [first | second | zeros] -> the two frames of
+ * `hop` samples, unclipped, scaled by `scale`; `first` may be NULL */
+struct gdg_fir_rawjob {
+    const double2 *Y;
+    double *first, *second;
+    int hop, pad;
 };
 
 /* launchers implemented in fir.hip; all return hipError_t */
@@ -47,6 +59,7 @@ hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s);
 hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, hipStream_t s);
 hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
+hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Segments -- the per-sample units between FIR units, fused into one launch (seg.hip).

@@ -128,6 +128,10 @@ int gdg_chain_set(gdg_ctx *ctx, int channel, const int *handles, const uint8_t *
  * N workers, controller/controller.go:2682-2705).  in[c] / out[c] are host buffers of `frames`
  * float64 each; the call stages them through pinned memory, runs the batch and blocks until
  * out is written.  in[c] is not modified.
+ * `frames` may change from call to call (1 .. max_frames): like filter.Process (filter/filter.go:370-428, tail and transform
+ * sizes depend on the filter length only) a power amp carries its convolution state across the change -- its delay line is
+ * re-partitioned once per change.  A (frames, filter length) pair on which the reference itself panics (frames not a power
+ * of two and a nextpow2(L)-sized block starting beyond the frame, filter.go:443-453) is rejected with GDG_ERR_UNSUPPORTED.
  */
 int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int frames, uint32_t sample_rate);
 

@@ -76,15 +76,70 @@ def test_device_resident_path(pkg, oracle):
     ctx.close()
 
 
-def test_frame_size_change_with_live_fir_state_fails_loudly(pkg):
+@pytest.mark.parametrize("taps,sizes", [(3000, [1024, 1024, 512, 512, 1024, 64, 64, 2048]),
+                                        (65536, [8192, 8192, 1024, 1000, 1000, 8192, 8192]),
+                                        (5000, [1000, 480, 480, 8192, 37, 4096, 1000, 1000]),
+                                        (77, [256, 1024, 100, 100, 1]),
+                                        (20000, [64, 8192, 64, 64, 8192])])
+def test_frame_size_sequence_carries_the_convolution_state(pkg, oracle, taps, sizes):
+    """filter.Process takes any N from call to call: tail and transform sizes depend on L only (filter/filter.go:370-389,
+    :419-428), so a stream cut into blocks of changing size is ONE convolution.  The HIP path re-partitions its delay line."""
+    sr = 48000
+    ctx = pkg.Context(2, 8192)
+    h = [synth_ir(taps, seed=77 + c) * (2.5 if c else 1.0) for c in range(2)]          # channel 1 clips
+    refs = []
+    for c in range(2):
+        ctx.append_unit(c, "compressor")
+        ctx.append_unit(c, "power_amp", fir=h[c])
+        r = oracle.Chain()
+        r.append_unit("compressor")
+        r.append_unit("power_amp", fir=h[c])
+        refs.append(r)
+    x = np.stack([synth_signal(c, sum(sizes), sr) for c in range(2)])
+    got, want = np.zeros_like(x), np.zeros_like(x)
+    at = 0
+    for n in sizes:
+        blk = np.ascontiguousarray(x[:, at:at + n])
+        got[:, at:at + n] = ctx.process(blk, sr)
+        for c in range(2):
+            want[c, at:at + n] = refs[c].process(blk[c], sr)
+        at += n
+    for c in range(2):
+        assert rms(got[c] - want[c]) <= TOL_RMS, "channel %d: RMS %.3e" % (c, rms(got[c] - want[c]))
+    ctx.close()
+
+
+def test_frame_size_change_matches_direct_convolution(pkg):
+    """Second, oracle-free formulation of the same property: y = clip(x * h) over the whole stream."""
+    sr, taps, sizes = 96000, 9000, [2048, 300, 300, 8192, 1024, 5, 4096]
+    ctx = pkg.Context(1, 8192)
+    h = synth_ir(taps, seed=5)
+    ctx.append_unit(0, "power_amp", fir=h)
+    x = synth_signal(3, sum(sizes), sr)
+    got, at = np.zeros_like(x), 0
+    for n in sizes:
+        got[at:at + n] = ctx.process(np.ascontiguousarray(x[None, at:at + n]), sr)[0]
+        at += n
+    direct = np.clip(np.convolve(x, h)[:x.size], -1.0, 1.0)
+    assert rms(got - direct) <= TOL_RMS
+    ctx.close()
+
+
+def test_frame_size_the_reference_panics_on_is_rejected_with_a_message(pkg, oracle):
+    """N = 600, L = 100: nextpow2(N) = 1024 is cut into 8 blocks of 128, the sixth starts at 640 > N and the reference panics on
+    the slice bounds (filter/filter.go:443-453).  The oracle reports it, the HIP path rejects the pair and says why."""
+    with pytest.raises(ValueError, match="rc=-3"):
+        oracle.Filter(synth_ir(100), 48000).process(np.zeros(600))
+    oracle.Filter(synth_ir(100), 48000).process(np.zeros(900))    # the last of the 8 blocks starts at 896 <= N: legal
     ctx = pkg.Context(1, 1024)
-    h = ctx.append_unit(0, "power_amp", fir=synth_ir(3000))
-    ctx.process(np.zeros((1, 1024)), 48000)
+    ctx.append_unit(0, "power_amp", fir=synth_ir(100))
     with pytest.raises(pkg.GdgError) as e:
-        ctx.process(np.zeros((1, 512)), 48000)
-    assert e.value.code == pkg.GDG_ERR_UNSUPPORTED
-    ctx.unit_reset(h)
-    ctx.process(np.zeros((1, 512)), 48000)                      # after a reset the new partition size is accepted
+        ctx.process(np.zeros((1, 600)), 48000)
+    assert e.value.code == pkg.GDG_ERR_UNSUPPORTED and "reference panics" in str(e.value) and "filter.go:443-453" in str(e.value)
+    y = ctx.process(np.zeros((1, 512)), 48000)                   # the context stays usable: a legal size runs
+    assert y.shape == (1, 512)
+    y = ctx.process(np.zeros((1, 900)), 48000)                   # 7 x 128 = 896 <= 900: every block starts inside the frame
+    assert y.shape == (1, 900)
     ctx.close()
 
 

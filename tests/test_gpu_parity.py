@@ -71,7 +71,7 @@ def test_fir_set_fir_resets_state(pkg, oracle):
     ctx.close()
 
 
-def test_fir_frame_size_changes_need_a_reset_and_odd_sizes_work_in_chains(pkg, oracle):
+def test_fir_odd_frame_sizes_work_in_chains(pkg, oracle):
     """Any frame size up to 8192 runs (the reference's filter.Process takes any block length); a full chain at 1000 frames."""
     sr, frames = 44100, 1000
     ctx = pkg.Context(2, frames)
