@@ -36,8 +36,8 @@ ABI_SYMBOLS = [
     "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_ctx_share_ir_spectra", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
     "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_compile_fir", "gdg_unit_get_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_subset", "gdg_process_device",
     "gdg_staging_buffers", "gdg_process_staged", "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_profile_enable",
-    "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_analyze", "gdg_tuner_note_name",
-    "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device",
+    "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_enqueue_staged", "gdg_tuner_analyze", "gdg_tuner_note_name",
+    "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device", "gdg_spatialize_staged",
     "gdg_wave_bytes_per_sample", "gdg_wave_decode", "gdg_wave_decode_device", "gdg_wave_encode", "gdg_wave_encode_device",
     "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
@@ -107,12 +107,14 @@ def lib():
             "gdg_profile_read": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(i32)]),
             "gdg_tuner_enqueue": (i32, [vp, vp, i32, u32]),
             "gdg_tuner_enqueue_device": (i32, [vp, vp, i32, u32]),
+            "gdg_tuner_enqueue_staged": (i32, [vp, i32, u32]),
             "gdg_tuner_analyze": (i32, [vp, C.POINTER(TunerResult)]),
             "gdg_tuner_note_name": (C.c_char_p, [i32]),
             "gdg_spatializer_set_position": (i32, [vp, i32, dbl, dbl, dbl]),
             "gdg_spatializer_set_sample_rate": (i32, [vp, u32]),
             "gdg_spatialize": (i32, [vp, vp, vp, vp, i32]),
             "gdg_spatialize_device": (i32, [vp, vp, vp, i32]),
+            "gdg_spatialize_staged": (i32, [vp, i32, vp, vp, i32]),
             "gdg_wave_bytes_per_sample": (i32, [i32]),
             "gdg_wave_decode": (i32, [vp, i32, vp, C.c_size_t, C.c_uint, vp]),
             "gdg_wave_decode_device": (i32, [vp, i32, vp, C.c_size_t, C.c_uint, vp]),

@@ -106,6 +106,7 @@ struct gdg_ctx {
     double *d_w0 = nullptr, *d_w1 = nullptr, *d_scratch = nullptr;
     double *d_stage_in = nullptr, *d_stage_out = nullptr;
     double *h_stage_in = nullptr, *h_stage_out = nullptr;
+    int stage_out_stride = 0;         /* > 0: d_stage_out holds one complete block of chain outputs, row c = channel c, this stride */
     int *d_error = nullptr;
     /* tables */
     std::map<int, std::pair<double2 *, double2 *>> fir_tables;
@@ -1228,8 +1229,14 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
         if (b == a) return hipSuccess;
         return hipMemcpyAsync(ctx->h_stage_out + a * row, ctx->d_stage_out + a * row, (b - a) * row * sizeof(double), hipMemcpyDeviceToHost, s);
     };
+    ctx->stage_out_stride = 0;
     rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, 0, false, G, &before, &after);
     if (rc != GDG_OK) return rc;
+    {   /* all channels, in order: the compact rows are a complete block (gdg_spatialize_staged may mix it without an upload) */
+        bool complete = n == ctx->nch;
+        for (int i = 0; complete && i < n; i++) complete = active[(size_t)i] == i;
+        if (complete) ctx->stage_out_stride = frames;
+    }
     for (int g = 0; g < G; g++) {
         if (G > 1) HIP_TRY(ctx, hipStreamSynchronize(ctx->gstreams[(size_t)g]));
         else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1288,8 +1295,10 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
     };
     GroupHook before = [&](int g, hipStream_t s) { return copy_runs(g, ctx->d_stage_in, ctx->h_stage_in, hipMemcpyHostToDevice, s); };
     GroupHook after = [&](int g, hipStream_t s) { return copy_runs(g, ctx->h_stage_out, ctx->d_stage_out, hipMemcpyDeviceToHost, s); };
+    ctx->stage_out_stride = 0;
     rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true, G, &before, &after);
     if (rc != GDG_OK) return rc;
+    if (n == ctx->nch) ctx->stage_out_stride = ctx->max_frames;          /* rows by channel: every channel took part */
     return check_device_error(ctx);
 }
 
@@ -1362,6 +1371,22 @@ int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *samples, int frames, ui
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < ctx->nch; c++) memcpy(ctx->h_stage_in + (size_t)c * frames, samples[c], (size_t)frames * sizeof(double));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, ctx->h_stage_in, (size_t)ctx->nch * frames * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = gdg_tuner_enqueue_device(ctx, ctx->d_stage_in, frames, sample_rate);
+    if (rc != GDG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+int gdg_tuner_enqueue_staged(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (frames < 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    hipSetDevice(ctx->device);
+    int rc = ensure_staging(ctx);
+    if (rc != GDG_OK) return rc;
+    if (frames == 0) return GDG_OK;
+    /* pinned rows (stride max_frames) -> compact device rows */
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_stage_in, (size_t)frames * sizeof(double), ctx->h_stage_in, (size_t)ctx->max_frames * sizeof(double),
+                                  (size_t)frames * sizeof(double), (size_t)ctx->nch, hipMemcpyHostToDevice, ctx->stream));
     rc = gdg_tuner_enqueue_device(ctx, ctx->d_stage_in, frames, sample_rate);
     if (rc != GDG_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1518,6 +1543,35 @@ int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, doub
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out_left, ctx->h_stage_out, (size_t)frames * sizeof(double));
     memcpy(out_right, ctx->h_stage_out + frames, (size_t)frames * sizeof(double));
+    return GDG_OK;
+}
+
+int gdg_spatialize_staged(gdg_ctx *ctx, int from_outputs, double *out_left, double *out_right, int frames) {
+    if (!ctx || !out_left || !out_right) return GDG_ERR_INVALID;
+    if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
+    hipSetDevice(ctx->device);
+    int rc = ensure_staging(ctx);
+    if (rc == GDG_OK) rc = ensure_spatializer(ctx);
+    if (rc != GDG_OK) return rc;
+    if (ctx->sp_dirty) { rc = upload_spat_chans(ctx); if (rc != GDG_OK) return rc; }
+    const double *d_rows = ctx->d_stage_out;                 /* what the last gdg_process / gdg_process_staged left on the device */
+    int stride = ctx->stage_out_stride;
+    if (from_outputs && stride <= 0)
+        return fail(ctx, GDG_ERR_INVALID, "no complete block of chain outputs on the device (the last host-buffer call did not cover all %d channels)", ctx->nch);
+    if (!from_outputs) {
+        stride = ctx->max_frames;
+        HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_stage_in, (size_t)ctx->max_frames * sizeof(double), ctx->h_stage_in, (size_t)ctx->max_frames * sizeof(double),
+                                      (size_t)frames * sizeof(double), (size_t)ctx->nch, hipMemcpyHostToDevice, ctx->stream));
+        d_rows = ctx->d_stage_in;
+    }
+    {
+        ProfScope ps(ctx, GDG_K_SPATIALIZER);
+        HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_rows, stride, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
+                                            ctx->d_sp_out, frames, ctx->max_frames, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(out_left, ctx->d_sp_out, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_right, ctx->d_sp_out + frames, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GDG_OK;
 }
 

@@ -38,6 +38,14 @@ def lib():
             "gdgh_engine_create": (vp, [i32, i32, i32]), "gdgh_engine_destroy": (None, [vp]),
             "gdgh_engine_set_rendezvous": (None, [vp, i32, i32]), "gdgh_engine_last_error": (cs, [vp]),
             "gdgh_engine_process_all": (cs, [vp, vp, vp, i32, C.c_uint32]),
+            "gdgh_engine_create_sharded": (vp, [i32, i32, vp, i32]), "gdgh_engine_shards": (i32, [vp]), "gdgh_engine_shard_of": (i32, [vp, i32]),
+            "gdgh_spatializer_create": (vp, [vp, C.c_uint32]), "gdgh_spatializer_destroy": (None, [vp]),
+            "gdgh_spatializer_set": (cs, [vp, i32, C.c_uint32, C.c_double]), "gdgh_spatializer_get": (cs, [vp, i32, C.c_uint32, C.POINTER(C.c_double)]),
+            "gdgh_spatializer_input_count": (C.c_uint32, [vp]), "gdgh_spatializer_output_count": (C.c_uint32, [vp]),
+            "gdgh_spatializer_set_sample_rate": (None, [vp, C.c_uint32]),
+            "gdgh_spatializer_process": (None, [vp, vp, vp, vp, vp, i32, i32]),
+            "gdgh_tuner_create": (vp, [i32]), "gdgh_tuner_destroy": (None, [vp]), "gdgh_tuner_process": (None, [vp, vp, i32, C.c_uint32]),
+            "gdgh_tuner_analyze": (cs, [vp, C.POINTER(i32), C.POINTER(C.c_double), vp, i32]),
             "gdgh_irs_create": (vp, []), "gdgh_irs_destroy": (None, [vp]),
             "gdgh_irs_add": (None, [vp, cs, C.c_uint32, C.c_int32, vp, i32]),
             "gdgh_chain_create": (vp, [vp, vp]), "gdgh_chain_destroy": (None, [vp]),
@@ -83,10 +91,21 @@ class ImpulseResponses:
 
 
 class Engine:
-    def __init__(self, n_channels, max_frames=8192, device=0):
-        self._h = lib().gdgh_engine_create(n_channels, max_frames, device)
+    def __init__(self, n_channels, max_frames=8192, device=0, devices=None):
+        """devices: one shard (context) per entry -- the same device may appear several times (independent contexts)."""
+        if devices is None:
+            self._h = lib().gdgh_engine_create(n_channels, max_frames, device)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            self._h = lib().gdgh_engine_create_sharded(n_channels, max_frames, arr, len(devices))
         self.n_channels = n_channels
         self.chains = []
+
+    def shards(self):
+        return lib().gdgh_engine_shards(self._h)
+
+    def shard_of(self, channel):
+        return lib().gdgh_engine_shard_of(self._h, channel)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -196,6 +215,65 @@ class Chain:
         out = np.full(n_out, np.nan)
         lib().gdgh_chain_process(self._h, x.ctypes.data, x.size, out.ctypes.data, n_out, sample_rate)
         return out
+
+
+class Spatializer:
+    """spatializer.Spatializer: the ten methods of spatializer/spatializer.go:30-41 on top of an Engine's shards."""
+
+    def __init__(self, engine, input_channels):
+        self._engine = engine
+        self._h = lib().gdgh_spatializer_create(engine._h, input_channels)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gdgh_spatializer_destroy(self._h)
+            self._h = None
+
+    def _get(self, what, ch):
+        v = C.c_double(0.0)
+        _err(lib().gdgh_spatializer_get(self._h, what, ch, C.byref(v)))
+        return v.value
+
+    def GetAzimuth(self, ch): return self._get(0, ch)
+    def GetDistance(self, ch): return self._get(1, ch)
+    def GetLevel(self, ch): return self._get(2, ch)
+    def SetAzimuth(self, ch, v): _err(lib().gdgh_spatializer_set(self._h, 0, ch, float(v)))
+    def SetDistance(self, ch, v): _err(lib().gdgh_spatializer_set(self._h, 1, ch, float(v)))
+    def SetLevel(self, ch, v): _err(lib().gdgh_spatializer_set(self._h, 2, ch, float(v)))
+    def GetInputCount(self): return lib().gdgh_spatializer_input_count(self._h)
+    def GetOutputCount(self): return lib().gdgh_spatializer_output_count(self._h)
+    def SetSampleRate(self, rate): lib().gdgh_spatializer_set_sample_rate(self._h, rate)
+
+    def Process(self, x, aux=None, reuse_chain_outputs=False):
+        x = _f64(x)
+        n = x.shape[1]
+        ins = (C.c_void_p * x.shape[0])(*[x[i].ctypes.data for i in range(x.shape[0])])
+        a = _f64(aux) if aux is not None else None
+        left, right = np.full(n, np.nan), np.full(n, np.nan)
+        lib().gdgh_spatializer_process(self._h, ins, a.ctypes.data if a is not None else None, left.ctypes.data, right.ctypes.data, n,
+                                       1 if reuse_chain_outputs else 0)
+        return left, right
+
+
+class Tuner:
+    """tuner.Tuner (tuner/tuner.go:62-65)."""
+
+    def __init__(self, device=0):
+        self._h = lib().gdgh_tuner_create(device)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gdgh_tuner_destroy(self._h)
+            self._h = None
+
+    def Process(self, samples, sample_rate):
+        s = _f64(samples)
+        lib().gdgh_tuner_process(self._h, s.ctypes.data, s.size, sample_rate)
+
+    def Analyze(self):
+        cents, freq, note = C.c_int(0), C.c_double(0.0), C.create_string_buffer(64)
+        _err(lib().gdgh_tuner_analyze(self._h, C.byref(cents), C.byref(freq), note, 64))
+        return {"cents": cents.value, "frequency": freq.value, "note": note.value.decode()}
 
 
 class Unit:

@@ -18,6 +18,7 @@
 #include <complex>
 #include <map>
 #include <sstream>
+#include <thread>
 
 namespace gdg {
 
@@ -418,21 +419,38 @@ std::vector<std::string> UnitTypes() {
              "reverb", "power_amp", "cabinet" };
 }
 
-/* push parameters / taps of one unit to the device context it lives in */
+Unit::Snapshot Unit::snapshot(uint64_t pushedFir) const {
+    std::lock_guard<std::mutex> lk(mutex_);
+    Snapshot snap;
+    snap.paramVersion = paramVersion;
+    snap.firVersion = firVersion;
+    snap.nValues = std::min<int>(8, (int)params_.size());
+    if (unitType_ == UNIT_POWERAMP) snap.nValues = 1;
+    for (int i = 0; i < 8; i++) {
+        snap.values[i] = 0;
+        if ((size_t)i < params_.size()) snap.values[i] = (params_[(size_t)i].Type == PARAMETER_TYPE_NUMERIC) ? params_[(size_t)i].NumericValue : params_[(size_t)i].DiscreteValueIndex;
+    }
+    snap.withTaps = unitType_ == UNIT_POWERAMP && pushedFir != firVersion;
+    if (snap.withTaps) snap.taps = firTaps;            /* a COPY: a concurrent setter may reassign firTaps as soon as the lock is gone */
+    return snap;
+}
+
+/* Push parameters / taps of one unit to the device context it lives in.  Step 1: ONE snapshot under the unit's lock (version
+ * counters, resolved values, a copy of the taps).  Step 2: the ABI calls, without the lock.  Step 3: remember the SNAPSHOT's
+ * versions -- a setter that lands in between bumps the live counters and is pushed with the next block. */
 static Error pushUnit(Unit &u) {
     gdg_ctx *ctx = u.backing.ctx;
-    if (u.pushedParamVersion != u.paramVersion) {
-        int32_t v[8];
-        u.resolved(v);
-        int n = std::min<int>(8, (int)u.Parameters().size());
-        if (u.Type() == UNIT_POWERAMP) n = 1;
-        for (int i = 0; i < n; i++)
-            if (gdg_unit_set_param(ctx, u.backing.handle, i, v[i]) != GDG_OK) return gdg_last_error(ctx);
-        u.pushedParamVersion = u.paramVersion;
+    const Unit::Snapshot snap = u.snapshot(u.pushedFirVersion);
+    if (u.pushedParamVersion != snap.paramVersion) {
+        for (int i = 0; i < snap.nValues; i++)
+            if (gdg_unit_set_param(ctx, u.backing.handle, i, snap.values[i]) != GDG_OK) return gdg_last_error(ctx);
+        u.pushedParamVersion = snap.paramVersion;
     }
-    if (u.Type() == UNIT_POWERAMP && u.pushedFirVersion != u.firVersion) {
-        if (gdg_unit_set_fir(ctx, u.backing.handle, u.firTaps.data(), (int)u.firTaps.size()) != GDG_OK) return gdg_last_error(ctx);
-        u.pushedFirVersion = u.firVersion;
+    if (snap.withTaps) {
+        /* every successful Set of a power amp parameter -- the same value or not -- replaced currentFilter in the reference
+         * (poweramp.go:131-181), i.e. fresh convolution state: gdg_unit_set_fir resets it */
+        if (gdg_unit_set_fir(ctx, u.backing.handle, snap.taps.data(), (int)snap.taps.size()) != GDG_OK) return gdg_last_error(ctx);
+        u.pushedFirVersion = snap.firVersion;
     }
     return "";
 }
@@ -574,6 +592,22 @@ std::shared_ptr<Chain> CreateChain(const filter::ImpulseResponses *responses) {
 static Engine *g_default = nullptr;
 static std::mutex g_default_mu;
 
+static std::vector<int> devicesFromEnv() {
+    /* GDG_DEVICES = "0,1,2,..." (one shard per entry); GDG_DEVICE = a single device; default: every visible device */
+    std::vector<int> devs;
+    if (const char *list = getenv("GDG_DEVICES")) {
+        std::stringstream ss(list);
+        std::string item;
+        while (std::getline(ss, item, ',')) if (!item.empty()) devs.push_back(atoi(item.c_str()));
+    } else if (const char *one = getenv("GDG_DEVICE")) {
+        devs.push_back(atoi(one));
+    } else {
+        int n = gdg_device_count();
+        for (int d = 0; d < std::max(n, 1); d++) devs.push_back(d);
+    }
+    return devs;
+}
+
 void Engine::Configure(int nChannels, int maxFrames, int device) {
     std::lock_guard<std::mutex> lk(g_default_mu);
     delete g_default;
@@ -583,28 +617,63 @@ void Engine::Configure(int nChannels, int maxFrames, int device) {
 Engine &Engine::Default() {
     std::lock_guard<std::mutex> lk(g_default_mu);
     if (!g_default) {
-        const char *ch = getenv("GDG_CHANNELS"), *dev = getenv("GDG_DEVICE");
-        g_default = new Engine(ch ? atoi(ch) : 1, GDG_HOST_MAX_FRAMES, dev ? atoi(dev) : 0);
+        const char *ch = getenv("GDG_CHANNELS");
+        g_default = new Engine(ch ? atoi(ch) : 1, GDG_HOST_MAX_FRAMES, devicesFromEnv());
     }
     return *g_default;
 }
 
-Engine::Engine(int nChannels, int maxFrames, int device) : nChannels_(nChannels), maxFrames_(maxFrames), device_(device) {}
+Engine::Engine(int nChannels, int maxFrames, std::vector<int> devices) : nChannels_(nChannels), maxFrames_(maxFrames) {
+    if (devices.empty()) devices.push_back(0);
+    int G = std::min<int>((int)devices.size(), std::max(nChannels, 1));      /* never more shards than channels */
+    for (int g = 0; g < G; g++) {
+        std::unique_ptr<Shard> sh(new Shard());
+        sh->device = devices[(size_t)g];
+        sh->first = (int)(((long long)g * nChannels) / G);                    /* contiguous blocks */
+        sh->count = (int)(((long long)(g + 1) * nChannels) / G) - sh->first;
+        shards_.push_back(std::move(sh));
+    }
+}
 
 Engine::~Engine() {
     chains_.clear();
-    if (ctx_) gdg_ctx_destroy(ctx_);
+    for (auto &sh : shards_) if (sh->ctx) gdg_ctx_destroy(sh->ctx);
 }
 
-gdg_ctx *Engine::context() {
-    if (!ctx_) {
-        int rc = gdg_ctx_create(nChannels_, maxFrames_, device_, &ctx_);
-        if (rc != GDG_OK) { ctx_ = nullptr; lastError_ = format("gdg_ctx_create failed with %d (no usable HIP device; there is no CPU fallback)", rc); }
+int Engine::shardOf(int channel, int *local) const {
+    for (size_t g = 0; g < shards_.size(); g++)
+        if (channel >= shards_[g]->first && channel < shards_[g]->first + shards_[g]->count) {
+            if (local) *local = channel - shards_[g]->first;
+            return (int)g;
+        }
+    return -1;
+}
+
+void Engine::shardRange(int shard, int *first, int *count) const {
+    *first = shards_[(size_t)shard]->first;
+    *count = shards_[(size_t)shard]->count;
+}
+
+std::mutex &Engine::shardMutex(int shard) { return shards_[(size_t)shard]->mu; }
+
+void Engine::setError(const Error &e) {
+    std::lock_guard<std::mutex> lk(errMu_);
+    lastError_ = e;
+}
+
+gdg_ctx *Engine::context(int shard) {
+    Shard &sh = *shards_[(size_t)shard];
+    if (!sh.ctx && sh.count > 0) {
+        int rc = gdg_ctx_create(sh.count, maxFrames_, sh.device, &sh.ctx);
+        if (rc != GDG_OK) { sh.ctx = nullptr; setError(format("gdg_ctx_create failed with %d on device %d (no usable HIP device; there is no CPU fallback)", rc, sh.device)); }
     }
-    return ctx_;
+    return sh.ctx;
 }
 
-std::string Engine::LastError() const { return lastError_; }
+std::string Engine::LastError() const {
+    std::lock_guard<std::mutex> lk(errMu_);
+    return lastError_;
+}
 
 std::pair<std::shared_ptr<signal::Chain>, Error> Engine::CreateChain(const filter::ImpulseResponses *responses) {
     std::lock_guard<std::mutex> lk(mu_);
@@ -615,11 +684,18 @@ std::pair<std::shared_ptr<signal::Chain>, Error> Engine::CreateChain(const filte
     return { c, "" };
 }
 
-/* bring the device side of the listed chains up to date: units, parameters, taps, slot lists */
-Error Engine::sync(const std::vector<signal::Chain *> &chains, uint32_t sampleRate) {
-    gdg_ctx *ctx = context();
-    if (!ctx) return lastError_;
+/* Bring the device side of the listed chains (all on `shard`) up to date: units, parameters, taps, slot lists.  THE algorithm
+ * (the Go shim's chainStruct.sync is the same, statement for statement -- INTEGRATION.md section 3):
+ *   1. destroy the device units of removed slots;
+ *   2. per slot: create the device unit if it has none; a NON-bypassed power amp notices a new sample rate and recompiles
+ *      (poweramp.go:191-203); push the unit from ONE snapshot taken under its lock (pushUnit);
+ *   3. send the slot list (handles + bypass flags) if the layout changed. */
+Error Engine::sync(int shard, const std::vector<signal::Chain *> &chains, uint32_t sampleRate) {
+    gdg_ctx *ctx = context(shard);
+    if (!ctx) return LastError();
     for (signal::Chain *ch : chains) {
+        int local = 0;
+        shardOf(ch->channel_, &local);
         std::lock_guard<std::mutex> lk(ch->mutex_);
         for (auto &u : ch->retired_)
             if (u->backing.ctx == ctx && u->backing.handle >= 0) { gdg_unit_destroy(ctx, u->backing.handle); u->backing.handle = -1; u->backing.ctx = nullptr; }
@@ -627,7 +703,7 @@ Error Engine::sync(const std::vector<signal::Chain *> &chains, uint32_t sampleRa
         for (auto &s : ch->slots_) {
             effects::Unit &u = *s.unit;
             if (u.backing.handle < 0) {
-                if (gdg_unit_create(ctx, ch->channel_, u.Type(), &u.backing.handle) != GDG_OK) return gdg_last_error(ctx);
+                if (gdg_unit_create(ctx, local, u.Type(), &u.backing.handle) != GDG_OK) return gdg_last_error(ctx);
                 u.backing.ctx = ctx;
                 u.pushedParamVersion = 0;
                 u.pushedFirVersion = 0;
@@ -641,38 +717,66 @@ Error Engine::sync(const std::vector<signal::Chain *> &chains, uint32_t sampleRa
             std::vector<int> handles;
             std::vector<uint8_t> bypass;
             for (auto &s : ch->slots_) { handles.push_back(s.unit->backing.handle); bypass.push_back(s.bypass ? 1 : 0); }
-            if (gdg_chain_set(ctx, ch->channel_, handles.data(), bypass.data(), (int)handles.size()) != GDG_OK) return gdg_last_error(ctx);
+            if (gdg_chain_set(ctx, local, handles.data(), bypass.data(), (int)handles.size()) != GDG_OK) return gdg_last_error(ctx);
             ch->pushedLayoutVersion_ = ch->layoutVersion_;
         }
     }
     return "";
 }
 
+/* one shard's part of a batch: sync, then ONE gdg_process_subset over its channels (local indices) */
+Error Engine::runShard(int shard, std::vector<Pending> &group, int frames, uint32_t sr) {
+    std::lock_guard<std::mutex> lk(shards_[(size_t)shard]->mu);
+    std::vector<signal::Chain *> chains;
+    std::vector<int> channels;
+    std::vector<const double *> ins;
+    std::vector<double *> outs;
+    for (auto &p : group) {
+        int local = 0;
+        shardOf(p.chain->channel(), &local);
+        chains.push_back(p.chain); channels.push_back(local); ins.push_back(p.in); outs.push_back(p.out);
+    }
+    Error e = sync(shard, chains, sr);
+    gdg_ctx *ctx = shards_[(size_t)shard]->ctx;
+    if (e.empty() && gdg_process_subset(ctx, channels.data(), (int)channels.size(), ins.data(), outs.data(), frames, sr) != GDG_OK)
+        e = gdg_last_error(ctx);
+    if (!e.empty()) {
+        /* the reference's Process has no error return: failures produce zeros (effects/poweramp.go:210-214) */
+        setError(e);
+        for (auto &p : group) memset(p.out, 0, sizeof(double) * (size_t)p.frames);
+    }
+    return e;
+}
+
 void Engine::runBatch(std::vector<Pending> batch) {
-    /* one launch per distinct (frames, sample rate) among the deposited calls -- in practice exactly one */
+    /* one launch per distinct (frames, sample rate) among the deposited calls -- in practice exactly one -- and per shard;
+     * the shards (GPUs) of one group run concurrently: channels are independent, there is nothing to exchange */
     while (!batch.empty()) {
         int frames = batch[0].frames;
         uint32_t sr = batch[0].sampleRate;
         std::vector<Pending> group, rest;
         for (auto &p : batch) ((p.frames == frames && p.sampleRate == sr) ? group : rest).push_back(p);
         std::sort(group.begin(), group.end(), [](const Pending &a, const Pending &b) { return a.chain->channel() < b.chain->channel(); });
-        std::vector<signal::Chain *> chains;
-        std::vector<int> channels;
-        std::vector<const double *> ins;
-        std::vector<double *> outs;
-        for (auto &p : group) { chains.push_back(p.chain); channels.push_back(p.chain->channel()); ins.push_back(p.in); outs.push_back(p.out); }
-        Error e = sync(chains, sr);
-        if (e.empty() && gdg_process_subset(ctx_, channels.data(), (int)channels.size(), ins.data(), outs.data(), frames, sr) != GDG_OK)
-            e = gdg_last_error(ctx_);
-        if (!e.empty()) {
-            /* the reference's Process has no error return: failures produce zeros (effects/poweramp.go:210-214) */
-            lastError_ = e;
-            for (auto &p : group) memset(p.out, 0, sizeof(double) * (size_t)p.frames);
+        std::vector<std::vector<Pending>> perShard(shards_.size());
+        for (auto &p : group) {
+            int g = shardOf(p.chain->channel());
+            if (g >= 0) perShard[(size_t)g].push_back(p);
         }
+        std::vector<std::thread> workers;
+        int first = -1;
+        for (size_t g = 0; g < perShard.size(); g++) {
+            if (perShard[g].empty()) continue;
+            if (first < 0) { first = (int)g; continue; }                 /* the caller's thread takes the first shard itself */
+            workers.emplace_back([this, g, &perShard, frames, sr]() { runShard((int)g, perShard[g], frames, sr); });
+        }
+        if (first >= 0) runShard(first, perShard[(size_t)first], frames, sr);
+        for (auto &w : workers) w.join();
         batch.swap(rest);
     }
 }
 
+/* Chain.Process = rendezvous (controller.go:2682-2705 keeps exactly N calls in flight): deposit, and either wait for the batch
+ * this call joined to finish, or -- as the last arrival, or after the grace period -- run it. */
 void Engine::process(signal::Chain *chain, const double *in, double *out, int frames, uint32_t sampleRate) {
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [&] { return !executing_; });
@@ -702,10 +806,147 @@ Error Engine::ProcessAll(const double *const *in, double *const *out, int frames
         std::lock_guard<std::mutex> lk(mu_);
         for (size_t c = 0; c < chains_.size(); c++) batch.push_back(Pending{ chains_[c].get(), in[c], out[c], frames, sampleRate });
     }
-    lastError_.clear();
+    setError("");
     runBatch(batch);
-    return lastError_;
+    return LastError();
 }
+
+/* ================================ spatializer ============================================= */
+namespace spatializer {
+
+Spatializer::Spatializer(Engine *engine, uint32_t inputChannels) : engine_(engine), inputCount_(inputChannels), positions_(inputChannels) {}
+
+/* the reference checks `inputChannel > inputCount` (spatializer.go:73, :93 ...) and would index out of range for
+ * inputChannel == inputCount; here that one value is an error as well */
+#define SPAT_CHECK(what, failure)                                                                                   \
+    if (inputChannel >= inputCount_) return failure(format("Cannot " what " for channel %u: Only %u channels exist.", inputChannel, inputCount_));
+
+std::pair<double, Error> Spatializer::GetAzimuth(uint32_t inputChannel) const {
+    auto failure = [](const std::string &e) { return std::make_pair(0.0, e); };
+    SPAT_CHECK("get azimuth", failure)
+    std::lock_guard<std::mutex> lk(mutex_);
+    return { positions_[inputChannel].azimuth, "" };
+}
+std::pair<double, Error> Spatializer::GetDistance(uint32_t inputChannel) const {
+    auto failure = [](const std::string &e) { return std::make_pair(0.0, e); };
+    SPAT_CHECK("get distance", failure)
+    std::lock_guard<std::mutex> lk(mutex_);
+    return { positions_[inputChannel].distance, "" };
+}
+std::pair<double, Error> Spatializer::GetLevel(uint32_t inputChannel) const {
+    auto failure = [](const std::string &e) { return std::make_pair(0.0, e); };
+    SPAT_CHECK("get level", failure)
+    std::lock_guard<std::mutex> lk(mutex_);
+    return { positions_[inputChannel].level, "" };
+}
+
+void Spatializer::push(uint32_t channel) {                 /* called with mutex_ held */
+    int local = 0;
+    int g = engine_->shardOf((int)channel, &local);
+    if (g < 0) return;
+    std::lock_guard<std::mutex> lk(engine_->shardMutex(g));
+    gdg_ctx *ctx = engine_->context(g);
+    const Position &p = positions_[channel];
+    if (ctx) gdg_spatializer_set_position(ctx, local, p.azimuth, p.distance, p.level);
+}
+
+Error Spatializer::SetAzimuth(uint32_t inputChannel, double azimuth) {
+    SPAT_CHECK("set azimuth", Error)
+    std::lock_guard<std::mutex> lk(mutex_);
+    positions_[inputChannel].azimuth = azimuth;
+    push(inputChannel);
+    return "";
+}
+Error Spatializer::SetDistance(uint32_t inputChannel, double distance) {
+    SPAT_CHECK("set distance", Error)
+    if (distance < 0.0 || distance > 10.0) return "Failed to set distance: Value must be within [0, 10].";
+    std::lock_guard<std::mutex> lk(mutex_);
+    positions_[inputChannel].distance = distance;
+    push(inputChannel);
+    return "";
+}
+Error Spatializer::SetLevel(uint32_t inputChannel, double level) {
+    SPAT_CHECK("set distance", Error)                      /* the reference's message says "distance" here too (spatializer.go:395) */
+    if (level < 0.0 || level > 1.0) return "Failed to set level: Value must be within [0, 1].";
+    std::lock_guard<std::mutex> lk(mutex_);
+    positions_[inputChannel].level = level;
+    push(inputChannel);
+    return "";
+}
+
+void Spatializer::SetSampleRate(uint32_t rate) {           /* spatializer.go:418-431: new (zeroed) history buffers */
+    for (int g = 0; g < engine_->shards(); g++) {
+        std::lock_guard<std::mutex> lk(engine_->shardMutex(g));
+        gdg_ctx *ctx = engine_->context(g);
+        if (ctx) gdg_spatializer_set_sample_rate(ctx, rate);
+    }
+}
+
+void Spatializer::Process(const double *const *inputBuffers, const double *auxInputBuffer, double *const *outputBuffers, size_t n, bool reuseChainOutputs) {
+    double *left = outputBuffers[0], *right = outputBuffers[1];
+    for (size_t i = 0; i < n; i++) { left[i] = 0.0; right[i] = 0.0; }
+    const int G = engine_->shards();
+    std::vector<std::vector<double>> part((size_t)G * 2, std::vector<double>(n, 0.0));
+    std::vector<std::thread> workers;
+    auto one = [&](int g) {
+        int first = 0, count = 0;
+        engine_->shardRange(g, &first, &count);
+        if (count <= 0 || (uint32_t)first >= inputCount_) return;
+        std::lock_guard<std::mutex> lk(engine_->shardMutex(g));
+        gdg_ctx *ctx = engine_->context(g);
+        if (!ctx) return;
+        double *pl = part[(size_t)g * 2].data(), *pr = part[(size_t)g * 2 + 1].data();
+        int rc;
+        if (reuseChainOutputs) rc = gdg_spatialize_staged(ctx, 1, pl, pr, (int)n);
+        else rc = gdg_spatialize(ctx, inputBuffers + first, pl, pr, (int)n);
+        if (rc != GDG_OK) { std::fill(pl, pl + n, 0.0); std::fill(pr, pr + n, 0.0); }
+    };
+    for (int g = 1; g < G; g++) workers.emplace_back(one, g);
+    one(0);
+    for (auto &w : workers) w.join();
+    /* host-side sum of the partials in shard order, then the aux input (spatializer.go:300-310) */
+    for (int g = 0; g < G; g++)
+        for (size_t i = 0; i < n; i++) { left[i] += part[(size_t)g * 2][i]; right[i] += part[(size_t)g * 2 + 1][i]; }
+    if (auxInputBuffer)
+        for (size_t i = 0; i < n; i++) { left[i] += auxInputBuffer[i]; right[i] += auxInputBuffer[i]; }
+}
+
+std::shared_ptr<Spatializer> Create(Engine *engine, uint32_t inputChannels) { return std::make_shared<Spatializer>(engine, inputChannels); }
+
+}  // namespace spatializer
+
+/* ================================ tuner =================================================== */
+namespace tuner {
+
+Tuner::Tuner(int device) : device_(device) {}
+Tuner::~Tuner() { if (ctx_) gdg_ctx_destroy(ctx_); }
+
+void Tuner::Process(const double *samples, size_t n, uint32_t sampleRate) {      /* tuner.go:582-587 */
+    std::lock_guard<std::mutex> lk(mutex_);
+    if (!ctx_ && gdg_ctx_create(1, GDG_HOST_MAX_FRAMES, device_, &ctx_) != GDG_OK) { ctx_ = nullptr; return; }
+    /* circular.Enqueue takes any number of samples; the context takes at most max_frames per call */
+    for (size_t at = 0; at < n; at += GDG_HOST_MAX_FRAMES) {
+        size_t m = std::min<size_t>(GDG_HOST_MAX_FRAMES, n - at);
+        const double *rows[1] = { samples + at };
+        gdg_tuner_enqueue(ctx_, rows, (int)m, sampleRate);
+    }
+}
+
+std::pair<Result, Error> Tuner::Analyze() {                                        /* tuner.go:379-577 */
+    std::lock_guard<std::mutex> lk(mutex_);
+    Result r{ 0, 0.0, "Unknown" };
+    if (!ctx_ && gdg_ctx_create(1, GDG_HOST_MAX_FRAMES, device_, &ctx_) != GDG_OK) { ctx_ = nullptr; return { r, "no usable HIP device; there is no CPU fallback" }; }
+    gdg_tuner_result res;
+    if (gdg_tuner_analyze(ctx_, &res) != GDG_OK) return { r, std::string("Failed to analyze: ") + gdg_last_error(ctx_) };
+    r.cents = res.cents;
+    r.frequency = res.frequency;
+    r.note = gdg_tuner_note_name(res.note_index);
+    return { r, "" };
+}
+
+std::shared_ptr<Tuner> Create(int device) { return std::make_shared<Tuner>(device); }
+
+}  // namespace tuner
 
 }  // namespace gdg
 
@@ -730,6 +971,44 @@ void gdgh_engine_set_rendezvous(void *e, int expected, int timeout_ms) { ((Engin
 const char *gdgh_engine_last_error(void *e) { t_err = ((Engine *)e)->LastError(); return t_err.c_str(); }
 const char *gdgh_engine_process_all(void *e, const double *const *in, double *const *out, int frames, uint32_t sr) {
     return ret(((Engine *)e)->ProcessAll(in, out, frames, sr));
+}
+
+void *gdgh_engine_create_sharded(int n_channels, int max_frames, const int *devices, int n_devices) {
+    return new Engine(n_channels, max_frames, std::vector<int>(devices, devices + n_devices));
+}
+int gdgh_engine_shards(void *e) { return ((Engine *)e)->shards(); }
+int gdgh_engine_shard_of(void *e, int channel) { return ((Engine *)e)->shardOf(channel); }
+
+/* spatializer.Spatializer */
+void *gdgh_spatializer_create(void *engine, uint32_t input_channels) { return new std::shared_ptr<spatializer::Spatializer>(spatializer::Create((Engine *)engine, input_channels)); }
+void gdgh_spatializer_destroy(void *sp) { delete (std::shared_ptr<spatializer::Spatializer> *)sp; }
+#define SP(sp) (*(std::shared_ptr<spatializer::Spatializer> *)(sp))
+const char *gdgh_spatializer_set(void *sp, int what, uint32_t channel, double value) {
+    return ret(what == 0 ? SP(sp)->SetAzimuth(channel, value) : what == 1 ? SP(sp)->SetDistance(channel, value) : SP(sp)->SetLevel(channel, value));
+}
+const char *gdgh_spatializer_get(void *sp, int what, uint32_t channel, double *value) {
+    auto r = what == 0 ? SP(sp)->GetAzimuth(channel) : what == 1 ? SP(sp)->GetDistance(channel) : SP(sp)->GetLevel(channel);
+    *value = r.first;
+    return ret(r.second);
+}
+uint32_t gdgh_spatializer_input_count(void *sp) { return SP(sp)->GetInputCount(); }
+uint32_t gdgh_spatializer_output_count(void *sp) { return SP(sp)->GetOutputCount(); }
+void gdgh_spatializer_set_sample_rate(void *sp, uint32_t rate) { SP(sp)->SetSampleRate(rate); }
+void gdgh_spatializer_process(void *sp, const double *const *in, const double *aux, double *left, double *right, int n, int reuse) {
+    double *outs[2] = { left, right };
+    SP(sp)->Process(in, aux, outs, (size_t)n, reuse != 0);
+}
+
+/* tuner.Tuner */
+void *gdgh_tuner_create(int device) { return new std::shared_ptr<tuner::Tuner>(tuner::Create(device)); }
+void gdgh_tuner_destroy(void *t) { delete (std::shared_ptr<tuner::Tuner> *)t; }
+void gdgh_tuner_process(void *t, const double *samples, int n, uint32_t sr) { (*(std::shared_ptr<tuner::Tuner> *)t)->Process(samples, (size_t)n, sr); }
+const char *gdgh_tuner_analyze(void *t, int *cents, double *frequency, char *note, int cap) {
+    auto r = (*(std::shared_ptr<tuner::Tuner> *)t)->Analyze();
+    *cents = r.first.cents;
+    *frequency = r.first.frequency;
+    snprintf(note, (size_t)cap, "%s", r.first.note.c_str());
+    return ret(r.second);
 }
 
 void *gdgh_irs_create(void) { return new filter::ImpulseResponses(); }

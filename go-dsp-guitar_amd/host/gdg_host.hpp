@@ -114,6 +114,10 @@ public:
     const filter::ImpulseResponses *impulseResponses = nullptr;
     void resolved(int32_t out[8]) const;                   /* numeric values / discrete indices of the first <= 8 parameters */
     void onSampleRate(uint32_t sampleRate);                /* poweramp.go:191-203 */
+    /* Everything sync() sends to the device, taken under the unit's lock in ONE step: control-plane setters run concurrently with
+     * the batch leader (controller.go:3493-3498), so versions, resolved values and taps must belong together. */
+    struct Snapshot { uint64_t paramVersion, firVersion; int32_t values[8]; int nValues; std::vector<double> taps; bool withTaps; };
+    Snapshot snapshot(uint64_t pushedFir) const;
 private:
     friend Error PreparePowerAmp(Unit &unit, const filter::ImpulseResponses *responses);
     Error setDiscrete(const std::string &name, const std::string &value);
@@ -182,9 +186,12 @@ std::shared_ptr<Chain> CreateChain(const filter::ImpulseResponses *responses);
  */
 class Engine {
 public:
-    Engine(int nChannels, int maxFrames, int device);
+    /* one shard (context) per entry of `devices`; channel c lives on shard c * G / N (contiguous blocks).  The same
+     * device may be listed more than once (independent contexts): that is how the routing is tested on a one-GPU box. */
+    Engine(int nChannels, int maxFrames, std::vector<int> devices);
+    Engine(int nChannels, int maxFrames, int device) : Engine(nChannels, maxFrames, std::vector<int>{ device }) {}
     ~Engine();
-    static Engine &Default();                              /* configured by Configure() or GDG_CHANNELS / GDG_DEVICE */
+    static Engine &Default();                              /* configured by Configure() or GDG_CHANNELS / GDG_DEVICES */
     static void Configure(int nChannels, int maxFrames, int device);
     std::pair<std::shared_ptr<signal::Chain>, Error> CreateChain(const filter::ImpulseResponses *responses);
     void SetRendezvous(int expected, int timeoutMs) { expected_ = expected; timeoutMs_ = timeoutMs; }
@@ -192,16 +199,24 @@ public:
     Error ProcessAll(const double *const *in, double *const *out, int frames, uint32_t sampleRate);
     std::string LastError() const;
     int channels() const { return nChannels_; }
-    gdg_ctx *context();                                    /* creates the device context on first use */
+    int shards() const { return (int)shards_.size(); }
+    /* shard of a channel and the channel's index inside it */
+    int shardOf(int channel, int *local = nullptr) const;
+    void shardRange(int shard, int *first, int *count) const;
+    gdg_ctx *context(int shard = 0);                       /* creates the device context on first use */
+    std::mutex &shardMutex(int shard);                     /* a context takes one call at a time (include/gdg.h) */
 
 private:
     friend class signal::Chain;
     struct Pending { signal::Chain *chain; const double *in; double *out; int frames; uint32_t sampleRate; };
+    struct Shard { int device = 0, first = 0, count = 0; gdg_ctx *ctx = nullptr; std::mutex mu; };
     void process(signal::Chain *chain, const double *in, double *out, int frames, uint32_t sampleRate);
     void runBatch(std::vector<Pending> batch);
-    Error sync(const std::vector<signal::Chain *> &chains, uint32_t sampleRate);
-    int nChannels_, maxFrames_, device_;
-    gdg_ctx *ctx_ = nullptr;
+    Error runShard(int shard, std::vector<Pending> &group, int frames, uint32_t sampleRate);
+    Error sync(int shard, const std::vector<signal::Chain *> &chains, uint32_t sampleRate);
+    void setError(const Error &e);
+    int nChannels_, maxFrames_;
+    std::vector<std::unique_ptr<Shard>> shards_;
     std::vector<std::shared_ptr<signal::Chain>> chains_;
     std::mutex mu_;
     std::condition_variable cv_;
@@ -209,8 +224,58 @@ private:
     bool executing_ = false;
     uint64_t generation_ = 0;
     int expected_ = 0, timeoutMs_ = 50;
+    mutable std::mutex errMu_;
     std::string lastError_;
 };
+
+/* ---- spatializer.Spatializer (spatializer/spatializer.go:30-41): the ten methods, on top of an engine's shards -------------
+ * Every shard mixes its block of channels to a partial (left, right) pair; the host adds the partials in shard order and then the
+ * aux input (spatializer.go:300-310).  Error strings are the reference's. */
+namespace spatializer {
+constexpr uint32_t OUTPUT_COUNT = 2;
+class Spatializer {
+public:
+    Spatializer(Engine *engine, uint32_t inputChannels);
+    std::pair<double, Error> GetAzimuth(uint32_t inputChannel) const;
+    std::pair<double, Error> GetDistance(uint32_t inputChannel) const;
+    std::pair<double, Error> GetLevel(uint32_t inputChannel) const;
+    uint32_t GetInputCount() const { return inputCount_; }
+    uint32_t GetOutputCount() const { return OUTPUT_COUNT; }
+    /* inputBuffers: inputCount rows of n samples; auxInputBuffer may be null; outputBuffers: 2 rows of n samples.
+     * reuseChainOutputs: the inputs ARE the outputs of the engine's last block (what controller.process() passes,
+     * controller.go:2744-2761) and are still on the devices: nothing is uploaded. */
+    void Process(const double *const *inputBuffers, const double *auxInputBuffer, double *const *outputBuffers, size_t n, bool reuseChainOutputs = false);
+    Error SetAzimuth(uint32_t inputChannel, double azimuth);
+    Error SetDistance(uint32_t inputChannel, double distance);
+    Error SetLevel(uint32_t inputChannel, double level);
+    void SetSampleRate(uint32_t rate);
+private:
+    void push(uint32_t channel);
+    Engine *engine_;
+    uint32_t inputCount_;
+    mutable std::mutex mutex_;
+    struct Position { double azimuth = 0.0, distance = 0.0, level = 1.0; };
+    std::vector<Position> positions_;
+};
+std::shared_ptr<Spatializer> Create(Engine *engine, uint32_t inputChannels);       /* spatializer.go:436-469 */
+}  // namespace spatializer
+
+/* ---- tuner.Tuner (tuner/tuner.go:62-65): Process enqueues, Analyze runs the 262144-point autocorrelation on the device ---- */
+namespace tuner {
+struct Result { int8_t cents; double frequency; std::string note; };              /* tuner.go:30-46 */
+class Tuner {
+public:
+    explicit Tuner(int device);
+    ~Tuner();
+    std::pair<Result, Error> Analyze();
+    void Process(const double *samples, size_t n, uint32_t sampleRate);
+private:
+    std::mutex mutex_;
+    gdg_ctx *ctx_ = nullptr;
+    int device_;
+};
+std::shared_ptr<Tuner> Create(int device = 0);                                     /* tuner.go:592-610 */
+}  // namespace tuner
 
 }  // namespace gdg
 

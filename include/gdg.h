@@ -196,6 +196,9 @@ typedef struct {
 /* tuner.Process for every channel: enqueue `frames` samples per channel into the 96000-sample rings. */
 int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *samples, int frames, uint32_t sample_rate);
 int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *d_samples, int frames, uint32_t sample_rate);
+/* the same from the pinned INPUT slab of gdg_staging_buffers (row c = channel c): for hosts that may not hand over their own
+ * pointers (the Go overlay of tuner.Tuner copies in[tunerChannel] into row 0 of a one-channel context) */
+int gdg_tuner_enqueue_staged(gdg_ctx *ctx, int frames, uint32_t sample_rate);
 /* tuner.Analyze for every channel; results has n_channels entries.  Blocks. */
 int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results);
 const char *gdg_tuner_note_name(int note_index);
@@ -211,6 +214,13 @@ int gdg_spatializer_set_sample_rate(gdg_ctx *ctx, uint32_t rate);
  */
 int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, double *out_right, int frames);
 int gdg_spatialize_device(gdg_ctx *ctx, const double *d_in, double *d_out_lr, int frames);
+/*
+ * The same for hosts with the cgo pointer rules.  from_outputs == 0: the inputs are the rows of the pinned INPUT slab
+ * (gdg_staging_buffers).  from_outputs != 0: the inputs are the chain outputs of the last gdg_process_staged, which are
+ * still on the device -- controller.process() mixes exactly those (controller.go:2744-2761), so nothing is uploaded again.
+ * out_left / out_right: `frames` float64 each, host memory.
+ */
+int gdg_spatialize_staged(gdg_ctx *ctx, int from_outputs, double *out_left, double *out_right, int frames);
 
 /* ---- data formats either side of the path ---------------------------------------- */
 

@@ -253,3 +253,174 @@ def test_standalone_unit_process_and_process_all(host, oracle):
     for c in range(2):
         assert rms(got[c] - refs[c].process(xx[c], sr)) <= TOL_RMS
     eng.close()
+
+
+# ---- shards, spatializer.Spatializer, tuner.Tuner, power-amp reset semantics ---------------------------------------
+def test_shard_routing_is_contiguous_blocks(host):
+    """Channel c lives on shard c * G / N; never more shards than channels.  No GPU needed: contexts are lazy."""
+    eng = host.Engine(8, devices=[0, 0, 0])
+    assert eng.shards() == 3
+    assert [eng.shard_of(c) for c in range(8)] == [0, 0, 1, 1, 1, 2, 2, 2]
+    eng.close()
+    eng = host.Engine(512, devices=list(range(8)))
+    assert [eng.shard_of(c) for c in (0, 63, 64, 127, 448, 511)] == [0, 0, 1, 1, 7, 7]
+    eng.close()
+    eng = host.Engine(2, devices=[0, 1, 2, 3])
+    assert eng.shards() == 2
+    eng.close()
+
+
+def test_spatializer_interface_and_error_strings(host):
+    """spatializer/spatializer.go:68-413: getters, setters, range checks and their messages."""
+    eng = host.Engine(3)
+    sp = host.Spatializer(eng, 3)
+    assert (sp.GetInputCount(), sp.GetOutputCount()) == (3, 2)
+    assert (sp.GetAzimuth(1), sp.GetDistance(1), sp.GetLevel(1)) == (0.0, 0.0, 1.0)        # spatializer.go:436-447: level 1 by default
+    sp.SetAzimuth(1, -35.5)
+    sp.SetDistance(1, 2.5)
+    sp.SetLevel(1, 0.25)
+    assert (sp.GetAzimuth(1), sp.GetDistance(1), sp.GetLevel(1)) == (-35.5, 2.5, 0.25)
+    with pytest.raises(host.HostError, match=r"Failed to set distance: Value must be within \[0, 10\]\."):
+        sp.SetDistance(0, 10.5)
+    with pytest.raises(host.HostError, match=r"Failed to set level: Value must be within \[0, 1\]\."):
+        sp.SetLevel(0, -0.1)
+    with pytest.raises(host.HostError, match=r"Cannot set azimuth for channel 7: Only 3 channels exist\."):
+        sp.SetAzimuth(7, 1.0)
+    with pytest.raises(host.HostError, match=r"Cannot get level for channel 4: Only 3 channels exist\."):
+        sp.GetLevel(4)
+    with pytest.raises(host.HostError, match=r"Cannot set distance for channel 5: Only 3 channels exist\."):
+        sp.SetLevel(5, 0.5)                                  # the reference's SetLevel message says "distance" (spatializer.go:395)
+    del sp
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_sharded_engine_matches_oracle(host, oracle):
+    """Three shards (three independent contexts on device 0) behind ONE rendezvous: the Go shim's N/8 routing, on one GPU."""
+    sr, frames, nch, blocks = 48000, 1024, 7, 3
+    taps = {"Cab": synth_ir(2000, seed=3), "Room": synth_ir(5000, seed=4)}
+    irs = host.ImpulseResponses()
+    irs.add("Cab", sr, -20, taps["Cab"])
+    irs.add("Room", sr, -10, taps["Room"])
+    eng = host.Engine(nch, frames, devices=[0, 0, 0])
+    chains, refs = [], []
+    for c in range(nch):
+        ch, ref = eng.create_chain(irs), oracle.Chain()
+        _full_chain(ch, ref, oracle, sr, taps)
+        chains.append(ch)
+        refs.append(ref)
+    eng.set_rendezvous(nch, 2000)
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(nch)])
+    got = np.zeros_like(x)
+    for b in range(blocks):
+        sl = slice(b * frames, (b + 1) * frames)
+
+        def work(c):
+            got[c, sl] = chains[c].Process(x[c, sl], sr)
+
+        threads = [threading.Thread(target=work, args=(c,)) for c in range(nch)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    assert eng.last_error() == ""
+    for c in range(nch):
+        want = np.concatenate([refs[c].process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+        assert rms(got[c] - want) <= TOL_RMS, "channel %d (shard %d)" % (c, eng.shard_of(c))
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_power_amp_set_to_its_current_value_resets_the_filter_like_the_reference(host, oracle):
+    """poweramp.go:131-181: EVERY successful Set compiles a new filter object -- fresh tail -- even if the value did not change.
+    The oracle models that with set_fir(same taps); the twin (and the Go shim) count successful sets, not value changes."""
+    sr, frames = 48000, 512
+    taps = synth_ir(4000, seed=8)
+    irs = host.ImpulseResponses()
+    irs.add("Cab", sr, -20, taps)
+    eng = host.Engine(1, frames)
+    ch = eng.create_chain(irs)
+    i = ch.AppendUnit(19)
+    ch.SetDiscreteValue(i, "filter_1", "Cab")
+    ch.SetNumericValue(i, "level_1", -6)
+    ch.SetBypass(i, False)
+    composite = oracle.Filter(taps, sr, 10.0 ** (0.05 * -20)).normalize().multiply(10.0 ** (0.05 * -6)).coefficients()
+    ref = oracle.Chain()
+    ref.append_unit("power_amp", fir=composite)
+    x = synth_signal(0, frames * 6, sr)
+    got, want = np.zeros_like(x), np.zeros_like(x)
+    for b in range(6):
+        sl = slice(b * frames, (b + 1) * frames)
+        if b == 2:
+            ch.SetNumericValue(i, "level_1", -6)              # the SAME value: the reference still replaces currentFilter
+            ref.unit(0).set_fir(composite)
+        if b == 4:
+            ch.SetBypass(i, True)                             # bypass toggles do NOT touch the filter (signal.go:390-401)
+            ch.SetBypass(i, False)
+        got[sl] = ch.Process(x[sl], sr)
+        want[sl] = ref.process(x[sl], sr)
+    assert rms(got - want) <= TOL_RMS
+    # and a version WITHOUT the reset differs audibly, i.e. the test can tell the two semantics apart
+    ref2 = oracle.Chain()
+    ref2.append_unit("power_amp", fir=composite)
+    cont = np.concatenate([ref2.process(x[b * frames:(b + 1) * frames], sr) for b in range(6)])
+    assert rms(cont - want) > 1e-4
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_spatializer_twin_matches_oracle_over_shards(host, oracle):
+    """Partial mixes per shard + host sum + aux (spatializer.go:300-310); also the no-upload path that mixes the chain outputs
+    still on the devices (what controller.process() feeds it, controller.go:2744-2761)."""
+    sr, frames, nch, blocks = 96000, 2048, 6, 3
+    rng = np.random.default_rng(11)
+    eng = host.Engine(nch, frames, devices=[0, 0])
+    chains, refs = [], []
+    for c in range(nch):
+        ch = eng.create_chain()
+        i = ch.AppendUnit(11)
+        ch.SetBypass(i, False)
+        chains.append(ch)
+        r = oracle.Chain()
+        r.append_unit("tone_stack")
+        refs.append(r)
+    sp = host.Spatializer(eng, nch)
+    sp.SetSampleRate(sr)
+    ref_sp = oracle.Spatializer(nch)
+    ref_sp.set_sample_rate(sr)
+    for c in range(nch):
+        a, d, l = float(rng.uniform(-180, 180)), float(rng.uniform(0, 10)), float(rng.uniform(0, 1))
+        sp.SetAzimuth(c, a); sp.SetDistance(c, d); sp.SetLevel(c, l)
+        ref_sp.set_azimuth(c, a); ref_sp.set_distance(c, d); ref_sp.set_level(c, l)
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(nch)])
+    aux = 0.1 * synth_signal(50, frames * blocks, sr)
+    for b in range(blocks):
+        sl = slice(b * frames, (b + 1) * frames)
+        y = eng.process_all(x[:, sl], sr)
+        want_y = np.stack([refs[c].process(x[c, sl], sr) for c in range(nch)])
+        want_l, want_r = ref_sp.process(want_y, aux=aux[sl])
+        if b == 1:
+            got_l, got_r = sp.Process(y, aux[sl], reuse_chain_outputs=True)          # nothing uploaded
+        else:
+            got_l, got_r = sp.Process(y, aux[sl])
+        assert rms(got_l - want_l) <= TOL_RMS and rms(got_r - want_r) <= TOL_RMS, "block %d" % b
+    del sp
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_tuner_twin(host, oracle):
+    """tuner.Tuner: Process enqueues, Analyze reports note / cents / frequency (criterion of tuner_test.go:95-106)."""
+    sr = 96000
+    t = host.Tuner()
+    ref = oracle.Tuner()
+    n = np.arange(96000)
+    for freq, note in ((110.0, "A2"), (146.8324, "D3"), (329.6276, "E4")):
+        tone = sum((0.5 / k) * np.sin(2 * np.pi * k * freq * n / sr) for k in (1, 2, 3))
+        for at in range(0, tone.size, 8192):
+            t.Process(tone[at:at + 8192], sr)
+            ref.process(tone[at:at + 8192], sr)
+        got, want = t.Analyze(), ref.analyze()
+        assert got["note"] == note == want["note"]
+        assert got["cents"] == want["cents"] and abs(got["cents"]) <= 5
+        assert abs(got["frequency"] - want["frequency"]) / want["frequency"] <= 1e-9
