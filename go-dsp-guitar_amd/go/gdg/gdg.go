@@ -17,16 +17,27 @@ import "C"
 
 import (
 	"fmt"
+	"os"
+	"strconv"
+	"strings"
+	"sync"
 	"unsafe"
 )
 
-// Context is one shard of channels on one GPU (gdg_ctx).
+// Context is one shard of channels on one GPU (gdg_ctx).  A context takes ONE call at a time (include/gdg.h): callers that
+// share it serialise on Shard.Mutex.
 type Context struct {
-	ctx    *C.gdg_ctx
-	in     unsafe.Pointer // pinned host slab, row c = channel c (gdg_staging_buffers)
-	out    unsafe.Pointer
-	stride int
+	ctx      *C.gdg_ctx
+	in       unsafe.Pointer // pinned host slab, row c = channel c (gdg_staging_buffers)
+	out      unsafe.Pointer
+	stride   int
+	channels int
+	scratch  unsafe.Pointer // C memory for MetersProcess: [ports pointers | ports x frames float64]
+	scratchN int
 }
+
+// DeviceCount: HIP devices visible to the process (0 without a driver).
+func DeviceCount() int { return int(C.gdg_device_count()) }
 
 func (this *Context) err(rc C.int) error {
 	if rc == C.GDG_OK {
@@ -48,11 +59,20 @@ func CreateContext(channels int, maxFrames int, device int) (*Context, error) {
 	if err := c.err(C.gdg_staging_buffers(c.ctx, &in, &out, &stride)); err != nil {
 		return nil, err
 	}
-	c.in, c.out, c.stride = unsafe.Pointer(in), unsafe.Pointer(out), int(stride)
+	c.in, c.out, c.stride, c.channels = unsafe.Pointer(in), unsafe.Pointer(out), int(stride), channels
 	return c, nil
 }
 
-func (this *Context) Destroy() { C.gdg_ctx_destroy(this.ctx) }
+func (this *Context) Destroy() {
+	if this.scratch != nil {
+		C.free(this.scratch)
+		this.scratch = nil
+	}
+	C.gdg_ctx_destroy(this.ctx)
+}
+
+func (this *Context) Channels() int  { return this.channels }
+func (this *Context) MaxFrames() int { return this.stride }
 
 // UnitCreate: effects.CreateUnit(unitType) on the device side (effects/effects.go:443-516).
 func (this *Context) UnitCreate(channel int, unitType int) (int, error) {
@@ -123,12 +143,20 @@ func (this *Context) ChainSet(channel int, handles []int, bypass []bool) error {
 	return this.err(C.gdg_chain_set(this.ctx, C.int(channel), &hs[0], &bs[0], C.int(n)))
 }
 
-// Row returns channel c's rows of the pinned staging slabs as Go slices over C memory.
-func (this *Context) Row(channel int, frames int) (in []float64, out []float64) {
+// Row returns channel c's rows of the pinned staging slabs as Go slices over C memory.  The slab has `channels` rows of
+// `stride` (= max_frames) float64: anything outside is an error, never a slice (a longer slice would run into the next
+// channel's row and, for the last channel, past the hipHostMalloc slab).
+func (this *Context) Row(channel int, frames int) (in []float64, out []float64, err error) {
+	if channel < 0 || channel >= this.channels {
+		return nil, nil, fmt.Errorf("gdg: channel %d out of range (the context has %d)", channel, this.channels)
+	}
+	if frames < 0 || frames > this.stride {
+		return nil, nil, fmt.Errorf("gdg: %d frames do not fit a staging row of %d", frames, this.stride)
+	}
 	off := uintptr(channel * this.stride * 8)
 	in = unsafe.Slice((*float64)(unsafe.Pointer(uintptr(this.in)+off)), frames)
 	out = unsafe.Slice((*float64)(unsafe.Pointer(uintptr(this.out)+off)), frames)
-	return in, out
+	return in, out, nil
 }
 
 // ProcessStaged runs the chains of the listed channels on the frames deposited in the staging rows.
@@ -138,6 +166,153 @@ func (this *Context) ProcessStaged(channels []int, frames int, sampleRate uint32
 		cs[i] = C.int(c)
 	}
 	return this.err(C.gdg_process_staged(this.ctx, &cs[0], C.int(len(cs)), C.int(frames), C.uint32_t(sampleRate)))
+}
+
+// ---- tuner: tuner.Process / tuner.Analyze (tuner/tuner.go:379-587) ------------------------------------------------
+
+type TunerResult struct {
+	Frequency float64
+	NoteIndex int // index into the 61-note table, -1 = "Unknown"
+	Cents     int8
+}
+
+// TunerEnqueueStaged: tuner.Process for every channel of the context from the pinned INPUT rows (fill them through Row).
+func (this *Context) TunerEnqueueStaged(frames int, sampleRate uint32) error {
+	return this.err(C.gdg_tuner_enqueue_staged(this.ctx, C.int(frames), C.uint32_t(sampleRate)))
+}
+
+// TunerAnalyze: tuner.Analyze for every channel of the context.
+func (this *Context) TunerAnalyze() ([]TunerResult, error) {
+	n := this.channels
+	raw := (*[1 << 20]C.gdg_tuner_result)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.gdg_tuner_result{}))))
+	defer C.free(unsafe.Pointer(raw))
+	if err := this.err(C.gdg_tuner_analyze(this.ctx, &raw[0])); err != nil {
+		return nil, err
+	}
+	res := make([]TunerResult, n)
+	for i := 0; i < n; i++ {
+		res[i] = TunerResult{Frequency: float64(raw[i].frequency), NoteIndex: int(raw[i].note_index), Cents: int8(raw[i].cents)}
+	}
+	return res, nil
+}
+
+// TunerNoteName: name of a note of the reference's table (tuner/tuner.go:79-324), "Unknown" for -1.
+func TunerNoteName(index int) string { return C.GoString(C.gdg_tuner_note_name(C.int(index))) }
+
+// ---- spatializer: partial N -> 2 mix of this shard (spatializer/spatializer.go:140-335) -----------------------------
+
+func (this *Context) SpatializerSetPosition(channel int, azimuth float64, distance float64, level float64) error {
+	return this.err(C.gdg_spatializer_set_position(this.ctx, C.int(channel), C.double(azimuth), C.double(distance), C.double(level)))
+}
+
+func (this *Context) SpatializerSetSampleRate(rate uint32) error {
+	return this.err(C.gdg_spatializer_set_sample_rate(this.ctx, C.uint32_t(rate)))
+}
+
+// SpatializeStaged mixes this shard's channels into left / right (len = frames).  fromOutputs: the inputs are the chain outputs
+// of the last ProcessStaged over ALL channels of the context, still on the device (nothing is uploaded); otherwise the pinned
+// INPUT rows.  left / right are []float64 (no Go pointers inside): legal cgo arguments for the duration of the call.
+func (this *Context) SpatializeStaged(fromOutputs bool, left []float64, right []float64) error {
+	if len(left) == 0 || len(left) != len(right) {
+		return fmt.Errorf("gdg: bad output buffers")
+	}
+	f := C.int(0)
+	if fromOutputs {
+		f = 1
+	}
+	return this.err(C.gdg_spatialize_staged(this.ctx, f, (*C.double)(unsafe.Pointer(&left[0])), (*C.double)(unsafe.Pointer(&right[0])), C.int(len(left))))
+}
+
+// ---- shards: one context per GPU, channel c on shard c * G / N (contiguous blocks; SURVEY.md 8e, controller.go:3262-3269) ----
+
+type Shard struct {
+	Ctx    *Context
+	Device int
+	First  int // first global channel of the block
+	Count  int
+	Mutex  sync.Mutex // one call at a time per context
+}
+
+var (
+	shardMutex sync.Mutex
+	shardList  []*Shard
+	shardTotal int
+)
+
+// devices: GDG_DEVICES="0,1,2,..." (one shard per entry; an entry may repeat), else GDG_DEVICE, else every visible device.
+func devices() []int {
+	if list := os.Getenv("GDG_DEVICES"); list != "" {
+		var devs []int
+		for _, item := range strings.Split(list, ",") {
+			if d, err := strconv.Atoi(strings.TrimSpace(item)); err == nil {
+				devs = append(devs, d)
+			}
+		}
+		if len(devs) > 0 {
+			return devs
+		}
+	}
+	if one := os.Getenv("GDG_DEVICE"); one != "" {
+		d, _ := strconv.Atoi(one)
+		return []int{d}
+	}
+	n := DeviceCount()
+	if n < 1 {
+		n = 1
+	}
+	devs := make([]int, n)
+	for i := range devs {
+		devs[i] = i
+	}
+	return devs
+}
+
+// Shards creates (once) the contexts for a job of totalChannels channels and returns them.  The same algorithm as
+// gdg::Engine::Engine in host/gdg_host.cpp: never more shards than channels, shard g owns [g N / G, (g + 1) N / G).
+func Shards(totalChannels int, maxFrames int) ([]*Shard, error) {
+	shardMutex.Lock()
+	defer shardMutex.Unlock()
+	if shardList != nil {
+		if totalChannels > shardTotal {
+			return nil, fmt.Errorf("gdg: the shards were created for %d channels, %d requested", shardTotal, totalChannels)
+		}
+		return shardList, nil
+	}
+	devs := devices()
+	G := len(devs)
+	if G > totalChannels {
+		G = totalChannels
+	}
+	if G < 1 {
+		G = 1
+	}
+	list := make([]*Shard, 0, G)
+	for g := 0; g < G; g++ {
+		first := g * totalChannels / G
+		count := (g+1)*totalChannels/G - first
+		ctx, err := CreateContext(count, maxFrames, devs[g])
+		if err != nil {
+			for _, sh := range list {
+				sh.Ctx.Destroy()
+			}
+			return nil, err
+		}
+		list = append(list, &Shard{Ctx: ctx, Device: devs[g], First: first, Count: count})
+	}
+	shardList, shardTotal = list, totalChannels
+	return shardList, nil
+}
+
+// ShardOf: the shard of a global channel and the channel's index inside it (nil before Shards() or out of range).
+func ShardOf(channel int) (*Shard, int) {
+	shardMutex.Lock()
+	defer shardMutex.Unlock()
+	for _, sh := range shardList {
+		if channel >= sh.First && channel < sh.First+sh.Count {
+			return sh, channel - sh.First
+		}
+	}
+	return nil, -1
 }
 
 // ---- the data formats either side of the chain (optional; include/gdg.h "data formats" section) ----------------
@@ -206,6 +381,39 @@ func (this *Context) MetersSetEnabled(port int, enabled bool) error {
 	}
 	return this.err(C.gdg_meter_set_enabled(this.ctx, C.int(port), e))
 }
+
+// MetersProcess: level.Meter.Process over `buffers` (one per port, level/level.go:302-325).  A [][]float64 is a pointer to Go
+// pointers and cannot cross cgo, so the buffers are copied into C memory owned by the context.
+func (this *Context) MetersProcess(buffers [][]float64, sampleRate uint32) error {
+	ports := len(buffers)
+	if ports == 0 {
+		return nil
+	}
+	frames := len(buffers[0])
+	ptrBytes := ports * int(unsafe.Sizeof(uintptr(0)))
+	need := ptrBytes + ports*frames*8
+	if need > this.scratchN {
+		if this.scratch != nil {
+			C.free(this.scratch)
+		}
+		this.scratch = C.malloc(C.size_t(need))
+		this.scratchN = need
+	}
+	ptrs := (*[1 << 20]*C.double)(this.scratch)
+	data := unsafe.Pointer(uintptr(this.scratch) + uintptr(ptrBytes))
+	for p, buf := range buffers {
+		if len(buf) != frames {
+			return fmt.Errorf("gdg: meter buffers must be of equal length")
+		}
+		row := unsafe.Pointer(uintptr(data) + uintptr(p*frames*8))
+		if frames > 0 {
+			C.memcpy(row, unsafe.Pointer(&buf[0]), C.size_t(frames*8))
+		}
+		ptrs[p] = (*C.double)(row) // a C pointer stored in C memory: allowed
+	}
+	return this.err(C.gdg_meter_process(this.ctx, (**C.double)(this.scratch), C.int(frames), C.uint32_t(sampleRate)))
+}
+
 func (this *Context) MetersAnalyze(ports int) (levels []int32, peaks []int32, err error) {
 	levels, peaks = make([]int32, ports), make([]int32, ports)
 	if ports == 0 {

@@ -5,13 +5,21 @@
 //
 // so that controller.process() and everything above it stay byte-identical.  The reference's
 // effects.Unit objects are kept as the PARAMETER STORE (tables, name lookup, range checks and error
-// strings are theirs); their Process methods are never called: audio runs in libgdg.so on the GPU.
-// NOT compiled in the authoring container (no Go toolchain); the C++ twin in ../../host/ is what the
-// test-suite drives.  Structure and rendezvous are the same as gdg::Engine there.
+// strings are theirs); their Process methods are never called: audio runs in libgdg.so on the GPUs.
+//
+// NOT compiled in the authoring container (no Go toolchain).  The algorithm below is the one of the
+// C++ twin (../../host/gdg_host.cpp), which the test-suite drives on the GPU -- INTEGRATION.md
+// section 3 lists it once, and the two files follow it statement for statement:
+//
+//	gdg::Engine::process   <->  chainStruct.Process     rendezvous: deposit, last arrival (or grace period) runs the batch
+//	gdg::Engine::runBatch  <->  runBatch                per shard (GPU): sync, stage, ONE batched call, copy back; shards in parallel
+//	gdg::Engine::sync      <->  chainStruct.sync        retire, create, rate change -> recompile, push from ONE snapshot, slot list
+//	effects::Unit setters  <->  chainStruct.Set*Value   count every successful set; a power amp recompiles AT the set (poweramp.go:131-181)
 package signal
 
 import (
 	"fmt"
+	"log"
 	"math"
 	"os"
 	"strconv"
@@ -24,13 +32,18 @@ import (
 	"gdg" // ../gdg, the cgo binding
 )
 
+const blockSize = 8192 // controller/controller.go:36 BLOCK_SIZE
+
+// slotStruct: one unit of a chain.  Everything below `unit` and `bypass` is guarded by the chain's mutex.
 type slotStruct struct {
-	unit          effects.Unit
-	bypass        bool
-	handle        int      // device unit, -1 until materialised
-	pushed        []int32  // resolved parameters last sent
-	firSampleRate uint32   // power amp: rate the composite filter was compiled for
-	firKey        string   // power amp: parameter signature of the compiled filter
+	unit   effects.Unit
+	bypass bool
+	handle int // device unit inside the chain's shard, -1 until materialised
+
+	paramVersion, pushedParamVersion uint64 // bumped by every successful Set*Value (twin: Unit::paramVersion)
+	firVersion, pushedFirVersion     uint64 // power amp: bumped by every successful compile (twin: Unit::firVersion)
+	firTaps                          []float64
+	sampleRate                       uint32 // power amp: poweramp.sampleRate, changes only when the unit is PROCESSED
 }
 
 // Chain: identical to the reference (signal/signal.go:21-36).
@@ -52,15 +65,16 @@ type Chain interface {
 }
 
 type chainStruct struct {
-	channel   int
+	channel   int // GLOBAL channel number = index of the CreateChain call (controller.go:3267-3269)
 	responses filter.ImpulseResponses
 	mutex     sync.RWMutex
 	slots     []*slotStruct
-	retired   []int
-	dirty     bool
+	retired   []int // device handles of removed units
+
+	layoutVersion, pushedLayoutVersion uint64
 }
 
-// ---- the shard: one context, N chains, N-way rendezvous (controller.go:2682-2705 keeps exactly N calls in flight) ----
+// ---- the job: N chains, G shards, ONE N-way rendezvous (controller.go:2682-2705 keeps exactly N calls in flight) ----
 
 type pendingStruct struct {
 	chain      *chainStruct
@@ -71,27 +85,26 @@ type pendingStruct struct {
 var (
 	g_mutex      sync.Mutex
 	g_cond       = sync.NewCond(&g_mutex)
-	g_ctx        *gdg.Context
 	g_chains     []*chainStruct
 	g_pending    []pendingStruct
 	g_generation uint64
 	g_executing  bool
+	g_logOnce    sync.Once
 )
 
-func context() *gdg.Context {
-	if g_ctx == nil {
-		n, _ := strconv.Atoi(os.Getenv("GDG_CHANNELS")) // = the -channels flag of main.go:14
-		if n < len(g_chains) {
-			n = len(g_chains)
-		}
-		dev, _ := strconv.Atoi(os.Getenv("GDG_DEVICE"))
-		ctx, err := gdg.CreateContext(n, 8192, dev) // BLOCK_SIZE, controller.go:36
-		if err != nil {
-			panic(err) // no GPU: fail loudly, there is no CPU fallback
-		}
-		g_ctx = ctx
+func logOnce(err error) {
+	g_logOnce.Do(func() { log.Printf("gdg: %v (outputs are zeros, like the reference's failure mode inside Process)", err) })
+}
+
+// shards: the contexts of the job, created at the first block (GDG_CHANNELS = the -channels flag of main.go:14, if set).
+func shards() ([]*gdg.Shard, error) {
+	n, _ := strconv.Atoi(os.Getenv("GDG_CHANNELS"))
+	g_mutex.Lock()
+	if n < len(g_chains) {
+		n = len(g_chains)
 	}
-	return g_ctx
+	g_mutex.Unlock()
+	return gdg.Shards(n, blockSize)
 }
 
 // resolved parameters in table order: numeric value or discrete index
@@ -108,106 +121,215 @@ func resolve(unit effects.Unit) []int32 {
 	return res
 }
 
-// compile mirrors effects/poweramp.go:25-127 through the reference's PUBLIC filter API.
-func compile(unit effects.Unit, irs filter.ImpulseResponses, sampleRate uint32) ([]float64, string) {
-	key := fmt.Sprint(sampleRate, resolve(unit))
+// compile mirrors effects/poweramp.go:25-127 through the reference's PUBLIC filter API (twin: effects::Unit::compile).
+func compile(unit effects.Unit, irs filter.ImpulseResponses, sampleRate uint32) ([]float64, error) {
 	if irs == nil {
-		return nil, key
+		return nil, fmt.Errorf("%s", "Could not compile filter: No impulse responses were loaded.")
 	}
-	orderString, _ := unit.GetDiscreteValue("filter_order")
-	order64, _ := strconv.ParseUint(orderString, 10, 32)
+	orderString, err := unit.GetDiscreteValue("filter_order")
+	if err != nil {
+		return nil, err
+	}
+	order64, err := strconv.ParseUint(orderString, 10, 32)
+	if err != nil {
+		return nil, fmt.Errorf("Could not parse filter target order: '%s'", orderString)
+	}
 	composite := filter.Empty(sampleRate)
 	for i := 1; i <= effects.NUM_FILTERS; i++ {
 		s := strconv.Itoa(i)
-		name, _ := unit.GetDiscreteValue("filter_" + s)
-		level, _ := unit.GetNumericValue("level_" + s)
+		name, errName := unit.GetDiscreteValue("filter_" + s)
+		level, errLevel := unit.GetNumericValue("level_" + s)
+		if errName != nil || errLevel != nil {
+			return nil, fmt.Errorf("Error parsing values for filter %d.", i-1)
+		}
 		if name == effects.STRING_NONE {
 			continue
 		}
 		flt := irs.CreateFilter(name, sampleRate)
 		if flt == nil {
-			return nil, key
+			return nil, fmt.Errorf("Failed to load filter '%s' for sample rate '%d'.", name, sampleRate)
 		}
 		if order64 > 0 {
 			flt = flt.Reduce(uint32(order64))
 		}
 		fac := math.Pow(10.0, 0.05*float64(level))
 		flt = flt.Normalize().Multiply(fac)
-		composite, _ = composite.Add(flt)
+		sum, errAdd := composite.Add(flt)
+		if errAdd != nil {
+			return nil, fmt.Errorf("Failed to add filter: %s", errAdd.Error())
+		}
+		composite = sum
 	}
-	return composite.Coefficients(), key
+	return composite.Coefficients(), nil
 }
 
-// bring the device side of one chain up to date (called by the batch leader only)
-func (this *chainStruct) sync(ctx *gdg.Context, sampleRate uint32) {
+// recompile (chain mutex held): on success the power amp gets a NEW filter -- fresh convolution state on the device --
+// on failure the previous one stays (poweramp.go:147-151).  Twin: effects::Unit::recompile.
+func (this *chainStruct) recompile(slot *slotStruct) {
+	taps, err := compile(slot.unit, this.responses, slot.sampleRate)
+	if err == nil {
+		slot.firTaps = taps
+		slot.firVersion++
+	}
+}
+
+// bring the device side of this chain up to date (batch leader of the chain's shard only; shard mutex held).
+// Twin: gdg::Engine::sync.
+func (this *chainStruct) sync(ctx *gdg.Context, local int, sampleRate uint32) error {
 	this.mutex.Lock()
 	defer this.mutex.Unlock()
+	// 1. removed units
 	for _, h := range this.retired {
 		ctx.UnitDestroy(h)
 	}
 	this.retired = nil
 	for _, slot := range this.slots {
+		// 2a. materialise
 		if slot.handle < 0 {
-			slot.handle, _ = ctx.UnitCreate(this.channel, slot.unit.Type())
-			slot.pushed = nil
-			this.dirty = true
+			h, err := ctx.UnitCreate(local, slot.unit.Type())
+			if err != nil {
+				return err
+			}
+			slot.handle = h
+			slot.pushedParamVersion, slot.pushedFirVersion = 0, 0
+			this.pushedLayoutVersion = 0
 		}
-		res := resolve(slot.unit)
-		if slot.unit.Type() == effects.UNIT_POWERAMP {
-			if !slot.bypass {
-				taps, key := compile(slot.unit, this.responses, sampleRate)
-				if key != slot.firKey { // any parameter set or a rate change => new filter => fresh state
-					ctx.UnitSetFir(slot.handle, taps)
-					slot.firKey = key
+		isAmp := slot.unit.Type() == effects.UNIT_POWERAMP
+		// 2b. only a PROCESSED power amp notices a new sample rate (poweramp.go:191-203)
+		if isAmp && !slot.bypass && sampleRate != slot.sampleRate {
+			slot.sampleRate = sampleRate
+			this.recompile(slot)
+		}
+		// 2c. push from ONE consistent snapshot: the chain mutex is held, setters bump the versions under the same mutex
+		if slot.pushedParamVersion != slot.paramVersion {
+			res := resolve(slot.unit)
+			n := len(res)
+			if n > 8 {
+				n = 8
+			}
+			if isAmp {
+				n = 1 // filter_order; the filter_N / level_N values only matter through the compiled taps
+			}
+			for i := 0; i < n; i++ {
+				if err := ctx.UnitSetParam(slot.handle, i, res[i]); err != nil {
+					return err
 				}
 			}
-			continue
+			slot.pushedParamVersion = slot.paramVersion
 		}
-		for i, v := range res {
-			if i >= 8 {
-				break
+		if isAmp && slot.pushedFirVersion != slot.firVersion {
+			// every successful Set -- the same value or not -- replaced currentFilter in the reference: fresh tail
+			if err := ctx.UnitSetFir(slot.handle, slot.firTaps); err != nil {
+				return err
 			}
-			if slot.pushed == nil || slot.pushed[i] != v {
-				ctx.UnitSetParam(slot.handle, i, v)
-			}
+			slot.pushedFirVersion = slot.firVersion
 		}
-		slot.pushed = res
 	}
-	if this.dirty {
+	// 3. slot list
+	if this.pushedLayoutVersion != this.layoutVersion {
 		handles := make([]int, len(this.slots))
 		bypass := make([]bool, len(this.slots))
 		for i, slot := range this.slots {
 			handles[i], bypass[i] = slot.handle, slot.bypass
 		}
-		ctx.ChainSet(this.channel, handles, bypass)
-		this.dirty = false
+		if err := ctx.ChainSet(local, handles, bypass); err != nil {
+			return err
+		}
+		this.pushedLayoutVersion = this.layoutVersion
+	}
+	return nil
+}
+
+func zero(buf []float64) {
+	for i := range buf {
+		buf[i] = 0.0
 	}
 }
 
-func runBatch(batch []pendingStruct) {
-	ctx := context()
-	frames, sampleRate := len(batch[0].in), batch[0].sampleRate
-	channels := make([]int, 0, len(batch))
-	for _, p := range batch {
-		p.chain.sync(ctx, sampleRate)
-		row, _ := ctx.Row(p.chain.channel, frames)
-		copy(row, p.in) // Go memory -> pinned C slab: no Go pointer crosses the boundary
-		channels = append(channels, p.chain.channel)
-	}
-	err := ctx.ProcessStaged(channels, frames, sampleRate)
-	for _, p := range batch {
-		_, row := ctx.Row(p.chain.channel, frames)
-		if err != nil {
-			for i := range p.out { // the reference's failure mode inside Process: zeros (poweramp.go:210-214)
-				p.out[i] = 0.0
-			}
-		} else {
-			copy(p.out, row)
+// one shard's part of a batch: sync, stage, ONE gdg_process_staged over its channels, copy back.  Twin: gdg::Engine::runShard.
+func runShard(sh *gdg.Shard, group []pendingStruct, frames int, sampleRate uint32) {
+	sh.Mutex.Lock()
+	defer sh.Mutex.Unlock()
+	fail := func(err error) {
+		logOnce(err)
+		for _, p := range group { // the reference's failure mode inside Process: zeros (poweramp.go:210-214)
+			zero(p.out)
 		}
 	}
+	channels := make([]int, 0, len(group))
+	for _, p := range group {
+		local := p.chain.channel - sh.First
+		if err := p.chain.sync(sh.Ctx, local, sampleRate); err != nil {
+			fail(err)
+			return
+		}
+		row, _, err := sh.Ctx.Row(local, frames) // checked: frames <= row stride, channel inside the shard
+		if err != nil {
+			fail(err)
+			return
+		}
+		copy(row, p.in) // Go memory -> pinned C slab: no Go pointer crosses the boundary
+		channels = append(channels, local)
+	}
+	if err := sh.Ctx.ProcessStaged(channels, frames, sampleRate); err != nil {
+		fail(err)
+		return
+	}
+	for _, p := range group {
+		_, row, _ := sh.Ctx.Row(p.chain.channel-sh.First, frames)
+		copy(p.out, row)
+	}
 }
 
-// Process: signal/signal.go:361-414.  Length mismatch is a silent no-op.
+// Twin: gdg::Engine::runBatch.  One group per distinct (frames, sample rate) -- in controller.process() exactly one --
+// and inside it one goroutine per shard: channels are independent, the GPUs have nothing to exchange.
+func runBatch(batch []pendingStruct) {
+	list, err := shards()
+	if err != nil {
+		logOnce(err) // no GPU: fail loudly, there is no CPU fallback
+		for _, p := range batch {
+			zero(p.out)
+		}
+		return
+	}
+	for len(batch) > 0 {
+		frames, sampleRate := len(batch[0].in), batch[0].sampleRate
+		var rest []pendingStruct
+		perShard := make([][]pendingStruct, len(list))
+		for _, p := range batch {
+			if len(p.in) != frames || p.sampleRate != sampleRate {
+				rest = append(rest, p)
+				continue
+			}
+			placed := false
+			for g, sh := range list {
+				if p.chain.channel >= sh.First && p.chain.channel < sh.First+sh.Count {
+					perShard[g] = append(perShard[g], p)
+					placed = true
+					break
+				}
+			}
+			if !placed {
+				zero(p.out)
+			}
+		}
+		var wg sync.WaitGroup
+		for g, group := range perShard {
+			if len(group) == 0 {
+				continue
+			}
+			wg.Add(1)
+			go func(sh *gdg.Shard, group []pendingStruct) {
+				defer wg.Done()
+				runShard(sh, group, frames, sampleRate)
+			}(list[g], group)
+		}
+		wg.Wait()
+		batch = rest
+	}
+}
+
+// Process: signal/signal.go:361-414.  Length mismatch is a silent no-op.  Twin: gdg::Engine::process.
 func (this *chainStruct) Process(in []float64, out []float64, sampleRate uint32) {
 	if len(in) != len(out) {
 		return
@@ -236,7 +358,7 @@ func (this *chainStruct) Process(in []float64, out []float64, sampleRate uint32)
 	g_pending = nil
 	g_executing = true
 	g_mutex.Unlock()
-	runBatch(batch) // all frames have the same length and rate in controller.process()
+	runBatch(batch)
 	g_mutex.Lock()
 	g_executing = false
 	g_generation++
@@ -244,7 +366,7 @@ func (this *chainStruct) Process(in []float64, out []float64, sampleRate uint32)
 	g_mutex.Unlock()
 }
 
-// ---- slot bookkeeping: the reference's code with the device hand-off flags added ----
+// ---- slot bookkeeping: the reference's code with the device hand-off versions added ----
 
 func (this *chainStruct) AppendUnit(unitType int) (int, error) {
 	unit := effects.CreateUnit(unitType)
@@ -255,8 +377,8 @@ func (this *chainStruct) AppendUnit(unitType int) (int, error) {
 		effects.PreparePowerAmp(unit, this.responses)
 	}
 	this.mutex.Lock()
-	this.slots = append(this.slots, &slotStruct{unit: unit, bypass: true, handle: -1})
-	this.dirty = true
+	this.slots = append(this.slots, &slotStruct{unit: unit, bypass: true, handle: -1, paramVersion: 1}) // new units start bypassed (signal.go:74)
+	this.layoutVersion++
 	n := len(this.slots) - 1
 	this.mutex.Unlock()
 	return n, nil
@@ -272,7 +394,7 @@ func (this *chainStruct) RemoveUnit(id int) error {
 		this.retired = append(this.retired, this.slots[id].handle)
 	}
 	this.slots = append(this.slots[:id], this.slots[id+1:]...)
-	this.dirty = true
+	this.layoutVersion++
 	return nil
 }
 
@@ -283,7 +405,7 @@ func (this *chainStruct) MoveUp(id int) error {
 		return fmt.Errorf("Cannot move unit %d up.", id)
 	}
 	this.slots[id], this.slots[id-1] = this.slots[id-1], this.slots[id]
-	this.dirty = true
+	this.layoutVersion++
 	return nil
 }
 
@@ -294,7 +416,7 @@ func (this *chainStruct) MoveDown(id int) error {
 		return fmt.Errorf("Cannot move unit %d down.", id)
 	}
 	this.slots[id], this.slots[id+1] = this.slots[id+1], this.slots[id]
-	this.dirty = true
+	this.layoutVersion++
 	return nil
 }
 
@@ -325,8 +447,8 @@ func (this *chainStruct) SetBypass(id int, bypass bool) error {
 		return err
 	}
 	this.mutex.Lock()
-	s.bypass = bypass
-	this.dirty = true
+	s.bypass = bypass // a bypass toggle does not touch the filter: state stays with the unit (signal.go:390-401)
+	this.layoutVersion++
 	this.mutex.Unlock()
 	return nil
 }
@@ -336,7 +458,20 @@ func (this *chainStruct) GetBypass(id int) (bool, error) {
 	if err != nil {
 		return false, err
 	}
+	this.mutex.RLock()
+	defer this.mutex.RUnlock()
 	return s.bypass, nil
+}
+
+// after a SUCCESSFUL set: count it, and a power amp compiles a new filter right here, at the rate it was last processed at
+// (poweramp.go:131-181) -- the same value or not.  Twin: effects::Unit::SetDiscreteValue / SetNumericValue.
+func (this *chainStruct) afterSet(s *slotStruct) {
+	this.mutex.Lock()
+	s.paramVersion++
+	if s.unit.Type() == effects.UNIT_POWERAMP {
+		this.recompile(s)
+	}
+	this.mutex.Unlock()
 }
 
 func (this *chainStruct) SetDiscreteValue(id int, name string, value string) error {
@@ -344,7 +479,11 @@ func (this *chainStruct) SetDiscreteValue(id int, name string, value string) err
 	if err != nil {
 		return err
 	}
-	return s.unit.SetDiscreteValue(name, value)
+	err = s.unit.SetDiscreteValue(name, value)
+	if err == nil {
+		this.afterSet(s)
+	}
+	return err
 }
 
 func (this *chainStruct) GetDiscreteValue(id int, name string) (string, error) {
@@ -360,7 +499,11 @@ func (this *chainStruct) SetNumericValue(id int, name string, value int32) error
 	if err != nil {
 		return err
 	}
-	return s.unit.SetNumericValue(name, value)
+	err = s.unit.SetNumericValue(name, value)
+	if err == nil {
+		this.afterSet(s)
+	}
+	return err
 }
 
 func (this *chainStruct) GetNumericValue(id int, name string) (int32, error) {
@@ -389,7 +532,7 @@ func (this *chainStruct) Length() int {
 func CreateChain(responses filter.ImpulseResponses) Chain {
 	g_mutex.Lock()
 	defer g_mutex.Unlock()
-	chain := &chainStruct{channel: len(g_chains), responses: responses}
+	chain := &chainStruct{channel: len(g_chains), responses: responses, layoutVersion: 1}
 	g_chains = append(g_chains, chain)
 	return chain
 }
