@@ -1335,6 +1335,19 @@ int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
     return GDG_OK;
 }
 
+/* strided device-to-device copy of n_rows rows of row_len float64, enqueued on the context's stream: what the batch loop's
+ * copy(inputBuffers[i], input[offsetStart:offsetEnd]) / copy(output[offsetStart:offsetEnd], outputBuffers[i]) become when the
+ * whole files live in HBM (controller/controller.go:3088-3099) */
+int gdg_copy_rows_device(gdg_ctx *ctx, double *d_dst, size_t dst_stride, const double *d_src, size_t src_stride, size_t row_len, size_t n_rows) {
+    if (!ctx || !d_dst || !d_src) return GDG_ERR_INVALID;
+    if (row_len > dst_stride || row_len > src_stride) return fail(ctx, GDG_ERR_INVALID, "row length %zu exceeds a row stride", row_len);
+    if (row_len == 0 || n_rows == 0) return GDG_OK;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpy2DAsync(d_dst, dst_stride * sizeof(double), d_src, src_stride * sizeof(double), row_len * sizeof(double), n_rows,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    return GDG_OK;
+}
+
 /* ---- tuner: tuner.Process / tuner.Analyze for every channel of the shard ------------------------------------------ */
 
 static int ensure_tuner(gdg_ctx *ctx) {

@@ -164,6 +164,10 @@ int gdg_device_alloc(gdg_ctx *ctx, size_t bytes, void **d_ptr);
 int gdg_device_free(gdg_ctx *ctx, void *d_ptr);
 int gdg_copy_to_device(gdg_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* n_rows rows of row_len float64 from one strided device array to another (strides in float64), enqueued on the context's stream,
+ * not synchronised: cuts an 8192-frame block out of whole files resident in HBM and puts a processed block back
+ * (controller/controller.go:3088-3099) */
+int gdg_copy_rows_device(gdg_ctx *ctx, double *d_dst, size_t dst_stride, const double *d_src, size_t src_stride, size_t row_len, size_t n_rows);
 
 /* ---- per-kernel timing on the context's stream (HIP events), for bench.py's roofline ---------- */
 

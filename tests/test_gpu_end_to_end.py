@@ -1,0 +1,150 @@
+"""The batch run end to end ON THE DEVICE against the oracle: what controller.processFiles does between "the WAV data sections are
+in memory" and "the output data sections are in memory" (controller/controller.go:2884-3219):
+
+    bytesToSamples (six sample formats) -> resample.Time to the target rate -> zero-pad to a multiple of BLOCK_SIZE = 8192 ->
+    per block: copy in, N x Chain.Process, metronome, spatializer N -> 2, level meters over the 2N+3 ports, copy out ->
+    samplesToBytes of the N + 3 outputs.
+
+Every stage runs as a HIP kernel through the *_device entry points of the C-ABI; nothing touches host memory between the upload of
+the file bytes and the download of the result bytes.  The oracle runs the same stages on the CPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import TOL_RMS, package, rms, synth_ir, synth_signal
+
+pytestmark = pytest.mark.gpu
+
+BLOCK = 8192                                             # controller/controller.go:36
+FORMATS = ["lpcm8", "lpcm16", "lpcm24", "lpcm32", "ieee32", "ieee64"]
+CHAIN = [("compressor", [1, 30, -20]), ("overdrive", [0, 15, 80, -3, 1, 0]), ("tone_stack", None), ("chorus", None),
+         ("power_amp", "ir"), ("cabinet", None), ("reverb", [30])]
+
+
+class DevBytes:
+    """A byte buffer in the context's device memory."""
+
+    def __init__(self, ctx, pkg, nbytes):
+        self.ctx, self.pkg, self.nbytes = ctx, pkg, nbytes
+        p = C.c_void_p()
+        ctx._check(pkg.lib().gdg_device_alloc(ctx._h, max(nbytes, 8), C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        self.ctx._check(self.pkg.lib().gdg_copy_to_device(self.ctx._h, self.ptr, a.ctypes.data, a.nbytes))
+
+    def download(self, dtype=np.uint8):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self.ctx._check(self.pkg.lib().gdg_copy_to_host(self.ctx._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+
+def test_batch_run_on_device_matches_oracle(oracle):
+    pkg = package()
+    lib = pkg.lib()
+    nch, src_rate, rate, n_src = len(FORMATS), 44100, 48000, 30000
+    rng = np.random.default_rng(3)
+    irs = [synth_ir(3000, seed=20 + c) for c in range(nch)]
+    positions = [(float(rng.uniform(-90, 90)), float(rng.uniform(0.3, 5)), float(rng.uniform(0.2, 1))) for _ in range(nch)]
+    tick, tock = rng.uniform(-0.5, 0.5, 1200), rng.uniform(-0.5, 0.5, 700)
+    # ---- the "files": one mono data section per input, each in another sample format -----------------------------------
+    sources = [0.8 * synth_signal(c, n_src, src_rate) for c in range(nch)]
+    file_bytes = [oracle.wave_encode(FORMATS[c], sources[c]) for c in range(nch)]
+    n_out = lib.gdg_resample_time_length(n_src, src_rate, rate)
+    length = BLOCK * ((n_out + BLOCK - 1) // BLOCK)           # controller.go:3014-3016
+    blocks = length // BLOCK
+    ports = 2 * nch + 3
+
+    # ---- oracle -------------------------------------------------------------------------------------------------------------
+    ref_in = np.zeros((nch, length))
+    for c in range(nch):
+        ref_in[c, :n_out] = oracle.resample_time(oracle.wave_decode(FORMATS[c], file_bytes[c]), src_rate, rate)
+    chains = []
+    for c in range(nch):
+        ch = oracle.Chain()
+        for name, p in CHAIN:
+            ch.append_unit(name, fir=irs[c]) if p == "ir" else ch.append_unit(name, params=p)
+        chains.append(ch)
+    ref_sp = oracle.Spatializer(nch)
+    ref_sp.set_sample_rate(rate)
+    for c, (a, d, l) in enumerate(positions):
+        ref_sp.set_azimuth(c, a); ref_sp.set_distance(c, d); ref_sp.set_level(c, l)
+    ref_met = oracle.Metronome()
+    ref_met.tick, ref_met.tock = tick, tock
+    ref_met.s.beats_per_period, ref_met.s.bpm_speed, ref_met.s.sample_rate = 4, 140, rate
+    ref_meters = [oracle.ChannelMeter() for _ in range(ports)]
+    for m in ref_meters:
+        m.set_enabled(True)
+    ref_out = np.zeros((nch + 3, length))
+    for b in range(blocks):
+        sl = slice(b * BLOCK, (b + 1) * BLOCK)
+        for c in range(nch):
+            ref_out[c, sl] = chains[c].process(ref_in[c, sl], rate)
+        ref_out[nch + 2, sl] = ref_met.process(BLOCK)                                    # controller.go:2721-2742
+        ref_out[nch, sl], ref_out[nch + 1, sl] = ref_sp.process(ref_out[:nch, sl])       # :2744-2761, metronome not in the master mix
+        rows = [ref_in[c, sl] for c in range(nch)] + [ref_out[c, sl] for c in range(nch)] + [ref_out[nch + 2, sl], ref_out[nch, sl], ref_out[nch + 1, sl]]
+        for m, r in zip(ref_meters, rows):                                               # :2707-2781: inputs, outputs, metronome, master L/R
+            m.process(r, rate)
+
+    # ---- device -------------------------------------------------------------------------------------------------------------
+    ctx = pkg.Context(nch, BLOCK)
+    for c in range(nch):
+        for name, p in CHAIN:
+            ctx.append_unit(c, name, fir=irs[c]) if p == "ir" else ctx.append_unit(c, name, params=p)
+    ctx.spatializer_set_sample_rate(rate)
+    for c, (a, d, l) in enumerate(positions):
+        ctx.spatializer_set_position(c, a, d, l)
+    ctx.metronome_set_sounds(tick, tock)
+    ctx.metronome_configure(4, 140, rate)
+    ctx.meter_configure(ports)
+    ctx.meter_set_enabled(True)
+    d_inputs = ctx.alloc(nch, length)                         # whole (padded) files, resident in HBM
+    d_outputs = ctx.alloc(nch + 3, length)
+    d_inputs.upload(np.zeros((nch, length)))
+    d_src = ctx.alloc(1, n_src)
+    for c in range(nch):
+        raw = DevBytes(ctx, pkg, file_bytes[c].nbytes)
+        raw.upload(file_bytes[c])
+        ctx._check(lib.gdg_wave_decode_device(ctx._h, pkg.WAVE_FORMATS[FORMATS[c]], raw.ptr, n_src, 1, d_src.ptr))
+        ctx._check(lib.gdg_resample_time_device(ctx._h, d_src.ptr, n_src, src_rate, rate, d_inputs.ptr + 8 * c * length, n_out))
+    d_in_blk, d_out_blk, d_meter_blk = ctx.alloc(nch, BLOCK), ctx.alloc(nch + 3, BLOCK), ctx.alloc(ports, BLOCK)
+    rows = lambda buf, r: buf.ptr + 8 * r * BLOCK
+    for b in range(blocks):
+        off = 8 * b * BLOCK
+        ctx._check(lib.gdg_copy_rows_device(ctx._h, d_in_blk.ptr, BLOCK, d_inputs.ptr + off, length, BLOCK, nch))        # copy in
+        ctx.process_device(d_in_blk, rows(d_out_blk, 0), BLOCK, rate)                                                  # N x Chain.Process
+        ctx._check(lib.gdg_metronome_process_device(ctx._h, rows(d_out_blk, nch + 2), BLOCK))
+        ctx._check(lib.gdg_spatialize_device(ctx._h, rows(d_out_blk, 0), rows(d_out_blk, nch), BLOCK))                 # -> rows N, N + 1
+        ctx._check(lib.gdg_copy_rows_device(ctx._h, rows(d_meter_blk, 0), BLOCK, d_in_blk.ptr, BLOCK, BLOCK, nch))
+        ctx._check(lib.gdg_copy_rows_device(ctx._h, rows(d_meter_blk, nch), BLOCK, rows(d_out_blk, 0), BLOCK, BLOCK, nch))
+        ctx._check(lib.gdg_copy_rows_device(ctx._h, rows(d_meter_blk, 2 * nch), BLOCK, rows(d_out_blk, nch + 2), BLOCK, BLOCK, 1))
+        ctx._check(lib.gdg_copy_rows_device(ctx._h, rows(d_meter_blk, 2 * nch + 1), BLOCK, rows(d_out_blk, nch), BLOCK, BLOCK, 2))
+        ctx.meter_process_device(d_meter_blk, BLOCK, BLOCK, rate)
+        ctx._check(lib.gdg_copy_rows_device(ctx._h, d_outputs.ptr + off, length, d_out_blk.ptr, BLOCK, BLOCK, nch + 3))  # copy out
+    # ---- the output files: out_i in the input's own format, masters as 24-bit and 64-bit float, metronome as 16-bit --------
+    out_formats = FORMATS + ["lpcm24", "ieee64", "lpcm16"]
+    got_bytes = []
+    for r, fmt in enumerate(out_formats):
+        w = lib.gdg_wave_bytes_per_sample(pkg.WAVE_FORMATS[fmt])
+        enc = DevBytes(ctx, pkg, w * length)
+        ctx._check(lib.gdg_wave_encode_device(ctx._h, pkg.WAVE_FORMATS[fmt], d_outputs.ptr + 8 * r * length, length, 1, enc.ptr))
+        got_bytes.append(enc.download())
+    lv, pk = ctx.meter_analyze()
+    got_out = d_outputs.download()
+    ctx.close()
+
+    # ---- compare ---------------------------------------------------------------------------------------------------------------
+    for r in range(nch + 3):
+        assert rms(got_out[r] - ref_out[r]) <= TOL_RMS, "output %d: RMS %.3e" % (r, rms(got_out[r] - ref_out[r]))
+    for r, fmt in enumerate(out_formats):
+        want = oracle.wave_encode(fmt, ref_out[r])
+        if fmt in ("ieee32", "ieee64"):
+            # float containers keep the 1e-16 differences of the device transcendentals: compare the decoded samples
+            assert rms(oracle.wave_decode(fmt, got_bytes[r]) - oracle.wave_decode(fmt, want)) <= TOL_RMS, fmt
+        else:
+            # integer containers: identical bytes (a 1e-15 difference moves a truncation with probability ~1e-10 per sample)
+            np.testing.assert_array_equal(got_bytes[r], want, err_msg="output %d (%s)" % (r, fmt))
+    for p, m in enumerate(ref_meters):
+        assert (lv[p], pk[p]) == m.analyze(), "meter port %d" % p
