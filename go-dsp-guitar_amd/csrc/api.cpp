@@ -1335,6 +1335,88 @@ int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
     return GDG_OK;
 }
 
+/* fft.RealFourier / fft.RealInverseFourier (fft/fft.go:744-856, :863-990) as the FIR path computes them: the packed-real transforms
+ * of fir.hip, stand-alone, so that the HIP FFT has known-answer tests of its own.  n real samples <->
+ * n / 2 + 1 complex bins (re, im interleaved), n = 128 ... 16384 a power of two.  Forward unscaled, inverse scaled by 1 / n, the
+ * reference's SCALING_DEFAULT. */
+static int fft_size_ok(gdg_ctx *ctx, int n) {
+    int P = n / 2;
+    if (n < 2 * GDG_MIN_FIR_FRAMES || n > 2 * GDG_MAX_FRAMES || (n & (n - 1)) != 0)
+        return fail(ctx, GDG_ERR_INVALID, "transform size %d: a power of two from %d to %d", n, 2 * GDG_MIN_FIR_FRAMES, 2 * GDG_MAX_FRAMES);
+    (void)P;
+    return GDG_OK;
+}
+
+int gdg_fft_real(gdg_ctx *ctx, const double *samples, int n, double *spectrum) {
+    if (!ctx || !samples || !spectrum) return GDG_ERR_INVALID;
+    int rc = fft_size_ok(ctx, n);
+    if (rc != GDG_OK) return rc;
+    hipSetDevice(ctx->device);
+    const int P = n / 2;
+    double2 *tw, *tw2;
+    rc = fir_tables(ctx, P, &tw, &tw2);
+    if (rc != GDG_OK) return rc;
+    double *d_x = nullptr;
+    double2 *d_out = nullptr;
+    gdg_fir_irjob *d_job = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(ctx, hipMalloc((void **)&d_x, (size_t)n * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&d_out, (size_t)P * sizeof(double2)));
+        HIP_TRY(ctx, hipMalloc((void **)&d_job, sizeof(gdg_fir_irjob)));
+        gdg_fir_irjob job;
+        memset(&job, 0, sizeof(job));
+        job.a = d_x; job.b = d_x + P; job.hop = P; job.out = d_out;
+        HIP_TRY(ctx, hipMemcpyAsync(d_x, samples, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, gdg_launch_fir_ir(P, d_job, 1, 1.0, tw, tw2, ctx->stream));
+        std::vector<double2> packed((size_t)P);
+        HIP_TRY(ctx, hipMemcpyAsync(packed.data(), d_out, (size_t)P * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        /* bin 0 of the packed half spectrum carries (Re X[0], Re X[P]) */
+        spectrum[0] = packed[0].x; spectrum[1] = 0.0;
+        for (int k = 1; k < P; k++) { spectrum[2 * k] = packed[(size_t)k].x; spectrum[2 * k + 1] = packed[(size_t)k].y; }
+        spectrum[2 * P] = packed[0].y; spectrum[2 * P + 1] = 0.0;
+        return GDG_OK;
+    };
+    rc = body();
+    hipFree(d_x); hipFree(d_out); hipFree(d_job);
+    return rc;
+}
+
+int gdg_fft_real_inverse(gdg_ctx *ctx, const double *spectrum, int n, double *samples) {
+    if (!ctx || !samples || !spectrum) return GDG_ERR_INVALID;
+    int rc = fft_size_ok(ctx, n);
+    if (rc != GDG_OK) return rc;
+    hipSetDevice(ctx->device);
+    const int P = n / 2;
+    double2 *tw, *tw2;
+    rc = fir_tables(ctx, P, &tw, &tw2);
+    if (rc != GDG_OK) return rc;
+    double *d_x = nullptr;
+    double2 *d_Y = nullptr;
+    gdg_fir_rawjob *d_job = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(ctx, hipMalloc((void **)&d_x, (size_t)n * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&d_Y, (size_t)P * sizeof(double2)));
+        HIP_TRY(ctx, hipMalloc((void **)&d_job, sizeof(gdg_fir_rawjob)));
+        std::vector<double2> packed((size_t)P);
+        packed[0] = make_double2(spectrum[0], spectrum[2 * P]);          /* like fft.go:899-906 only Re X[0], Re X[n/2] are used */
+        for (int k = 1; k < P; k++) packed[(size_t)k] = make_double2(spectrum[2 * k], spectrum[2 * k + 1]);
+        gdg_fir_rawjob job;
+        memset(&job, 0, sizeof(job));
+        job.Y = d_Y; job.first = d_x; job.second = d_x + P; job.hop = P;
+        HIP_TRY(ctx, hipMemcpyAsync(d_Y, packed.data(), (size_t)P * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, gdg_launch_fir_raw_inv(P, d_job, 1, 1.0 / (double)n, tw, tw2, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(samples, d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return GDG_OK;
+    };
+    rc = body();
+    hipFree(d_x); hipFree(d_Y); hipFree(d_job);
+    return rc;
+}
+
 /* strided device-to-device copy of n_rows rows of row_len float64, enqueued on the context's stream: what the batch loop's
  * copy(inputBuffers[i], input[offsetStart:offsetEnd]) / copy(output[offsetStart:offsetEnd], outputBuffers[i]) become when the
  * whole files live in HBM (controller/controller.go:3088-3099) */

@@ -169,6 +169,17 @@ int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
  * (controller/controller.go:3088-3099) */
 int gdg_copy_rows_device(gdg_ctx *ctx, double *d_dst, size_t dst_stride, const double *d_src, size_t src_stride, size_t row_len, size_t n_rows);
 
+/* ---- the transforms underneath the power amp, stand-alone ------------------------------------ */
+
+/*
+ * fft.RealFourier / fft.RealInverseFourier (fft/fft.go:744-856, :863-990) as fir.hip computes them (packed-real Stockham
+ * transforms in registers + LDS): n real samples <-> n / 2 + 1 complex bins (re, im interleaved; the other half is the
+ * conjugate mirror the reference also stores).  n = 128 ... 16384, a power of two.  Forward unscaled, inverse scaled by 1 / n
+ * (SCALING_DEFAULT); like the reference the inverse reads only the real parts of bins 0 and n / 2.  Host buffers, blocking.
+ */
+int gdg_fft_real(gdg_ctx *ctx, const double *samples, int n, double *spectrum);
+int gdg_fft_real_inverse(gdg_ctx *ctx, const double *spectrum, int n, double *samples);
+
 /* ---- per-kernel timing on the context's stream (HIP events), for bench.py's roofline ---------- */
 
 enum gdg_kernel_kind {

@@ -1,0 +1,106 @@
+"""Third-formulation pins for the rows the reference itself has no vectors for: literal first samples from zero
+state, derived from the math of SURVEY.md Appendix B (tests/golden/make_units_handcalc.py), against the oracle (CPU) AND the HIP
+path (GPU).  Plus known-answer tests of the HIP FFT itself against numpy.fft (row a18)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from helpers import package, rms
+
+TOL = 1e-12
+
+with open(os.path.join(entry.ROOT, "tests", "golden", "units_handcalc.json")) as f:
+    GOLD = json.load(f)
+IDS = ["%s-%d" % (c["unit"], i) for i, c in enumerate(GOLD["units"])]
+
+
+def test_every_unit_type_has_a_handcalc_case():
+    units = {c["unit"] for c in GOLD["units"]}
+    assert len(units) == 21, sorted(units)                 # all 21 effects units incl. the power amp
+
+
+@pytest.mark.parametrize("case", GOLD["units"], ids=IDS)
+def test_oracle_reproduces_handcalc(oracle, case):
+    ch = oracle.Chain()
+    ch.append_unit(case["unit"], params=case["params"], fir=case.get("fir"))
+    got = ch.process(np.array(case["x"]), case["sample_rate"])
+    assert np.max(np.abs(got - np.array(case["y"]))) <= TOL, (case["source"], case["note"], got.tolist(), case["y"])
+
+
+def test_oracle_spatializer_reproduces_handcalc(oracle):
+    s = GOLD["spatializer"]
+    sp = oracle.Spatializer(1)
+    sp.set_sample_rate(s["sample_rate"])
+    sp.set_azimuth(0, s["azimuth"]); sp.set_distance(0, s["distance"]); sp.set_level(0, s["level"])
+    left, right = sp.process(np.array([s["x"]]))
+    assert np.max(np.abs(left - np.array(s["left"]))) <= TOL and np.max(np.abs(right - np.array(s["right"]))) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GOLD["units"], ids=IDS)
+def test_hip_reproduces_handcalc(case):
+    pkg = package()
+    x = np.array(case["x"])
+    ctx = pkg.Context(1, max(64, x.size))
+    ctx.append_unit(0, case["unit"], params=case["params"], fir=case.get("fir"))
+    got = ctx.process(x[None, :], case["sample_rate"])[0]
+    ctx.close()
+    assert np.max(np.abs(got - np.array(case["y"]))) <= 1e-11, (case["source"], case["note"], got.tolist(), case["y"])
+
+
+@pytest.mark.gpu
+def test_hip_spatializer_reproduces_handcalc():
+    pkg = package()
+    s = GOLD["spatializer"]
+    ctx = pkg.Context(1, 64)
+    ctx.spatializer_set_sample_rate(s["sample_rate"])
+    ctx.spatializer_set_position(0, s["azimuth"], s["distance"], s["level"])
+    left, right = ctx.spatialize(np.array([s["x"]]))
+    ctx.close()
+    assert np.max(np.abs(left - np.array(s["left"]))) <= TOL and np.max(np.abs(right - np.array(s["right"]))) <= TOL
+
+
+# ---- the HIP FFT by itself (fft.RealFourier / RealInverseFourier conventions: e^{-2 pi i}, unscaled forward, 1/n inverse) ----------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_hip_fft_known_answers(n):
+    pkg = package()
+    ctx = pkg.Context(1, 64)
+    k = np.arange(n)
+    # 1. closed forms: impulse -> all ones; shifted impulse -> a phase ramp; a cosine on a bin -> n/2 in that bin; DC -> n in bin 0
+    imp = np.zeros(n); imp[0] = 1.0
+    np.testing.assert_allclose(ctx.fft_real(imp), np.ones(n // 2 + 1), rtol=0, atol=1e-15)
+    sh = np.zeros(n); sh[3] = 1.0
+    np.testing.assert_allclose(ctx.fft_real(sh), np.exp(-2j * np.pi * 3 * np.arange(n // 2 + 1) / n), rtol=0, atol=1e-14)
+    b = n // 8 + 1
+    spec = ctx.fft_real(np.cos(2 * np.pi * b * k / n))
+    want = np.zeros(n // 2 + 1, dtype=complex); want[b] = n / 2
+    np.testing.assert_allclose(spec, want, rtol=0, atol=1e-11 * n)
+    np.testing.assert_allclose(ctx.fft_real(np.ones(n))[0], n, rtol=1e-15)
+    nyq = ctx.fft_real(np.cos(np.pi * k))                           # alternating signs: everything in the Nyquist bin, real
+    assert abs(nyq[n // 2] - n) <= 1e-12 * n and np.max(np.abs(nyq[:n // 2])) <= 1e-11 * n
+    # 2. random data against numpy.fft (second implementation), relative to the spectrum's scale
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+    got, ref = ctx.fft_real(x), np.fft.rfft(x)
+    assert np.max(np.abs(got - ref)) <= 2e-15 * np.sqrt(n) * np.max(np.abs(ref)) + 1e-13
+    # 3. the inverse: 1/n scaling, only Re of bins 0 and n/2 used (fft.go:899-906), round trip
+    back = ctx.fft_real_inverse(ref, n)
+    assert np.max(np.abs(back - x)) <= 1e-13
+    dirty = ref.copy(); dirty[0] += 5j; dirty[-1] -= 7j               # imaginary parts of DC / Nyquist are ignored
+    assert np.max(np.abs(ctx.fft_real_inverse(dirty, n) - x)) <= 1e-13
+    assert rms(ctx.fft_real_inverse(ctx.fft_real(x), n) - x) <= 1e-14
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_fft_rejects_sizes_outside_the_lds_resident_range():
+    pkg = package()
+    ctx = pkg.Context(1, 64)
+    for n in (64, 100, 32768):
+        with pytest.raises(pkg.GdgError):
+            ctx.fft_real(np.zeros(n))
+    ctx.close()
