@@ -1493,16 +1493,27 @@ int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
     hipSetDevice(ctx->device);
     int rc = ensure_tuner(ctx);
     if (rc != GDG_OK) return rc;
-    if (!ctx->d_tuner_work) {
-        /* two complex work arrays of 131072 points per channel (2 x 2 MiB) */
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_work, (size_t)ctx->nch * 2 * (GDG_TUNER_FFT / 2) * sizeof(double2)));
-        HIP_TRY(ctx, gdg_tuner_tables_create(&ctx->d_tuner_twn, &ctx->d_tuner_twm));
-    }
-    double2 *tw512, *tw256, *unused;
-    rc = fir_tables(ctx, 512, &tw512, &unused);
-    if (rc == GDG_OK) rc = fir_tables(ctx, 256, &tw256, &unused);
-    if (rc != GDG_OK) return rc;
-    {
+    static int force_long = -1;
+    if (force_long < 0) { const char *e = getenv("GDG_TUNER_LONG"); force_long = e ? atoi(e) : 0; }
+    if (!force_long && gdg_tuner_short_ok((double)ctx->tuner_sr, GDG_NOTE_FREQS[0])) {
+        /* every standard rate: block-wise autocorrelation for the lags the analysis can look at; the ring is read once */
+        double2 *tw4096, *tw2_4096;
+        rc = fir_tables(ctx, 4096, &tw4096, &tw2_4096);
+        if (rc != GDG_OK) return rc;
+        ProfScope ps(ctx, GDG_K_TUNER);
+        HIP_TRY(ctx, gdg_launch_tuner_short(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, (double)ctx->tuner_sr, tw4096, tw2_4096,
+                                            ctx->d_note_freqs, GDG_NOTE_COUNT, ctx->d_tuner_out, ctx->stream));
+    } else {
+        /* rates above ~252 kHz: the window reaches past lag 4096 -- the reference's own scheme, a 262144-point transform pair */
+        if (!ctx->d_tuner_work) {
+            /* two complex work arrays of 131072 points per channel (2 x 2 MiB) */
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_work, (size_t)ctx->nch * 2 * (GDG_TUNER_FFT / 2) * sizeof(double2)));
+            HIP_TRY(ctx, gdg_tuner_tables_create(&ctx->d_tuner_twn, &ctx->d_tuner_twm));
+        }
+        double2 *tw512, *tw256, *unused;
+        rc = fir_tables(ctx, 512, &tw512, &unused);
+        if (rc == GDG_OK) rc = fir_tables(ctx, 256, &tw256, &unused);
+        if (rc != GDG_OK) return rc;
         ProfScope ps(ctx, GDG_K_TUNER);
         HIP_TRY(ctx, gdg_launch_tuner_analyze(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, (double)ctx->tuner_sr, ctx->d_tuner_work,
                                               ctx->d_tuner_twn, ctx->d_tuner_twm, tw512, tw256, ctx->d_note_freqs, GDG_NOTE_COUNT,

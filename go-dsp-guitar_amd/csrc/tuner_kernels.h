@@ -160,26 +160,31 @@ __device__ __forceinline__ double tuner_corr(const cplx *r, int lag) {
     return (lag & 1) ? z.y : z.x;
 }
 
-/* tuner.go:446-567: arg-max in the lag window, parabolic refinement, nearest note */
-__global__ void __launch_bounds__(256)
-tuner_pick_kernel(const cplx *__restrict__ R, double sample_rate, const double *__restrict__ note_freqs, int n_notes,
-                  gdg_tuner_out *__restrict__ out) {
-    __shared__ double s_val[256];
-    __shared__ int s_idx[256];
-    const int ch = blockIdx.x, tid = threadIdx.x;
-    const cplx *r = R + (size_t)ch * TUNER_N;
-    const int n = GDG_TUNER_RING;
-    const long long two_n = 2LL * n;
+/* tuner.go:446-567: arg-max in the lag window, parabolic refinement, nearest note.  corr(lag) = r[lag] up to a positive scale.
+ * One workgroup of 256 threads; s_val / s_idx: 256 entries of LDS each. */
+__device__ __forceinline__ void tuner_lag_window(double sample_rate, const double *__restrict__ note_freqs, int n_notes, long long *low_idx, long long *high_idx) {
+    const long long two_n = 2LL * GDG_TUNER_RING;
     const double low_freq = note_freqs[0], high_freq = note_freqs[n_notes - 1];
     double lo_f = (sample_rate / high_freq) + 0.5, hi_f = (sample_rate / low_freq) + 0.5;
-    long long low_idx = (lo_f == lo_f && fabs(lo_f) < 9e18) ? (long long)lo_f : -1;
-    if (low_idx < 0 || low_idx >= two_n) low_idx = 0;
-    long long high_idx = (hi_f == hi_f && fabs(hi_f) < 9e18) ? (long long)hi_f : -1;
-    if (high_idx < 0 || high_idx >= two_n) high_idx = two_n - 1;
+    long long lo = (lo_f == lo_f && fabs(lo_f) < 9e18) ? (long long)lo_f : -1;
+    if (lo < 0 || lo >= two_n) lo = 0;
+    long long hi = (hi_f == hi_f && fabs(hi_f) < 9e18) ? (long long)hi_f : -1;
+    if (hi < 0 || hi >= two_n) hi = two_n - 1;
+    *low_idx = lo;
+    *high_idx = hi;
+}
+
+template <class Corr>
+__device__ __forceinline__ void tuner_pick(Corr corr, double sample_rate, const double *__restrict__ note_freqs, int n_notes,
+                                           gdg_tuner_out *__restrict__ out_ch, double *s_val, int *s_idx) {
+    const int tid = threadIdx.x;
+    const int n = GDG_TUNER_RING;
+    long long low_idx, high_idx;
+    tuner_lag_window(sample_rate, note_freqs, n_notes, &low_idx, &high_idx);
     double best = -INFINITY;
     int best_i = -1;
     for (long long i = low_idx + tid; i < high_idx; i += 256) {
-        double v = tuner_corr(r, (int)i);
+        double v = corr((int)i);
         if (v > best) { best = v; best_i = (int)i; }            /* ascending i per thread: first maximum wins */
     }
     s_val[tid] = best; s_idx[tid] = best_i;
@@ -198,7 +203,7 @@ tuner_pick_kernel(const cplx *__restrict__ R, double sample_rate, const double *
         int idx = (s_idx[0] >= 0) ? s_idx[0] : (int)low_idx - 1;
         int idx_up = idx + 1; if (idx_up > n) idx_up = n;
         int idx_down = idx - 1; if (idx_down < 0) idx_down = 0;
-        double value_left = tuner_corr(r, idx_down), value_right = tuner_corr(r, idx_up);
+        double value_left = corr(idx_down), value_right = corr(idx_up);
         double idx_float = (double)idx;
         double value_diff = value_right - value_left;
         double value_sum = value_right + value_left;
@@ -219,10 +224,129 @@ tuner_pick_kernel(const cplx *__restrict__ R, double sample_rate, const double *
         }
         int cents_int = 0;
         if (!(isinf(cents) || isnan(cents))) cents_int = (int)(signed char)(int)cents;
-        out[ch].frequency = freq;
-        out[ch].note_index = note;
-        out[ch].cents = cents_int;
+        out_ch->frequency = freq;
+        out_ch->note_index = note;
+        out_ch->cents = cents_int;
     }
+}
+
+__global__ void __launch_bounds__(256)
+tuner_pick_kernel(const cplx *__restrict__ R, double sample_rate, const double *__restrict__ note_freqs, int n_notes,
+                  gdg_tuner_out *__restrict__ out) {
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    const cplx *r = R + (size_t)blockIdx.x * TUNER_N;
+    tuner_pick([&](int lag) { return tuner_corr(r, lag); }, sample_rate, note_freqs, n_notes, out + blockIdx.x, s_val, s_idx);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * The short-lag analysis (every standard rate: the lag window ends at sr / 61.7354 + 0.5 <= 3111 at 192 kHz).
+ *
+ * Only r[lag] for lag <= high index + 1 is ever looked at, so the 262144-point transform pair is not needed: the linear
+ * autocorrelation of the zero-padded signal (what tuner.go:408-444 computes) is, for lag < 4097,
+ *     r[l] = sum_b sum_{n in block b} x[n] x[n + l],      blocks of B = 4096 samples,
+ * and per block  sum_n a_b[n] c_b[n + l] = IFFT_8192( conj(A_b) C_b )[l]  with a_b = block b zero-padded to 8192 and
+ * c_b = blocks b, b + 1.  Since c_b = a_b + shift_4096(a_{b+1}), C_b = A_b + (-1)^k A_{b+1}: ONE forward transform per block,
+ *     S[k] = sum_b |A_b[k]|^2 + (-1)^k sum_b conj(A_b[k]) A_{b+1}[k],     r = IFFT_8192(S).
+ * One workgroup per channel: 24 packed-real forward transforms of 8192 points (4096 complex, registers + 70 KiB LDS), the
+ * running spectrum A_b and the sum S in registers, one inverse, the pick on the result in LDS.  HBM traffic = the ring, read
+ * ONCE: 768 kB per analysis -- the algorithmic minimum -- instead of ~19 MiB of four-step passes.
+ * Differs from the long transform by rounding only (~1e-15 relative in r).
+ * ---------------------------------------------------------------------------------------------- */
+#define TUNER_BLK 4096
+#define TUNER_SHORT_MAX_LAG TUNER_BLK          /* r[0 .. 4096] are free of wrap-around */
+
+__global__ void __launch_bounds__(256)
+tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate, const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
+                   const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out) {
+    constexpr int LOGN = 12, N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;      /* 4096 complex points, 256 threads */
+    __shared__ double s_all[2 * FftCfg<LOGN>::LDS];
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    double *sre = s_all, *sim = s_all + FftCfg<LOGN>::LDS;
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    const double *ring = rings + (size_t)ch * GDG_TUNER_RING;
+    /* per thread: bins k = tid + T i and n = N - k (i = 0: thread 0 holds (X[0], X[N]) as two reals and X[N/2]) */
+    cplx pk[ITER], pn[ITER], sk[ITER], sn[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; i++) { pk[i] = pn[i] = sk[i] = sn[i] = make_double2(0.0, 0.0); }
+    constexpr int NBLK = (GDG_TUNER_RING + TUNER_BLK - 1) / TUNER_BLK;                          /* 24 */
+    constexpr int LR0 = sched_lr(LOGN, 0), R0 = 1 << LR0, B0 = 16 / R0;
+    for (int blk = 0; blk < NBLK; blk++) {
+        /* pass 0 straight from the ring: packed element e = (a[2e], a[2e+1]), a = block `blk` then 4096 zeros */
+        cplx v[16];
+#pragma unroll
+        for (int b = 0; b < B0; b++) {
+            const int j = tid + T * b;
+#pragma unroll
+            for (int t = 0; t < R0; t++) {
+                const int e = j + t * (N / R0);
+                cplx val = make_double2(0.0, 0.0);
+                if (e < TUNER_BLK / 2) {
+                    const int i0 = blk * TUNER_BLK + 2 * e;                                     /* oldest-first sample index */
+                    if (i0 < GDG_TUNER_RING) { int p = wp + i0; if (p >= GDG_TUNER_RING) p -= GDG_TUNER_RING; val.x = gload1(ring + p); }
+                    if (i0 + 1 < GDG_TUNER_RING) { int p = wp + i0 + 1; if (p >= GDG_TUNER_RING) p -= GDG_TUNER_RING; val.y = gload1(ring + p); }
+                }
+                v[b * R0 + t] = val;
+            }
+        }
+        pass_compute<LOGN, LR0, 0, false>(v, tw, tid);
+        pass_store<LOGN, LR0, 0>(v, sre, sim, tid);
+        __syncthreads();
+        run_lds_passes<LOGN, 1, sched_npass(LOGN), false>(v, sre, sim, tw, tid);
+        /* un-pack Z -> the real sequence's bins, accumulate |A|^2 and (-1)^k conj(A_prev) A */
+#pragma unroll
+        for (int i = 0; i < ITER; i++) {
+            const int k = tid + T * i;
+            cplx ak, an;
+            if (k == 0) {
+                const double zx = sre[0], zy = sim[0];
+                ak = make_double2(zx + zy, zx - zy);                                            /* X[0], X[N]: two reals */
+                an = make_double2(sre[GDG_PAD(N / 2)], -sim[GDG_PAD(N / 2)]);                   /* X[N/2] */
+                sk[i].x += ak.x * ak.x + pk[i].x * ak.x;                                        /* bins 0 and N (= 4096) are even */
+                sk[i].y += ak.y * ak.y + pk[i].y * ak.y;
+                sn[i].x += an.x * an.x + an.y * an.y + (pn[i].x * an.x + pn[i].y * an.y);       /* N/2 = 2048 is even */
+                sn[i].y += pn[i].x * an.y - pn[i].y * an.x;
+            } else {
+                const int n = N - k;
+                const cplx zk = make_double2(sre[GDG_PAD(k)], sim[GDG_PAD(k)]), zn = make_double2(sre[GDG_PAD(n)], sim[GDG_PAD(n)]);
+                const cplx A = make_double2(zk.x + zn.x, zk.y - zn.y), Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+                const cplx cw = cmul(tw2[k], Bv);
+                ak = make_double2((A.x + cw.y) * 0.5, (A.y - cw.x) * 0.5);
+                an = make_double2((A.x - cw.y) * 0.5, (-A.y - cw.x) * 0.5);
+                const double sg = (k & 1) ? -1.0 : 1.0;                                         /* n = N - k has the parity of k */
+                sk[i].x += ak.x * ak.x + ak.y * ak.y + sg * (pk[i].x * ak.x + pk[i].y * ak.y);  /* conj(p) a */
+                sk[i].y += sg * (pk[i].x * ak.y - pk[i].y * ak.x);
+                sn[i].x += an.x * an.x + an.y * an.y + sg * (pn[i].x * an.x + pn[i].y * an.y);
+                sn[i].y += sg * (pn[i].x * an.y - pn[i].y * an.x);
+            }
+            pk[i] = ak; pn[i] = an;
+        }
+        __syncthreads();                                                                        /* everyone is done reading Z */
+    }
+    /* inverse packed-real transform of S: r[2n], r[2n + 1] = Re, Im of z[n] (unscaled: arg-max and parabola are scale free) */
+#pragma unroll
+    for (int i = 0; i < ITER; i++) inv_head_store<LOGN>(tid + T * i, sk[i], sn[i], sre, sim, tw2);
+    __syncthreads();
+    cplx v[16];
+    constexpr int NP = sched_npass(LOGN);
+    run_lds_passes<LOGN, 0, NP - 1, true>(v, sre, sim, tw, tid);
+    constexpr int LR = sched_lr(LOGN, NP - 1), LNS = sched_lns(LOGN, NP - 1), R = 1 << LR, B = 16 / R;
+    pass_load<LOGN, LR>(v, sre, sim, tid);
+    pass_compute<LOGN, LR, LNS, true>(v, tw, tid);
+    __syncthreads();                                                                            /* all inputs of the last pass are in registers */
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const int j = tid + T * b;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const int n = j + t * (N / R);
+            s_all[2 * n] = v[b * R + t].x;                                                      /* linear: 8192 <= 2 * LDS */
+            s_all[2 * n + 1] = v[b * R + t].y;
+        }
+    }
+    __syncthreads();
+    tuner_pick([&](int lag) { return s_all[lag]; }, sample_rate, note_freqs, n_notes, out + ch, s_val, s_idx);
 }
 
 hipError_t gdg_launch_tuner_enqueue(double *d_rings, int nch, int wp, const double *d_samples, int stride, int frames, hipStream_t s) {
@@ -233,6 +357,19 @@ hipError_t gdg_launch_tuner_enqueue(double *d_rings, int nch, int wp, const doub
 
 /* d_tw_n: exp(-2 pi i m / N), m < N;  d_tw_m: exp(-i pi k / N), k <= N/2 */
 hipError_t gdg_tuner_tables_create(cplx **d_tw_n, cplx **d_tw_m) { return gdg_fir_tables_create(TUNER_N, d_tw_n, d_tw_m); }
+
+/* 1 when every lag the analysis can look at (window end + 1, tuner.go:454-500) lies inside the short-lag kernel's range */
+int gdg_tuner_short_ok(double sample_rate, double lowest_note_frequency) {
+    double hi_f = (sample_rate / lowest_note_frequency) + 0.5;
+    if (!(hi_f == hi_f) || hi_f < 0.0) return 0;
+    return hi_f + 1.0 <= (double)TUNER_SHORT_MAX_LAG;
+}
+
+hipError_t gdg_launch_tuner_short(const double *d_rings, int nch, int wp, double sample_rate, const cplx *tw4096, const cplx *tw2_4096,
+                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s) {
+    tuner_short_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_rings, wp, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out);
+    return hipGetLastError();
+}
 
 hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, double sample_rate, cplx *d_work,
                                     const cplx *d_tw_n, const cplx *d_tw_m, const cplx *tw512, const cplx *tw256,

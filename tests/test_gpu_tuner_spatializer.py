@@ -24,7 +24,8 @@ def tone(freq, n, sr, detune_cents=0.0, phase=0.0):
     return sum(a * np.sin(2 * np.pi * f * h * t + phase * h) for h, a in ((1, 0.5), (2, 0.25), (3, 0.12), (4, 0.06)))
 
 
-@pytest.mark.parametrize("sr,frames", [(96000, 8192), (192000, 8192), (44100, 1000)])
+# 300 kHz: the lag window reaches past 4096, i.e. the long (262144-point) analysis; the other rates take the short-lag kernel
+@pytest.mark.parametrize("sr,frames", [(96000, 8192), (192000, 8192), (44100, 1000), (22050, 512), (300000, 8192)])
 def test_tuner_matches_oracle_on_string_tones(pkg, oracle, sr, frames):
     nch = len(STRINGS)
     total = 96000 + 3 * frames                      # wraps the ring
