@@ -490,8 +490,14 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         d.dp[2] = sr;
         int C = (int)floor((0.05 * sr) + 0.5);
         d.jp[0] = C;
+        /* the history ring holds the reference's C samples PLUS one frame (the frame is appended BEFORE the delays are read, so every
+         * tap -- in the frame or before it -- is one ring access), rounded up to a power of two (index masks) + one guard cell that
+         * mirrors cell 0 (a sample pair never wraps).  Re-made (zeroed) when the reference re-makes its buffer: when C changes. */
+        size_t cp = 1;
+        while (cp < (size_t)C + (size_t)ctx->max_frames) cp <<= 1;
+        d.jp[1] = (int)(cp - 1);
         if (u.hist_key != C) rc = zero_is(ctx, u, 0, 1);
-        if (rc == GDG_OK) rc = ensure_hist(ctx, u, (size_t)C, C);
+        if (rc == GDG_OK) rc = ensure_hist(ctx, u, cp + 1, C);
         d.hist = u.d_hist;
         break;
     }

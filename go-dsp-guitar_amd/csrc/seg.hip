@@ -43,7 +43,7 @@ static_assert(CHK * SEG_T == GDG_MAX_FRAMES, "chunk size");
 __shared__ double s_a[SEG_LBUF];                     /* frame ping */
 __shared__ double s_b[SEG_LBUF];                     /* frame pong */
 __shared__ double s_scr[SEG_SCR];                    /* oversampling / run-list tile */
-__shared__ double s_tmp[2 * 4 * (SEG_T / 64) + 32];  /* scan scratch: (A, B) x up to 4 recurrences x waves; + 32 state cells */
+__shared__ double s_tmp[2 * 4 * (SEG_T / 64) + 32 + 8];  /* scan scratch: (A, B) x up to 4 recurrences x waves; + 32 state cells + 16 unit types */
 #define SEG_STASH (2 * 4 * (SEG_T / 64))          /* first state cell inside s_tmp */
 
 /* every unit is its own function (own register allocation); `flip` says which LDS frame is the input */
@@ -928,13 +928,39 @@ UNIT_FN unit_cabinet(UNIT_ARGS) {
 }
 
 /* ---- chorus: effects/chorus.go:19-131 ------------------------------------------------------------------
- * dp0 depth (0..10), dp1 angular speed, dp2 sample rate; jp0 ring capacity; ds0 previousPhase; is0 ring wp */
+ * dp0 depth (0..10), dp1 angular speed, dp2 sample rate; jp0 history length C of the reference, jp1 ring mask (capacity - 1,
+ * capacity = a power of two >= C + max frames); ds0 previousPhase; is0 ring write position.
+ * The frame is appended to the ring FIRST: sample t of the virtual sequence [history | frame] (t = -C .. N - 1) is then
+ * ring[(wp + t) & mask] whether it lies in the frame or before it -- one 16-byte load fetches the two neighbours of a fractional
+ * delay, no LDS-or-ring branch, no modulo.  (The first version branched per tap between LDS and ring and between pair and
+ * single loads: ~60 instructions and 6 branches per tap, 300 per sample.) */
 UNIT_FN unit_chorus(UNIT_ARGS) {
     UNIT_PROLOGUE
-    const double depth = U->dp[0], angular = U->dp[1], sr = U->dp[2];
-    const int C = U->jp[0], wp = U->is[0];
-    const double prev = U->ds[0];
-    const double *ring = U->hist;
+    const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
+    const double depth = Uc->dp[0], angular = Uc->dp[1], sr = Uc->dp[2];
+    const int C = Uc->jp[0], mask = Uc->jp[1];
+    GDG_GLOBAL double *ring = as_global(Uc->hist);
+    GDG_GLOBAL int *is = as_global(Uc->is);
+    GDG_GLOBAL double *ds = as_global(Uc->ds);
+    const int wp = is[0];
+    const double prev = ds[0];
+    /* 1. append the frame (pairs where possible); cell 0 is mirrored into the guard cell mask + 1 */
+    if ((N & 1) == 0 && (wp & 1) == 0) {
+        for (int i = 2 * (int)threadIdx.x; i < N; i += 2 * SEG_T) {
+            const int p = (wp + i) & mask;                          /* even, so p + 1 <= mask */
+            seg_v2d v = { in[LX(i)], in[LX(i + 1)] };
+            *(GDG_GLOBAL seg_v2d *)(ring + p) = v;
+            if (p == 0) ring[mask + 1] = v.x;
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += SEG_T) {
+            const int p = (wp + i) & mask;
+            const double v = in[LX(i)];
+            ring[p] = v;
+            if (p == 0) ring[mask + 1] = v;
+        }
+    }
+    __syncthreads();                                                /* the frame is in the ring (visible to the whole workgroup) */
     /* sin(zero_phase + j 2pi/5) by the angle-addition formula from ONE sincos (the five LFOs are 72 degrees apart):
      * differs from the reference's sin(fmod(zero_phase + j 2pi/5, 2pi)) by ~1e-16, i.e. ~1e-13 samples of delay */
     const double cj[5] = { 1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410, 0.30901699437494742410 };
@@ -948,31 +974,64 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
         sincos(zero_phase, &s0, &c0);
         sincos(angular * ((double)SEG_T / sr), &sd, &cd);
     }
-    auto sample = [&](int i) {
-        double effected = 0.0;
+    /* G samples at a time: first every address and ALL 5 G tap loads (16 bytes each), then the arithmetic -- written as two
+     * loops because the compiler otherwise waits for each load right where it is used: 40 exposed L2 / HBM latencies per thread
+     * were the whole cost of this unit (the ALU work is a third of it) */
+    auto samples = [&](const int (&idx)[2], int G) {
+        seg_v2d v[2][5];
+        double frs[2][5];
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            double offset = depth * ((s0 * cj[j]) + (c0 * sj[j]));
-            double delay_time = 0.001 * (40.0 + offset);
-            double delay_samples = delay_time * sr;
-            effected += 0.2 * frac_delay(in, ring, C, wp, i, delay_samples);
+        for (int g = 0; g < 2; g++) {
+            if (g < G) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    double offset = depth * ((s0 * cj[j]) + (c0 * sj[j]));
+                    double delay_time = 0.001 * (40.0 + offset);
+                    double delay_samples = delay_time * sr;
+                    /* chorus.go:63-90: early = floor, late = ceil, weights 1 - (d - early) and 1 - (late - d).  With fr = d - early
+                     * (exact): fr != 0: late = early + 1 and the weights are exactly 1 - fr and fr; fr == 0: late = early, both 1 */
+                    const double early = floor(delay_samples);
+                    frs[g][j] = delay_samples - early;
+                    const int t = idx[g] - (int)early - 1;          /* the older neighbour; t >= -C - 1, and t = -C - 1 only with fr == 0 */
+                    v[g][j] = *(const GDG_GLOBAL seg_v2d *)(ring + ((wp + t) & mask));      /* (V[t], V[t + 1]) */
+                }
+                double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
+                s0 = sn; c0 = cn;
+            }
         }
-        out[LX(i)] = (0.5 * in[LX(i)]) + (0.5 * effected);
-        double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
-        s0 = sn; c0 = cn;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (g < G) {
+                double effected = 0.0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const double fr = frs[g][j];
+                    const bool whole = fr == 0.0;
+                    const double se = v[g][j].y, sl = whole ? v[g][j].y : v[g][j].x;
+                    const double we = whole ? 1.0 : 1.0 - fr, wl = whole ? 1.0 : fr;
+                    effected += 0.2 * ((we * se) + (wl * sl));
+                }
+                out[LX(idx[g])] = (0.5 * in[LX(idx[g])]) + (0.5 * effected);
+            }
+        }
     };
     if (N == CHK * SEG_T) {
 #pragma unroll
-        for (int q = 0; q < CHK; q++) sample((int)threadIdx.x + q * SEG_T);     /* the batch block size: a fixed trip count */
+        for (int q = 0; q < CHK; q += 2) {                         /* the batch block size: a fixed trip count */
+            const int idx[2] = { (int)threadIdx.x + q * SEG_T, (int)threadIdx.x + (q + 1) * SEG_T };
+            samples(idx, 2);
+        }
     } else {
-        for (int i = threadIdx.x; i < N; i += SEG_T) sample(i);
+        for (int i = threadIdx.x; i < N; i += 2 * SEG_T) {
+            const int idx[2] = { i, i + SEG_T };
+            samples(idx, (i + SEG_T < N) ? 2 : 1);
+        }
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
         double buffer_time = (double)C / sr;          /* quirk: advances by the buffer length, not by N */
-        U->ds[0] = fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI);
+        ds[0] = fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI);
+        is[0] = (wp + N) & mask;
     }
-    ring_append(U->hist, C, &U->is[0], in, N);
 }
 
 /* ---- flanger / phaser: effects/flanger.go:19-119, effects/phaser.go:19-125 --------------------------------
@@ -1135,10 +1194,12 @@ UNIT_FN unit_siggen(UNIT_ARGS) {
 template <int Q>
 __device__ __forceinline__ void allpass_fetch(const double *ring, int M, int rp, int N, double (&pm0)[Q]) {
     const int cnt = min(M, N);
+    /* unconditional loads (index clamped into the ring): a load under a lane condition is waited for at the end of its branch, which
+     * turned these twelve "prefetches" into twelve exposed latencies */
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         int r = (int)threadIdx.x + q * SEG_T;
-        pm0[q] = (r < cnt) ? as_global(ring)[(rp + r) % M] : 0.0;
+        pm0[q] = as_global(ring)[(r < cnt) ? (rp + r) % M : 0];
     }
 }
 template <int Q>
@@ -1173,21 +1234,23 @@ __device__ __attribute__((noinline)) void allpass_generic(double *buf, double *r
 
 UNIT_FN unit_reverb(UNIT_ARGS) {
     UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
     const int tid = threadIdx.x;
-    const double dry = U->dp[0], half_wet = U->dp[1];
+    const double dry = Uc->dp[0], half_wet = Uc->dp[1];
     const double coeff[4] = { 0.1855, 0.18325, 0.17875, 0.17425 };
     int taps[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) taps[j] = U->jp[j];
-    const int DL = U->jp[4];
-    double *dl_ring = U->hist;
-    const int dl_wp = U->is[0];
+    for (int j = 0; j < 4; j++) taps[j] = Uc->jp[j];
+    const int DL = Uc->jp[4];
+    double *dl_ring = Uc->hist;
+    int *is_state = Uc->is;
+    const int dl_wp = as_global(is_state)[0];
     int M[3], rp[3];
     double *ring[3];
     {
         double *r = dl_ring + DL;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { M[k] = U->jp[5 + k] - 1; rp[k] = U->is[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
+        for (int k = 0; k < 3; k++) { M[k] = Uc->jp[5 + k] - 1; rp[k] = as_global(is_state)[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
     }
     /* ring heads of the three all-passes first (in-order return: they are home before the tap loads below are consumed) */
     const bool fast = min(M[1], N) <= 3 * SEG_T && min(M[2], N) <= SEG_T;
@@ -1206,21 +1269,31 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
          * wrap between the two samples of a pair falls back to two loads), half the load instructions of the sample-wise walk.
          * dlr[2q], dlr[2q + 1] hold the pair; the final mix below uses the same mapping. */
         const GDG_GLOBAL double *g = as_global((const double *)dl_ring);
+        /* all sixteen pair loads first, branch free (a pair that would wrap -- p = DL - 1, once per tap and frame -- is served from
+         * the pair below it and from cell 0), then the arithmetic */
+        const double g0 = g[0];
+        seg_v2d tv[REVERB_QMAX / 2][4];
+        int wrapm = 0;
+#pragma unroll
+        for (int q = 0; q < REVERB_QMAX / 2; q++) {
+            const int i0 = 2 * (tid + q * SEG_T);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int p = dl_wp + (i0 - taps[j]);
+                if (p < 0) p += DL;
+                const bool wraps = p + 1 >= DL;
+                wrapm |= wraps ? (1 << (q * 4 + j)) : 0;
+                tv[q][j] = *(const GDG_GLOBAL seg_v2d *)(g + (wraps ? DL - 2 : p));
+            }
+        }
 #pragma unroll
         for (int q = 0; q < REVERB_QMAX / 2; q++) {
             const int i0 = 2 * (tid + q * SEG_T);
             double pre0 = 0.0, pre1 = 0.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                int p = dl_wp + (i0 - taps[j]);
-                if (p < 0) p += DL;
-                double c0, c1;
-                if (p + 1 < DL) {
-                    seg_v2d v = *(const GDG_GLOBAL seg_v2d *)(g + p);
-                    c0 = v.x; c1 = v.y;
-                } else {
-                    c0 = g[p]; c1 = g[0];
-                }
+                const bool wraps = (wrapm >> (q * 4 + j)) & 1;
+                const double c0 = wraps ? tv[q][j].y : tv[q][j].x, c1 = wraps ? g0 : tv[q][j].y;
                 pre0 += coeff[j] * c0;
                 pre1 += coeff[j] * c1;
             }
@@ -1252,13 +1325,13 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
      * needed here anyway), then the barrier */
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (M[0] >= 1) allpass_chains<REVERB_QMAX>(out, ring[0], M[0], rp[0], N, pm_a, &U->is[1]);
+    if (M[0] >= 1) allpass_chains<REVERB_QMAX>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1]);
     if (fast) {
-        if (M[1] >= 1) allpass_chains<3>(out, ring[1], M[1], rp[1], N, pm_b, &U->is[2]);
-        if (M[2] >= 1) allpass_chains<1>(out, ring[2], M[2], rp[2], N, pm_c, &U->is[3]);
+        if (M[1] >= 1) allpass_chains<3>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2]);
+        if (M[2] >= 1) allpass_chains<1>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3]);
     } else {
-        if (M[1] >= 1) allpass_generic(out, ring[1], M[1], rp[1], N, &U->is[2]);
-        if (M[2] >= 1) allpass_generic(out, ring[2], M[2], rp[2], N, &U->is[3]);
+        if (M[1] >= 1) allpass_generic(out, ring[1], M[1], rp[1], N, &is_state[2]);
+        if (M[2] >= 1) allpass_generic(out, ring[2], M[2], rp[2], N, &is_state[3]);
     }
 #pragma unroll
     for (int q = 0; q < REVERB_QMAX; q++) {
@@ -1269,7 +1342,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         }
     }
     __syncthreads();
-    ring_append(dl_ring, DL, &U->is[0], in, N);
+    ring_append(dl_ring, DL, &is_state[0], in, N);
 }
 
 /* ---- generic one-pole section on an in-place sequence ----------------------------------------------------------------
@@ -1723,19 +1796,35 @@ __global__ void __launch_bounds__(SEG_T)
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, gdg_os_tables os, int *d_error) {
     const gdg_seg_chan ch = chans[blockIdx.x];
     const int tid = threadIdx.x;
-    if (((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0) {
+    /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
+    int *s_types = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32);       /* 16 ints behind the stash cells */
+    int my_type = 0;
+    if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
+    const bool aligned = ((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0;
+    if (aligned && N == CHK * SEG_T) {
+        /* the batch block size: every load of the thread is in flight before the first one is consumed (a loop waits for
+         * each load in turn: four exposed HBM latencies per workgroup) */
+        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)ch.src;
+        seg_v2d v[CHK / 2];
+#pragma unroll
+        for (int q = 0; q < CHK / 2; q++) v[q] = s2[tid + q * SEG_T];
+#pragma unroll
+        for (int q = 0; q < CHK / 2; q++) { const int i = tid + q * SEG_T; s_a[LX(2 * i)] = v[q].x; s_a[LX(2 * i + 1)] = v[q].y; }
+    } else if (aligned) {
         /* 16 bytes per lane: half the load instructions, 1 KiB per wave access */
         const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)ch.src;
         for (int i = tid; i < N / 2; i += SEG_T) { seg_v2d v = s2[i]; s_a[LX(2 * i)] = v.x; s_a[LX(2 * i + 1)] = v.y; }
     } else {
         for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = as_global(ch.src)[i];
     }
+    if (tid < ch.unit_count && tid < 16) s_types[tid] = my_type;
     __syncthreads();
     int flip = 0;                                   /* 0: s_a holds the current frame, 1: s_b */
     for (int u = 0; u < ch.unit_count; u++) {
         double *out = flip ? s_a : s_b;
         const gdg_seg_unit *U = units + ch.unit_begin + u;
-        switch (U->type) {
+        const int type = (u < 16) ? __builtin_amdgcn_readfirstlane(s_types[u]) : U->type;
+        switch (type) {
         case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N); break;
         case GDG_UNIT_OVERDRIVE:
         case GDG_UNIT_DISTORTION:
@@ -1760,7 +1849,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         case GDG_UNIT_OCTAVER: unit_octaver(U, flip, N); break;
         case GDG_UNIT_NOISEGATE: unit_noisegate(U, flip, N); break;
         default:
-            if (tid == 0) atomicExch(d_error, 1 + U->type);
+            if (tid == 0) atomicExch(d_error, 1 + type);
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
             break;
         }
@@ -1768,7 +1857,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         flip ^= 1;
     }
     const double *fin = flip ? s_b : s_a;
-    if (((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0) {
+    if (aligned) {
         GDG_GLOBAL seg_v2d *d2 = (GDG_GLOBAL seg_v2d *)ch.dst;
         for (int i = tid; i < N / 2; i += SEG_T) { seg_v2d v = { fin[LX(2 * i)], fin[LX(2 * i + 1)] }; d2[i] = v; }
     } else {
