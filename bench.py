@@ -297,6 +297,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (barrier + max of one scalar): gloo, so that NO RCCL / xGMI traffic exists anywhere in this job
         dist.init_process_group("gloo")
+    if os.environ.get("GDG_BENCH_ONE_DEVICE"):            # harness self-test on a one-GPU box: every rank shares device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
