@@ -368,24 +368,29 @@ fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict
     const double *bsrc = ch.src;
     cplx *out = ch.fdl + (size_t)(pos % ch.K) * N;
 
-    /* step A: radix-8 across the workgroup, straight from global memory (element e = n1 + 1024 n2: e < N/2 is the previous frame) */
+    /* step A: radix-8 across the workgroup, straight from global memory (element e = n1 + 1024 n2: e < N/2 is the previous frame).
+     * All sixteen frame loads and both twiddle loads of the thread are issued before anything is consumed: the copy of the frame
+     * into `prev` used to sit right behind each load, and the compiler waited for the loads one by one. */
+    cplx ua[2][8], wa[2];
 #pragma unroll
     for (int b = 0; b < 2; b++) {
         const int n1 = tid + T * b;
-        cplx u[8];
+        wa[b] = tw[n1];
 #pragma unroll
         for (int n2 = 0; n2 < 8; n2++) {
             const int e = n1 + 1024 * n2;
-            if (n2 < 4) u[n2] = gload(reinterpret_cast<const cplx *>(a + 2 * e));
-            else {
-                u[n2] = gload(reinterpret_cast<const cplx *>(bsrc + 2 * (e - N / 2)));
-                gstore(reinterpret_cast<cplx *>(prev_out + 2 * (e - N / 2)), u[n2]);
-            }
+            ua[b][n2] = (n2 < 4) ? gload(reinterpret_cast<const cplx *>(a + 2 * e)) : gload(reinterpret_cast<const cplx *>(bsrc + 2 * (e - N / 2)));
         }
-        Dft<8, false>::run(u);
-        twiddle_powers8(u, tw[n1]);
+    }
 #pragma unroll
-        for (int k2 = 0; k2 < 8; k2++) { sre[k2 * GDG_W_RL + GDG_PAD(n1)] = u[k2].x; sim[k2 * GDG_W_RL + GDG_PAD(n1)] = u[k2].y; }
+    for (int b = 0; b < 2; b++) {
+        const int n1 = tid + T * b;
+#pragma unroll
+        for (int n2 = 4; n2 < 8; n2++) gstore(reinterpret_cast<cplx *>(prev_out + 2 * (n1 + 1024 * n2 - N / 2)), ua[b][n2]);
+        Dft<8, false>::run(ua[b]);
+        twiddle_powers8(ua[b], wa[b]);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) { sre[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].x; sim[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].y; }
     }
     __syncthreads();
     /* step B: wave w transforms region w; X[8 k1 + w] back into the region in natural k1 order */
