@@ -227,12 +227,23 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ok = ok && hipMalloc((void **)&ctx->d_error, sizeof(int)) == hipSuccess;
     ok = ok && hipMemset(ctx->d_error, 0, sizeof(int)) == hipSuccess;
     /* oversampling tables: 77 + 155 taps, 6 + 18 Lanczos-3 weights (resample.go:36-66 evaluated once per phase) */
-    std::vector<double> tab(77 + 155 + 6 + 18);
+    const size_t os_base = 77 + 155 + 6 + 18;
+    std::vector<double> tab(os_base + 2 * GDG_OS_NE(2) + 4 * GDG_OS_NE(4), 0.0);
     for (int k = 0; k < 39; k++) { tab[k] = GDG_AA2_HALF[k]; tab[76 - k] = GDG_AA2_HALF[k]; }
     for (int k = 0; k < 78; k++) { tab[77 + k] = GDG_AA4_HALF[k]; tab[77 + 154 - k] = GDG_AA4_HALF[k]; }
     for (int q = 0; q < 6; q++) tab[232 + q] = lanczos_kernel((double)(2 - q) + 0.5, 3.0);
     for (int r = 1; r < 4; r++)
         for (int q = 0; q < 6; q++) tab[238 + (r - 1) * 6 + q] = lanczos_kernel((double)(2 - q) + 0.25 * (double)r, 3.0);
+    for (int F = 2; F <= 4; F += 2) {
+        /* phase-major, zero padded copies for the register-blocked decimator (seg.hip os_decimate) */
+        double *tp = tab.data() + os_base + (F == 4 ? 2 * GDG_OS_NE(2) : 0);
+        const double *taps = tab.data() + (F == 4 ? 77 : 0);
+        for (int r = 0; r < F; r++)
+            for (int e = 0; e < GDG_OS_NE(F); e++) {
+                int b = e - GDG_OS_PADLO(F), k = F * b - r;
+                tp[r * GDG_OS_NE(F) + e] = (b >= 0 && k >= 0 && k < GDG_OS_TAPS(F)) ? taps[k] : 0.0;
+            }
+    }
     ok = ok && hipMalloc((void **)&ctx->d_os, tab.size() * sizeof(double)) == hipSuccess;
     ok = ok && hipMemcpy(ctx->d_os, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { gdg_ctx_destroy(ctx); return GDG_ERR_HIP; }
@@ -240,6 +251,8 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ctx->os.taps4 = ctx->d_os + 77;
     ctx->os.lanczos2 = ctx->d_os + 232;
     ctx->os.lanczos4 = ctx->d_os + 238;
+    ctx->os.tapsP2 = ctx->d_os + os_base;
+    ctx->os.tapsP4 = ctx->d_os + os_base + 2 * GDG_OS_NE(2);
     *out = ctx;
     return GDG_OK;
 }

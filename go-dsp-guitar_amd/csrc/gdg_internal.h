@@ -101,7 +101,17 @@ struct gdg_os_tables {
     const double *taps4;      /* 155 */
     const double *lanczos2;   /* [1][6] weights of the half-sample phase */
     const double *lanczos4;   /* [3][6] weights of phases 1/4, 2/4, 3/4 */
+    /* the decimator taps again, phase-major and zero padded for the register-blocked decimator of seg.hip:
+     * tp[r][e] = taps[F (e - GDG_OS_PADLO(F)) - r] where that index exists, else 0 */
+    const double *tapsP2;     /* [2][GDG_OS_NE(2)] */
+    const double *tapsP4;     /* [4][GDG_OS_NE(4)] */
 };
+#define GDG_OS_TAPS(F) ((F) == 2 ? 77 : 155)
+#define GDG_OS_BACK(F) ((GDG_OS_TAPS(F) - 1 + (F) - 1) / (F))      /* 38 / 39 */
+#define GDG_OS_R(F) ((F) == 2 ? 4 : 2)                              /* consecutive outputs per thread */
+#define GDG_OS_NC 48                                                /* slots per phase walked by a thread (>= BACK + R, multiple of 8) */
+#define GDG_OS_PADLO(F) (GDG_OS_NC - 1 - GDG_OS_BACK(F))
+#define GDG_OS_NE(F) (GDG_OS_NC + GDG_OS_R(F) - 1 + 1)              /* table entries per phase (+1: even) */
 
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames,
                           gdg_os_tables os, int *d_error, hipStream_t s);

@@ -653,88 +653,137 @@ __device__ __forceinline__ double shape(const Shaper &S, double sample) {
  *   stage 1: one thread per INPUT sample: the six-sample Lanczos window is read once and gives all F phases
  *            (resample.go:148-176: phase 0 is the input sample itself), each shaped and stored in a POLYPHASE layout
  *            (sample m at [m mod F][m div F]), so that stage 2's lanes walk consecutive LDS words;
- *   stage 2: one thread per OUTPUT sample: y = clip(sum_k h[k] w[F o - k]) * 0.944 (filter.Process semantics), k ascending as
- *            in the reference; the taps come through the scalar cache (uniform index, constant address space), the samples
- *            from LDS without bank conflicts.  (The first version read taps per lane from global memory and walked LDS with
- *            a stride of F doubles: 8-way conflicts at 4x.)
- * hist: [8 inputs | TAPS - 1 oversampled samples of the previous call]. */
+ *   stage 2: y = clip(sum_k h[k] w[F o - k]) * 0.944 (filter.Process semantics; the reference computes this sum by FFT, so there
+ *            is no operation order to keep: fused multiply-adds).  The decimator was LDS-bandwidth bound -- 155 eight-byte reads
+ *            per output sample -- so every thread now makes R = 2 (4x) or 4 (2x) CONSECUTIVE outputs from one sliding window:
+ *            16-byte loads of slot pairs, each loaded value feeding up to R accumulators (taps through the scalar cache).
+ * To give all 1024 threads R outputs a tile has S = 2048 (4x) / 4096 (2x) outputs: the staging area is the whole OUTPUT frame
+ * buffer (8448 words), and the tiles are walked from the END of the frame so that a tile's results can overwrite its own inputs in
+ * the INPUT buffer (lower tiles only read inputs below it): the unit works in place and the caller does not flip the buffers.
+ * 4 (or 2) tiles and 8 (4) barriers per frame instead of 11 tiles of 792 outputs with 23 % of the lanes idle.
+ * hist: [8 inputs | TAPS - 1 oversampled samples of the previous call]; scr: the previous call's tail, saved before it is replaced. */
 __device__ __forceinline__ const double *uniform_ptr(const double *p) {
     unsigned long long v = (unsigned long long)p;
     unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const double *)(((unsigned long long)hi << 32) | lo);
 }
+
+template <int F> struct OsCfg {
+    static constexpr int TAPS = GDG_OS_TAPS(F);
+    static constexpr int BACK = GDG_OS_BACK(F);                   /* input samples reached back by the filter: ceil((TAPS-1)/F) */
+    static constexpr int R = GDG_OS_R(F);                         /* outputs per thread */
+    static constexpr int S = R * SEG_T;                           /* outputs per tile */
+    static constexpr int NC = GDG_OS_NC;                          /* slots per phase a thread walks: R t .. R t + NC - 1 */
+    static constexpr int PH = (S - R + NC + 1) & ~1;              /* capacity of one phase array (even: pair loads stay aligned) */
+    static constexpr int NE = GDG_OS_NE(F), PADLO = GDG_OS_PADLO(F);
+    static_assert(NC >= BACK + R && NC % 8 == 0, "slot window");
+    static_assert(F * PH <= SEG_LBUF, "the staging area is one frame buffer");
+};
+
+/* The decimating filter for the R consecutive outputs of thread t.  Output j reads slot R t + c of phase r with tap
+ * F (j + BACK - c) - r; the phase-major table tp[r][.] is zero where that tap does not exist, so the walk over c = 0 .. NC - 1 is
+ * branch free.  Eight slots (four 16-byte LDS loads) and their 8 + R - 1 table entries (scalar loads, consecutive) per step. */
 template <int F>
-__device__ __forceinline__ void shaper_oversampled(const Shaper &S, const double *in, double *out, double *scr, double *hist_generic,
+__device__ __forceinline__ void os_decimate(const double *stage, const GDG_CONST double *tp, int t, double (&acc)[OsCfg<F>::R]) {
+    constexpr int BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, PH = OsCfg<F>::PH, NC = OsCfg<F>::NC, NE = OsCfg<F>::NE, PADLO = OsCfg<F>::PADLO;
+#pragma unroll
+    for (int j = 0; j < R; j++) acc[j] = 0.0;
+#pragma unroll 1
+    for (int r = 0; r < F; r++) {
+        const double *ph = stage + r * PH + R * t;                /* R t is even and r PH is even: 16-byte aligned pairs */
+        const GDG_CONST double *tr = tp + r * NE;
+#pragma unroll 1
+        for (int cb = 0; cb < NC / 8; cb++) {
+            seg_v2d w2[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) w2[q] = *reinterpret_cast<const seg_v2d *>(ph + 8 * cb + 2 * q);
+            /* entry of (slot c = 8 cb + i, output j): (j + BACK - c) + PADLO = (NC - 1 - 8 cb - 7) + (j - i + 7) */
+            const GDG_CONST double *te = tr + (NC - 8 - 8 * cb);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double w = (i & 1) ? w2[i >> 1].y : w2[i >> 1].x;
+#pragma unroll
+                for (int j = 0; j < R; j++) acc[j] = fma(te[j - i + 7], w, acc[j]);
+            }
+        }
+    }
+    (void)BACK; (void)PADLO;
+}
+
+template <int F>
+__device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, double *stage, double *scr, double *hist_generic,
                                                    const double *taps_generic, const double *lw_generic, int N) {
-    constexpr int TAPS = (F == 2) ? 77 : 155;
-    constexpr int PH = SEG_SCR / F;                           /* capacity of one phase array */
-    constexpr int BACK = (TAPS - 1 + F - 1) / F;              /* input samples reached back by the filter: ceil((TAPS-1)/F) */
-    constexpr int TILE = PH - BACK - 1;                       /* output samples per tile */
+    constexpr int TAPS = OsCfg<F>::TAPS, BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, TILE = OsCfg<F>::S, PH = OsCfg<F>::PH;
     /* wave-uniform table pointers in SGPRs + constant address space: the taps arrive through scalar loads */
-    const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);
+    const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);      /* phase-major, zero padded */
     const GDG_CONST double *lw = (const GDG_CONST double *)uniform_ptr(lw_generic);
     GDG_GLOBAL double *hist = as_global(hist_generic);
     const int tid = threadIdx.x;
+    /* the previous call's state, before it is replaced: scr[0 .. TAPS-2] the oversampled tail, scr[TAPS-1 .. TAPS+6] the 8 inputs */
+    for (int q = tid; q < TAPS - 1 + 8; q += SEG_T) scr[q] = (q < TAPS - 1) ? hist[8 + q] : hist[q - (TAPS - 1)];
+    __syncthreads();
     /* stream sample s[k]: k < 0 from the 8-sample history, else the frame */
-    auto s_at = [&](int k) -> double { return k >= 0 ? in[LX(k)] : hist[8 + k]; };
-    for (int o0 = 0; o0 < N; o0 += TILE) {
+    auto s_at = [&](int k) -> double { return k >= 0 ? in[LX(k)] : scr[TAPS - 1 + 8 + k]; };
+    /* last 8 inputs (concatenation with the old history when N < 8): taken now, the frame is overwritten below */
+    double keep = 0.0;
+    if (tid < 8) keep = s_at(N - 8 + tid);
+    const int n_tiles = (N + TILE - 1) / TILE;
+    for (int tile = n_tiles - 1; tile >= 0; tile--) {
+        const int o0 = tile * TILE;
         const int S_out = min(TILE, N - o0);
         const int I0 = o0 - BACK;                             /* input index held at slot 0 of every phase array */
         const int slots = S_out + BACK;                       /* slots I0 .. o0 + S_out - 1 */
-        for (int idx = tid; idx < slots; idx += SEG_T) {
+        for (int idx = tid; idx < min(slots + OsCfg<F>::NC, PH); idx += SEG_T) {
             const int i = I0 + idx;
-            if (i < 0) {
+            if (idx >= slots) {
+                /* a thread's walk reaches up to NC - BACK - 1 slots past the tile: defined values that only ever meet zero entries */
+#pragma unroll
+                for (int r = 0; r < F; r++) stage[r * PH + idx] = 0.0;
+            } else if (i < 0) {
                 /* oversampled samples of the previous call (m = F i + r < 0); older than the stored tail: never read */
 #pragma unroll
                 for (int r = 0; r < F; r++) {
                     const int m = F * i + r;
-                    scr[r * PH + idx] = (m >= -(TAPS - 1)) ? hist[8 + (TAPS - 1) + m] : 0.0;
+                    stage[r * PH + idx] = (m >= -(TAPS - 1)) ? scr[(TAPS - 1) + m] : 0.0;
                 }
             } else {
                 double w6[6];
 #pragma unroll
                 for (int t = 0; t < 6; t++) w6[t] = s_at(i - 6 + t);
-                scr[idx] = shape(S, w6[2]);                   /* phase 0: s[i - 4], resample.go:160-164 */
+                stage[idx] = shape(S, w6[2]);                 /* phase 0: s[i - 4], resample.go:160-164 */
 #pragma unroll
                 for (int r = 1; r < F; r++) {
                     double up = 0.0;
 #pragma unroll
                     for (int t = 0; t < 6; t++) up += w6[t] * lw[(r - 1) * 6 + t];
-                    scr[r * PH + idx] = shape(S, up);
+                    stage[r * PH + idx] = shape(S, up);
                 }
             }
         }
         __syncthreads();
-        for (int o = tid; o < S_out; o += SEG_T) {
-            /* w[F (o0 + o) - k] lives in phase (-k mod F) at slot o + BACK - ceil(k / F) */
-            const double *base = scr + o + BACK;
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < TAPS; k++) {
-                const int r = (F - (k % F)) % F, back = (k + F - 1) / F;
-                acc += taps[k] * base[r * PH - back];
-            }
-            out[LX(o0 + o)] = ATTENUATION_HALF_DECIBEL * clip1(acc);
-        }
-        if (o0 + TILE >= N) {
+        if (tile == n_tiles - 1) {
             /* keep the last TAPS - 1 oversampled samples m = F N - (TAPS - 1) .. F N - 1 */
             for (int q = tid; q < TAPS - 1; q += SEG_T) {
                 const int m = F * N - (TAPS - 1) + q;
                 const int i = (m >= 0) ? m / F : -((-m + F - 1) / F);
                 const int r = m - i * F;
-                hist[8 + q] = scr[r * PH + (i - I0)];          /* i >= I0 always: F * BACK >= TAPS - 1 */
+                hist[8 + q] = stage[r * PH + (i - I0)];       /* i >= I0 always: F * BACK >= TAPS - 1 */
             }
+        }
+        if (R * tid < S_out) {
+            double acc[R];
+            os_decimate<F>(stage, taps, tid, acc);
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                if (R * tid + j < S_out) in[LX(o0 + R * tid + j)] = ATTENUATION_HALF_DECIBEL * clip1(acc[j]);     /* in place */
         }
         __syncthreads();
     }
-    /* last 8 inputs (concatenation with the old history when N < 8) */
-    double keep = 0.0;
-    if (tid < 8) keep = s_at(N - 8 + tid);
-    __syncthreads();
     if (tid < 8) hist[tid] = keep;
 }
 
-UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
+/* returns 1 when the result is in the INPUT buffer (oversampled: in place), 0 when it is in the other one */
+__device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
     UNIT_PROLOGUE
     Shaper S;
     S.type = U->type; S.valve = U->ip[4];
@@ -742,10 +791,11 @@ UNIT_FN unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
     const int f = U->jp[0];
     if (f <= 1) {
         for (int i = threadIdx.x; i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
-        return;
+        return 0;
     }
-    if (f == 2) shaper_oversampled<2>(S, in, out, scr, U->hist, os.taps2, os.lanczos2, N);
-    else shaper_oversampled<4>(S, in, out, scr, U->hist, os.taps4, os.lanczos4, N);
+    if (f == 2) shaper_oversampled<2>(S, in, out, scr, U->hist, os.tapsP2, os.lanczos2, N);
+    else shaper_oversampled<4>(S, in, out, scr, U->hist, os.tapsP4, os.lanczos4, N);
+    return 1;
 }
 
 /* ---- tone stack: effects/tonestack.go:19-100 ------------------------------------------------------
@@ -1824,11 +1874,12 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         double *out = flip ? s_a : s_b;
         const gdg_seg_unit *U = units + ch.unit_begin + u;
         const int type = (u < 16) ? __builtin_amdgcn_readfirstlane(s_types[u]) : U->type;
+        int inplace = 0;
         switch (type) {
         case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N); break;
         case GDG_UNIT_OVERDRIVE:
         case GDG_UNIT_DISTORTION:
-        case GDG_UNIT_EXCESS: unit_shaper(U, flip, N, os); break;
+        case GDG_UNIT_EXCESS: inplace = unit_shaper(U, flip, N, os); break;
         case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N); break;
         case GDG_UNIT_CABINET: unit_cabinet(U, flip, N); break;
         case GDG_UNIT_CHORUS: unit_chorus(U, flip, N); break;
@@ -1854,7 +1905,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
             break;
         }
         __syncthreads();
-        flip ^= 1;
+        if (!__builtin_amdgcn_readfirstlane(inplace)) flip ^= 1;
     }
     const double *fin = flip ? s_b : s_a;
     if (aligned) {
