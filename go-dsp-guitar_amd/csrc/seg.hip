@@ -1675,7 +1675,48 @@ UNIT_FN unit_autoyoy(UNIT_ARGS) {
 /* ---- auto-wah: effects/autowah.go:20-130 -------------------------------------------------------------------------------------------
  * ip0 follow; dp0 level A, dp1 level B, dp2 freq A, dp3 freq B, dp4 slope, dp5 exp(-20/sr), dp6 1 - dp5, dp7 sr;
  * ds0 envelope, ds1..8 hcv, ds9..16 lcv.  CLOBBERS its input buffer (it is free: the next unit overwrites it anyway). */
+/* the batch block size: the frame chunk, the per-sample coefficients and the running signal stay in registers through all sixteen
+ * time-varying sections (the generic version below walks two LDS arrays four times per section and is LDS bound) */
+__device__ __forceinline__ void autowah_full(const gdg_seg_unit *Ug, int flip) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
+    double *st = tmp + SEG_STASH;                    /* [0] envelope, [1..8] hcv, [9..16] lcv */
+    GDG_GLOBAL double *ds = as_global(U->ds);
+    if (threadIdx.x < 17) st[threadIdx.x] = ds[threadIdx.x];
+    const double la = U->dp[0], lb = U->dp[1], fa = U->dp[2], fb = U->dp[3], slope = U->dp[4], sr = U->dp[7];
+    const ChunkT<true> c = full_chunk();
+    double v[CHK], al[CHK];
+    chunk_load(in, c, v);
+    __syncthreads();
+    {
+        double e[CHK], s = st[0];
+        envelope_reg(v, e, c, U->ip[0], U->dp[5], U->dp[6], s, tmp);
+        if (c.last) ds[0] = s;
+#pragma unroll
+        for (int i = 0; i < CHK; i++) {
+            double level = 20.0 * log10(e[i]);
+            double frequency;
+            if (level <= la) frequency = fa;
+            else if (level >= lb) frequency = fb;
+            else frequency = fa + (slope * (level - la));
+            double arg = -frequency / sr;
+            al[i] = 1.0 - exp(arg);
+        }
+    }
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+        double hs = st[1 + j], ls = st[9 + j];
+        onepole_reg_var<OP_DIFF_OLD>(v, al, c, hs, tmp);
+        onepole_reg_var<OP_NEW>(v, al, c, ls, tmp);
+        if (c.last) { ds[1 + j] = hs; ds[9 + j] = ls; }
+    }
+#pragma unroll
+    for (int i = 0; i < CHK; i++) v[i] = clip1(256.0 * v[i]);
+    chunk_store(out, c, v);
+}
+
 UNIT_FN unit_autowah(UNIT_ARGS) {
+    if (N == CHK * SEG_T) { autowah_full(U, flip); return; }
     UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
     const double la = U->dp[0], lb = U->dp[1], fa = U->dp[2], fb = U->dp[3], slope = U->dp[4], sr = U->dp[7];
