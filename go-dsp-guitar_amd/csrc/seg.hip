@@ -1573,8 +1573,137 @@ __device__ __forceinline__ void fir_decimate_linear(const double *scr, const dou
     }
 }
 
-UNIT_FN unit_fuzz_os(UNIT_ARGS, const gdg_os_tables &os) {
+/* Frames that are a multiple of the big tile (the batch block size): the oversampled stream of a tile is exactly CHK = 8 samples per
+ * thread, so the follower and the coupling capacitor run as constant-coefficient scans on register chunks (lin_scan), the shaped
+ * samples go to the polyphase staging area in the OUTPUT frame buffer and the register-blocked decimator of the memoryless shapers
+ * finishes the tile in place.  Tiles go FORWARD (the follower's state does), so the last eight inputs of a tile are saved before its
+ * results overwrite them.  4 (4x) / 2 (2x) tiles per frame instead of 21 / 11 with ten barriers each and 40 % of the lanes idle. */
+template <int F>
+__device__ __forceinline__ void fuzz_os_tiles(const gdg_seg_unit *Ug, double *in, double *stage, double *scr, double *tmp, const gdg_os_tables &os, int N) {
+    constexpr int TAPS = OsCfg<F>::TAPS, BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, TILE = OsCfg<F>::S, PH = OsCfg<F>::PH;
+    static_assert(F * R == CHK, "a thread's share of a tile is one register chunk");
+    const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
+    const int tid = threadIdx.x, follow = U->ip[0];
+    const double bias = U->dp[0], gain = U->dp[1], fuzz = U->dp[2], fuzz_inv = U->dp[3], level = U->dp[4];
+    const double d_inv = U->dp[5], d = U->dp[6];
+    const GDG_CONST double *tp = (const GDG_CONST double *)uniform_ptr(F == 2 ? os.tapsP2 : os.tapsP4);
+    const GDG_CONST double *lw = (const GDG_CONST double *)uniform_ptr(F == 2 ? os.lanczos2 : os.lanczos4);
+    GDG_GLOBAL double *hist = as_global(U->hist);
+    GDG_GLOBAL double *ds = as_global(U->ds);
+    double *tab_env = scr, *tab_cap = scr + LT_SIZE, *carry8 = scr + 2 * LT_SIZE, *old_tail = scr + 2 * LT_SIZE + 8;
+    /* the two carried states, double buffered by tile: a fast wave finishes a tile's replay (and stores the new state) before a
+     * slow one has read the old state inside the same scan */
+    double *st = tmp + SEG_STASH + 16;               /* [2 * (tile & 1) + {0: envelope, 1: coupling capacitor}] */
+    if (tid == 0) { st[0] = ds[0]; st[1] = ds[1]; }
+    if (tid < 64) { if (follow == 0) lin_tab_build<true>(tab_env, 0.0, d_inv); else lin_tab_build<false>(tab_env, d, d_inv); }
+    else if (tid < 128) lin_tab_build<false>(tab_cap, d, 1.0 - d);
+    for (int q = tid; q < TAPS - 1 + 8; q += SEG_T) { if (q < 8) carry8[q] = hist[q]; else old_tail[q - 8] = hist[q]; }
+    __syncthreads();
+    int parity = 0, tile = 0;
+    for (int o0 = 0; o0 < N; o0 += TILE, tile++) {
+        const int I0 = o0 - BACK;
+        const double *st_in = st + 2 * (tile & 1);
+        double *st_out = st + 2 * ((tile + 1) & 1);
+        /* inputs before this tile: the eight saved ones (previous tile's last inputs, or the previous call's) */
+        auto s_at = [&](int k) -> double { return k >= o0 ? in[LX(k)] : carry8[k - (o0 - 8)]; };
+        /* 1. this thread's R inputs -> CHK oversampled samples (oversampling.go:54-115) */
+        double w[CHK];
+#pragma unroll
+        for (int g = 0; g < R; g++) {
+            const int i = o0 + R * tid + g;
+            double w6[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) w6[t] = s_at(i - 6 + t);
+            w[F * g] = w6[2];
+#pragma unroll
+            for (int r = 1; r < F; r++) {
+                double up = 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; t++) up += w6[t] * lw[(r - 1) * 6 + t];
+                w[F * g + r] = up;
+            }
+        }
+        double keep8 = 0.0;
+        if (tid < 8) keep8 = in[LX(o0 + TILE - 8 + tid)];
+        /* 2. follower at the oversampled rate, fuzz curve, coupling capacitor (fuzz.go:47-106) */
+        double e[CHK];
+        if (follow == 0) {
+            double s = lin_scan<true>(lin_chunk_map<true>(w, tab_env), tab_env, &st_in[0], tmp + parity * 2 * LX_SLOT);
+#pragma unroll
+            for (int i = 0; i < CHK; i++) { s *= d_inv; double q = fabs(w[i]); if (q > s) s = q; e[i] = s; }
+            if (tid == SEG_T - 1) st_out[0] = s;
+        } else if (follow == 1) {
+            double s = lin_scan<false>(lin_chunk_map<false, true>(w, tab_env), tab_env, &st_in[0], tmp + parity * 2 * LX_SLOT);
+#pragma unroll
+            for (int i = 0; i < CHK; i++) { double diff = fabs(w[i]) - s; s += diff * d; e[i] = s; }
+            if (tid == SEG_T - 1) st_out[0] = s;
+        } else {
+#pragma unroll
+            for (int i = 0; i < CHK; i++) e[i] = 1.0;
+            if (tid == SEG_T - 1) st_out[0] = 1.0;
+        }
+        parity ^= 1;
+#pragma unroll
+        for (int i = 0; i < CHK; i++) {
+            double sample = w[i];
+            double bias_voltage = bias * e[i];
+            double pre = clip1(gain * (sample - bias_voltage));
+            w[i] = (fuzz * pre) + (fuzz_inv * sample);
+        }
+        {
+            double s = lin_scan<false>(lin_chunk_map<false>(w, tab_cap), tab_cap, &st_in[1], tmp + parity * 2 * LX_SLOT);
+#pragma unroll
+            for (int i = 0; i < CHK; i++) { double diff = w[i] - s; s += diff * d; w[i] = level * clip1(w[i] - s); }
+            if (tid == SEG_T - 1) st_out[1] = s;
+        }
+        parity ^= 1;
+        /* 3. polyphase staging: slot of input i is i - I0; the BACK slots before the tile come from the previous tile / call */
+#pragma unroll
+        for (int g = 0; g < R; g++)
+#pragma unroll
+            for (int r = 0; r < F; r++) stage[r * PH + BACK + R * tid + g] = w[F * g + r];
+        if (o0 == 0) {
+            for (int q = tid; q < F * BACK; q += SEG_T) {
+                const int r = q / BACK, idx = q - r * BACK, m = F * (I0 + idx) + r;          /* m < 0: the previous call's tail */
+                stage[r * PH + idx] = (m >= -(TAPS - 1)) ? old_tail[(TAPS - 1) + m] : 0.0;
+            }
+        }
+        for (int q = tid; q < F * (OsCfg<F>::NC - BACK); q += SEG_T) {                        /* the walk's overrun: zeros */
+            const int r = q / (OsCfg<F>::NC - BACK), idx = q - r * (OsCfg<F>::NC - BACK);
+            if (BACK + TILE + idx < PH) stage[r * PH + BACK + TILE + idx] = 0.0;
+        }
+        __syncthreads();
+        if (tid < 8) carry8[tid] = keep8;
+        if (o0 + TILE >= N) {
+            for (int q = tid; q < TAPS - 1; q += SEG_T) {
+                const int m = F * N - (TAPS - 1) + q;
+                const int i = m / F, r = m - i * F;                                              /* m >= 0: N >= TILE > TAPS */
+                hist[8 + q] = stage[r * PH + (i - I0)];
+            }
+        }
+        /* 4. decimate in place */
+        double acc[R];
+        os_decimate<F>(stage, tp, tid, acc);
+#pragma unroll
+        for (int j = 0; j < R; j++) in[LX(o0 + R * tid + j)] = ATTENUATION_HALF_DECIBEL * clip1(acc[j]);
+        /* 5. slide: the last BACK slots of every phase become the head of the next tile */
+        double keep = 0.0;
+        const bool mine = tid < F * BACK;
+        const int kr = tid / BACK, kidx = tid - kr * BACK;
+        if (mine) keep = stage[kr * PH + TILE + kidx];
+        __syncthreads();
+        if (mine) stage[kr * PH + kidx] = keep;
+        __syncthreads();
+    }
+    if (tid < 8) hist[tid] = carry8[tid];
+    if (tid == 0) { ds[0] = st[2 * (tile & 1)]; ds[1] = st[2 * (tile & 1) + 1]; }
+}
+
+/* returns 1 when the result is in the INPUT buffer */
+__device__ __attribute__((noinline)) int unit_fuzz_os(UNIT_ARGS, const gdg_os_tables &os) {
     UNIT_PROLOGUE
+    if (U->jp[0] == 4 && N % OsCfg<4>::S == 0) { fuzz_os_tiles<4>(U, in, out, scr, tmp, os, N); return 1; }
+    if (U->jp[0] == 2 && N % OsCfg<2>::S == 0) { fuzz_os_tiles<2>(U, in, out, scr, tmp, os, N); return 1; }
     const int tid = threadIdx.x;
     const int f = U->jp[0];
     const int follow = U->ip[0];
@@ -1645,6 +1774,7 @@ UNIT_FN unit_fuzz_os(UNIT_ARGS, const gdg_os_tables &os) {
     __syncthreads();
     if (tid < 8) hist[tid] = keep8;
     if (tid == 0) { U->ds[0] = st[0]; U->ds[1] = st[1]; }
+    return 0;
 }
 
 /* ---- auto-yoy: effects/autoyoy.go:19-157 ----------------------------------------------------------------------------------------
@@ -1932,7 +2062,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N); break;
         case GDG_UNIT_REVERB: unit_reverb(U, flip, N); break;
         case GDG_UNIT_FUZZ:
-            if (U->jp[0] > 1) unit_fuzz_os(U, flip, N, os);
+            if (U->jp[0] > 1) inplace = unit_fuzz_os(U, flip, N, os);
             else unit_fuzz(U, flip, N);
             break;
         case GDG_UNIT_AUTOYOY: unit_autoyoy(U, flip, N); break;
