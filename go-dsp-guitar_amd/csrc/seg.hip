@@ -1871,7 +1871,43 @@ UNIT_FN unit_autowah(UNIT_ARGS) {
 }
 
 /* ---- bandpass: effects/bandpass.go:20-98.  jp0 half order; dp0 high-pass coefficient, dp1 low-pass coefficient; ds0..3 hcv, ds4..7 lcv */
+/* the batch block size: every stage is a high-pass feeding a low-pass with the SAME two coefficients -- one 2 x 2 scan per stage
+ * (lin2_scan, one table for all stages), then the reference's loop body and the clip between stages */
+__device__ __forceinline__ void bandpass_full(const gdg_seg_unit *Ug, int flip) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
+    double *st = tmp + SEG_STASH;                    /* [0..3] hcv, [4..7] lcv */
+    GDG_GLOBAL double *ds = as_global(U->ds);
+    const double aH = U->dp[0], aL = U->dp[1];
+    const int half = U->jp[0];
+    if (threadIdx.x < 8) st[threadIdx.x] = ds[threadIdx.x];
+    if (threadIdx.x < 64) lin2_tab_build(scr, aH, aL);
+    const ChunkT<true> c = full_chunk();
+    double v[CHK];
+    chunk_load(in, c, v);
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < half; j++) {
+        double h = 0.0, l = 0.0;
+#pragma unroll
+        for (int i = 0; i < CHK; i++) { h = fma(scr[L2_W + 2 * i], v[i], h); l = fma(scr[L2_W + 2 * i + 1], v[i], l); }
+        lin2_scan(h, l, scr, &st[j], &st[4 + j], tmp + (j & 1) * 2 * LX_SLOT);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) {                      /* bandpass.go:70-91 */
+            double diff = v[i] - h;
+            h += diff * aH;
+            diff -= l;
+            double iv = l;
+            l += diff * aL;
+            v[i] = clip1(iv);
+        }
+        if (c.last) { ds[j] = h; ds[4 + j] = l; }
+    }
+    chunk_store(out, c, v);
+}
+
 UNIT_FN unit_bandpass(UNIT_ARGS) {
+    if (N == CHK * SEG_T) { bandpass_full(U, flip); return; }
     UNIT_PROLOGUE
     const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
