@@ -1924,7 +1924,92 @@ UNIT_FN unit_bandpass(UNIT_ARGS) {
  * ip0 follow; dp0 up, dp1 clean, dp2 dist, dp3 down1, dp4 down2, dp5 hysteresis factors, dp6 exp(-20/sr), dp7 1 - dp6;
  * ds0 envelope, ds1 coupling cap; is0 previousPolarity (-1, 0, 1), is1 octaveRegister.
  * The polarity FSM is scanned as a map  pp_in -> (pp_out, register increment):  f = {has, s1, drest, pp_out}. */
+/* the batch block size: follower and coupling capacitor as constant-coefficient scans on the register chunk, the polarity FSM as
+ * before (a scan of small maps); nothing but the frame itself goes through LDS */
+__device__ __forceinline__ void octaver_full(const gdg_seg_unit *Ug, int flip) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
+    double *st = tmp + SEG_STASH;                    /* [0] envelope, [1] coupling capacitor */
+    GDG_GLOBAL double *ds = as_global(U->ds);
+    GDG_GLOBAL int *is = as_global(U->is);
+    const int tid = threadIdx.x, follow = U->ip[0];
+    const double f_up = U->dp[0], f_clean = U->dp[1], f_dist = U->dp[2], f_d1 = U->dp[3], f_d2 = U->dp[4], f_hyst = U->dp[5];
+    const double d_inv = U->dp[6], d = U->dp[7];
+    double *tab_env = scr, *tab_cap = scr + LT_SIZE;
+    if (tid < 2) st[tid] = ds[tid];
+    if (tid < 64) { if (follow == 0) lin_tab_build<true>(tab_env, 0.0, d_inv); else lin_tab_build<false>(tab_env, d, d_inv); }
+    else if (tid < 128) lin_tab_build<false>(tab_cap, d, 1.0 - d);
+    const int pp0 = is[0], reg0 = is[1];
+    const ChunkT<true> c = full_chunk();
+    double x[CHK], e[CHK];
+    chunk_load(in, c, x);
+    __syncthreads();
+    if (follow == 0) {
+        double s = lin_scan<true>(lin_chunk_map<true>(x, tab_env), tab_env, &st[0], tmp);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) { s *= d_inv; double q = fabs(x[i]); if (q > s) s = q; e[i] = s; }
+        if (c.last) ds[0] = s;
+    } else if (follow == 1) {
+        double s = lin_scan<false>(lin_chunk_map<false, true>(x, tab_env), tab_env, &st[0], tmp);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) { double diff = fabs(x[i]) - s; s += diff * d; e[i] = s; }
+        if (c.last) ds[0] = s;
+    } else {
+#pragma unroll
+        for (int i = 0; i < CHK; i++) e[i] = 1.0;
+        if (c.last) ds[0] = 1.0;
+    }
+    /* polarity FSM: chunk map pp_in -> (pp_out, register increment), f = {has, first sign, flips after it, last sign} */
+    IMap mine = { { 0, 0, 0, 0, 0 } }, ident = { { 0, 0, 0, 0, 0 } };
+#pragma unroll
+    for (int i = 0; i < CHK; i++) {
+        const double sample = x[i];
+        const int sg = sample < 0.0 ? -1 : (sample > 0.0 ? 1 : 0);
+        if (sg != 0 && fabs(sample) > e[i] * f_hyst) {
+            if (!mine.f[0]) { mine.f[0] = 1; mine.f[1] = sg; mine.f[2] = 0; mine.f[3] = sg; }
+            else if (sg != mine.f[3]) { mine.f[2]++; mine.f[3] = sg; }
+        }
+    }
+    auto comp = [](const IMap &f, const IMap &g) -> IMap {
+        if (!g.f[0]) return f;
+        if (!f.f[0]) return g;
+        IMap r = f;
+        r.f[2] = f.f[2] + (f.f[3] != g.f[1] ? 1 : 0) + g.f[2];
+        r.f[3] = g.f[3];
+        return r;
+    };
+    IMap pre = block_scan_imap(mine, ident, comp, reinterpret_cast<int *>(tmp + 2 * LX_SLOT));
+    int pp = pp0;
+    unsigned reg = (unsigned)reg0;
+    if (pre.f[0]) { reg = (reg + (unsigned)pre.f[2] + (pp0 != pre.f[1] ? 1u : 0u)) & 7u; pp = pre.f[3]; }
+    double p[CHK];
+#pragma unroll
+    for (int i = 0; i < CHK; i++) {                  /* octaver.go:86-131 */
+        const double sample = x[i], envelope = e[i];
+        const double sample_abs = fabs(sample), square = sample * sample;
+        const int sg = sample < 0.0 ? -1 : (sample > 0.0 ? 1 : 0);
+        const double sign = (double)sg, hysteresis = envelope * f_hyst;
+        if ((sg != 0) && (sg != pp) && (sample_abs > hysteresis)) { reg = (reg + 1u) & 7u; pp = sg; }
+        const double first_down = (reg & 2u) ? -1.0 : 1.0, second_down = (reg & 4u) ? -1.0 : 1.0;
+        double q = f_clean * sample;
+        if (envelope > 0.0001) q += f_up * (square / envelope);
+        q += f_dist * (sign * envelope);
+        q += f_d1 * (first_down * envelope);
+        q += f_d2 * (second_down * envelope);
+        p[i] = q;
+    }
+    if (c.last) { is[0] = pp; is[1] = (int)reg; }
+    {
+        double s = lin_scan<false>(lin_chunk_map<false>(p, tab_cap), tab_cap, &st[1], tmp + 2 * LX_SLOT);
+#pragma unroll
+        for (int i = 0; i < CHK; i++) { double diff = p[i] - s; s += diff * d; p[i] = clip1(p[i] - s); }
+        if (c.last) ds[1] = s;
+    }
+    chunk_store(out, c, p);
+}
+
 UNIT_FN unit_octaver(UNIT_ARGS) {
+    if (N == CHK * SEG_T) { octaver_full(U, flip); return; }
     UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[6], U->dp[7], &U->ds[0], tmp);
     const double f_up = U->dp[0], f_clean = U->dp[1], f_dist = U->dp[2], f_d1 = U->dp[3], f_d2 = U->dp[4], f_hyst = U->dp[5];
