@@ -546,6 +546,12 @@ __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int ti
             xn[i] = mac_load<true>(x + n);
             hn[i] = mac_load<HNT>(h + n);
         }
+        /* The waves of the workgroup meet HERE, with the partition's loads in flight: nobody runs more than one partition ahead,
+         * and a wave that waits for the others waits with 32 loads outstanding.  Without the barrier the waves drift apart by up to
+         * a fifth of the phase (cycle stamps, profiles/experiments/README.md: wave 0 spent 40 000 of the workgroup's 186 000 cycles
+         * at the barrier in front of the transform while the late waves finished with a fraction of the CU's loads in flight):
+         * 198 -> 190 us per launch. */
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < ITER; i++) {
             kr[i] += xk[i].x * hk[i].x - xk[i].y * hk[i].y;
