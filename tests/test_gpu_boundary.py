@@ -171,3 +171,30 @@ def test_identical_filters_share_spectra_without_changing_results(pkg, oracle):
     ref.append_unit("power_amp", fir=ir_a)
     want = np.concatenate([ref.process(x[0, b * frames:(b + 1) * frames], sr) for b in range(4)])
     assert rms(shared[0] - want) <= TOL_RMS
+
+
+@pytest.mark.parametrize("nch,frames,taps", [(1, 8192, 65536), (8, 8192, 20000), (5, 1024, 5000), (3, 1000, 3000)])
+def test_fir_launch_shapes_agree(pkg, oracle, nch, frames, taps):
+    """Few channels take the split shape (bin-tiled multiply-accumulate over 32 workgroups per channel + inverse), many the fused
+    kernel (one workgroup per channel); GDG_FIR_FUSED forces one.  Same results from both, and both match the oracle."""
+    import os
+    sr, blocks = 96000, 3
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(nch)])
+    irs = [synth_ir(taps, seed=300 + c) for c in range(nch)]
+    outs = {}
+    for forced in ("0", "1"):
+        os.environ["GDG_FIR_FUSED"] = forced
+        try:
+            ctx = pkg.Context(nch, frames)                          # the environment is read when the context is created
+        finally:
+            del os.environ["GDG_FIR_FUSED"]
+        for c in range(nch):
+            ctx.append_unit(c, "power_amp", fir=irs[c])
+        outs[forced] = np.concatenate([ctx.process(x[:, b * frames:(b + 1) * frames], sr) for b in range(blocks)], axis=1)
+        ctx.close()
+    assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-13
+    for c in range(nch):
+        ref = oracle.Chain()
+        ref.append_unit("power_amp", fir=irs[c])
+        want = np.concatenate([ref.process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+        assert rms(outs["0"][c] - want) <= TOL_RMS and rms(outs["1"][c] - want) <= TOL_RMS
