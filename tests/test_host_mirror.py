@@ -424,3 +424,81 @@ def test_tuner_twin(host, oracle):
         assert got["note"] == note == want["note"]
         assert got["cents"] == want["cents"] and abs(got["cents"]) <= 5
         assert abs(got["frequency"] - want["frequency"]) / want["frequency"] <= 1e-9
+
+
+@pytest.mark.gpu
+def test_control_plane_setters_race_with_processing(host, oracle):
+    """Setters run on the controller's message pump while the workers process (controller.go:3493-3498).  A unit is pushed from ONE
+    locked snapshot (versions, resolved values, a copy of the taps): hammer the setters from a second thread -- nothing crashes, no
+    error is reported, every block is finite, and once the hammering stops the stream follows the oracle with the final parameters."""
+    sr, frames, blocks = 48000, 1024, 60
+    taps = {"Cab": synth_ir(3000, seed=21), "Room": synth_ir(700, seed=22)}
+    irs = host.ImpulseResponses()
+    irs.add("Cab", sr, -20, taps["Cab"])
+    irs.add("Room", sr, -10, taps["Room"])
+    eng = host.Engine(2, frames)
+    chains = [eng.create_chain(irs) for _ in range(2)]
+    for ch in chains:
+        for t in (5, 19, 11):                                  # compressor, power amp, tone stack
+            ch.SetBypass(ch.AppendUnit(t), False)
+        ch.SetDiscreteValue(1, "filter_1", "Cab")
+    eng.set_rendezvous(2, 2000)
+    stop = threading.Event()
+
+    def hammer():
+        k = 0
+        while not stop.is_set():
+            k += 1
+            chains[k & 1].SetNumericValue(0, "target_level", -30 + (k % 25))
+            chains[k & 1].SetNumericValue(2, "middle", -(k % 20))
+            chains[(k >> 1) & 1].SetDiscreteValue(1, "filter_2", "Room" if k & 2 else "- NONE -")
+            chains[k & 1].SetNumericValue(1, "level_1", -(k % 12))
+
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(2)])
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        for b in range(blocks // 2):
+            sl = slice(b * frames, (b + 1) * frames)
+            outs = [None, None]
+
+            def work(c):
+                outs[c] = chains[c].Process(x[c, sl], sr)
+
+            ws = [threading.Thread(target=work, args=(c,)) for c in range(2)]
+            for w in ws:
+                w.start()
+            for w in ws:
+                w.join()
+            assert all(np.all(np.isfinite(o)) for o in outs)
+    finally:
+        stop.set()
+        th.join()
+    assert eng.last_error() == ""
+    # quiesce: set final values, then compare a fresh stretch with the oracle (the final Set of the power amp resets its tail)
+    refs = []
+    for c, ch in enumerate(chains):
+        ch.SetNumericValue(0, "target_level", -18)
+        ch.SetNumericValue(2, "middle", -4)
+        ch.SetDiscreteValue(1, "filter_2", "Room")
+        ch.SetNumericValue(1, "level_1", -3)
+    got = np.zeros((2, frames * (blocks - blocks // 2)))
+    for b in range(blocks // 2, blocks):
+        sl = slice(b * frames, (b + 1) * frames)
+        y = eng.process_all(x[:, sl], sr)
+        got[:, (b - blocks // 2) * frames:(b - blocks // 2 + 1) * frames] = y
+    # the compressor's and tone stack's STATE carries over from the hammered stretch, which the oracle (started here, from zero
+    # state, with the final parameters) does not know: compare where the one-pole states of both have converged -- the power
+    # amp's tail is exact (fresh filter at the final Set)
+    a = oracle.Filter(taps["Cab"], sr, 10.0 ** (0.05 * -20)).normalize().multiply(10.0 ** (0.05 * -3))
+    bflt = oracle.Filter(taps["Room"], sr, 10.0 ** (0.05 * -10)).normalize().multiply(1.0)
+    composite = oracle.Filter([], sr).add(a).add(bflt).coefficients()
+    for c in range(2):
+        ref = oracle.Chain()
+        ref.append_unit("compressor", params=[1, 30, -18])
+        ref.append_unit("power_amp", fir=composite)
+        ref.append_unit("tone_stack", params=[0, -4, -5, -5])
+        want = np.concatenate([ref.process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks // 2, blocks)])
+        tail = slice(28 * frames, None)                        # the level follower forgets with exp(-t / 2400 samples): e^-12 by then
+        assert rms(got[c, tail] - want[tail]) <= 1e-6, "channel %d" % c
+    eng.close()
