@@ -414,12 +414,13 @@ def main():
         seg = kernels["segment"]
         # HBM traffic from the PMC counters cannot be sampled from inside this process: it is taken from the committed
         # rocprofv3 --pmc passes of the SAME workload (profiles/pmc_fir_mac.json), else null
-        traffic = None
+        traffic, seg_traffic = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_fir_mac.json")) as f:
                 pmc = json.load(f)
             if pmc.get("workload_key") == "%dx%dx%d" % (nch, frames, taps) and n_distinct == 0 and bool(pmc.get("fused")) == fused:
                 traffic = pmc["traffic_bytes_per_launch"]
+                seg_traffic = pmc.get("segment_kernel", {}).get("traffic_bytes_per_launch")
         except (OSError, ValueError, KeyError):
             pass
         value = total_channels * frames * args.steps / elapsed / 1e6
@@ -457,7 +458,10 @@ def main():
                                                "frac": (fir_gbs / HBM_PEAK_GBS) if fir_gbs else None},
                 "kernels_ms": kernels,
                 "segment_kernel": {"bytes_per_channel_sample_frame_only": 16.0,
-                                   "achieved": (seg["launches"] * samples_per_step * 16.0 / (seg["ms_total"] * 1e-3) / 1e9) if seg["ms_total"] else None},
+                                   "achieved": (seg["launches"] * samples_per_step * 16.0 / (seg["ms_total"] * 1e-3) / 1e9) if seg["ms_total"] else None,
+                                   # counter traffic incl. the state of the delay-type units (rings that cannot stay on chip)
+                                   "traffic": seg_traffic,
+                                   "achieved_incl_state": (seg_traffic / (seg["avg_ms"] * 1e-3) / 1e9) if (seg_traffic and seg["avg_ms"]) else None},
             },
         }
         out.update(extras)
