@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
     "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
+    "gdg_batch_length", "gdg_batch_run",
 ]
 
 
@@ -53,6 +54,16 @@ class GdgError(RuntimeError):
 
 class TunerResult(C.Structure):
     _fields_ = [("frequency", C.c_double), ("note_index", C.c_int32), ("cents", C.c_int8)]
+
+
+class BatchInput(C.Structure):          # gdg_batch_input
+    _fields_ = [("bytes", C.c_void_p), ("samples_per_channel", C.c_size_t), ("format", C.c_int), ("sample_rate", C.c_uint32),
+                ("channels", C.c_uint), ("channel", C.c_uint)]
+
+
+class BatchOptions(C.Structure):        # gdg_batch_options
+    _fields_ = [("target_rate", C.c_uint32), ("out_format", C.c_int), ("metronome_to_master", C.c_int), ("run_meters", C.c_int),
+                ("tuner_enqueue", C.c_int)]
 
 
 def build(force=False):
@@ -137,6 +148,8 @@ def lib():
             "gdg_metronome_configure": (i32, [vp, u32, u32, u32]),
             "gdg_metronome_process": (i32, [vp, vp, i32]),
             "gdg_metronome_process_device": (i32, [vp, vp, i32]),
+            "gdg_batch_length": (i32, [vp, vp, i32, u32, C.POINTER(C.c_size_t)]),
+            "gdg_batch_run": (i32, [vp, vp, i32, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -452,6 +465,35 @@ class Context:
 
     def metronome_configure(self, beats_per_period, bpm_speed, sample_rate):
         self._check(lib().gdg_metronome_configure(self._h, beats_per_period, bpm_speed, sample_rate))
+
+    def batch_run(self, inputs, target_rate, out_format, metronome_to_master=False, run_meters=False, tuner_enqueue=False, outs=None):
+        """controller.processFiles on the device (controller/controller.go:2809-3219 without prompts and file I/O).
+        inputs: per channel None ("leaving channel empty") or (data-section bytes, format, sample_rate[, channels, channel]);
+        returns the N + 3 output data sections (uint8 arrays): out_0 .. out_{N-1}, master left, master right, metronome."""
+        n = len(inputs)
+        arr = (BatchInput * n)()
+        keep = []
+        for i, it in enumerate(inputs):
+            if it is None:
+                continue
+            data, fmt, rate = it[0], it[1], it[2]
+            channels, channel = (it[3], it[4]) if len(it) > 3 else (1, 0)
+            f = WAVE_FORMATS[fmt] if isinstance(fmt, str) else fmt
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            keep.append(data)
+            w = max(lib().gdg_wave_bytes_per_sample(f), 1)
+            arr[i] = BatchInput(data.ctypes.data if data.size else None, data.size // (w * max(channels, 1)), f, rate, channels, channel)
+        fo = WAVE_FORMATS[out_format] if isinstance(out_format, str) else out_format
+        opt = BatchOptions(target_rate, fo, int(bool(metronome_to_master)), int(bool(run_meters)), int(bool(tuner_enqueue)))
+        length = C.c_size_t(0)
+        self._check(lib().gdg_batch_length(self._h, arr, n, target_rate, C.byref(length)))
+        wo = lib().gdg_wave_bytes_per_sample(fo)
+        if outs is None:
+            outs = [np.zeros(length.value * wo, dtype=np.uint8) for _ in range(n + 3)]
+        assert len(outs) == n + 3 and all(o.dtype == np.uint8 and o.size == length.value * wo for o in outs)
+        ptrs = (C.c_void_p * (n + 3))(*[(o.ctypes.data if o.size else None) for o in outs])
+        self._check(lib().gdg_batch_run(self._h, arr, n, C.byref(opt), ptrs))
+        return outs
 
     def metronome_process(self, frames):
         out = np.empty(frames, dtype=np.float64)

@@ -143,6 +143,11 @@ struct gdg_ctx {
     size_t io_cap[2] = { 0, 0 };
     gdg_meter_rec *d_meter = nullptr;
     int n_meter = 0;
+    /* the batch run's PCIe side: two pinned halves, a copy stream and events (ensure_batch_pipe) */
+    unsigned char *h_batch[2] = { nullptr, nullptr };
+    size_t h_batch_cap = 0;
+    hipStream_t batch_stream = nullptr;
+    hipEvent_t batch_ready[2] = { nullptr, nullptr }, batch_moved[2] = { nullptr, nullptr };
     /* channel groups of the host-buffer paths: group g's upload, kernels and download run on stream g, so one group's
      * PCIe transfers overlap the other groups' kernels (channels are independent) */
     int plan_groups = 1;
@@ -279,6 +284,12 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     for (auto st : ctx->gstreams) hipStreamDestroy(st);
     for (auto e : ctx->gjoin) hipEventDestroy(e);
     if (ctx->gfork) hipEventDestroy(ctx->gfork);
+    for (int h = 0; h < 2; h++) {
+        if (ctx->h_batch[h]) hipHostFree(ctx->h_batch[h]);
+        if (ctx->batch_ready[h]) hipEventDestroy(ctx->batch_ready[h]);
+        if (ctx->batch_moved[h]) hipEventDestroy(ctx->batch_moved[h]);
+    }
+    if (ctx->batch_stream) hipStreamDestroy(ctx->batch_stream);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1860,11 +1871,8 @@ int gdg_meter_set_enabled(gdg_ctx *ctx, int port, int enabled) {
     return GDG_OK;
 }
 
-int gdg_meter_process_device(gdg_ctx *ctx, const double *d_rows, size_t row_stride, int frames, uint32_t sample_rate) {
-    if (!ctx) return GDG_ERR_INVALID;
-    if (ctx->n_meter == 0 || frames == 0) return GDG_OK;
-    if (!d_rows || frames < 0 || sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "invalid meter input");
-    hipSetDevice(ctx->device);
+/* ports [port0, port0 + n_ports) over one buffer each (rows of d_rows) */
+static int meter_rows(gdg_ctx *ctx, const double *d_rows, size_t row_stride, int port0, int n_ports, int frames, uint32_t sample_rate) {
     double sr = (double)sample_rate;                                   /* level.go:166-171 */
     unsigned long long hold = (unsigned long long)(METER_PEAK_HOLD_SECONDS * sr);
     double decay = pow(10.0, -1.0 / (METER_TIME_CONSTANT * sr));
@@ -1873,9 +1881,17 @@ int gdg_meter_process_device(gdg_ctx *ctx, const double *d_rows, size_t row_stri
     ProfScope ps(ctx, GDG_K_METER);
     for (int off = 0; off < frames; off += seg) {
         int n = frames - off < seg ? frames - off : seg;
-        HIP_TRY(ctx, gdg_launch_meter(d_rows + off, row_stride, ctx->n_meter, n, ctx->d_meter, decay, hold, ctx->stream));
+        HIP_TRY(ctx, gdg_launch_meter(d_rows + off, row_stride, n_ports, n, ctx->d_meter + port0, decay, hold, ctx->stream));
     }
     return GDG_OK;
+}
+
+int gdg_meter_process_device(gdg_ctx *ctx, const double *d_rows, size_t row_stride, int frames, uint32_t sample_rate) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (ctx->n_meter == 0 || frames == 0) return GDG_OK;
+    if (!d_rows || frames < 0 || sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "invalid meter input");
+    hipSetDevice(ctx->device);
+    return meter_rows(ctx, d_rows, row_stride, 0, ctx->n_meter, frames, sample_rate);
 }
 
 int gdg_meter_process(gdg_ctx *ctx, const double *const *buffers, int frames, uint32_t sample_rate) {
@@ -2066,6 +2082,205 @@ int gdg_metronome_process(gdg_ctx *ctx, double *out, int frames) {
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_io[1], (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GDG_OK;
+}
+
+/* ================================================================================================
+ * The batch run (controller.processFiles, controller/controller.go:2809-3219, without prompts and file I/O)
+ * ============================================================================================== */
+
+#define GDG_BLOCK_SIZE 8192           /* controller/controller.go:36 */
+
+int gdg_batch_length(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, uint32_t target_rate, size_t *samples) {
+    if (!ctx || !inputs || !samples || n_inputs <= 0) return GDG_ERR_INVALID;
+    size_t max_len = 0;
+    for (int i = 0; i < n_inputs; i++) {
+        const gdg_batch_input &in = inputs[i];
+        size_t len = (in.bytes && in.samples_per_channel) ? in.samples_per_channel : 0;
+        if (len > 0x7fffffff) return fail(ctx, GDG_ERR_INVALID, "input %d is too long", i);
+        if (len > 0 && in.sample_rate != target_rate) {                       /* controller.go:2993-2999 */
+            int r = gdg_resample_time_length((int)len, in.sample_rate, target_rate);
+            len = r > 0 ? (size_t)r : 0;
+        }
+        if (len > max_len) max_len = len;
+    }
+    if (max_len % GDG_BLOCK_SIZE) max_len = GDG_BLOCK_SIZE * (max_len / GDG_BLOCK_SIZE + 1);       /* :3014-3016 */
+    *samples = max_len;
+    return GDG_OK;
+}
+
+static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes) {
+    if (!ctx->batch_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->batch_stream, hipStreamNonBlocking));
+        for (int h = 0; h < 2; h++) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_ready[h], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_moved[h], hipEventDisableTiming));
+        }
+    }
+    if (half_bytes > ctx->h_batch_cap) {
+        for (int h = 0; h < 2; h++) {
+            if (ctx->h_batch[h]) hipHostFree(ctx->h_batch[h]);
+            ctx->h_batch[h] = nullptr;
+        }
+        ctx->h_batch_cap = 0;
+        for (int h = 0; h < 2; h++) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_batch[h], half_bytes, hipHostMallocDefault));
+        ctx->h_batch_cap = half_bytes;
+    }
+    return GDG_OK;
+}
+
+/* host memcpy pieces (dst, src, bytes), spread over the copy threads */
+struct BatchPiece { unsigned char *dst; const unsigned char *src; size_t bytes; };
+static void move_pieces(const std::vector<BatchPiece> &pieces) {
+    size_t total = 0;
+    for (auto &p : pieces) total += p.bytes;
+    copy_rows_parallel(0, pieces.size(), [&](size_t i) { memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); },
+                       pieces.empty() ? 0 : total / pieces.size());
+}
+
+/*
+ * Phases (all device work on the context's stream; PCIe on the copy stream through two pinned halves):
+ *   1. the file bytes of all inputs, packed into one arena, go up in half-sized chunks: the copy threads gather chunk k + 1 while
+ *      the DMA engine moves chunk k; then one decode (+ resample.Time) per input into its row of the [N][length] inputs.
+ *   2. per block: copy in, tuner, N x Chain.Process, metronome, spatializer, meters, encode the block's N + 3 rows in one launch;
+ *      the encoded block (N + 3 rows x 8192 x width bytes) goes down on the copy stream while the next block computes, and the
+ *      copy threads scatter it into the caller's N + 3 buffers.
+ */
+int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *opt, void *const *out_bytes) {
+    if (!ctx || !inputs || !opt || !out_bytes) return GDG_ERR_INVALID;
+    if (n_inputs != ctx->nch) return fail(ctx, GDG_ERR_INVALID, "the batch has %d inputs, the context %d channels", n_inputs, ctx->nch);
+    if (ctx->max_frames < GDG_BLOCK_SIZE)
+        return fail(ctx, GDG_ERR_INVALID, "the batch loop runs blocks of %d frames, the context allows %d", GDG_BLOCK_SIZE, ctx->max_frames);
+    const int out_width = gdg_wave_bytes_per_sample(opt->out_format);
+    if (!out_width) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", opt->out_format);
+    if (opt->target_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
+    const int N = n_inputs, NO = N + 3, B = GDG_BLOCK_SIZE, ports = 2 * N + 3;
+    std::vector<size_t> arena_off((size_t)N, 0);
+    size_t arena_bytes = 0, src_cap = 0;
+    for (int i = 0; i < N; i++) {
+        const gdg_batch_input &in = inputs[i];
+        if (!in.bytes || !in.samples_per_channel) continue;
+        const int w = gdg_wave_bytes_per_sample(in.format);
+        if (!w) return fail(ctx, GDG_ERR_UNSUPPORTED, "input %d: unknown sample format %d", i, in.format);
+        if (in.channels == 0 || in.channel >= in.channels) return fail(ctx, GDG_ERR_INVALID, "input %d: channel %u of %u", i, in.channel, in.channels);
+        if (in.sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "input %d: sample rate must be positive", i);
+        const size_t count = in.samples_per_channel * in.channels;
+        arena_off[(size_t)i] = arena_bytes;
+        arena_bytes += (count * (size_t)w + 15) & ~(size_t)15;
+        if (!(in.sample_rate == opt->target_rate && in.channels == 1) && count > src_cap) src_cap = count;
+    }
+    size_t length = 0;
+    int rc = gdg_batch_length(ctx, inputs, n_inputs, opt->target_rate, &length);
+    if (rc != GDG_OK) return rc;
+    if (length == 0) return GDG_OK;                                            /* every output has 0 samples */
+    if (opt->run_meters && ctx->n_meter != ports)
+        return fail(ctx, GDG_ERR_INVALID, "level meters: %d ports configured, the batch needs 2 N + 3 = %d", ctx->n_meter, ports);
+    hipSetDevice(ctx->device);
+    const size_t enc_bytes = (size_t)NO * B * (size_t)out_width;               /* one encoded block */
+    const size_t half = std::max(enc_bytes, (size_t)8 << 20);
+    rc = ensure_batch_pipe(ctx, half);
+    if (rc != GDG_OK) return rc;
+    double *d_inputs = nullptr, *d_blk = nullptr, *d_src = nullptr;
+    unsigned char *d_arena = nullptr, *d_enc = nullptr;
+    auto body = [&]() -> int {
+        int r;
+        HIP_TRY(ctx, hipMalloc((void **)&d_inputs, (size_t)N * length * sizeof(double)));
+        /* one block: the N inputs, then the N + 3 outputs in the output files' order (out_0 .. out_{N-1}, master left, master right,
+         * metronome, controller.go:3123-3219) */
+        HIP_TRY(ctx, hipMalloc((void **)&d_blk, (size_t)(N + NO) * B * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&d_enc, 2 * enc_bytes));
+        if (arena_bytes) HIP_TRY(ctx, hipMalloc((void **)&d_arena, arena_bytes));
+        if (src_cap) HIP_TRY(ctx, hipMalloc((void **)&d_src, src_cap * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(d_inputs, 0, (size_t)N * length * sizeof(double), ctx->stream));     /* the zero padding, :3018-3045 */
+        double *d_in_blk = d_blk, *d_out_blk = d_blk + (size_t)N * B, *d_master = d_out_blk + (size_t)N * B, *d_metro = d_master + 2 * (size_t)B;
+
+        /* 1a. the arena goes up */
+        int used[2] = { 0, 0 };
+        int next_input = 0;
+        for (size_t k = 0, lo = 0; lo < arena_bytes; k++, lo += half) {
+            const size_t hi = std::min(arena_bytes, lo + half);
+            const int h = (int)(k & 1);
+            if (used[h]) HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h]));
+            std::vector<BatchPiece> pieces;
+            while (next_input < N && (!inputs[next_input].bytes || !inputs[next_input].samples_per_channel)) next_input++;
+            for (int i = next_input; i < N; i++) {
+                const gdg_batch_input &in = inputs[i];
+                if (!in.bytes || !in.samples_per_channel) continue;
+                const size_t a = arena_off[(size_t)i], nb = in.samples_per_channel * in.channels * (size_t)gdg_wave_bytes_per_sample(in.format);
+                if (a >= hi) break;
+                if (a + nb <= lo) { if (i == next_input) next_input++; continue; }
+                size_t s0 = std::max(a, lo), s1 = std::min(a + nb, hi);
+                for (size_t q = s0; q < s1; q += (size_t)1 << 20)                 /* pieces of <= 1 MiB */
+                    pieces.push_back({ ctx->h_batch[h] + (q - lo), static_cast<const unsigned char *>(in.bytes) + (q - a), std::min(s1 - q, (size_t)1 << 20) });
+            }
+            move_pieces(pieces);
+            HIP_TRY(ctx, hipMemcpyAsync(d_arena + lo, ctx->h_batch[h], hi - lo, hipMemcpyHostToDevice, ctx->batch_stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
+            used[h] = 1;
+        }
+        for (int h = 0; h < 2; h++) if (used[h]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_moved[h], 0));
+        /* 1b. decode (+ resample.Time) every input into its row */
+        for (int i = 0; i < N; i++) {
+            const gdg_batch_input &in = inputs[i];
+            if (!in.bytes || !in.samples_per_channel) continue;               /* "leaving channel empty" */
+            const size_t per = in.samples_per_channel;
+            double *row = d_inputs + (size_t)i * length;
+            const bool direct = in.sample_rate == opt->target_rate && in.channels == 1;
+            if ((r = gdg_wave_decode_device(ctx, in.format, d_arena + arena_off[(size_t)i], per, in.channels, direct ? row : d_src)) != GDG_OK) return r;
+            if (direct) continue;
+            const double *chan = d_src + (size_t)in.channel * per;           /* planar: samplesToChannels */
+            if (in.sample_rate == opt->target_rate)
+                HIP_TRY(ctx, hipMemcpyAsync(row, chan, per * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            else {
+                int n_out = gdg_resample_time_length((int)per, in.sample_rate, opt->target_rate);
+                if (n_out > 0 && (r = gdg_resample_time_device(ctx, chan, (int)per, in.sample_rate, opt->target_rate, row, n_out)) != GDG_OK) return r;
+            }
+        }
+        /* the pinned halves change direction: every upload has been consumed by the DMA engine (events above), nothing else reads them */
+        for (int h = 0; h < 2; h++) if (used[h]) HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h]));
+
+        /* 2. the block loop, controller.go:3076-3107 around controller.process (:2648-2783) */
+        const size_t blocks = length / B, row_bytes = (size_t)B * out_width;
+        auto scatter = [&](size_t b) {                                           /* block b's bytes from its pinned half into the files */
+            const unsigned char *src = ctx->h_batch[b & 1];
+            copy_rows_parallel(0, (size_t)NO, [&](size_t o) {
+                if (out_bytes[o]) memcpy(static_cast<unsigned char *>(out_bytes[o]) + b * row_bytes, src + o * row_bytes, row_bytes);   /* NULL: "skipping output" (:3143) */
+            }, row_bytes);
+        };
+        for (size_t b = 0; b < blocks; b++) {
+            const size_t off = b * B;
+            const int h = (int)(b & 1);
+            unsigned char *enc = d_enc + h * enc_bytes;
+            if ((r = gdg_copy_rows_device(ctx, d_in_blk, B, d_inputs + off, length, B, (size_t)N)) != GDG_OK) return r;
+            if (opt->tuner_enqueue && (r = gdg_tuner_enqueue_device(ctx, d_in_blk, B, opt->target_rate)) != GDG_OK) return r;
+            if ((r = gdg_process_device(ctx, d_in_blk, d_out_blk, B, opt->target_rate)) != GDG_OK) return r;
+            if ((r = gdg_metronome_process_device(ctx, d_metro, B)) != GDG_OK) return r;
+            if ((r = gdg_spatialize_device(ctx, d_out_blk, d_master, B)) != GDG_OK) return r;
+            if (opt->metronome_to_master) HIP_TRY(ctx, gdg_launch_add_aux(d_master, d_master + B, d_metro, B, ctx->stream));
+            if (opt->run_meters) {                                               /* ports: inputs | outputs | metronome | left, right (:2707-2777) */
+                if ((r = meter_rows(ctx, d_blk, B, 0, 2 * N, B, opt->target_rate)) != GDG_OK) return r;
+                if ((r = meter_rows(ctx, d_metro, B, 2 * N, 1, B, opt->target_rate)) != GDG_OK) return r;
+                if ((r = meter_rows(ctx, d_master, B, 2 * N + 1, 2, B, opt->target_rate)) != GDG_OK) return r;
+            }
+            if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_moved[h], 0));     /* block b - 2 has left enc */
+            if ((r = gdg_wave_encode_device(ctx, opt->out_format, d_out_blk, (size_t)NO * B, 1, enc)) != GDG_OK) return r;
+            HIP_TRY(ctx, hipEventRecord(ctx->batch_ready[h], ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_stream, ctx->batch_ready[h], 0));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, enc_bytes, hipMemcpyDeviceToHost, ctx->batch_stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
+            if (b >= 1) {                                                        /* while block b runs: block b - 1 into the files */
+                HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h ^ 1]));
+                scatter(b - 1);
+            }
+        }
+        HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[(blocks - 1) & 1]));
+        scatter(blocks - 1);
+        return check_device_error(ctx);
+    };
+    rc = body();
+    hipStreamSynchronize(ctx->batch_stream);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_inputs); hipFree(d_blk); hipFree(d_src); hipFree(d_arena); hipFree(d_enc);
+    return rc;
 }
 
 }  /* extern "C" */

@@ -159,6 +159,8 @@ hipError_t gdg_launch_resample_time(const double *d_in, int n, double dx, double
 hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, int n, gdg_meter_rec *d_state,
                             double decay, unsigned long long hold, hipStream_t s);
 
+/* dst_a[i] += src[i]; dst_b[i] += src[i]  (the aux input of the spatializer, spatializer.go:300-310) */
+hipError_t gdg_launch_add_aux(double *d_a, double *d_b, const double *d_src, int n, hipStream_t s);
 hipError_t gdg_launch_metronome(const double *d_tick, unsigned n_tick, const double *d_tock, unsigned n_tock, double *d_out, int n,
                                 unsigned sc0, unsigned tc0, unsigned spb, unsigned beats, unsigned j0, hipStream_t s);
 

@@ -244,6 +244,16 @@ metronome_kernel(const double *__restrict__ tick, unsigned n_tick, const double 
     }
 }
 
+__global__ void __launch_bounds__(256) add_aux_kernel(double *__restrict__ a, double *__restrict__ b, const double *__restrict__ src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const double v = src[i]; a[i] += v; b[i] += v; }
+}
+hipError_t gdg_launch_add_aux(double *d_a, double *d_b, const double *d_src, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    add_aux_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_a, d_b, d_src, n);
+    return hipGetLastError();
+}
+
 hipError_t gdg_launch_metronome(const double *d_tick, unsigned n_tick, const double *d_tock, unsigned n_tock, double *d_out, int n,
                                 unsigned sc0, unsigned tc0, unsigned spb, unsigned beats, unsigned j0, hipStream_t s) {
     if (n <= 0) return hipSuccess;

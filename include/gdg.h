@@ -282,6 +282,41 @@ int gdg_metronome_configure(gdg_ctx *ctx, uint32_t beats_per_period, uint32_t bp
 int gdg_metronome_process(gdg_ctx *ctx, double *out, int frames);
 int gdg_metronome_process_device(gdg_ctx *ctx, double *d_out, int frames);
 
+/* ---- the batch run: controller.processFiles between "the files are read" and "the files are written" ------------- */
+
+/*
+ * One input of the batch run (controller/controller.go:2884-2990): the data section of a RIFF/WAVE file -- `channels` interleaved
+ * channels of `samples_per_channel` samples in `format` -- of which channel `channel` feeds the input.  bytes == NULL or
+ * samples_per_channel == 0 is the reference's "leaving channel empty" (silence; its rate does not matter).
+ */
+typedef struct {
+    const void *bytes;
+    size_t samples_per_channel;
+    int format;                 /* enum gdg_wave_format */
+    uint32_t sample_rate;
+    unsigned channels, channel;
+} gdg_batch_input;
+
+typedef struct {
+    uint32_t target_rate;       /* the session rate every input is resampled to (resample.Time, controller.go:2991-3003) */
+    int out_format;             /* enum gdg_wave_format of the N + 3 outputs (the "lpcm" / "float" + bit depth prompts, :2821-2880) */
+    int metronome_to_master;    /* metrMasterOutput: the metronome is the spatializer's aux input (:2744-2761) */
+    int run_meters;             /* levelMeterEnabled: meters over the 2N + 3 ports configured with gdg_meter_configure (:2707-2781) */
+    int tuner_enqueue;          /* != 0: every block also goes into the tuner rings (tuner.Process, :2668-2672) */
+} gdg_batch_options;
+
+/* samples of every output: the longest resampled input, rounded up to a multiple of BLOCK_SIZE = 8192 (controller.go:3005-3045) */
+int gdg_batch_length(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, uint32_t target_rate, size_t *samples);
+/*
+ * The whole batch on the device: decode -> resample.Time (inputs whose rate differs from the target) -> zero-pad -> for every
+ * 8192-frame block: N x Chain.Process, metronome, spatializer (+ aux), meters -> encode.  n_inputs must equal the context's channel
+ * count and max_frames must be >= 8192.  out_bytes: N + 3 host buffers (out_0 .. out_{N-1}, master_left, master_right, metronome,
+ * controller.go:3123-3219; NULL = "skipping output") of gdg_batch_length() * gdg_wave_bytes_per_sample(out_format) bytes each.
+ * Only file bytes cross PCIe: the samples stay in HBM from decode to encode.  Chains, spatializer positions, metronome and meters
+ * are whatever was configured on the context; their state carries on from earlier calls, like the reference's.
+ */
+int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *options, void *const *out_bytes);
+
 #ifdef __cplusplus
 
 

@@ -148,3 +148,128 @@ def test_batch_run_on_device_matches_oracle(oracle):
             np.testing.assert_array_equal(got_bytes[r], want, err_msg="output %d (%s)" % (r, fmt))
     for p, m in enumerate(ref_meters):
         assert (lv[p], pk[p]) == m.analyze(), "meter port %d" % p
+
+
+def _interleave(rows):
+    return np.ascontiguousarray(np.stack(rows, axis=1)).reshape(-1)
+
+
+def test_batch_run_one_call_matches_oracle(oracle):
+    """gdg_batch_run: the same batch in ONE call of the C-ABI (controller.go:2809-3219): a stereo file whose second channel is
+    taken and whose rate already is the target (no resampling, :2993), an empty input (:2935), inputs at two other rates, the
+    metronome in the master mix (metrMasterOutput), meters on, tuner fed."""
+    pkg = package()
+    rate, nch = 48000, 5
+    rng = np.random.default_rng(11)
+    irs = [synth_ir(2000, seed=40 + c) for c in range(nch)]
+    positions = [(float(rng.uniform(-90, 90)), float(rng.uniform(0.3, 5)), float(rng.uniform(0.2, 1))) for _ in range(nch)]
+    tick, tock = rng.uniform(-0.5, 0.5, 900), rng.uniform(-0.5, 0.5, 500)
+    ports = 2 * nch + 3
+    # channel: (format, rate, samples, file channels, channel taken) -- channel 3 stays empty
+    files = {0: ("lpcm16", 48000, 20000, 2, 1), 1: ("lpcm24", 44100, 30000, 1, 0), 2: ("ieee32", 96000, 50000, 3, 2), 4: ("lpcm32", 48000, 9000, 1, 0)}
+    inputs, decoded = [None] * nch, {}
+    for c, (fmt, r, n, chans, take) in files.items():
+        chan_samples = [0.7 * synth_signal(10 * c + k, n, r) for k in range(chans)]
+        w = pkg.lib().gdg_wave_bytes_per_sample(pkg.WAVE_FORMATS[fmt])
+        per_chan = [oracle.wave_encode(fmt, s).reshape(n, w) for s in chan_samples]
+        data = np.ascontiguousarray(np.stack(per_chan, axis=1)).reshape(-1)           # interleaved frames (wave.go:237-270)
+        inputs[c] = (data, fmt, r, chans, take)
+        x = oracle.wave_decode(fmt, per_chan[take].reshape(-1))
+        decoded[c] = x if r == rate else oracle.resample_time(x, r, rate)
+    longest = max(len(x) for x in decoded.values())
+    length = BLOCK * ((longest + BLOCK - 1) // BLOCK)
+    ref_in = np.zeros((nch, length))
+    for c, x in decoded.items():
+        ref_in[c, :len(x)] = x
+
+    # ---- oracle ---------------------------------------------------------------------------------------------------------
+    chains = []
+    for c in range(nch):
+        ch = oracle.Chain()
+        for name, p in CHAIN:
+            ch.append_unit(name, fir=irs[c]) if p == "ir" else ch.append_unit(name, params=p)
+        chains.append(ch)
+    ref_sp = oracle.Spatializer(nch)
+    ref_sp.set_sample_rate(rate)
+    for c, (a, d, l) in enumerate(positions):
+        ref_sp.set_azimuth(c, a); ref_sp.set_distance(c, d); ref_sp.set_level(c, l)
+    ref_met = oracle.Metronome()
+    ref_met.tick, ref_met.tock = tick, tock
+    ref_met.s.beats_per_period, ref_met.s.bpm_speed, ref_met.s.sample_rate = 3, 200, rate
+    ref_meters = [oracle.ChannelMeter() for _ in range(ports)]
+    for m in ref_meters:
+        m.set_enabled(True)
+    ref_tuners = [oracle.Tuner() for _ in range(nch)]
+    ref_out = np.zeros((nch + 3, length))
+    for b in range(length // BLOCK):
+        sl = slice(b * BLOCK, (b + 1) * BLOCK)
+        for c in range(nch):
+            ref_tuners[c].process(ref_in[c, sl], rate)
+            ref_out[c, sl] = chains[c].process(ref_in[c, sl], rate)
+        ref_out[nch + 2, sl] = ref_met.process(BLOCK)
+        ref_out[nch, sl], ref_out[nch + 1, sl] = ref_sp.process(ref_out[:nch, sl], aux=ref_out[nch + 2, sl])
+        rows = [ref_in[c, sl] for c in range(nch)] + [ref_out[c, sl] for c in range(nch)] + [ref_out[nch + 2, sl], ref_out[nch, sl], ref_out[nch + 1, sl]]
+        for m, r in zip(ref_meters, rows):
+            m.process(r, rate)
+
+    # ---- device: one call -------------------------------------------------------------------------------------------------
+    def configured():
+        ctx = pkg.Context(nch, BLOCK)
+        for c in range(nch):
+            for name, p in CHAIN:
+                ctx.append_unit(c, name, fir=irs[c]) if p == "ir" else ctx.append_unit(c, name, params=p)
+        ctx.spatializer_set_sample_rate(rate)
+        for c, (a, d, l) in enumerate(positions):
+            ctx.spatializer_set_position(c, a, d, l)
+        ctx.metronome_set_sounds(tick, tock)
+        ctx.metronome_configure(3, 200, rate)
+        ctx.meter_configure(ports)
+        ctx.meter_set_enabled(True)
+        return ctx
+
+    for out_fmt in ("ieee64", "lpcm24"):
+        ctx = configured()
+        outs = ctx.batch_run(inputs, rate, out_fmt, metronome_to_master=True, run_meters=True, tuner_enqueue=True)
+        lv, pk = ctx.meter_analyze()
+        tuned = ctx.tuner_analyze()
+        ctx.close()
+        assert len(outs) == nch + 3
+        for r in range(nch + 3):
+            want = oracle.wave_encode(out_fmt, ref_out[r])
+            assert outs[r].size == want.size == length * (8 if out_fmt == "ieee64" else 3)
+            if out_fmt == "ieee64":
+                err = rms(outs[r].view(np.float64) - ref_out[r])
+                assert err <= TOL_RMS, "output %d: RMS %.3e" % (r, err)
+            else:
+                np.testing.assert_array_equal(outs[r], want, err_msg="output %d" % r)
+        for p, m in enumerate(ref_meters):
+            assert (lv[p], pk[p]) == m.analyze(), "meter port %d" % p
+        for c in range(nch):
+            want = ref_tuners[c].analyze()
+            assert tuned[c]["note_index"] == want["note_index"] and tuned[c]["cents"] == want["cents"], (c, tuned[c], want)
+            if np.isnan(want["frequency"]):                                    # the empty input: an all-zero correlation, 0/0 in the reference too
+                assert np.isnan(tuned[c]["frequency"])
+            else:
+                assert abs(tuned[c]["frequency"] - want["frequency"]) <= 1e-9 * max(1.0, abs(want["frequency"]))
+
+
+def test_batch_run_rejections_and_empty_batch():
+    pkg = package()
+    ctx = pkg.Context(2, BLOCK)
+    data = np.zeros(200, dtype=np.uint8)
+    with pytest.raises(pkg.GdgError, match="the batch has 1 inputs, the context 2 channels"):
+        ctx.batch_run([(data, "lpcm16", 48000)], 48000, "lpcm16")
+    with pytest.raises(pkg.GdgError, match="channel 2 of 2"):
+        ctx.batch_run([(data, "lpcm16", 48000, 2, 2), None], 48000, "lpcm16")
+    with pytest.raises(pkg.GdgError, match="level meters: 0 ports configured, the batch needs 2 N \\+ 3 = 7"):
+        ctx.batch_run([(data, "lpcm16", 48000), None], 48000, "lpcm16", run_meters=True)
+    outs = ctx.batch_run([None, None], 48000, "lpcm16")              # every channel left empty: outputs of 0 samples
+    assert [o.size for o in outs] == [0] * 5
+    outs = ctx.batch_run([(data, "lpcm16", 48000), None], 48000, "lpcm16")      # 100 samples -> one block, chains empty = pass-through
+    assert all(o.size == 2 * BLOCK for o in outs)
+    np.testing.assert_array_equal(outs[0], np.zeros(2 * BLOCK, dtype=np.uint8))
+    ctx.close()
+    small = pkg.Context(2, 1024)
+    with pytest.raises(pkg.GdgError, match="blocks of 8192 frames"):
+        small.batch_run([(data, "lpcm16", 48000), None], 48000, "lpcm16")
+    small.close()
