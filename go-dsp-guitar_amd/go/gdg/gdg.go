@@ -455,3 +455,88 @@ func (this *Context) MetronomeProcess(out []float64) error {
 	}
 	return this.err(C.gdg_metronome_process(this.ctx, (*C.double)(unsafe.Pointer(&out[0])), C.int(len(out))))
 }
+
+// BatchInput: one input file of the batch run -- the data section of a RIFF/WAVE file (wave.go:840-1100 parses the header and
+// knows Format / BitDepth / SampleRate / ChannelCount), and the channel of it that feeds the input.  Data == nil leaves the
+// channel empty (controller.go:2935).
+type BatchInput struct {
+	Data       []byte
+	Format     int // gdg_wave_format
+	SampleRate uint32
+	Channels   int
+	Channel    int
+}
+
+type BatchOptions struct {
+	TargetRate        uint32
+	OutFormat         int
+	MetronomeToMaster bool
+	RunMeters         bool
+	TunerEnqueue      bool
+}
+
+func cbool(b bool) C.int {
+	if b {
+		return 1
+	}
+	return 0
+}
+
+// BatchRun: controller.processFiles between "the files are read" and "the files are written" (controller/controller.go:2884-3219)
+// in one call.  The C structs hold pointers, so the file bytes live in C memory for the duration of the call (C.CBytes: one
+// copy; with Go >= 1.21 a runtime.Pinner on the []byte would avoid it), and so do the N + 3 output data sections.
+func (this *Context) BatchRun(inputs []BatchInput, opt BatchOptions) ([][]byte, error) {
+	n := len(inputs)
+	if n == 0 {
+		return nil, fmt.Errorf("gdg: no inputs")
+	}
+	arr := (*[1 << 20]C.gdg_batch_input)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.gdg_batch_input{}))))
+	defer C.free(unsafe.Pointer(arr))
+	var owned []unsafe.Pointer
+	defer func() {
+		for _, p := range owned {
+			C.free(p)
+		}
+	}()
+	for i, in := range inputs {
+		width := int(C.gdg_wave_bytes_per_sample(C.int(in.Format)))
+		if len(in.Data) == 0 || width == 0 || in.Channels <= 0 {
+			continue
+		}
+		p := C.CBytes(in.Data)
+		owned = append(owned, p)
+		arr[i].bytes = p
+		arr[i].samples_per_channel = C.size_t(len(in.Data) / (width * in.Channels))
+		arr[i].format = C.int(in.Format)
+		arr[i].sample_rate = C.uint32_t(in.SampleRate)
+		arr[i].channels = C.uint(in.Channels)
+		arr[i].channel = C.uint(in.Channel)
+	}
+	o := C.gdg_batch_options{target_rate: C.uint32_t(opt.TargetRate), out_format: C.int(opt.OutFormat),
+		metronome_to_master: cbool(opt.MetronomeToMaster), run_meters: cbool(opt.RunMeters), tuner_enqueue: cbool(opt.TunerEnqueue)}
+	var samples C.size_t
+	if e := this.err(C.gdg_batch_length(this.ctx, &arr[0], C.int(n), o.target_rate, &samples)); e != nil {
+		return nil, e
+	}
+	each := int(samples) * int(C.gdg_wave_bytes_per_sample(o.out_format))
+	outs := make([][]byte, n+3)
+	if each == 0 {
+		for i := range outs {
+			outs[i] = []byte{}
+		}
+		return outs, nil
+	}
+	ptrs := (*[1 << 20]unsafe.Pointer)(C.calloc(C.size_t(n+3), C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(ptrs))
+	for i := 0; i < n+3; i++ {
+		ptrs[i] = C.malloc(C.size_t(each))
+		owned = append(owned, ptrs[i])
+	}
+	if e := this.err(C.gdg_batch_run(this.ctx, &arr[0], C.int(n), &o, (*unsafe.Pointer)(unsafe.Pointer(ptrs)))); e != nil {
+		return nil, e
+	}
+	for i := range outs {
+		outs[i] = C.GoBytes(ptrs[i], C.int(each))
+	}
+	return outs, nil
+}
