@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
     "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
-    "gdg_batch_length", "gdg_batch_run",
+    "gdg_batch_length", "gdg_batch_run", "gdg_ctx_set_window", "gdg_process_window_device",
 ]
 
 
@@ -148,6 +148,8 @@ def lib():
             "gdg_metronome_configure": (i32, [vp, u32, u32, u32]),
             "gdg_metronome_process": (i32, [vp, vp, i32]),
             "gdg_metronome_process_device": (i32, [vp, vp, i32]),
+            "gdg_ctx_set_window": (i32, [vp, i32]),
+            "gdg_process_window_device": (i32, [vp, vp, vp, C.c_size_t, i32, u32]),
             "gdg_batch_length": (i32, [vp, vp, i32, u32, C.POINTER(C.c_size_t)]),
             "gdg_batch_run": (i32, [vp, vp, i32, vp, vp]),
         }
@@ -465,6 +467,15 @@ class Context:
 
     def metronome_configure(self, beats_per_period, bpm_speed, sample_rate):
         self._check(lib().gdg_metronome_configure(self._h, beats_per_period, bpm_speed, sample_rate))
+
+    def set_window(self, frames_per_call):
+        """Time blocking: up to `frames_per_call` (1, 2, 4, 8) consecutive 8192-sample frames per channel and call."""
+        self._check(lib().gdg_ctx_set_window(self._h, frames_per_call))
+
+    def process_window_device(self, d_in, d_out, row_stride, frames_in_window, sample_rate):
+        pi = d_in.ptr if isinstance(d_in, DeviceBuffer) else d_in
+        po = d_out.ptr if isinstance(d_out, DeviceBuffer) else d_out
+        self._check(lib().gdg_process_window_device(self._h, pi, po, row_stride, frames_in_window, sample_rate))
 
     def batch_run(self, inputs, target_rate, out_format, metronome_to_master=False, run_meters=False, tuner_enqueue=False, outs=None):
         """controller.processFiles on the device (controller/controller.go:2809-3219 without prompts and file I/O).

@@ -63,6 +63,7 @@ struct Unit {
     bool fir_dirty = true;
     bool fir_live = false;
     int fir_P = 0, fir_K = 0, fir_hop = 0;     /* transform half size (power of two), partitions, samples per frame */
+    int fir_R = 0;                             /* delay-line ring slots: fir_K + window - 1 */
     uint32_t fir_sr = 0;
     double *d_prev = nullptr;
     double2 *d_fdl = nullptr, *d_Y = nullptr;
@@ -104,6 +105,8 @@ struct gdg_ctx {
     size_t units_offset = 0;
     /* buffers */
     double *d_w0 = nullptr, *d_w1 = nullptr, *d_scratch = nullptr;
+    int window = 1;                            /* frames per channel and call of gdg_process_window_device (time blocking) */
+    size_t w_stride = 0;                       /* row stride of d_w0 / d_w1: window * max_frames */
     double *d_stage_in = nullptr, *d_stage_out = nullptr;
     double *h_stage_in = nullptr, *h_stage_out = nullptr;
     int stage_out_stride = 0;         /* > 0: d_stage_out holds one complete block of chain outputs, row c = channel c, this stride */
@@ -216,6 +219,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     gdg_ctx *ctx = new gdg_ctx();
     ctx->nch = n_channels;
     ctx->max_frames = max_frames;
+    ctx->w_stride = (size_t)max_frames;
     ctx->device = device;
     ctx->chains.resize((size_t)n_channels);
     { const char *e = getenv("GDG_SHARE_IR_SPECTRA"); if (e) ctx->share_spectra = atoi(e) != 0; }
@@ -807,18 +811,21 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
         u.fir_dirty = true;
         u.fir_live = false;
     }
-    if (!u.fir_dirty && u.fir_hop == hop) return GDG_OK;
+    const int W = (hop == GDG_MAX_FRAMES) ? ctx->window : 1;      /* time blocking exists for the batch block size only */
+    if (!u.fir_dirty && u.fir_hop == hop && u.fir_R == u.fir_K + W - 1) return GDG_OK;
     int L = (int)u.taps.size();
     if (reference_panics(hop, L))
         return fail(ctx, GDG_ERR_UNSUPPORTED, "frame size %d with a %d-tap filter: the reference panics on this pair (filter/filter.go:443-453: a block of "
                     "nextpow2(L) samples starts beyond the frame); rejected, not replicated", hop, L);
     int K = (L + hop - 1) / hop;
     if (K < 1) K = 1;                 /* filter.Empty: one all-zero partition => zeros out */
-    const bool carry = !u.fir_dirty && u.fir_live && u.fir_hop != hop && L > 0 && u.d_fdl && u.d_pos;
+    const int R = K + W - 1;
+    /* a live delay line moves into the new layout when the frame size OR the ring size (gdg_ctx_set_window) changes */
+    const bool carry = !u.fir_dirty && u.fir_live && (u.fir_hop != hop || u.fir_R != R) && L > 0 && u.d_fdl && u.d_pos;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     /* the old state, kept until the new delay line is built */
     double *o_prev = u.d_prev; double2 *o_fdl = u.d_fdl, *o_Y = u.d_Y; int *o_pos = u.d_pos;
-    const int K1 = u.fir_K, P1 = u.fir_P, hop1 = u.fir_hop;
+    const int K1 = u.fir_K, P1 = u.fir_P, hop1 = u.fir_hop, R1 = u.fir_R;
     auto free_old = [&]() { hipFree(o_prev); hipFree(o_fdl); hipFree(o_Y); hipFree(o_pos); };
     u.d_prev = nullptr; u.d_fdl = nullptr; u.d_Y = nullptr; u.d_pos = nullptr;
     double *d_old_hist = nullptr, *d_new_hist = nullptr;
@@ -835,8 +842,8 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
             HIP_TRY(ctx, hipMalloc((void **)&d_old_hist, old_len * sizeof(double)));
             std::vector<gdg_fir_rawjob> jobs((size_t)K1);
             for (int j = 0; j < K1; j++) {
-                int m = K1 - 1 - j;                                   /* frame t - m, t = the latest one, sits in slot (pos - 1 - m) mod K1 */
-                int slot = (((pos - 1 - m) % K1) + K1) % K1;
+                int m = K1 - 1 - j;                                   /* frame t - m, t = the latest one, sits in slot (pos - 1 - m) mod R1 */
+                int slot = (((pos - 1 - m) % R1) + R1) % R1;
                 jobs[(size_t)j].Y = o_fdl + (size_t)slot * P1;
                 jobs[(size_t)j].first = (j == 0) ? d_old_hist : nullptr;
                 jobs[(size_t)j].second = d_old_hist + (size_t)(j + 1) * hop1;
@@ -850,10 +857,10 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             hipFree(d_jobs); d_jobs = nullptr;
         }
-        size_t spec = (size_t)K * (size_t)P * sizeof(double2);
+        size_t spec = (size_t)R * (size_t)P * sizeof(double2);
         HIP_TRY(ctx, hipMalloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
         HIP_TRY(ctx, hipMalloc((void **)&u.d_fdl, spec));
-        HIP_TRY(ctx, hipMalloc((void **)&u.d_Y, (size_t)P * sizeof(double2)));
+        HIP_TRY(ctx, hipMalloc((void **)&u.d_Y, (size_t)W * (size_t)P * sizeof(double2)));
         HIP_TRY(ctx, hipMalloc((void **)&u.d_pos, sizeof(int)));
         HIP_TRY(ctx, hipMemsetAsync(u.d_prev, 0, 2 * (size_t)P * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(u.d_fdl, 0, spec, ctx->stream));
@@ -867,7 +874,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
             HIP_TRY(ctx, hipMemsetAsync(d_new_hist, 0, new_len * sizeof(double), ctx->stream));
             size_t n = std::min(old_len, new_len);
             HIP_TRY(ctx, hipMemcpyAsync(d_new_hist + (new_len - n), d_old_hist + (old_len - n), n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-            /* 3. slot f = spectrum of [frame f - 1 | frame f], f = 1 .. K - 1; the next frame goes to slot K mod K = 0 */
+            /* 3. slot f = spectrum of [frame f - 1 | frame f], f = 1 .. K - 1; the next frame goes to slot K mod R */
             if (K > 1) {
                 std::vector<gdg_fir_irjob> jobs((size_t)(K - 1));
                 for (int f = 1; f < K; f++) {
@@ -896,6 +903,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
     if (rc != GDG_OK) { u.fir_dirty = true; u.fir_live = false; return rc; }
     u.fir_P = P;
     u.fir_K = K;
+    u.fir_R = R;
     u.fir_hop = hop;
     u.fir_dirty = false;
     u.fir_live = carry;
@@ -958,7 +966,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
             bool last = (done[(size_t)c] + 1 == n_ops[(size_t)c]);
             double *dst;
             if (last) dst = d_out + (size_t)row_of[(size_t)c] * stride;
-            else dst = ((done[(size_t)c] & 1) ? ctx->d_w1 : ctx->d_w0) + (size_t)c * ctx->max_frames;
+            else dst = ((done[(size_t)c] & 1) ? ctx->d_w1 : ctx->d_w0) + (size_t)c * ctx->w_stride;
             if (is_fir) {
                 Unit &u = ctx->units[(size_t)op.handles[0]];
                 int rc = prepare_fir(ctx, u, frames, sample_rate);
@@ -966,7 +974,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 gdg_fir_chan f;
                 memset(&f, 0, sizeof(f));
                 f.src = cur[(size_t)c]; f.dst = dst; f.prev = u.d_prev; f.fdl = u.d_fdl; f.H = u.H->d_H; f.Y = u.d_Y;
-                f.pos = u.d_pos; f.K = u.fir_K; f.hop = frames;
+                f.pos = u.d_pos; f.K = u.fir_K; f.R = u.fir_R; f.hop = frames;
                 fd.push_back(f);
                 u.fir_live = true;
             } else {
@@ -1100,7 +1108,8 @@ static int check_device_error(gdg_ctx *ctx);
 typedef std::function<hipError_t(int g, hipStream_t s)> GroupHook;
 
 static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
-                        int stride = 0, bool rows_by_channel = false, int groups = 1, const GroupHook *before = nullptr, const GroupHook *after = nullptr) {
+                        int stride = 0, bool rows_by_channel = false, int groups = 1, const GroupHook *before = nullptr, const GroupHook *after = nullptr,
+                        int window = 1) {
     if (stride == 0) stride = frames;
     if (d_in == d_out) return fail(ctx, GDG_ERR_INVALID, "in-place processing is not supported");
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
@@ -1141,6 +1150,15 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             if (n == 0) continue;
             if (st.is_fir) {
                 const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset) + first;
+                if (window > 1) {
+                    /* `window` frames per channel: every spectrum is read once for all of them (fir.hip, "Time blocking") */
+                    const int sh = st.shared_spectra ? 1 : 0;
+                    { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 0, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 1, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 2, s));
+                      HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 3, s)); }
+                    continue;
+                }
                 { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, s)); }
                 const bool fused = ctx->fir_fused < 0 ? (n > ctx->fir_split_max) : (ctx->fir_fused != 0);
                 if (fused) {
@@ -1154,7 +1172,8 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);
-                HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, ctx->os, ctx->d_error, s));
+                for (int j = 0; j < window; j++)           /* the units' state runs through the frames in order */
+                    HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, (size_t)j * (size_t)frames, ctx->os, ctx->d_error, s));
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));
@@ -1179,6 +1198,40 @@ int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int fram
     if (!ctx || !d_in || !d_out) return GDG_ERR_INVALID;
     if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
     return process_rows(ctx, ctx->all_channels, d_in, d_out, frames, sample_rate);
+}
+
+int gdg_ctx_set_window(gdg_ctx *ctx, int frames_per_call) {
+    if (!ctx) return GDG_ERR_INVALID;
+    const int W = frames_per_call;
+    if (W != 1 && W != 2 && W != 4 && W != 8) return fail(ctx, GDG_ERR_INVALID, "window of %d frames: 1, 2, 4 or 8", W);
+    if (W > 1 && ctx->max_frames != GDG_MAX_FRAMES)
+        return fail(ctx, GDG_ERR_UNSUPPORTED, "windows are made of %d-sample frames, the context allows %d", GDG_MAX_FRAMES, ctx->max_frames);
+    if (W == ctx->window) return GDG_OK;
+    hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t stride = (size_t)W * (size_t)ctx->max_frames, bytes = (size_t)ctx->nch * stride * sizeof(double);
+    double *w0 = nullptr, *w1 = nullptr;
+    if (hipMalloc((void **)&w0, bytes) != hipSuccess || hipMalloc((void **)&w1, bytes) != hipSuccess) {
+        hipFree(w0);
+        return fail(ctx, GDG_ERR_NOMEM, "cannot allocate the window's intermediate frames");
+    }
+    hipFree(ctx->d_w0); hipFree(ctx->d_w1);
+    ctx->d_w0 = w0; ctx->d_w1 = w1;
+    ctx->w_stride = stride;
+    ctx->window = W;           /* the power amps' delay lines follow at their next frame (prepare_fir: ring of K + W - 1 slots) */
+    ctx->dirty = true;
+    return GDG_OK;
+}
+
+int gdg_process_window_device(gdg_ctx *ctx, const double *d_in, double *d_out, size_t row_stride, int frames_in_window, uint32_t sample_rate) {
+    if (!ctx || !d_in || !d_out) return GDG_ERR_INVALID;
+    const int W = frames_in_window;
+    if (W < 1 || W > ctx->window) return fail(ctx, GDG_ERR_INVALID, "window of %d frames, the context is set up for %d (gdg_ctx_set_window)", W, ctx->window);
+    if (W != 1 && W != 2 && W != 4 && W != 8) return fail(ctx, GDG_ERR_INVALID, "window of %d frames: 1, 2, 4 or 8", W);
+    if (row_stride < (size_t)W * (size_t)ctx->max_frames || row_stride > 0x7fffffff)
+        return fail(ctx, GDG_ERR_INVALID, "row stride %zu is shorter than the window (%d x %d)", row_stride, W, ctx->max_frames);
+    if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
+    return process_rows(ctx, ctx->all_channels, d_in, d_out, ctx->max_frames, sample_rate, (int)row_stride, false, 1, nullptr, nullptr, W);
 }
 
 static int check_device_error(gdg_ctx *ctx) {

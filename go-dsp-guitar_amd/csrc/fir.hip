@@ -9,9 +9,9 @@
  *   fir_fwd   one workgroup per channel: [x_{t-1} | x_t] (2P reals) -> packed P-point complex
  *             Stockham FFT held entirely in registers + LDS (P = 8192: 16 points per thread,
  *             512 threads, 139 KiB of LDS -- only possible with CDNA4's 160 KiB) -> half spectrum
- *             written to slot pos % K of the channel's frequency-domain delay line (FDL) in HBM.
+ *             written to slot pos % R of the channel's frequency-domain delay line (FDL) in HBM.
  *   fir_inv   one workgroup per channel.  Default (FUSED): the spectrum multiply-accumulate
- *             Y[b] = sum_k FDL[(pos - k) % K][b] * H[k][b] runs HERE, partition by partition through all bins
+ *             Y[b] = sum_k FDL[(pos - k) % R][b] * H[k][b] runs HERE, partition by partition through all bins
  *             (two long sequential streams per workgroup, 32 sixteen-byte loads per lane in flight), and lands
  *             directly in the inverse transform's first stage in LDS -> packed inverse FFT -> second half ->
  *             clip -> out.  This is the HBM-bound kernel (the roofline one).
@@ -249,7 +249,7 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
         a = ch.prev + (size_t)((pos + 1) & 1) * N;       /* previous frame */
         prev_out = ch.prev + (size_t)(pos & 1) * N;       /* where this frame is kept for the next call */
         bsrc = ch.src;
-        out = ch.fdl + (size_t)(pos % ch.K) * N;
+        out = ch.fdl + (size_t)(pos % ch.R) * N;
         hop = ch.hop;
     }
 
@@ -355,18 +355,24 @@ __device__ __forceinline__ void twiddle_powers8(cplx (&u)[8], cplx w) {
     u[5] = cmul(u[5], w5); u[6] = cmul(u[6], w6); u[7] = cmul(u[7], w7);
 }
 
+/* TB = 0: one frame per channel (blockIdx.x = channel).  TB = 1: a window of W consecutive frames per channel (time blocking):
+ * blockIdx.x = channel * W + j; frame j's predecessor is frame j - 1 of the same call (only frame 0 looks into `prev`), nothing is
+ * written to `prev` and the frame counter is left alone -- fir_tb_finish_kernel does both once the window is through. */
+template <int TB>
 __global__ void __launch_bounds__(512)
-fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, int W, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
     constexpr int N = 8192, T = 512;
     __shared__ double sre[GDG_W_LDS];
     __shared__ double sim[GDG_W_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    gdg_fir_chan ch = chans[blockIdx.x];
+    const int jw = TB ? (int)(blockIdx.x % (unsigned)W) : 0;
+    gdg_fir_chan ch = chans[TB ? blockIdx.x / (unsigned)W : blockIdx.x];
     const int pos = *ch.pos;
     const double *a = ch.prev + (size_t)((pos + 1) & 1) * N;       /* previous frame */
+    if (TB && jw > 0) a = ch.src + (size_t)jw * N - N;
     double *prev_out = ch.prev + (size_t)(pos & 1) * N;            /* where this frame is kept for the next call */
-    const double *bsrc = ch.src;
-    cplx *out = ch.fdl + (size_t)(pos % ch.K) * N;
+    const double *bsrc = ch.src + (size_t)jw * N;
+    cplx *out = ch.fdl + (size_t)((pos + jw) % ch.R) * N;
 
     /* step A: radix-8 across the workgroup, straight from global memory (element e = n1 + 1024 n2: e < N/2 is the previous frame).
      * All sixteen frame loads and both twiddle loads of the thread are issued before anything is consumed: the copy of the frame
@@ -385,8 +391,10 @@ fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict
 #pragma unroll
     for (int b = 0; b < 2; b++) {
         const int n1 = tid + T * b;
+        if constexpr (!TB) {
 #pragma unroll
-        for (int n2 = 4; n2 < 8; n2++) gstore(reinterpret_cast<cplx *>(prev_out + 2 * (n1 + 1024 * n2 - N / 2)), ua[b][n2]);
+            for (int n2 = 4; n2 < 8; n2++) gstore(reinterpret_cast<cplx *>(prev_out + 2 * (n1 + 1024 * n2 - N / 2)), ua[b][n2]);
+        }
         Dft<8, false>::run(ua[b]);
         twiddle_powers8(ua[b], wa[b]);
 #pragma unroll
@@ -450,8 +458,8 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     gdg_fir_chan ch = chans[SWAP ? blockIdx.x : blockIdx.y];
     const int b0 = ((SWAP ? blockIdx.y : blockIdx.x) * blockDim.x + threadIdx.x) * BPT;
     if (b0 >= P) return;
-    const int K = ch.K;
-    const int cur = (*ch.pos) % K;
+    const int K = ch.K, R = ch.R;
+    const int cur = (*ch.pos) % R;
     const cplx *__restrict__ fdl = ch.fdl + b0;
     const cplx *__restrict__ H = ch.H + b0;
     double ar[BPT], ai[BPT], br = 0.0, bi = 0.0;       /* complex product sums; component-wise sum for bin 0 */
@@ -463,7 +471,7 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             int slot = cur - (k + u);
-            if (slot < 0) slot += K;
+            if (slot < 0) slot += R;
 #pragma unroll
             for (int q = 0; q < BPT; q++) {
                 x[u][q] = mac_load<NT>(fdl + (size_t)slot * P + q);
@@ -483,7 +491,7 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     }
     for (; k < K; k++) {
         int slot = cur - k;
-        if (slot < 0) slot += K;
+        if (slot < 0) slot += R;
 #pragma unroll
         for (int q = 0; q < BPT; q++) {
             cplx x = gload(fdl + (size_t)slot * P + q), h = gload(H + (size_t)k * P + q);
@@ -534,7 +542,7 @@ __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int ti
     for (int i = 0; i < ITER; i++) { kr[i] = 0.0; ki[i] = 0.0; nr[i] = 0.0; ni[i] = 0.0; }
     for (int u = 0; u < K; u++) {
         int slot = cur - u;
-        if (slot < 0) slot += K;
+        if (slot < 0) slot += ch.R;
         const cplx *__restrict__ x = ch.fdl + (size_t)slot * N;
         const cplx *__restrict__ h = ch.H + (size_t)u * N;
         cplx xk[ITER], hk[ITER], xn[ITER], hn[ITER];
@@ -574,15 +582,18 @@ __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int ti
  * profiles/probes/); 2 = the IR spectra are shared between channels and read with cacheable loads. */
 template <int LOGN, int FUSED>
 __global__ void __launch_bounds__(FftCfg<LOGN>::T)
-fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
     __shared__ double sre[FftCfg<LOGN>::LDS];
     __shared__ double sim[FftCfg<LOGN>::LDS];
     const int tid = threadIdx.x;
-    gdg_fir_chan ch = chans[blockIdx.x];
-    const cplx *__restrict__ Y = ch.Y;
+    /* FUSED 3: frame j of a window of W frames (blockIdx.x = channel * W + j): Y holds W spectra, dst W frames, the frame
+     * counter stays (fir_tb_finish_kernel) */
+    const int jw = (FUSED == 3) ? (int)(blockIdx.x % (unsigned)W) : 0;
+    gdg_fir_chan ch = chans[(FUSED == 3) ? blockIdx.x / (unsigned)W : blockIdx.x];
+    const cplx *__restrict__ Y = ch.Y + (size_t)jw * N;
     int cur = 0;
-    if constexpr (FUSED != 0) cur = (*ch.pos) % ch.K;
+    if constexpr (FUSED == 1 || FUSED == 2) cur = (*ch.pos) % ch.R;
 
     if constexpr (FUSED == 1) mac_head<LOGN, true>(ch, cur, tid, sre, sim, tw2);
     else if constexpr (FUSED == 2) mac_head<LOGN, false>(ch, cur, tid, sre, sim, tw2);
@@ -604,8 +615,8 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
     constexpr int LR = sched_lr(LOGN, NP - 1), LNS = sched_lns(LOGN, NP - 1), R = 1 << LR, B = 16 / R;
     pass_load<LOGN, LR>(v, sre, sim, tid);
     pass_compute<LOGN, LR, LNS, true>(v, tw, tid);
-    double *__restrict__ dst = ch.dst;
     const int hop = ch.hop;
+    double *__restrict__ dst = ch.dst + (size_t)jw * hop;
     if (hop == N) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
@@ -635,9 +646,9 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, const cplx *__restrict__ 
             }
         }
     }
-    if (tid == 0) {
+    if (FUSED != 3 && tid == 0) {
         int pos = *ch.pos + 1;
-        int wrap = 2 * ch.K;
+        int wrap = 2 * ch.R;
         *ch.pos = (pos >= wrap) ? pos - wrap : pos;
     }
 }
@@ -683,6 +694,74 @@ fir_raw_inv_kernel(const gdg_fir_rawjob *__restrict__ jobs, double scale, const 
             }
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Time blocking.  A caller that holds W consecutive frames of every channel (the batch run: whole files live in HBM) gets the W
+ * outputs  Y_j = sum_k H[k] X[t0 + j - k],  j = 0 .. W - 1,  from ONE pass over the IR spectra and one over the K + W - 1 delay
+ * line slots they touch: (2 K + W - 1) spectrum reads for W frames instead of 2 K W.  The ring has R >= K + W - 1 slots so the
+ * W new spectra do not overwrite what the early frames of the window still need.
+ *
+ * One thread per bin.  Partitions are walked in chunks of W: chunk c needs H[cW .. cW + W - 1] and the 2 W - 1 slots
+ * X[t0 - cW + d], d = -(W - 1) .. W - 1, all loaded before the W x W multiply-adds, whose indices are compile-time constants.
+ * Every Y_j accumulates its terms in ascending k -- the order of the per-frame kernels; the results differ from W single-frame
+ * calls only where the compiler contracts a multiply-add differently (last bit).
+ * ---------------------------------------------------------------------------------------------- */
+template <int W, bool HNT>
+__global__ void __launch_bounds__(256)
+fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
+    gdg_fir_chan ch = chans[blockIdx.y];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= P) return;
+    const int K = ch.K, R = ch.R;
+    const int pos0 = (*ch.pos) % R;                       /* slot of X[t0] (frame 0 of the window) */
+    const cplx *__restrict__ fdl = ch.fdl + b;
+    const cplx *__restrict__ H = ch.H + b;
+    double ar[W], ai[W], br[W], bi[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) { ar[j] = 0.0; ai[j] = 0.0; br[j] = 0.0; bi[j] = 0.0; }
+    for (int c = 0; c * W < K; c++) {
+        cplx x[2 * W - 1], h[W];
+#pragma unroll
+        for (int d = 0; d < 2 * W - 1; d++) {
+            int slot = (pos0 + (d - (W - 1)) - c * W) % R;      /* |argument| < 3 R: one correction is not enough for the remainder's sign */
+            if (slot < 0) slot += R;
+            x[d] = mac_load<true>(fdl + (size_t)slot * P);
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const int k = c * W + i;
+            h[i] = (k < K) ? mac_load<HNT>(H + (size_t)k * P) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (c * W + i < K) {
+#pragma unroll
+                for (int j = 0; j < W; j++) {
+                    const cplx xv = x[j - i + W - 1];
+                    ar[j] += xv.x * h[i].x - xv.y * h[i].y;
+                    ai[j] += xv.x * h[i].y + xv.y * h[i].x;
+                    br[j] += xv.x * h[i].x;              /* bin 0 = (DC, Nyquist) as two reals: component-wise */
+                    bi[j] += xv.y * h[i].y;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; j++) gstore(ch.Y + (size_t)j * P + b, (b == 0) ? make_double2(br[j], bi[j]) : make_double2(ar[j], ai[j]));
+}
+
+/* after a window of W frames: the last frame becomes the overlap-save history of the next call, the frame counter moves on */
+__global__ void __launch_bounds__(256)
+fir_tb_finish_kernel(const gdg_fir_chan *__restrict__ chans, int W) {
+    gdg_fir_chan ch = chans[blockIdx.x];
+    const int N = ch.hop;
+    const int pos = *ch.pos;
+    __syncthreads();
+    const cplx *src = reinterpret_cast<const cplx *>(ch.src + (size_t)(W - 1) * N);
+    cplx *dst = reinterpret_cast<cplx *>(ch.prev + (size_t)((pos + W + 1) & 1) * N);
+    for (int i = threadIdx.x; i < N / 2; i += 256) gstore(dst + i, gload(src + i));
+    if (threadIdx.x == 0) *ch.pos = (pos + W) % (2 * ch.R);
 }
 
 /* ---- host side ------------------------------------------------------------------------------- */
@@ -737,9 +816,27 @@ template <int LG> static void launch_raw_inv(const gdg_fir_rawjob *d_jobs, int n
     fir_raw_inv_kernel<LG><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_jobs, scale, tw, tw2);
 }
 template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, hipStream_t s) {
-    if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
-    else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
-    else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, tw, tw2);
+    if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, tw, tw2);
+    else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, tw, tw2);
+    else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, tw, tw2);
+}
+
+/* a window of W frames of 8192 samples per channel (W in {2, 4, 8}); the four launches of one power-amp step */
+template <int W> static void launch_mac_tb(const gdg_fir_chan *d_chans, int n, bool shared, hipStream_t s) {
+    if (shared) fir_mac_tb_kernel<W, false><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
+    else fir_mac_tb_kernel<W, true><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
+}
+hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const cplx *d_tw, const cplx *d_tw2, int what, hipStream_t s) {
+    if (n_chans <= 0) return hipSuccess;
+    if (W != 2 && W != 4 && W != 8) return hipErrorInvalidValue;
+    if (what == 0) fir_fwd13w_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, d_tw, d_tw2);
+    else if (what == 1) {
+        if (W == 2) launch_mac_tb<2>(d_chans, n_chans, shared_spectra != 0, s);
+        else if (W == 4) launch_mac_tb<4>(d_chans, n_chans, shared_spectra != 0, s);
+        else launch_mac_tb<8>(d_chans, n_chans, shared_spectra != 0, s);
+    } else if (what == 2) fir_inv_kernel<13, 3><<<dim3(n_chans * W), dim3(FftCfg<13>::T), 0, s>>>(d_chans, W, d_tw, d_tw2);
+    else fir_tb_finish_kernel<<<dim3(n_chans), dim3(256), 0, s>>>(d_chans, W);
+    return hipGetLastError();
 }
 
 hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
@@ -747,7 +844,7 @@ hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n
     static int wave_fft = -1;
     if (wave_fft < 0) { const char *e = getenv("GDG_WAVE_FFT"); wave_fft = e ? atoi(e) : 1; }
     if (P == 8192 && hop == P && (wave_fft & 1)) {
-        fir_fwd13w_kernel<<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, d_tw, d_tw2);
+        fir_fwd13w_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, d_tw, d_tw2);
         return hipGetLastError();
     }
     int L = ilog2_exact(P);

@@ -31,6 +31,7 @@ struct gdg_fir_chan {
     double2 *Y;
     int *pos;
     int K;
+    int R;                   /* slots of the delay-line ring: K, or K + W - 1 when the context runs windows of W blocks (time blocking) */
     int hop;                 /* samples per frame; == P for power-of-two frames, < P otherwise (the transform of
                               * [previous | current | zeros] still has 2P points, P = nextpow2(hop)) */
 };
@@ -57,6 +58,11 @@ struct gdg_fir_rawjob {
 hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
 hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s);
+/* time blocking: a window of W (2, 4 or 8) consecutive 8192-sample frames per channel; what = 0 forward transforms, 1 multiply-accumulate
+ * (reads every spectrum once for the W frames), 2 inverse transforms, 3 history + frame counter.  chans[].src / dst: frame 0 of the
+ * window, frame j at + j * 8192; chans[].Y holds W spectra; chans[].R >= K + W - 1. */
+hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const double2 *d_tw, const double2 *d_tw2,
+                                 int what, hipStream_t s);
 hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, hipStream_t s);
 hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
@@ -113,7 +119,7 @@ struct gdg_os_tables {
 #define GDG_OS_PADLO(F) (GDG_OS_NC - 1 - GDG_OS_BACK(F))
 #define GDG_OS_NE(F) (GDG_OS_NC + GDG_OS_R(F) - 1 + 1)              /* table entries per phase (+1: even) */
 
-hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames,
+hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, size_t frame_off,
                           gdg_os_tables os, int *d_error, hipStream_t s);
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);

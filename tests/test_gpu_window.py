@@ -1,0 +1,150 @@
+"""Time blocking (gdg_ctx_set_window / gdg_process_window_device): W consecutive 8192-sample frames per channel and call, every power
+amp reading its IR spectra and its delay line once for all W frames.  The sums keep the order of the per-frame kernels (the
+compiler contracts the multiply-adds differently from kernel to kernel, so the last bit may differ): the output must agree with W
+calls of gdg_process_device to 1e-14 per sample; against the oracle the usual 1e-9 RMS applies."""
+import numpy as np
+import pytest
+
+from helpers import TOL_RMS, package, rms, synth_ir, synth_signal
+
+pytestmark = pytest.mark.gpu
+
+B = 8192
+RATE = 96000
+PRE = [("compressor", [1, 30, -20]), ("overdrive", [0, 15, 80, -3, 1, 0]), ("chorus", None)]
+POST = [("cabinet", None), ("reverb", [30])]
+# channel: taps of the first amp, taps of the second amp (None: one amp only; K = 1, 3, 8 and 9 partitions, the last = two chunks at W = 8)
+TAPS = [(3000, None), (20000, 5000), (65536, 65536), (70000, 100), (0, None)]
+
+
+
+
+def make_ctx(pkg, irs):
+    ctx = pkg.Context(len(TAPS), B)
+    for c, (t1, t2) in enumerate(TAPS):
+        for name, p in PRE:
+            ctx.append_unit(c, name, params=p)
+        ctx.append_unit(c, "power_amp", fir=irs[c][0])
+        if t2 is not None:
+            ctx.append_unit(c, "tone_stack")
+            ctx.append_unit(c, "power_amp", fir=irs[c][1])
+        for name, p in POST:
+            ctx.append_unit(c, name, params=p)
+    return ctx
+
+
+def signals(blocks):
+    return np.stack([0.6 * synth_signal(c, blocks * B, RATE) for c in range(len(TAPS))])
+
+
+def impulse_responses():
+    return [(synth_ir(t1, seed=70 + c) if t1 else np.zeros(0), synth_ir(t2, seed=90 + c) if t2 else None) for c, (t1, t2) in enumerate(TAPS)]
+
+
+def per_frame(pkg, irs, x):
+    nch, n = x.shape
+    ctx = make_ctx(pkg, irs)
+    d_in, d_out = ctx.alloc(nch, B), ctx.alloc(nch, B)
+    out = np.zeros_like(x)
+    for b in range(n // B):
+        d_in.upload(np.ascontiguousarray(x[:, b * B:(b + 1) * B]))
+        ctx.process_device(d_in, d_out, B, RATE)
+        out[:, b * B:(b + 1) * B] = d_out.download()
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_window_equals_single_frames(W):
+    pkg = package()
+    irs = impulse_responses()
+    blocks = 2 * W + (W - 1)                      # two full windows, then the tail in windows of W/2, W/4, .., 1
+    x = signals(blocks)
+    want = per_frame(pkg, irs, x)
+    nch, n = x.shape
+    ctx = make_ctx(pkg, irs)
+    ctx.set_window(W)
+    d_in, d_out = ctx.alloc(nch, n), ctx.alloc(nch, n)         # "whole files" in HBM: the rows are the windows' row stride
+    d_in.upload(x)
+    done = 0
+    while done < blocks:
+        w = W
+        while w > blocks - done:
+            w //= 2
+        ctx.process_window_device(d_in.ptr + 8 * done * B, d_out.ptr + 8 * done * B, n, w, RATE)
+        done += w
+    got = d_out.download()
+    ctx.close()
+    for c in range(nch):
+        assert np.max(np.abs(got[c] - want[c])) <= 1e-14, "channel %d: max diff %.3e" % (c, np.max(np.abs(got[c] - want[c])))
+
+
+def test_window_against_the_oracle(oracle):
+    pkg = package()
+    irs = impulse_responses()
+    blocks = 8
+    x = signals(blocks)
+    nch, n = x.shape
+    ctx = make_ctx(pkg, irs)
+    ctx.set_window(4)
+    d_in, d_out = ctx.alloc(nch, n), ctx.alloc(nch, n)
+    d_in.upload(x)
+    for w0 in range(0, blocks, 4):
+        ctx.process_window_device(d_in.ptr + 8 * w0 * B, d_out.ptr + 8 * w0 * B, n, 4, RATE)
+    got = d_out.download()
+    ctx.close()
+    for c, (t1, t2) in enumerate(TAPS):
+        ch = oracle.Chain()
+        for name, p in PRE:
+            ch.append_unit(name, params=p)
+        ch.append_unit("power_amp", fir=irs[c][0])
+        if t2 is not None:
+            ch.append_unit("tone_stack")
+            ch.append_unit("power_amp", fir=irs[c][1])
+        for name, p in POST:
+            ch.append_unit(name, params=p)
+        want = np.concatenate([ch.process(x[c, b * B:(b + 1) * B], RATE) for b in range(blocks)])
+        assert rms(got[c] - want) <= TOL_RMS, "channel %d: RMS %.3e" % (c, rms(got[c] - want))
+
+
+def test_window_size_changes_mid_stream_keep_the_convolution_state():
+    """Single frames, then windows of 4, then of 8, then single frames again on a context that is back at W = 1: the delay lines move
+    into the larger (and back into the smaller) ring; the re-partitioning is exact to ~1e-16, not bit-exact."""
+    pkg = package()
+    irs = impulse_responses()
+    plan = [(1, 1), (1, 1), (1, 1), (4, 4), (4, 4), (8, 8), (1, 1), (1, 1)]          # (window set on the context, frames in the call)
+    blocks = sum(w for _, w in plan)
+    x = signals(blocks)
+    want = per_frame(pkg, irs, x)
+    nch, n = x.shape
+    ctx = make_ctx(pkg, irs)
+    d_in, d_out = ctx.alloc(nch, n), ctx.alloc(nch, n)
+    d_in.upload(x)
+    done = 0
+    for W, w in plan:
+        ctx.set_window(W)
+        ctx.process_window_device(d_in.ptr + 8 * done * B, d_out.ptr + 8 * done * B, n, w, RATE)
+        done += w
+    got = d_out.download()
+    ctx.close()
+    for c in range(nch):
+        assert rms(got[c] - want[c]) <= 1e-13, "channel %d: RMS %.3e" % (c, rms(got[c] - want[c]))
+
+
+def test_window_rejections():
+    pkg = package()
+    ctx = pkg.Context(2, B)
+    d_in, d_out = ctx.alloc(2, 8 * B), ctx.alloc(2, 8 * B)
+    with pytest.raises(pkg.GdgError, match="window of 3 frames: 1, 2, 4 or 8"):
+        ctx.set_window(3)
+    with pytest.raises(pkg.GdgError, match="window of 2 frames, the context is set up for 1"):
+        ctx.process_window_device(d_in, d_out, 8 * B, 2, RATE)
+    ctx.set_window(8)
+    with pytest.raises(pkg.GdgError, match="row stride 8192 is shorter than the window"):
+        ctx.process_window_device(d_in, d_out, B, 4, RATE)
+    ctx.process_window_device(d_in, d_out, 8 * B, 8, RATE)              # empty chains: a copy
+    ctx.close()
+    small = pkg.Context(2, 1024)
+    with pytest.raises(pkg.GdgError, match="windows are made of 8192-sample frames"):
+        small.set_window(2)
+    small.close()
