@@ -225,21 +225,54 @@ def end_to_end(pkg, ctx, nch, frames, sr, steps=6):
     return res
 
 
-def batch_run(pkg, ctx, nch, sr, blocks=16):
-    """gdg_batch_run on the SAME context: 16-bit files in, 24-bit files out (N + 3 of them), everything between in HBM."""
+def batch_run(pkg, ctx, nch, sr, blocks=32):
+    """gdg_batch_run on the SAME context: 16-bit files in, 24-bit files out (N + 3 of them), everything between in HBM;
+    per window size W of the block loop (1 = the reference's loop, 8 = time blocked)."""
     frames = 8192
     n = blocks * frames
     rng = np.random.default_rng(5)
     files = [(rng.integers(-20000, 20000, n, dtype=np.int16).view(np.uint8), "lpcm16", sr) for _ in range(nch)]
-    outs = ctx.batch_run(files, sr, "lpcm24")               # also touches the output pages once
-    t0 = time.perf_counter()
-    ctx.batch_run(files, sr, "lpcm24", outs=outs)
-    dt = time.perf_counter() - t0
-    return {"value": nch * n / dt / 1e6, "unit": "Msamples/s", "ms": dt * 1e3, "blocks": blocks, "files_in": "lpcm16 x %d" % nch,
-            "files_out": "lpcm24 x %d" % len(outs), "host_bytes_in_plus_out": sum(f[0].nbytes for f in files) + sum(o.nbytes for o in outs),
-            "what": "controller.processFiles between 'files read' and 'files written' in one call: H2D of the file bytes, decode, "
-                    "%d x (N chains + metronome + spatializer + encode, the encoded block going down while the next one runs); caller's "
-                    "buffers are pageable, already touched" % blocks}
+    res = {"blocks": blocks, "files_in": "lpcm16 x %d" % nch, "files_out": "lpcm24 x %d" % (nch + 3), "unit": "Msamples/s",
+           "what": "controller.processFiles between 'files read' and 'files written' in one call: H2D of the file bytes, decode, the block "
+                   "loop in steps of W blocks (N chains + metronome + spatializer + encode, the encoded step going down while the next one "
+                   "runs); caller's buffers are pageable, already touched"}
+    for W in (1, 8):
+        ctx.set_window(W)
+        outs = ctx.batch_run(files, sr, "lpcm24")               # also touches the output pages once
+        t0 = time.perf_counter()
+        ctx.batch_run(files, sr, "lpcm24", outs=outs)
+        dt = time.perf_counter() - t0
+        res["window_%d" % W] = {"value": nch * n / dt / 1e6, "ms": dt * 1e3}
+        res["host_bytes_in_plus_out"] = sum(f[0].nbytes for f in files) + sum(o.nbytes for o in outs)
+    res["value"] = res["window_8"]["value"]
+    ctx.set_window(1)
+    return res
+
+
+def time_blocked(pkg, ctx, nch, frames, sr, blocks=32):
+    """The same chains over `blocks` consecutive frames per channel resident in HBM (what the batch run holds), W frames per call:
+    every power amp reads its IR spectra and delay line once per W frames (gdg_process_window_device)."""
+    d_in, d_out = ctx.alloc(nch, blocks * frames), ctx.alloc(nch, blocks * frames)
+    d_in.upload(np.tile(synth_block(nch, frames, sr), (1, blocks)))
+    res = {"unit": "Msamples/s", "frames_per_channel": blocks,
+           "what": "device-resident, W consecutive 8192-sample frames per channel and call; W = 1 is the headline's per-frame call"}
+    for W in (1, 2, 4, 8):
+        ctx.set_window(W)
+
+        def run():
+            for b in range(0, blocks, W):
+                ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, blocks * frames, W, sr)
+        run()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        run()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / blocks
+        res["window_%d" % W] = {"value": nch * frames / dt / 1e6, "us_per_frame": dt * 1e6, "realtime_factor": frames / sr / dt}
+    ctx.set_window(1)
+    d_in.free()
+    d_out.free()
+    return res
 
 
 def other_configs(pkg, device):
@@ -372,6 +405,7 @@ def main():
             extras["end_to_end"] = end_to_end(pkg, ctx, nch, frames, sr)
             if frames == 8192:
                 extras["end_to_end"]["batch_run"] = batch_run(pkg, ctx, nch, sr)
+                extras["time_blocked"] = time_blocked(pkg, ctx, nch, frames, sr)
     ctx.close()
     del x, y
     if not args.no_extras and not strong:

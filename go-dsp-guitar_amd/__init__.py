@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
     "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
-    "gdg_batch_length", "gdg_batch_run", "gdg_ctx_set_window", "gdg_process_window_device",
+    "gdg_batch_length", "gdg_batch_run", "gdg_ctx_set_window", "gdg_process_window_device", "gdg_ctx_set_overlap",
 ]
 
 
@@ -149,6 +149,7 @@ def lib():
             "gdg_metronome_process": (i32, [vp, vp, i32]),
             "gdg_metronome_process_device": (i32, [vp, vp, i32]),
             "gdg_ctx_set_window": (i32, [vp, i32]),
+            "gdg_ctx_set_overlap": (i32, [vp, i32]),
             "gdg_process_window_device": (i32, [vp, vp, vp, C.c_size_t, i32, u32]),
             "gdg_batch_length": (i32, [vp, vp, i32, u32, C.POINTER(C.c_size_t)]),
             "gdg_batch_run": (i32, [vp, vp, i32, vp, vp]),
@@ -471,6 +472,10 @@ class Context:
     def set_window(self, frames_per_call):
         """Time blocking: up to `frames_per_call` (1, 2, 4, 8) consecutive 8192-sample frames per channel and call."""
         self._check(lib().gdg_ctx_set_window(self._h, frames_per_call))
+
+    def set_overlap(self, groups):
+        """Channel groups of the device-resident calls, free-running on streams of their own (include/gdg.h)."""
+        self._check(lib().gdg_ctx_set_overlap(self._h, groups))
 
     def process_window_device(self, d_in, d_out, row_stride, frames_in_window, sample_rate):
         pi = d_in.ptr if isinstance(d_in, DeviceBuffer) else d_in

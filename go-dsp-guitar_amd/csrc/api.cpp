@@ -96,7 +96,7 @@ struct gdg_ctx {
     const double *plan_in = nullptr;
     double *plan_out = nullptr;
     std::vector<int> plan_active, all_channels;
-    int plan_stride = 0;
+    int plan_stride = 0, plan_stride_out = 0;
     bool plan_by_channel = false;
     std::vector<StepDesc> steps;
     std::vector<unsigned char> blob;
@@ -154,6 +154,8 @@ struct gdg_ctx {
     /* channel groups of the host-buffer paths: group g's upload, kernels and download run on stream g, so one group's
      * PCIe transfers overlap the other groups' kernels (channels are independent) */
     int plan_groups = 1;
+    int overlap_groups = 0;                    /* 0: automatic (device_groups) */
+    bool groups_pending = false;               /* group streams hold work the context's stream has not been ordered after */
     std::vector<hipStream_t> gstreams;
     std::vector<hipEvent_t> gjoin;
     hipEvent_t gfork = nullptr;
@@ -171,6 +173,14 @@ static int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf;
     return code;
+}
+
+/* Device-resident calls may leave their channel groups running on streams of their own (process_rows, `free_run`); whatever
+ * touches the context next -- any entry point -- first makes the context's stream wait for them. */
+static void join_groups(gdg_ctx *ctx);
+static void enter(gdg_ctx *ctx) {
+    hipSetDevice(ctx->device);
+    join_groups(ctx);
 }
 
 #define HIP_TRY(ctx, call)                                                                          \
@@ -205,6 +215,15 @@ int gdg_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+static void join_groups(gdg_ctx *ctx) {
+    if (!ctx->groups_pending) return;
+    for (size_t g = 0; g < ctx->gstreams.size() && g < ctx->gjoin.size(); g++) {
+        hipEventRecord(ctx->gjoin[g], ctx->gstreams[g]);
+        hipStreamWaitEvent(ctx->stream, ctx->gjoin[g], 0);
+    }
+    ctx->groups_pending = false;
 }
 
 int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
@@ -274,7 +293,7 @@ static void free_unit(Unit &u) {
 
 int gdg_ctx_destroy(gdg_ctx *ctx) {
     if (!ctx) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (auto &u : ctx->units) if (u.alive) free_unit(u);
     for (auto &kv : ctx->fir_tables) { hipFree(kv.second.first); hipFree(kv.second.second); }
@@ -309,7 +328,11 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable) {
     ctx->share_spectra = enable != 0;       /* affects power amps prepared from now on */
     return GDG_OK;
 }
-void *gdg_ctx_stream(const gdg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+void *gdg_ctx_stream(const gdg_ctx *ctx) {
+    if (!ctx) return nullptr;
+    join_groups(const_cast<gdg_ctx *>(ctx));           /* work enqueued on the returned stream from here on follows everything already submitted */
+    return (void *)ctx->stream;
+}
 
 /* ---- units ------------------------------------------------------------------------------------- */
 
@@ -322,7 +345,7 @@ int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle) {
     if (!ctx || !handle) return GDG_ERR_INVALID;
     if (channel < 0 || channel >= ctx->nch) return fail(ctx, GDG_ERR_INVALID, "channel %d out of range", channel);
     if (unit_type < 0 || unit_type >= GDG_UNIT_COUNT) return fail(ctx, GDG_ERR_INVALID, "Failed to create effects unit.");
-    hipSetDevice(ctx->device);
+    enter(ctx);
     size_t h = 0;
     while (h < ctx->units.size() && ctx->units[h].alive) h++;
     if (h == ctx->units.size()) ctx->units.emplace_back();
@@ -347,7 +370,7 @@ int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle) {
 int gdg_unit_destroy(gdg_ctx *ctx, int handle) {
     Unit *u = get_unit(ctx, handle);
     if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
-    hipSetDevice(ctx->device);
+    enter(ctx);
     hipStreamSynchronize(ctx->stream);
     for (auto &chain : ctx->chains)
         chain.erase(std::remove_if(chain.begin(), chain.end(), [&](const Slot &s) { return s.handle == handle; }), chain.end());
@@ -399,7 +422,7 @@ static int zero_unit_state(gdg_ctx *ctx, Unit &u) {
 int gdg_unit_reset(gdg_ctx *ctx, int handle) {
     Unit *u = get_unit(ctx, handle);
     if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
-    hipSetDevice(ctx->device);
+    enter(ctx);
     ctx->dirty = true;
     return zero_unit_state(ctx, *u);
 }
@@ -914,8 +937,9 @@ struct Op { bool is_fir; std::vector<int> handles; };
 
 /* `active`: the channels taking part in this call; row i of d_in / d_out belongs to channel active[i] */
 static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
-                      int stride, bool rows_by_channel, int G) {
+                      int stride, int stride_out, bool rows_by_channel, int G) {
     const int nch = ctx->nch;
+    join_groups(ctx);                 /* a new plan replaces descriptors (and possibly unit state) the group streams may still be reading */
     /* channel groups: group of the i-th active channel = floor(i G / |active|), i.e. contiguous runs of `active` */
     std::vector<int> group_of((size_t)nch, 0);
     for (size_t i = 0; i < active.size(); i++) group_of[(size_t)active[i]] = (int)(i * (size_t)G / active.size());
@@ -965,7 +989,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
             Op &op = entry.second;
             bool last = (done[(size_t)c] + 1 == n_ops[(size_t)c]);
             double *dst;
-            if (last) dst = d_out + (size_t)row_of[(size_t)c] * stride;
+            if (last) dst = d_out + (size_t)row_of[(size_t)c] * stride_out;
             else dst = ((done[(size_t)c] & 1) ? ctx->d_w1 : ctx->d_w0) + (size_t)c * ctx->w_stride;
             if (is_fir) {
                 Unit &u = ctx->units[(size_t)op.handles[0]];
@@ -975,12 +999,14 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 memset(&f, 0, sizeof(f));
                 f.src = cur[(size_t)c]; f.dst = dst; f.prev = u.d_prev; f.fdl = u.d_fdl; f.H = u.H->d_H; f.Y = u.d_Y;
                 f.pos = u.d_pos; f.K = u.fir_K; f.R = u.fir_R; f.hop = frames;
+                f.flags = (done[(size_t)c] == 0 ? GDG_SRC_IS_INPUT : 0) | (last ? GDG_DST_IS_OUTPUT : 0);
                 fd.push_back(f);
                 u.fir_live = true;
             } else {
                 gdg_seg_chan s;
                 memset(&s, 0, sizeof(s));
                 s.src = cur[(size_t)c]; s.dst = dst;
+                s.flags = (done[(size_t)c] == 0 ? GDG_SRC_IS_INPUT : 0) | (last ? GDG_DST_IS_OUTPUT : 0);
                 s.scratch = ctx->d_scratch + (size_t)c * ctx->max_frames;
                 s.unit_begin = (int)seg_units.size();
                 s.unit_count = (int)op.handles.size();
@@ -1081,7 +1107,7 @@ int gdg_profile_enable(gdg_ctx *ctx, int enable) {
 
 int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
     if (!ctx || kind < 0 || kind >= GDG_K_COUNT) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     double total = 0.0;
     int n = 0;
@@ -1109,23 +1135,33 @@ typedef std::function<hipError_t(int g, hipStream_t s)> GroupHook;
 
 static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
                         int stride = 0, bool rows_by_channel = false, int groups = 1, const GroupHook *before = nullptr, const GroupHook *after = nullptr,
-                        int window = 1) {
+                        int window = 1, int stride_out = 0) {
     if (stride == 0) stride = frames;
+    if (stride_out == 0) stride_out = stride;
     if (d_in == d_out) return fail(ctx, GDG_ERR_INVALID, "in-place processing is not supported");
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
     if (sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     hipSetDevice(ctx->device);
     const int G = groups < 1 ? 1 : groups;
+    /* device-resident calls: the groups are not joined at the end of the call, so one group's kernels overlap the other's across calls
+     * (the join happens when anything else touches the context: enter()) */
+    const bool free_run = G > 1 && !before && !after;
+    if (!free_run || (int)ctx->gstreams.size() > G) join_groups(ctx);
     const int P2 = fir_transform_size(frames);
-    if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate || ctx->plan_in != d_in || ctx->plan_out != d_out ||
-        ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_by_channel != rows_by_channel || ctx->plan_groups != G) {
-        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, rows_by_channel, G);
+    /* the plan holds pointers into the buffers it was built on; other buffers of the same shape are reached by a shift */
+    if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate ||
+        ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_stride_out != stride_out || ctx->plan_by_channel != rows_by_channel ||
+        ctx->plan_groups != G) {
+        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, stride_out, rows_by_channel, G);
         ctx->plan_stride = stride;
+        ctx->plan_stride_out = stride_out;
         ctx->plan_by_channel = rows_by_channel;
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }
         ctx->plan_active = active;
     }
     const gdg_seg_unit *d_units = reinterpret_cast<const gdg_seg_unit *>(ctx->d_blob + ctx->units_offset);
+    const gdg_shift shift = { (long long)(((intptr_t)d_in - (intptr_t)ctx->plan_in) / (intptr_t)sizeof(double)),
+                              (long long)(((intptr_t)d_out - (intptr_t)ctx->plan_out) / (intptr_t)sizeof(double)) };
     double2 *tw = nullptr, *tw2 = nullptr;
     for (auto &st : ctx->steps)
         if (st.is_fir && st.n) { int rc = fir_tables(ctx, fir_transform_size(frames), &tw, &tw2); if (rc != GDG_OK) return rc; break; }
@@ -1153,31 +1189,32 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                 if (window > 1) {
                     /* `window` frames per channel: every spectrum is read once for all of them (fir.hip, "Time blocking") */
                     const int sh = st.shared_spectra ? 1 : 0;
-                    { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 0, s)); }
-                    { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 1, s)); }
-                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 2, s));
-                      HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 3, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 0, shift, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 1, shift, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 2, shift, s));
+                      HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 3, shift, s)); }
                     continue;
                 }
-                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, s)); }
+                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, shift, s)); }
                 const bool fused = ctx->fir_fused < 0 ? (n > ctx->fir_split_max) : (ctx->fir_fused != 0);
                 if (fused) {
                     /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel) */
                     ProfScope ps(ctx, GDG_K_FIR_MAC, s);
-                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, s));
+                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, shift, s));
                 } else {
                     { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(P2, d, n, st.shared_spectra ? 1 : 0, s)); }
-                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, shift, s)); }
                 }
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);
                 for (int j = 0; j < window; j++)           /* the units' state runs through the frames in order */
-                    HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, (size_t)j * (size_t)frames, ctx->os, ctx->d_error, s));
+                    HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, (size_t)j * (size_t)frames, shift, ctx->os, ctx->d_error, s));
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));
-        if (G > 1) {
+        if (free_run) ctx->groups_pending = true;
+        else if (G > 1) {
             HIP_TRY(ctx, hipEventRecord(ctx->gjoin[(size_t)g], s));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->gjoin[(size_t)g], 0));
         }
@@ -1194,10 +1231,30 @@ static int pcie_groups(int n) {
     return g < 1 ? 1 : (g > 16 ? 16 : g);
 }
 
+/* channel groups of the device-resident calls: the groups' kernels run on streams of their own and overlap (one group's
+ * latency-bound segment kernel with the other's HBM-bound convolution); env GDG_DEVICE_GROUPS overrides */
+static int device_groups(const gdg_ctx *ctx) {
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("GDG_DEVICE_GROUPS"); forced = e ? atoi(e) : 0; }
+    const int n = ctx->nch;
+    /* measured (profiles/device_groups_r02.txt): two groups gain 7-10 % from 512 channels on, nothing below, four lose */
+    int g = ctx->overlap_groups > 0 ? ctx->overlap_groups : (forced > 0 ? forced : (n >= 384 ? 2 : 1));
+    if (g > n) g = n;
+    return g < 1 ? 1 : (g > 16 ? 16 : g);
+}
+
 int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int frames, uint32_t sample_rate) {
     if (!ctx || !d_in || !d_out) return GDG_ERR_INVALID;
     if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
-    return process_rows(ctx, ctx->all_channels, d_in, d_out, frames, sample_rate);
+    return process_rows(ctx, ctx->all_channels, d_in, d_out, frames, sample_rate, 0, false, device_groups(ctx));
+}
+
+int gdg_ctx_set_overlap(gdg_ctx *ctx, int groups) {
+    if (!ctx) return GDG_ERR_INVALID;
+    if (groups < 0 || groups > 16) return fail(ctx, GDG_ERR_INVALID, "%d channel groups: 0 (automatic) to 16", groups);
+    enter(ctx);
+    ctx->overlap_groups = groups;
+    return GDG_OK;
 }
 
 int gdg_ctx_set_window(gdg_ctx *ctx, int frames_per_call) {
@@ -1207,7 +1264,7 @@ int gdg_ctx_set_window(gdg_ctx *ctx, int frames_per_call) {
     if (W > 1 && ctx->max_frames != GDG_MAX_FRAMES)
         return fail(ctx, GDG_ERR_UNSUPPORTED, "windows are made of %d-sample frames, the context allows %d", GDG_MAX_FRAMES, ctx->max_frames);
     if (W == ctx->window) return GDG_OK;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t stride = (size_t)W * (size_t)ctx->max_frames, bytes = (size_t)ctx->nch * stride * sizeof(double);
     double *w0 = nullptr, *w1 = nullptr;
@@ -1231,7 +1288,7 @@ int gdg_process_window_device(gdg_ctx *ctx, const double *d_in, double *d_out, s
     if (row_stride < (size_t)W * (size_t)ctx->max_frames || row_stride > 0x7fffffff)
         return fail(ctx, GDG_ERR_INVALID, "row stride %zu is shorter than the window (%d x %d)", row_stride, W, ctx->max_frames);
     if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
-    return process_rows(ctx, ctx->all_channels, d_in, d_out, ctx->max_frames, sample_rate, (int)row_stride, false, 1, nullptr, nullptr, W);
+    return process_rows(ctx, ctx->all_channels, d_in, d_out, ctx->max_frames, sample_rate, (int)row_stride, false, device_groups(ctx), nullptr, nullptr, W);
 }
 
 static int check_device_error(gdg_ctx *ctx) {
@@ -1247,7 +1304,7 @@ static int check_device_error(gdg_ctx *ctx) {
 
 int gdg_ctx_synchronize(gdg_ctx *ctx) {
     if (!ctx) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     return check_device_error(ctx);
 }
 
@@ -1292,7 +1349,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
         if (c < 0 || c >= ctx->nch || seen[(size_t)c]) return fail(ctx, GDG_ERR_INVALID, "bad or repeated channel %d", c);
         seen[(size_t)c] = 1;
     }
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
     /* rows travel compactly ([i][frames]); G channel groups: group g's rows are staged and uploaded on stream g while the
@@ -1337,7 +1394,7 @@ int gdg_process(gdg_ctx *ctx, const double *const *in, double *const *out, int f
 /* pinned host slabs for callers that must not hand Go (or other managed) pointers to C: row c = channel c */
 int gdg_staging_buffers(gdg_ctx *ctx, double **in, double **out, int *row_stride) {
     if (!ctx || !in || !out || !row_stride) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
     *in = ctx->h_stage_in;
@@ -1356,7 +1413,7 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
         if (c < 0 || c >= ctx->nch || seen[(size_t)c]) return fail(ctx, GDG_ERR_INVALID, "bad or repeated channel %d", c);
         seen[(size_t)c] = 1;
     }
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
     const size_t stride = (size_t)ctx->max_frames;
@@ -1389,14 +1446,14 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
 
 int gdg_device_alloc(gdg_ctx *ctx, size_t bytes, void **d_ptr) {
     if (!ctx || !d_ptr) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipMalloc(d_ptr, bytes));
     return GDG_OK;
 }
 
 int gdg_device_free(gdg_ctx *ctx, void *d_ptr) {
     if (!ctx) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(d_ptr));
     return GDG_OK;
@@ -1404,7 +1461,7 @@ int gdg_device_free(gdg_ctx *ctx, void *d_ptr) {
 
 int gdg_copy_to_device(gdg_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (!ctx) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GDG_OK;
@@ -1412,7 +1469,7 @@ int gdg_copy_to_device(gdg_ctx *ctx, void *d_dst, const void *h_src, size_t byte
 
 int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!ctx) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GDG_OK;
@@ -1434,7 +1491,7 @@ int gdg_fft_real(gdg_ctx *ctx, const double *samples, int n, double *spectrum) {
     if (!ctx || !samples || !spectrum) return GDG_ERR_INVALID;
     int rc = fft_size_ok(ctx, n);
     if (rc != GDG_OK) return rc;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     const int P = n / 2;
     double2 *tw, *tw2;
     rc = fir_tables(ctx, P, &tw, &tw2);
@@ -1470,7 +1527,7 @@ int gdg_fft_real_inverse(gdg_ctx *ctx, const double *spectrum, int n, double *sa
     if (!ctx || !samples || !spectrum) return GDG_ERR_INVALID;
     int rc = fft_size_ok(ctx, n);
     if (rc != GDG_OK) return rc;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     const int P = n / 2;
     double2 *tw, *tw2;
     rc = fir_tables(ctx, P, &tw, &tw2);
@@ -1507,7 +1564,7 @@ int gdg_copy_rows_device(gdg_ctx *ctx, double *d_dst, size_t dst_stride, const d
     if (!ctx || !d_dst || !d_src) return GDG_ERR_INVALID;
     if (row_len > dst_stride || row_len > src_stride) return fail(ctx, GDG_ERR_INVALID, "row length %zu exceeds a row stride", row_len);
     if (row_len == 0 || n_rows == 0) return GDG_OK;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipMemcpy2DAsync(d_dst, dst_stride * sizeof(double), d_src, src_stride * sizeof(double), row_len * sizeof(double), n_rows,
                                   hipMemcpyDeviceToDevice, ctx->stream));
     return GDG_OK;
@@ -1527,15 +1584,20 @@ static int ensure_tuner(gdg_ctx *ctx) {
     return GDG_OK;
 }
 
-int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *d_samples, int frames, uint32_t sample_rate) {
-    if (!ctx || !d_samples || frames < 0) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+static int tuner_enqueue_rows(gdg_ctx *ctx, const double *d_samples, size_t stride, int frames, uint32_t sample_rate) {
     int rc = ensure_tuner(ctx);
     if (rc != GDG_OK) return rc;
-    { ProfScope ps(ctx, GDG_K_TUNER); HIP_TRY(ctx, gdg_launch_tuner_enqueue(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, d_samples, frames, frames, ctx->stream)); }
+    if (stride > 0x7fffffff) return fail(ctx, GDG_ERR_INVALID, "row stride %zu too long", stride);
+    { ProfScope ps(ctx, GDG_K_TUNER); HIP_TRY(ctx, gdg_launch_tuner_enqueue(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, d_samples, (int)stride, frames, ctx->stream)); }
     if (frames < GDG_TUNER_RING) ctx->tuner_wp = (ctx->tuner_wp + frames) % GDG_TUNER_RING;
     ctx->tuner_sr = sample_rate;          /* tuner.go:582-587 */
     return GDG_OK;
+}
+
+int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *d_samples, int frames, uint32_t sample_rate) {
+    if (!ctx || !d_samples || frames < 0) return GDG_ERR_INVALID;
+    enter(ctx);
+    return tuner_enqueue_rows(ctx, d_samples, (size_t)frames, frames, sample_rate);
 }
 
 static int ensure_staging(gdg_ctx *ctx);
@@ -1543,7 +1605,7 @@ static int ensure_staging(gdg_ctx *ctx);
 int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *samples, int frames, uint32_t sample_rate) {
     if (!ctx || !samples) return GDG_ERR_INVALID;
     if (frames < 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1558,7 +1620,7 @@ int gdg_tuner_enqueue(gdg_ctx *ctx, const double *const *samples, int frames, ui
 int gdg_tuner_enqueue_staged(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
     if (!ctx) return GDG_ERR_INVALID;
     if (frames < 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_staging(ctx);
     if (rc != GDG_OK) return rc;
     if (frames == 0) return GDG_OK;
@@ -1573,7 +1635,7 @@ int gdg_tuner_enqueue_staged(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
 
 int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
     if (!ctx || !results) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_tuner(ctx);
     if (rc != GDG_OK) return rc;
     static int force_long = -1;
@@ -1649,7 +1711,7 @@ int gdg_spatializer_set_position(gdg_ctx *ctx, int channel, double azimuth, doub
 
 int gdg_spatializer_set_sample_rate(gdg_ctx *ctx, uint32_t rate) {
     if (!ctx) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     /* spatializer.go:418-431: new (zeroed) history buffers of ceil(rate * 6.3e-4) samples; this.sampleRate stays 96000 */
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(ctx->d_sp_hist);
@@ -1706,20 +1768,31 @@ static int upload_spat_chans(gdg_ctx *ctx) {
 int gdg_spatialize_device(gdg_ctx *ctx, const double *d_in, double *d_out_lr, int frames) {
     if (!ctx || !d_in || !d_out_lr) return GDG_ERR_INVALID;
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_spatializer(ctx);
     if (rc != GDG_OK) return rc;
     if (ctx->sp_dirty) { rc = upload_spat_chans(ctx); if (rc != GDG_OK) return rc; }
     ProfScope ps(ctx, GDG_K_SPATIALIZER);
     HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_in, frames, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
-                                        d_out_lr, frames, ctx->max_frames, ctx->stream));
+                                        d_out_lr, frames, frames, ctx->max_frames, ctx->stream));
+    return GDG_OK;
+}
+
+/* one frame out of rows of any stride (the batch run's windows): left to d_left, right to d_left + out_stride */
+static int spatialize_rows(gdg_ctx *ctx, const double *d_in, int in_stride, double *d_left, int out_stride, int frames) {
+    int rc = ensure_spatializer(ctx);
+    if (rc != GDG_OK) return rc;
+    if (ctx->sp_dirty) { rc = upload_spat_chans(ctx); if (rc != GDG_OK) return rc; }
+    ProfScope ps(ctx, GDG_K_SPATIALIZER);
+    HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_in, in_stride, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
+                                        d_left, out_stride, frames, ctx->max_frames, ctx->stream));
     return GDG_OK;
 }
 
 int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, double *out_right, int frames) {
     if (!ctx || !in || !out_left || !out_right) return GDG_ERR_INVALID;
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_staging(ctx);
     if (rc == GDG_OK) rc = ensure_spatializer(ctx);
     if (rc != GDG_OK) return rc;
@@ -1738,7 +1811,7 @@ int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, doub
 int gdg_spatialize_staged(gdg_ctx *ctx, int from_outputs, double *out_left, double *out_right, int frames) {
     if (!ctx || !out_left || !out_right) return GDG_ERR_INVALID;
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_staging(ctx);
     if (rc == GDG_OK) rc = ensure_spatializer(ctx);
     if (rc != GDG_OK) return rc;
@@ -1756,7 +1829,7 @@ int gdg_spatialize_staged(gdg_ctx *ctx, int from_outputs, double *out_left, doub
     {
         ProfScope ps(ctx, GDG_K_SPATIALIZER);
         HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_rows, stride, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
-                                            ctx->d_sp_out, frames, ctx->max_frames, ctx->stream));
+                                            ctx->d_sp_out, frames, frames, ctx->max_frames, ctx->stream));
     }
     HIP_TRY(ctx, hipMemcpyAsync(out_left, ctx->d_sp_out, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(out_right, ctx->d_sp_out + frames, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1788,7 +1861,7 @@ int gdg_wave_decode_device(gdg_ctx *ctx, int format, const void *d_bytes, size_t
     if (channels == 0) return fail(ctx, GDG_ERR_INVALID, "channel count must be positive");
     if (per == 0) return GDG_OK;
     if (!d_bytes || !d_samples) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     ProfScope ps(ctx, GDG_K_WAVE);
     HIP_TRY(ctx, gdg_launch_wave_decode(format, d_bytes, per, channels, d_samples, ctx->stream));
     return GDG_OK;
@@ -1800,7 +1873,7 @@ int gdg_wave_encode_device(gdg_ctx *ctx, int format, const double *d_samples, si
     if (channels == 0) return fail(ctx, GDG_ERR_INVALID, "channel count must be positive");
     if (per == 0) return GDG_OK;
     if (!d_bytes || !d_samples) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     ProfScope ps(ctx, GDG_K_WAVE);
     HIP_TRY(ctx, gdg_launch_wave_encode(format, d_samples, per, channels, d_bytes, ctx->stream));
     return GDG_OK;
@@ -1814,7 +1887,7 @@ int gdg_wave_decode(gdg_ctx *ctx, int format, const void *bytes, size_t per, uns
     size_t n = per * channels;
     if (n == 0) return GDG_OK;
     if (!bytes || !samples) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_io(ctx, 0, n * w);
     if (rc == GDG_OK) rc = ensure_io(ctx, 1, n * sizeof(double));
     if (rc != GDG_OK) return rc;
@@ -1834,7 +1907,7 @@ int gdg_wave_encode(gdg_ctx *ctx, int format, const double *samples, size_t per,
     size_t n = per * channels;
     if (n == 0) return GDG_OK;
     if (!bytes || !samples) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_io(ctx, 0, n * w);
     if (rc == GDG_OK) rc = ensure_io(ctx, 1, n * sizeof(double));
     if (rc != GDG_OK) return rc;
@@ -1865,7 +1938,7 @@ int gdg_resample_time_device(gdg_ctx *ctx, const double *d_samples, int n, uint3
                     gdg_resample_time_length(n, source_rate, target_rate));
     if (n_out == 0) return GDG_OK;
     if (!d_samples || !d_out) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     double dx = (double)source_rate / (double)target_rate;       /* resample.go:88-90 */
     ProfScope ps(ctx, GDG_K_RESAMPLE);
     HIP_TRY(ctx, gdg_launch_resample_time(d_samples, n, dx, d_out, n_out, ctx->stream));
@@ -1876,7 +1949,7 @@ int gdg_resample_time(gdg_ctx *ctx, const double *samples, int n, uint32_t sourc
     if (!ctx) return GDG_ERR_INVALID;
     if (n_out == 0 && n >= 0 && source_rate && target_rate && gdg_resample_time_length(n, source_rate, target_rate) == 0) return GDG_OK;
     if (!samples || !out || n <= 0 || n_out < 0) return fail(ctx, GDG_ERR_INVALID, "invalid buffers");
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_io(ctx, 0, (size_t)n * sizeof(double));
     if (rc == GDG_OK) rc = ensure_io(ctx, 1, (size_t)(n_out > 0 ? n_out : 1) * sizeof(double));
     if (rc != GDG_OK) return rc;
@@ -1895,7 +1968,7 @@ int gdg_resample_time(gdg_ctx *ctx, const double *samples, int n, uint32_t sourc
 
 int gdg_meter_configure(gdg_ctx *ctx, int n_ports) {
     if (!ctx || n_ports < 0) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_meter) { hipFree(ctx->d_meter); ctx->d_meter = nullptr; }
     ctx->n_meter = 0;
@@ -1910,7 +1983,7 @@ int gdg_meter_set_enabled(gdg_ctx *ctx, int port, int enabled) {
     if (!ctx) return GDG_ERR_INVALID;
     if (port >= ctx->n_meter) return fail(ctx, GDG_ERR_INVALID, "meter port %d out of range (%d configured)", port, ctx->n_meter);
     if (ctx->n_meter == 0) return GDG_OK;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     std::vector<gdg_meter_rec> st(ctx->n_meter);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(st.data(), ctx->d_meter, st.size() * sizeof(gdg_meter_rec), hipMemcpyDeviceToHost));
@@ -1943,7 +2016,7 @@ int gdg_meter_process_device(gdg_ctx *ctx, const double *d_rows, size_t row_stri
     if (!ctx) return GDG_ERR_INVALID;
     if (ctx->n_meter == 0 || frames == 0) return GDG_OK;
     if (!d_rows || frames < 0 || sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "invalid meter input");
-    hipSetDevice(ctx->device);
+    enter(ctx);
     return meter_rows(ctx, d_rows, row_stride, 0, ctx->n_meter, frames, sample_rate);
 }
 
@@ -1951,7 +2024,7 @@ int gdg_meter_process(gdg_ctx *ctx, const double *const *buffers, int frames, ui
     if (!ctx) return GDG_ERR_INVALID;
     if (ctx->n_meter == 0 || frames == 0) return GDG_OK;
     if (!buffers || frames < 0) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_io(ctx, 1, (size_t)ctx->n_meter * frames * sizeof(double));
     if (rc != GDG_OK) return rc;
     double *d = static_cast<double *>(ctx->d_io[1]);
@@ -1974,7 +2047,7 @@ static int32_t to_decibels_int(double value) {                         /* level.
 int gdg_meter_analyze(gdg_ctx *ctx, int32_t *levels, int32_t *peaks) {
     if (!ctx || !levels || !peaks) return GDG_ERR_INVALID;
     if (ctx->n_meter == 0) return GDG_OK;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     std::vector<gdg_meter_rec> st(ctx->n_meter);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(st.data(), ctx->d_meter, st.size() * sizeof(gdg_meter_rec), hipMemcpyDeviceToHost));
@@ -1984,7 +2057,7 @@ int gdg_meter_analyze(gdg_ctx *ctx, int32_t *levels, int32_t *peaks) {
 
 int gdg_meter_state(gdg_ctx *ctx, int port, double *current, double *peak, uint64_t *counter) {
     if (!ctx || port < 0 || port >= ctx->n_meter) return GDG_ERR_INVALID;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     gdg_meter_rec st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(&st, ctx->d_meter + port, sizeof(st), hipMemcpyDeviceToHost));
@@ -2002,7 +2075,7 @@ int gdg_unit_compile_fir(gdg_ctx *ctx, int handle, int n_filters, const double *
     if (!u) return fail(ctx, GDG_ERR_INVALID, "bad unit handle %d", handle);
     if (u->type != GDG_UNIT_POWERAMP) return fail(ctx, GDG_ERR_INVALID, "unit %d is not a power amp", handle);
     if (n_filters < 0 || (n_filters > 0 && (!taps || !lengths || !gain_compensation || !levels_db))) return fail(ctx, GDG_ERR_INVALID, "bad filter list");
-    hipSetDevice(ctx->device);
+    enter(ctx);
     /* lengths after Reduce, composite length = the longest (filter.go:167-236 Add pads with zeros) */
     size_t max_in = 0, max_out = 0, work_points = 0, pos_points = 0;
     for (int i = 0; i < n_filters; i++) {
@@ -2071,7 +2144,7 @@ int gdg_unit_get_fir(gdg_ctx *ctx, int handle, double *taps, int capacity, int *
 
 static int set_sound(gdg_ctx *ctx, double **d_buf, uint32_t *n_buf, const double *coeffs, int n) {
     if (n < 0) return fail(ctx, GDG_ERR_INVALID, "bad sound length");
-    hipSetDevice(ctx->device);
+    enter(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (*d_buf) { hipFree(*d_buf); *d_buf = nullptr; }
     *n_buf = 0;
@@ -2105,7 +2178,7 @@ int gdg_metronome_configure(gdg_ctx *ctx, uint32_t beats_per_period, uint32_t bp
 int gdg_metronome_process_device(gdg_ctx *ctx, double *d_out, int frames) {
     if (!ctx || (frames > 0 && !d_out) || frames < 0) return GDG_ERR_INVALID;
     if (frames == 0) return GDG_OK;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     const uint32_t sc0 = ctx->met_sample_counter, tc0 = ctx->met_tick_counter;
     const uint32_t spb = (60u * ctx->met_sr) / ctx->met_bpm;                    /* metronome.go:79, uint32 arithmetic */
     const uint32_t beats = ctx->met_beats == 0 ? 1u : ctx->met_beats;           /* :84-86 */
@@ -2127,7 +2200,7 @@ int gdg_metronome_process_device(gdg_ctx *ctx, double *d_out, int frames) {
 int gdg_metronome_process(gdg_ctx *ctx, double *out, int frames) {
     if (!ctx || (frames > 0 && !out) || frames < 0) return GDG_ERR_INVALID;
     if (frames == 0) return GDG_OK;
-    hipSetDevice(ctx->device);
+    enter(ctx);
     int rc = ensure_io(ctx, 1, (size_t)frames * sizeof(double));
     if (rc != GDG_OK) return rc;
     rc = gdg_metronome_process_device(ctx, static_cast<double *>(ctx->d_io[1]), frames);
@@ -2227,24 +2300,25 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     if (length == 0) return GDG_OK;                                            /* every output has 0 samples */
     if (opt->run_meters && ctx->n_meter != ports)
         return fail(ctx, GDG_ERR_INVALID, "level meters: %d ports configured, the batch needs 2 N + 3 = %d", ctx->n_meter, ports);
-    hipSetDevice(ctx->device);
-    const size_t enc_bytes = (size_t)NO * B * (size_t)out_width;               /* one encoded block */
+    enter(ctx);
+    const int W = ctx->window;                                                 /* frames per step (gdg_ctx_set_window; 1 = the reference's loop) */
+    const size_t enc_bytes = (size_t)NO * W * B * (size_t)out_width;           /* one encoded window */
     const size_t half = std::max(enc_bytes, (size_t)8 << 20);
+    if (length > 0x7fffffff) return fail(ctx, GDG_ERR_INVALID, "files of %zu samples are too long", length);
     rc = ensure_batch_pipe(ctx, half);
     if (rc != GDG_OK) return rc;
-    double *d_inputs = nullptr, *d_blk = nullptr, *d_src = nullptr;
+    double *d_inputs = nullptr, *d_win = nullptr, *d_src = nullptr;
     unsigned char *d_arena = nullptr, *d_enc = nullptr;
     auto body = [&]() -> int {
         int r;
         HIP_TRY(ctx, hipMalloc((void **)&d_inputs, (size_t)N * length * sizeof(double)));
-        /* one block: the N inputs, then the N + 3 outputs in the output files' order (out_0 .. out_{N-1}, master left, master right,
-         * metronome, controller.go:3123-3219) */
-        HIP_TRY(ctx, hipMalloc((void **)&d_blk, (size_t)(N + NO) * B * sizeof(double)));
+        /* one window of the N + 3 outputs, rows in the output files' order (out_0 .. out_{N-1}, master left, master right, metronome,
+         * controller.go:3123-3219); the inputs are read where they lie */
+        HIP_TRY(ctx, hipMalloc((void **)&d_win, (size_t)NO * W * B * sizeof(double)));
         HIP_TRY(ctx, hipMalloc((void **)&d_enc, 2 * enc_bytes));
         if (arena_bytes) HIP_TRY(ctx, hipMalloc((void **)&d_arena, arena_bytes));
         if (src_cap) HIP_TRY(ctx, hipMalloc((void **)&d_src, src_cap * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(d_inputs, 0, (size_t)N * length * sizeof(double), ctx->stream));     /* the zero padding, :3018-3045 */
-        double *d_in_blk = d_blk, *d_out_blk = d_blk + (size_t)N * B, *d_master = d_out_blk + (size_t)N * B, *d_metro = d_master + 2 * (size_t)B;
 
         /* 1a. the arena goes up */
         int used[2] = { 0, 0 };
@@ -2291,48 +2365,60 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         /* the pinned halves change direction: every upload has been consumed by the DMA engine (events above), nothing else reads them */
         for (int h = 0; h < 2; h++) if (used[h]) HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h]));
 
-        /* 2. the block loop, controller.go:3076-3107 around controller.process (:2648-2783) */
-        const size_t blocks = length / B, row_bytes = (size_t)B * out_width;
-        auto scatter = [&](size_t b) {                                           /* block b's bytes from its pinned half into the files */
-            const unsigned char *src = ctx->h_batch[b & 1];
+        /* 2. the block loop, controller.go:3076-3107 around controller.process (:2648-2783), `w` blocks per step */
+        if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
+        struct Step { size_t off; int w; };
+        std::vector<Step> steps;
+        for (size_t off = 0; off < length;) {
+            int w = W;
+            while ((size_t)w * B > length - off) w >>= 1;                        /* the tail: windows of W/2, W/4 .. 1 */
+            steps.push_back({ off, w });
+            off += (size_t)w * B;
+        }
+        auto scatter = [&](size_t i) {                                           /* step i's bytes from its pinned half into the files */
+            const unsigned char *src = ctx->h_batch[i & 1];
+            const size_t row_bytes = (size_t)steps[i].w * B * out_width, at = steps[i].off * out_width;
             copy_rows_parallel(0, (size_t)NO, [&](size_t o) {
-                if (out_bytes[o]) memcpy(static_cast<unsigned char *>(out_bytes[o]) + b * row_bytes, src + o * row_bytes, row_bytes);   /* NULL: "skipping output" (:3143) */
+                if (out_bytes[o]) memcpy(static_cast<unsigned char *>(out_bytes[o]) + at, src + o * row_bytes, row_bytes);   /* NULL: "skipping output" (:3143) */
             }, row_bytes);
         };
-        for (size_t b = 0; b < blocks; b++) {
-            const size_t off = b * B;
-            const int h = (int)(b & 1);
+        for (size_t i = 0; i < steps.size(); i++) {
+            const size_t off = steps[i].off;
+            const int w = steps[i].w, h = (int)(i & 1), wb = w * B;               /* the window's rows are wb long */
+            const double *d_in = d_inputs + off;
+            double *d_master = d_win + (size_t)N * wb, *d_metro = d_master + 2 * (size_t)wb;
             unsigned char *enc = d_enc + h * enc_bytes;
-            if ((r = gdg_copy_rows_device(ctx, d_in_blk, B, d_inputs + off, length, B, (size_t)N)) != GDG_OK) return r;
-            if (opt->tuner_enqueue && (r = gdg_tuner_enqueue_device(ctx, d_in_blk, B, opt->target_rate)) != GDG_OK) return r;
-            if ((r = gdg_process_device(ctx, d_in_blk, d_out_blk, B, opt->target_rate)) != GDG_OK) return r;
-            if ((r = gdg_metronome_process_device(ctx, d_metro, B)) != GDG_OK) return r;
-            if ((r = gdg_spatialize_device(ctx, d_out_blk, d_master, B)) != GDG_OK) return r;
-            if (opt->metronome_to_master) HIP_TRY(ctx, gdg_launch_add_aux(d_master, d_master + B, d_metro, B, ctx->stream));
+            if (opt->tuner_enqueue)
+                for (int j = 0; j < w; j++) if ((r = tuner_enqueue_rows(ctx, d_in + (size_t)j * B, length, B, opt->target_rate)) != GDG_OK) return r;
+            if ((r = process_rows(ctx, ctx->all_channels, d_in, d_win, B, opt->target_rate, (int)length, false, 1, nullptr, nullptr, w, wb)) != GDG_OK) return r;
+            if ((r = gdg_metronome_process_device(ctx, d_metro, wb)) != GDG_OK) return r;
+            for (int j = 0; j < w; j++) if ((r = spatialize_rows(ctx, d_win + (size_t)j * B, wb, d_master + (size_t)j * B, wb, B)) != GDG_OK) return r;
+            if (opt->metronome_to_master) HIP_TRY(ctx, gdg_launch_add_aux(d_master, d_master + wb, d_metro, wb, ctx->stream));
             if (opt->run_meters) {                                               /* ports: inputs | outputs | metronome | left, right (:2707-2777) */
-                if ((r = meter_rows(ctx, d_blk, B, 0, 2 * N, B, opt->target_rate)) != GDG_OK) return r;
-                if ((r = meter_rows(ctx, d_metro, B, 2 * N, 1, B, opt->target_rate)) != GDG_OK) return r;
-                if ((r = meter_rows(ctx, d_master, B, 2 * N + 1, 2, B, opt->target_rate)) != GDG_OK) return r;
+                if ((r = meter_rows(ctx, d_in, length, 0, N, wb, opt->target_rate)) != GDG_OK) return r;
+                if ((r = meter_rows(ctx, d_win, (size_t)wb, N, N, wb, opt->target_rate)) != GDG_OK) return r;
+                if ((r = meter_rows(ctx, d_metro, (size_t)wb, 2 * N, 1, wb, opt->target_rate)) != GDG_OK) return r;
+                if ((r = meter_rows(ctx, d_master, (size_t)wb, 2 * N + 1, 2, wb, opt->target_rate)) != GDG_OK) return r;
             }
-            if (b >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_moved[h], 0));     /* block b - 2 has left enc */
-            if ((r = gdg_wave_encode_device(ctx, opt->out_format, d_out_blk, (size_t)NO * B, 1, enc)) != GDG_OK) return r;
+            if (i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_moved[h], 0));     /* step i - 2 has left enc */
+            if ((r = gdg_wave_encode_device(ctx, opt->out_format, d_win, (size_t)NO * wb, 1, enc)) != GDG_OK) return r;
             HIP_TRY(ctx, hipEventRecord(ctx->batch_ready[h], ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_stream, ctx->batch_ready[h], 0));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, enc_bytes, hipMemcpyDeviceToHost, ctx->batch_stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, (size_t)NO * wb * out_width, hipMemcpyDeviceToHost, ctx->batch_stream));
             HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
-            if (b >= 1) {                                                        /* while block b runs: block b - 1 into the files */
+            if (i >= 1) {                                                        /* while step i runs: step i - 1 into the files */
                 HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h ^ 1]));
-                scatter(b - 1);
+                scatter(i - 1);
             }
         }
-        HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[(blocks - 1) & 1]));
-        scatter(blocks - 1);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[(steps.size() - 1) & 1]));
+        scatter(steps.size() - 1);
         return check_device_error(ctx);
     };
     rc = body();
     hipStreamSynchronize(ctx->batch_stream);
     hipStreamSynchronize(ctx->stream);
-    hipFree(d_inputs); hipFree(d_blk); hipFree(d_src); hipFree(d_arena); hipFree(d_enc);
+    hipFree(d_inputs); hipFree(d_win); hipFree(d_src); hipFree(d_arena); hipFree(d_enc);
     return rc;
 }
 

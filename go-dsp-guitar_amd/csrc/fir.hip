@@ -226,7 +226,7 @@ __device__ __forceinline__ void run_lds_passes(cplx (&v)[16], double *sre, doubl
  */
 template <int LOGN, bool IRJOB>
 __global__ void __launch_bounds__(FftCfg<LOGN>::T)
-fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__restrict__ jobs, double scale,
+fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__restrict__ jobs, double scale, gdg_shift shift,
                const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
     __shared__ double sre[FftCfg<LOGN>::LDS];
@@ -248,7 +248,7 @@ fir_fwd_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_irjob *__re
         int pos = *ch.pos;
         a = ch.prev + (size_t)((pos + 1) & 1) * N;       /* previous frame */
         prev_out = ch.prev + (size_t)(pos & 1) * N;       /* where this frame is kept for the next call */
-        bsrc = ch.src;
+        bsrc = (ch.flags & GDG_SRC_IS_INPUT) ? ch.src + shift.in : ch.src;
         out = ch.fdl + (size_t)(pos % ch.R) * N;
         hop = ch.hop;
     }
@@ -360,13 +360,14 @@ __device__ __forceinline__ void twiddle_powers8(cplx (&u)[8], cplx w) {
  * written to `prev` and the frame counter is left alone -- fir_tb_finish_kernel does both once the window is through. */
 template <int TB>
 __global__ void __launch_bounds__(512)
-fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, int W, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
     constexpr int N = 8192, T = 512;
     __shared__ double sre[GDG_W_LDS];
     __shared__ double sim[GDG_W_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jw = TB ? (int)(blockIdx.x % (unsigned)W) : 0;
     gdg_fir_chan ch = chans[TB ? blockIdx.x / (unsigned)W : blockIdx.x];
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     const int pos = *ch.pos;
     const double *a = ch.prev + (size_t)((pos + 1) & 1) * N;       /* previous frame */
     if (TB && jw > 0) a = ch.src + (size_t)jw * N - N;
@@ -582,7 +583,7 @@ __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int ti
  * profiles/probes/); 2 = the IR spectra are shared between channels and read with cacheable loads. */
 template <int LOGN, int FUSED>
 __global__ void __launch_bounds__(FftCfg<LOGN>::T)
-fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
     __shared__ double sre[FftCfg<LOGN>::LDS];
     __shared__ double sim[FftCfg<LOGN>::LDS];
@@ -616,7 +617,7 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, const cplx *__rest
     pass_load<LOGN, LR>(v, sre, sim, tid);
     pass_compute<LOGN, LR, LNS, true>(v, tw, tid);
     const int hop = ch.hop;
-    double *__restrict__ dst = ch.dst + (size_t)jw * hop;
+    double *__restrict__ dst = ch.dst + (size_t)jw * hop + ((ch.flags & GDG_DST_IS_OUTPUT) ? shift.out : 0);
     if (hop == N) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
@@ -753,8 +754,9 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
 
 /* after a window of W frames: the last frame becomes the overlap-save history of the next call, the frame counter moves on */
 __global__ void __launch_bounds__(256)
-fir_tb_finish_kernel(const gdg_fir_chan *__restrict__ chans, int W) {
+fir_tb_finish_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift) {
     gdg_fir_chan ch = chans[blockIdx.x];
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     const int N = ch.hop;
     const int pos = *ch.pos;
     __syncthreads();
@@ -806,19 +808,19 @@ hipError_t gdg_fir_tables_create(int P, cplx **d_tw, cplx **d_tw2) {
     default: return hipErrorInvalidValue;                                                           \
     }
 
-template <int LG> static void launch_fwd(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, hipStream_t s) {
-    fir_fwd_kernel<LG, false><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, nullptr, 1.0, tw, tw2);
+template <int LG> static void launch_fwd(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, gdg_shift shift, hipStream_t s) {
+    fir_fwd_kernel<LG, false><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, nullptr, 1.0, shift, tw, tw2);
 }
 template <int LG> static void launch_ir(const gdg_fir_irjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
-    fir_fwd_kernel<LG, true><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(nullptr, d_jobs, scale, tw, tw2);
+    fir_fwd_kernel<LG, true><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(nullptr, d_jobs, scale, gdg_shift{ 0, 0 }, tw, tw2);
 }
 template <int LG> static void launch_raw_inv(const gdg_fir_rawjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
     fir_raw_inv_kernel<LG><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_jobs, scale, tw, tw2);
 }
-template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, hipStream_t s) {
-    if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, tw, tw2);
-    else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, tw, tw2);
-    else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, tw, tw2);
+template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, gdg_shift shift, hipStream_t s) {
+    if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
+    else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
+    else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
 }
 
 /* a window of W frames of 8192 samples per channel (W in {2, 4, 8}); the four launches of one power-amp step */
@@ -826,29 +828,30 @@ template <int W> static void launch_mac_tb(const gdg_fir_chan *d_chans, int n, b
     if (shared) fir_mac_tb_kernel<W, false><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
     else fir_mac_tb_kernel<W, true><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
 }
-hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const cplx *d_tw, const cplx *d_tw2, int what, hipStream_t s) {
+hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const cplx *d_tw, const cplx *d_tw2, int what,
+                                 gdg_shift shift, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
     if (W != 2 && W != 4 && W != 8) return hipErrorInvalidValue;
-    if (what == 0) fir_fwd13w_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, d_tw, d_tw2);
+    if (what == 0) fir_fwd13w_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
     else if (what == 1) {
         if (W == 2) launch_mac_tb<2>(d_chans, n_chans, shared_spectra != 0, s);
         else if (W == 4) launch_mac_tb<4>(d_chans, n_chans, shared_spectra != 0, s);
         else launch_mac_tb<8>(d_chans, n_chans, shared_spectra != 0, s);
-    } else if (what == 2) fir_inv_kernel<13, 3><<<dim3(n_chans * W), dim3(FftCfg<13>::T), 0, s>>>(d_chans, W, d_tw, d_tw2);
-    else fir_tb_finish_kernel<<<dim3(n_chans), dim3(256), 0, s>>>(d_chans, W);
+    } else if (what == 2) fir_inv_kernel<13, 3><<<dim3(n_chans * W), dim3(FftCfg<13>::T), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
+    else fir_tb_finish_kernel<<<dim3(n_chans), dim3(256), 0, s>>>(d_chans, W, shift);
     return hipGetLastError();
 }
 
-hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
+hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, gdg_shift shift, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
     static int wave_fft = -1;
     if (wave_fft < 0) { const char *e = getenv("GDG_WAVE_FFT"); wave_fft = e ? atoi(e) : 1; }
     if (P == 8192 && hop == P && (wave_fft & 1)) {
-        fir_fwd13w_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, d_tw, d_tw2);
+        fir_fwd13w_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, shift, d_tw, d_tw2);
         return hipGetLastError();
     }
     int L = ilog2_exact(P);
-    GDG_DISPATCH_LOGN(L, launch_fwd<LG>(d_chans, n_chans, d_tw, d_tw2, s));
+    GDG_DISPATCH_LOGN(L, launch_fwd<LG>(d_chans, n_chans, d_tw, d_tw2, shift, s));
     return hipGetLastError();
 }
 
@@ -905,10 +908,10 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, i
 }
 
 /* fused: 0 = inverse only (Y from gdg_launch_fir_mac), 1 = MAC + inverse, 2 = MAC + inverse with shared (cacheable) IR spectra */
-hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, int fused, hipStream_t s) {
+hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, int fused, gdg_shift shift, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
     int L = ilog2_exact(P);
-    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, s));
+    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, shift, s));
     return hipGetLastError();
 }
 

@@ -22,6 +22,12 @@
  *   Y     [P]    cplx    accumulated product spectrum (scratch between MAC and inverse)
  *   pos   int            frame counter; slot of the current frame = pos % K
  * ---------------------------------------------------------------------------------------------- */
+/* A plan's descriptors hold absolute pointers; those into the caller's buffers are flagged, and every launch carries the distance
+ * (in samples) from the buffers the plan was built on to the ones of this call -- walking through a file does not rebuild the plan. */
+#define GDG_SRC_IS_INPUT 1
+#define GDG_DST_IS_OUTPUT 2
+struct gdg_shift { long long in, out; };
+
 struct gdg_fir_chan {
     const double *src;       /* current frame, `hop` samples */
     double *dst;             /* output frame, `hop` samples */
@@ -32,6 +38,7 @@ struct gdg_fir_chan {
     int *pos;
     int K;
     int R;                   /* slots of the delay-line ring: K, or K + W - 1 when the context runs windows of W blocks (time blocking) */
+    int flags;               /* GDG_SRC_IS_INPUT / GDG_DST_IS_OUTPUT */
     int hop;                 /* samples per frame; == P for power-of-two frames, < P otherwise (the transform of
                               * [previous | current | zeros] still has 2P points, P = nextpow2(hop)) */
 };
@@ -56,14 +63,14 @@ struct gdg_fir_rawjob {
 
 /* launchers implemented in fir.hip; all return hipError_t */
 hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
-hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
+hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, gdg_shift shift, hipStream_t s);
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s);
 /* time blocking: a window of W (2, 4 or 8) consecutive 8192-sample frames per channel; what = 0 forward transforms, 1 multiply-accumulate
  * (reads every spectrum once for the W frames), 2 inverse transforms, 3 history + frame counter.  chans[].src / dst: frame 0 of the
  * window, frame j at + j * 8192; chans[].Y holds W spectra; chans[].R >= K + W - 1. */
 hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const double2 *d_tw, const double2 *d_tw2,
-                                 int what, hipStream_t s);
-hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, hipStream_t s);
+                                 int what, gdg_shift shift, hipStream_t s);
+hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, gdg_shift shift, hipStream_t s);
 hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 
@@ -99,6 +106,8 @@ struct gdg_seg_chan {
     double *scratch;          /* one frame of per-channel global scratch */
     int unit_begin;
     int unit_count;
+    int flags;                /* GDG_SRC_IS_INPUT / GDG_DST_IS_OUTPUT */
+    int pad;
 };
 
 /* oversampling tables shared by all channels (device memory) */
@@ -119,7 +128,7 @@ struct gdg_os_tables {
 #define GDG_OS_PADLO(F) (GDG_OS_NC - 1 - GDG_OS_BACK(F))
 #define GDG_OS_NE(F) (GDG_OS_NC + GDG_OS_R(F) - 1 + 1)              /* table entries per phase (+1: even) */
 
-hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, size_t frame_off,
+hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, size_t frame_off, gdg_shift shift,
                           gdg_os_tables os, int *d_error, hipStream_t s);
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);
@@ -133,7 +142,7 @@ struct gdg_spat_chan {
     int mode, early, late, pad;
 };
 hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, double *d_hist, int H,
-                                  double *d_partial, double *d_out_lr, int frames, int max_frames, hipStream_t s);
+                                  double *d_partial, double *d_out_lr, int out_stride, int frames, int max_frames, hipStream_t s);   /* right = left + out_stride */
 int gdg_spat_groups(int nch);
 
 /* ------------------------------------------------------------------------------------------------

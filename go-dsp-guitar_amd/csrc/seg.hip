@@ -2135,10 +2135,13 @@ UNIT_FN unit_noisegate(UNIT_ARGS) {
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(SEG_T)
-seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, size_t frame_off, gdg_os_tables os, int *d_error) {
+seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, size_t frame_off, gdg_shift shift,
+           gdg_os_tables os, int *d_error) {
     gdg_seg_chan ch = chans[blockIdx.x];
     ch.src += frame_off;                    /* frame j of a window (gdg_process_window_device); 0 otherwise */
     ch.dst += frame_off;
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
+    if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
     const int tid = threadIdx.x;
     /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
     int *s_types = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32);       /* 16 ints behind the stash cells */
@@ -2223,9 +2226,9 @@ int gdg_seg_supported(int unit_type) {
     }
 }
 
-hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, size_t frame_off,
+hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, size_t frame_off, gdg_shift shift,
                           gdg_os_tables os, int *d_error, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_kernel, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, frame_off, os, d_error);
+    hipLaunchKernelGGL(seg_kernel, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, frame_off, shift, os, d_error);
     return hipGetLastError();
 }

@@ -46,7 +46,7 @@ spat_partial_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const doub
 }
 
 __global__ void __launch_bounds__(256)
-spat_reduce_kernel(const double *__restrict__ partial, int groups, double *__restrict__ out_lr, int frames, int max_frames) {
+spat_reduce_kernel(const double *__restrict__ partial, int groups, double *__restrict__ out_lr, int out_stride, int frames, int max_frames) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= frames) return;
     double L = 0.0, R = 0.0;
@@ -55,7 +55,7 @@ spat_reduce_kernel(const double *__restrict__ partial, int groups, double *__res
         R += partial[((size_t)g * 2 + 1) * max_frames + j];
     }
     out_lr[j] = L;
-    out_lr[frames + j] = R;
+    out_lr[(size_t)out_stride + j] = R;
 }
 
 /* history = the last H inputs of every channel (spatializer.go:313-331); one workgroup per channel */
@@ -76,12 +76,12 @@ spat_hist_kernel(const double *__restrict__ in, int in_stride, double *__restric
 }
 
 hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, double *d_hist, int H,
-                                  double *d_partial, double *d_out_lr, int frames, int max_frames, hipStream_t s) {
+                                  double *d_partial, double *d_out_lr, int out_stride, int frames, int max_frames, hipStream_t s) {
     if (H > 1024) return hipErrorInvalidValue;
     const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
     const int tiles = (frames + 255) / 256;
     spat_partial_kernel<<<dim3(tiles, groups), dim3(256), 0, s>>>(d_chans, nch, d_in, in_stride, d_hist, H, d_partial, frames, max_frames);
-    spat_reduce_kernel<<<dim3(tiles), dim3(256), 0, s>>>(d_partial, groups, d_out_lr, frames, max_frames);
+    spat_reduce_kernel<<<dim3(tiles), dim3(256), 0, s>>>(d_partial, groups, d_out_lr, out_stride, frames, max_frames);
     spat_hist_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_in, in_stride, d_hist, H, frames);
     return hipGetLastError();
 }

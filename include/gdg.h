@@ -171,6 +171,15 @@ int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int fram
  * frames_in_window in {1, 2, 4, 8}, <= W (the tail of a file).  Enqueued on gdg_ctx_stream(), not synchronised.
  */
 int gdg_ctx_set_window(gdg_ctx *ctx, int frames_per_call);
+/*
+ * Channel groups of the device-resident calls (gdg_process_device, gdg_process_window_device): the channels are cut into `groups`
+ * contiguous groups whose kernels run on streams of their own and are NOT joined at the end of the call, so one group's
+ * latency-bound segment kernel overlaps another group's HBM-bound convolution, also across calls.  The context's stream is ordered
+ * after them by the next library call of any other kind (including gdg_ctx_stream() and gdg_ctx_synchronize()): fetch the stream
+ * AFTER the process call if you enqueue your own work behind it.  0 = automatic (two groups from 384 channels on, else one; env
+ * GDG_DEVICE_GROUPS overrides), 1 = off.
+ */
+int gdg_ctx_set_overlap(gdg_ctx *ctx, int groups);
 int gdg_process_window_device(gdg_ctx *ctx, const double *d_in, double *d_out, size_t row_stride, int frames_in_window, uint32_t sample_rate);
 
 /* Device memory helpers for callers that have no HIP runtime of their own (e.g. the Go shim). */

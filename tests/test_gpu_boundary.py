@@ -69,7 +69,7 @@ def test_device_resident_path(pkg, oracle):
         for c in range(nch):
             assert rms(got[c] - pairs[c].ref.process(blk[c], sr)) <= TOL_RMS
     ms, n = ctx.profile_read(pkg.K_FIR_MAC)
-    assert n == 3 and ms > 0.0                                   # HIP-event timing of the MAC kernel is live
+    assert n >= 3 and n % 3 == 0 and ms > 0.0                    # HIP-event timing of the MAC kernel is live (x channel groups)
     with pytest.raises(pkg.GdgError):
         ctx.process_device(d_in, d_in, frames, sr)               # in-place is rejected
     d_in.free(); d_out.free()

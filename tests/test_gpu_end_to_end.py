@@ -166,7 +166,7 @@ def test_batch_run_one_call_matches_oracle(oracle):
     tick, tock = rng.uniform(-0.5, 0.5, 900), rng.uniform(-0.5, 0.5, 500)
     ports = 2 * nch + 3
     # channel: (format, rate, samples, file channels, channel taken) -- channel 3 stays empty
-    files = {0: ("lpcm16", 48000, 20000, 2, 1), 1: ("lpcm24", 44100, 30000, 1, 0), 2: ("ieee32", 96000, 50000, 3, 2), 4: ("lpcm32", 48000, 9000, 1, 0)}
+    files = {0: ("lpcm16", 48000, 20000, 2, 1), 1: ("lpcm24", 44100, 62000, 1, 0), 2: ("ieee32", 96000, 50000, 3, 2), 4: ("lpcm32", 48000, 9000, 1, 0)}
     inputs, decoded = [None] * nch, {}
     for c, (fmt, r, n, chans, take) in files.items():
         chan_samples = [0.7 * synth_signal(10 * c + k, n, r) for k in range(chans)]
@@ -227,8 +227,11 @@ def test_batch_run_one_call_matches_oracle(oracle):
         ctx.meter_set_enabled(True)
         return ctx
 
-    for out_fmt in ("ieee64", "lpcm24"):
+    assert length == 9 * BLOCK
+    # W: frames per step (time blocking, gdg_ctx_set_window): 9 blocks = 8 + 1 at W = 8, 2 + 2 + 2 + 2 + 1 at W = 2
+    for out_fmt, W in (("ieee64", 1), ("lpcm24", 8), ("ieee64", 2)):
         ctx = configured()
+        ctx.set_window(W)
         outs = ctx.batch_run(inputs, rate, out_fmt, metronome_to_master=True, run_meters=True, tuner_enqueue=True)
         lv, pk = ctx.meter_analyze()
         tuned = ctx.tuner_analyze()
