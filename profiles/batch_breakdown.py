@@ -1,7 +1,7 @@
 """Where gdg_batch_run's wall time goes (512 channels, 16 blocks, lpcm16 in / lpcm24 out): wall time vs the chain's own share."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from importlib import import_module
 pkg = import_module("go-dsp-guitar_amd")

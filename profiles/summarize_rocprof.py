@@ -18,11 +18,16 @@ def short(name):
 
 def kernel_stats(path):
     cur = sqlite3.connect(path).cursor()
-    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
-    total = sum(r[2] for r in rows) or 1
-    print("%-62s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
-    for name, n, tot, avg, mn, mx in rows[:14]:
-        print("%-62s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (short(name), n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
+    # launches of one kernel with different grids are different populations (channel groups halve the grid): keep them apart
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    grid = next((c for c in cols if "grid" in c.lower() and c.lower().endswith("x")), None)
+    key = "name, %s" % grid if grid else "name, 0"
+    rows = cur.execute("select %s, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by %s order by sum(duration) desc"
+                       % (key, key)).fetchall()
+    total = sum(r[3] for r in rows) or 1
+    print("%-62s %9s %7s %12s %10s %10s %10s %6s" % ("kernel", "grid_x", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+    for name, g, n, tot, avg, mn, mx in rows[:18]:
+        print("%-62s %9s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (short(name), g, n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
 
 
 def pmc(path, counter):

@@ -2,7 +2,7 @@
 driven round-robin from one host thread; W = 8 windows over 32 frames."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from importlib import import_module
 pkg = import_module("go-dsp-guitar_amd")

@@ -2,14 +2,14 @@
 W frames per call.  us per 8192-frame block, Msamples/s, and the HIP-event time of the four kernel kinds per block."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from importlib import import_module
 pkg = import_module("go-dsp-guitar_amd")
 nch, sr, frames, taps, blocks = 512, 192000, 8192, 65536, 32
 x = np.tile(bench.synth_block(nch, frames, sr), (1, blocks))
 print("W,us_per_block,Msamples_s,realtime_x,fir_fwd_us,fir_mac_us,fir_inv_us,segment_us")
-for W in (1, 2, 4, 8):
+for W in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
     ctx = bench.make_context(pkg, nch, frames, 0, taps)
     ctx.set_window(W)
     d_in, d_out = ctx.alloc(nch, blocks * frames), ctx.alloc(nch, blocks * frames)
