@@ -6,7 +6,8 @@ import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__fil
 import bench
 from importlib import import_module
 pkg = import_module("go-dsp-guitar_amd")
-nch, sr, frames, taps, blocks = 512, 192000, 8192, 65536, 32
+nch = int(os.environ.get("SWEEP_CHANNELS", "512"))
+sr, frames, taps, blocks = 192000, 8192, 65536, 32
 x = np.tile(bench.synth_block(nch, frames, sr), (1, blocks))
 print("W,us_per_block,Msamples_s,realtime_x,fir_fwd_us,fir_mac_us,fir_inv_us,segment_us")
 for W in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
