@@ -456,6 +456,17 @@ func (this *Context) MetronomeProcess(out []float64) error {
 	return this.err(C.gdg_metronome_process(this.ctx, (*C.double)(unsafe.Pointer(&out[0])), C.int(len(out))))
 }
 
+// SetWindow: the batch run steps through the files `frames` (1, 2, 4 or 8) blocks at a time; every power amp then reads its IR
+// spectra and its delay line once per step instead of once per block (gdg_ctx_set_window).
+func (this *Context) SetWindow(frames int) error {
+	return this.err(C.gdg_ctx_set_window(this.ctx, C.int(frames)))
+}
+
+// SetOverlap: channel groups of the device-resident calls (0 = automatic, 1 = off; gdg_ctx_set_overlap).
+func (this *Context) SetOverlap(groups int) error {
+	return this.err(C.gdg_ctx_set_overlap(this.ctx, C.int(groups)))
+}
+
 // BatchInput: one input file of the batch run -- the data section of a RIFF/WAVE file (wave.go:840-1100 parses the header and
 // knows Format / BitDepth / SampleRate / ChannelCount), and the channel of it that feeds the input.  Data == nil leaves the
 // channel empty (controller.go:2935).
