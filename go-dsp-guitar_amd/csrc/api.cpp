@@ -151,6 +151,11 @@ struct gdg_ctx {
     size_t h_batch_cap = 0;
     hipStream_t batch_stream = nullptr;
     hipEvent_t batch_ready[2] = { nullptr, nullptr }, batch_moved[2] = { nullptr, nullptr };
+    /* ... and the streamed upload of the inputs that need no resampling: two more pinned halves, a stream, events */
+    unsigned char *h_up[2] = { nullptr, nullptr };
+    size_t h_up_cap = 0;
+    hipStream_t batch_up_stream = nullptr;
+    hipEvent_t batch_up_ready[2] = { nullptr, nullptr }, batch_begin = nullptr;
     /* channel groups of the host-buffer paths: group g's upload, kernels and download run on stream g, so one group's
      * PCIe transfers overlap the other groups' kernels (channels are independent) */
     int plan_groups = 1;
@@ -313,6 +318,12 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
         if (ctx->batch_moved[h]) hipEventDestroy(ctx->batch_moved[h]);
     }
     if (ctx->batch_stream) hipStreamDestroy(ctx->batch_stream);
+    for (int h = 0; h < 2; h++) {
+        if (ctx->h_up[h]) hipHostFree(ctx->h_up[h]);
+        if (ctx->batch_up_ready[h]) hipEventDestroy(ctx->batch_up_ready[h]);
+    }
+    if (ctx->batch_begin) hipEventDestroy(ctx->batch_begin);
+    if (ctx->batch_up_stream) hipStreamDestroy(ctx->batch_up_stream);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -2234,13 +2245,25 @@ int gdg_batch_length(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, 
     return GDG_OK;
 }
 
-static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes) {
+static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes, size_t up_half_bytes) {
     if (!ctx->batch_stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->batch_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->batch_up_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_begin, hipEventDisableTiming));
         for (int h = 0; h < 2; h++) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_ready[h], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_moved[h], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_up_ready[h], hipEventDisableTiming));
         }
+    }
+    if (up_half_bytes > ctx->h_up_cap) {
+        for (int h = 0; h < 2; h++) {
+            if (ctx->h_up[h]) hipHostFree(ctx->h_up[h]);
+            ctx->h_up[h] = nullptr;
+        }
+        ctx->h_up_cap = 0;
+        for (int h = 0; h < 2; h++) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_up[h], up_half_bytes, hipHostMallocDefault));
+        ctx->h_up_cap = up_half_bytes;
     }
     if (half_bytes > ctx->h_batch_cap) {
         for (int h = 0; h < 2; h++) {
@@ -2280,8 +2303,12 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     if (!out_width) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", opt->out_format);
     if (opt->target_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     const int N = n_inputs, NO = N + 3, B = GDG_BLOCK_SIZE, ports = 2 * N + 3;
+    /* inputs that are mono and already at the target rate are STREAMED: their bytes go up step by step while the block loop runs;
+     * the others (a channel picked out of an interleaved file, resample.Time over the whole file) go up before the loop */
     std::vector<size_t> arena_off((size_t)N, 0);
-    size_t arena_bytes = 0, src_cap = 0;
+    std::vector<char> streamed((size_t)N, 0);
+    size_t arena_bytes = 0, src_cap = 0, up_sample_bytes = 0;
+    int n_streamed = 0;
     for (int i = 0; i < N; i++) {
         const gdg_batch_input &in = inputs[i];
         if (!in.bytes || !in.samples_per_channel) continue;
@@ -2290,9 +2317,15 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         if (in.channels == 0 || in.channel >= in.channels) return fail(ctx, GDG_ERR_INVALID, "input %d: channel %u of %u", i, in.channel, in.channels);
         if (in.sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "input %d: sample rate must be positive", i);
         const size_t count = in.samples_per_channel * in.channels;
+        if (in.sample_rate == opt->target_rate && in.channels == 1) {
+            streamed[(size_t)i] = 1;
+            n_streamed++;
+            up_sample_bytes += (size_t)w;
+            continue;
+        }
         arena_off[(size_t)i] = arena_bytes;
         arena_bytes += (count * (size_t)w + 15) & ~(size_t)15;
-        if (!(in.sample_rate == opt->target_rate && in.channels == 1) && count > src_cap) src_cap = count;
+        if (count > src_cap) src_cap = count;
     }
     size_t length = 0;
     int rc = gdg_batch_length(ctx, inputs, n_inputs, opt->target_rate, &length);
@@ -2305,10 +2338,13 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     const size_t enc_bytes = (size_t)NO * W * B * (size_t)out_width;           /* one encoded window */
     const size_t half = std::max(enc_bytes, (size_t)8 << 20);
     if (length > 0x7fffffff) return fail(ctx, GDG_ERR_INVALID, "files of %zu samples are too long", length);
-    rc = ensure_batch_pipe(ctx, half);
+    /* one step of the streamed inputs: the piece descriptors, then every piece on a 16-byte boundary */
+    const size_t up_rows_bytes = ((size_t)n_streamed * sizeof(gdg_decode_row) + 255) & ~(size_t)255;
+    const size_t up_half = n_streamed ? up_rows_bytes + up_sample_bytes * (size_t)W * B + 16 * (size_t)n_streamed : 0;
+    rc = ensure_batch_pipe(ctx, half, up_half);
     if (rc != GDG_OK) return rc;
     double *d_inputs = nullptr, *d_win = nullptr, *d_src = nullptr;
-    unsigned char *d_arena = nullptr, *d_enc = nullptr;
+    unsigned char *d_arena = nullptr, *d_enc = nullptr, *d_up = nullptr;
     auto body = [&]() -> int {
         int r;
         HIP_TRY(ctx, hipMalloc((void **)&d_inputs, (size_t)N * length * sizeof(double)));
@@ -2317,6 +2353,7 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         HIP_TRY(ctx, hipMalloc((void **)&d_win, (size_t)NO * W * B * sizeof(double)));
         HIP_TRY(ctx, hipMalloc((void **)&d_enc, 2 * enc_bytes));
         if (arena_bytes) HIP_TRY(ctx, hipMalloc((void **)&d_arena, arena_bytes));
+        if (up_half) HIP_TRY(ctx, hipMalloc((void **)&d_up, 2 * up_half));
         if (src_cap) HIP_TRY(ctx, hipMalloc((void **)&d_src, src_cap * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(d_inputs, 0, (size_t)N * length * sizeof(double), ctx->stream));     /* the zero padding, :3018-3045 */
 
@@ -2328,10 +2365,10 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
             const int h = (int)(k & 1);
             if (used[h]) HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h]));
             std::vector<BatchPiece> pieces;
-            while (next_input < N && (!inputs[next_input].bytes || !inputs[next_input].samples_per_channel)) next_input++;
+            while (next_input < N && (!inputs[next_input].bytes || !inputs[next_input].samples_per_channel || streamed[(size_t)next_input])) next_input++;
             for (int i = next_input; i < N; i++) {
                 const gdg_batch_input &in = inputs[i];
-                if (!in.bytes || !in.samples_per_channel) continue;
+                if (!in.bytes || !in.samples_per_channel || streamed[(size_t)i]) continue;
                 const size_t a = arena_off[(size_t)i], nb = in.samples_per_channel * in.channels * (size_t)gdg_wave_bytes_per_sample(in.format);
                 if (a >= hi) break;
                 if (a + nb <= lo) { if (i == next_input) next_input++; continue; }
@@ -2348,12 +2385,10 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         /* 1b. decode (+ resample.Time) every input into its row */
         for (int i = 0; i < N; i++) {
             const gdg_batch_input &in = inputs[i];
-            if (!in.bytes || !in.samples_per_channel) continue;               /* "leaving channel empty" */
+            if (!in.bytes || !in.samples_per_channel || streamed[(size_t)i]) continue;        /* "leaving channel empty" / comes with its step */
             const size_t per = in.samples_per_channel;
             double *row = d_inputs + (size_t)i * length;
-            const bool direct = in.sample_rate == opt->target_rate && in.channels == 1;
-            if ((r = gdg_wave_decode_device(ctx, in.format, d_arena + arena_off[(size_t)i], per, in.channels, direct ? row : d_src)) != GDG_OK) return r;
-            if (direct) continue;
+            if ((r = gdg_wave_decode_device(ctx, in.format, d_arena + arena_off[(size_t)i], per, in.channels, d_src)) != GDG_OK) return r;
             const double *chan = d_src + (size_t)in.channel * per;           /* planar: samplesToChannels */
             if (in.sample_rate == opt->target_rate)
                 HIP_TRY(ctx, hipMemcpyAsync(row, chan, per * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2382,9 +2417,48 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
                 if (out_bytes[o]) memcpy(static_cast<unsigned char *>(out_bytes[o]) + at, src + o * row_bytes, row_bytes);   /* NULL: "skipping output" (:3143) */
             }, row_bytes);
         };
+        /* the streamed inputs of step i: gathered into a pinned half by the copy threads, moved and decoded on the upload stream while
+         * the block loop is busy with the steps before */
+        HIP_TRY(ctx, hipEventRecord(ctx->batch_begin, ctx->stream));             /* rows zeroed, whole-file inputs decoded */
+        if (n_streamed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_up_stream, ctx->batch_begin, 0));
+        int up_used[2] = { 0, 0 };
+        auto stage = [&](size_t i) -> int {
+            if (!n_streamed || i >= steps.size()) return GDG_OK;
+            const int h = (int)(i & 1);
+            if (up_used[h]) HIP_TRY(ctx, hipEventSynchronize(ctx->batch_up_ready[h]));     /* step i - 2 has left this half */
+            unsigned char *hb = ctx->h_up[h], *db = d_up + (size_t)h * up_half;
+            gdg_decode_row *rows = reinterpret_cast<gdg_decode_row *>(hb);
+            std::vector<BatchPiece> pieces;
+            size_t cur = up_rows_bytes;
+            int n_rows = 0;
+            unsigned max_count = 0;
+            const size_t a = steps[i].off, span = (size_t)steps[i].w * B;
+            for (int c = 0; c < N; c++) {
+                if (!streamed[(size_t)c]) continue;
+                const gdg_batch_input &in = inputs[c];
+                if (a >= in.samples_per_channel) continue;                       /* the file ended in an earlier step: zeros */
+                const size_t cnt = std::min(in.samples_per_channel - a, span), width = (size_t)gdg_wave_bytes_per_sample(in.format);
+                rows[n_rows++] = gdg_decode_row{ db + cur, d_inputs + (size_t)c * length + a, (unsigned)cnt, in.format };
+                const unsigned char *src = static_cast<const unsigned char *>(in.bytes) + a * width;
+                for (size_t q = 0; q < cnt * width; q += (size_t)1 << 20)
+                    pieces.push_back({ hb + cur + q, src + q, std::min(cnt * width - q, (size_t)1 << 20) });
+                if (cnt > max_count) max_count = (unsigned)cnt;
+                cur += (cnt * width + 15) & ~(size_t)15;
+            }
+            up_used[h] = 1;
+            if (n_rows) {
+                move_pieces(pieces);
+                HIP_TRY(ctx, hipMemcpyAsync(db, hb, cur, hipMemcpyHostToDevice, ctx->batch_up_stream));
+                HIP_TRY(ctx, gdg_launch_wave_decode_rows(reinterpret_cast<const gdg_decode_row *>(db), n_rows, max_count, ctx->batch_up_stream));
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->batch_up_ready[h], ctx->batch_up_stream));
+            return GDG_OK;
+        };
+        if ((r = stage(0)) != GDG_OK) return r;
         for (size_t i = 0; i < steps.size(); i++) {
             const size_t off = steps[i].off;
             const int w = steps[i].w, h = (int)(i & 1), wb = w * B;               /* the window's rows are wb long */
+            if (n_streamed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_up_ready[h], 0));
             const double *d_in = d_inputs + off;
             double *d_master = d_win + (size_t)N * wb, *d_metro = d_master + 2 * (size_t)wb;
             unsigned char *enc = d_enc + h * enc_bytes;
@@ -2406,7 +2480,8 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_stream, ctx->batch_ready[h], 0));
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, (size_t)NO * wb * out_width, hipMemcpyDeviceToHost, ctx->batch_stream));
             HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
-            if (i >= 1) {                                                        /* while step i runs: step i - 1 into the files */
+            if ((r = stage(i + 1)) != GDG_OK) return r;                          /* while step i runs: the next step's inputs go up ... */
+            if (i >= 1) {                                                        /* ... and step i - 1 goes into the files */
                 HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h ^ 1]));
                 scatter(i - 1);
             }
@@ -2416,9 +2491,10 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         return check_device_error(ctx);
     };
     rc = body();
+    hipStreamSynchronize(ctx->batch_up_stream);
     hipStreamSynchronize(ctx->batch_stream);
     hipStreamSynchronize(ctx->stream);
-    hipFree(d_inputs); hipFree(d_win); hipFree(d_src); hipFree(d_arena); hipFree(d_enc);
+    hipFree(d_inputs); hipFree(d_win); hipFree(d_src); hipFree(d_arena); hipFree(d_enc); hipFree(d_up);
     return rc;
 }
 

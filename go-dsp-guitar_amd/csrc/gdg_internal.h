@@ -170,6 +170,9 @@ hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, doub
 struct gdg_meter_rec { double current, peak; unsigned long long counter; int enabled, pad; };
 hipError_t gdg_launch_wave_decode(int fmt, const void *d_bytes, size_t per, unsigned channels, double *d_out, hipStream_t s);
 hipError_t gdg_launch_wave_encode(int fmt, const double *d_in, size_t per, unsigned channels, void *d_bytes, hipStream_t s);
+/* many mono pieces in one launch (the batch run's streamed upload): piece r = `count` samples of format `fmt` at `src` -> dst */
+struct gdg_decode_row { const unsigned char *src; double *dst; unsigned count; int fmt; };
+hipError_t gdg_launch_wave_decode_rows(const gdg_decode_row *d_rows, int n_rows, unsigned max_count, hipStream_t s);
 hipError_t gdg_launch_resample_time(const double *d_in, int n, double dx, double *d_out, int n_out, hipStream_t s);
 hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, int n, gdg_meter_rec *d_state,
                             double decay, unsigned long long hold, hipStream_t s);

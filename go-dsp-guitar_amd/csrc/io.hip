@@ -393,6 +393,41 @@ static void launch_encode(const double *d_in, size_t per, unsigned channels, uns
     }
 }
 
+template <int FMT>
+__device__ __forceinline__ void decode_piece(const gdg_decode_row &r) {
+    constexpr int W = fmt_width<FMT>::W;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < r.count; i += gridDim.x * 256) {
+        unsigned code = 0;
+#pragma unroll
+        for (int k = 0; k < W; k++) code |= (unsigned)r.src[(size_t)i * W + k] << (8 * k);
+        r.dst[i] = decode_code<FMT>(code);
+    }
+}
+
+/* blockIdx.y = piece; every piece has its own format (uniform per workgroup), source and destination */
+__global__ void __launch_bounds__(256)
+wave_decode_rows_kernel(const gdg_decode_row *__restrict__ rows) {
+    const gdg_decode_row r = rows[blockIdx.y];
+    switch (r.fmt) {
+    case GDG_FMT_LPCM8: decode_piece<GDG_FMT_LPCM8>(r); break;
+    case GDG_FMT_LPCM16: decode_piece<GDG_FMT_LPCM16>(r); break;
+    case GDG_FMT_LPCM24: decode_piece<GDG_FMT_LPCM24>(r); break;
+    case GDG_FMT_LPCM32: decode_piece<GDG_FMT_LPCM32>(r); break;
+    case GDG_FMT_IEEE32: decode_piece<GDG_FMT_IEEE32>(r); break;
+    default:                                                   /* IEEE64 (wave.go:714-732): the bytes are the sample; src is 8-byte aligned */
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < r.count; i += gridDim.x * 256) r.dst[i] = reinterpret_cast<const double *>(r.src)[i];
+        break;
+    }
+}
+
+hipError_t gdg_launch_wave_decode_rows(const gdg_decode_row *d_rows, int n_rows, unsigned max_count, hipStream_t s) {
+    if (n_rows <= 0 || max_count == 0) return hipSuccess;
+    unsigned tiles = (max_count + 1023) / 1024;                /* four samples per thread */
+    if (tiles > 64) tiles = 64;
+    wave_decode_rows_kernel<<<dim3(tiles, (unsigned)n_rows), dim3(256), 0, s>>>(d_rows);
+    return hipGetLastError();
+}
+
 hipError_t gdg_launch_wave_decode(int fmt, const void *d_bytes, size_t per, unsigned channels, double *d_out, hipStream_t s) {
     size_t n = per * channels;
     if (n == 0) return hipSuccess;
