@@ -276,3 +276,27 @@ def test_batch_run_rejections_and_empty_batch():
     with pytest.raises(pkg.GdgError, match="blocks of 8192 frames"):
         small.batch_run([(data, "lpcm16", 48000), None], 48000, "lpcm16")
     small.close()
+
+
+def test_batch_run_streams_every_format_bit_exact(oracle):
+    """Mono inputs at the target rate go up step by step beside the block loop and are decoded piece-wise (wave_decode_rows_kernel):
+    with empty chains the float64 outputs are the decoded files, bit for bit, whatever the format, the file length and the window."""
+    pkg = package()
+    rate = 44100
+    lengths = [3 * BLOCK + 17, 1, BLOCK, 5 * BLOCK - 1, 2 * BLOCK + 4096, 7]
+    files, want = [], []
+    for c, fmt in enumerate(FORMATS):
+        data = oracle.wave_encode(fmt, 0.9 * synth_signal(50 + c, lengths[c], rate))
+        files.append((data, fmt, rate))
+        want.append(oracle.wave_decode(fmt, data))
+    total = 5 * BLOCK
+    for W in (1, 2, 4):
+        ctx = pkg.Context(len(FORMATS), BLOCK)
+        ctx.set_window(W)
+        outs = ctx.batch_run(files, rate, "ieee64")
+        ctx.close()
+        for c in range(len(FORMATS)):
+            got = outs[c].view(np.float64)
+            assert got.size == total
+            assert np.array_equal(got[:lengths[c]], want[c]), (W, FORMATS[c])
+            assert not got[lengths[c]:].any(), (W, FORMATS[c])
