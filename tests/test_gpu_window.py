@@ -148,3 +148,26 @@ def test_window_rejections():
     with pytest.raises(pkg.GdgError, match="windows are made of 8192-sample frames"):
         small.set_window(2)
     small.close()
+
+
+def test_window_with_shared_ir_spectra():
+    """Channels with identical IRs share one copy of the spectra (cacheable loads in the multiply-accumulate): same result."""
+    pkg = package()
+    ir = synth_ir(30000, seed=11)
+    blocks, nch = 8, 4
+    x = np.stack([0.6 * synth_signal(c, blocks * B, RATE) for c in range(nch)])
+    outs = []
+    for W in (1, 8):
+        ctx = pkg.Context(nch, B)
+        ctx.share_ir_spectra(True)
+        for c in range(nch):
+            ctx.append_unit(c, "power_amp", fir=ir)
+            ctx.append_unit(c, "cabinet")
+        ctx.set_window(W)
+        d_in, d_out = ctx.alloc(nch, blocks * B), ctx.alloc(nch, blocks * B)
+        d_in.upload(x)
+        for b in range(0, blocks, W):
+            ctx.process_window_device(d_in.ptr + 8 * b * B, d_out.ptr + 8 * b * B, blocks * B, W, RATE)
+        outs.append(d_out.download())
+        ctx.close()
+    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-14
