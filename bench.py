@@ -199,6 +199,27 @@ def leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, channel0=0, chain=
     return dt
 
 
+def window_leg_on_one_gpu(pkg, nch, frames, sr, taps, device, W=8, windows=4, channel0=0):
+    """Seconds per frame with W consecutive frames per call (batch mode, time blocked) over `windows` windows resident in HBM."""
+    ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0)
+    ctx.set_window(W)
+    n = W * windows * frames
+    d_in, d_out = ctx.alloc(nch, n), ctx.alloc(nch, n)
+    d_in.upload(np.tile(synth_block(nch, frames, sr, channel0=channel0), (1, W * windows)))
+
+    def run():
+        for b in range(0, W * windows, W):
+            ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, n, W, sr)
+    run()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    run()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / (W * windows)
+    ctx.close()
+    return dt
+
+
 def end_to_end(pkg, ctx, nch, frames, sr, steps=6):
     """The boundary's host-buffer entry points on the SAME context (PCIe both ways inside the call; never the headline)."""
     import ctypes as C
@@ -446,12 +467,27 @@ def main():
             for _ in range(max(args.warmup, 1)):
                 sstep()
             s_elapsed = shard.timed_steps(sstep, args.steps, ssync, dist, None)
-            sctx.close()
             extras["strong_split"] = {
                 "scaling": "strong", "total_channels": T, "channels_per_gpu": n_loc, "n_gpus": world,
                 "value": T * frames * args.steps / s_elapsed / 1e6, "unit": "Msamples/s",
                 "ms_per_step": s_elapsed / args.steps * 1e3, "realtime_factor": frames * args.steps / s_elapsed / sr,
             }
+            if frames == 8192:
+                # the same split in batch mode: 8 consecutive frames per call, time blocked (every rank walks 4 windows of its shard)
+                W, windows = 8, 4
+                sctx.set_window(W)
+                wx = sx.repeat(1, W * windows).contiguous()
+                wy = torch.empty_like(wx)
+
+                def wstep():
+                    for b in range(0, W * windows, W):
+                        sctx.process_window_device(wx.data_ptr() + 8 * b * frames, wy.data_ptr() + 8 * b * frames, W * windows * frames, W, sr)
+                wstep()
+                w_elapsed = shard.timed_steps(wstep, 1, ssync, dist, None) / (W * windows)
+                extras["strong_split"]["batch_mode_window_8"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
+                                                                 "realtime_factor": frames / sr / w_elapsed}
+                del wx, wy
+            sctx.close()
         elif rank == 0:
             legs = {}
             for n_loc in (64, 128, 256):
@@ -460,6 +496,10 @@ def main():
                                     "value_this_gpu": n_loc * frames / dt / 1e6,
                                     "predicted_job_value": args.channels * frames / dt / 1e6, "unit": "Msamples/s",
                                     "predicted_realtime_factor": frames / sr / dt}
+                if frames == 8192:
+                    dtw = window_leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank)
+                    legs[str(n_loc)]["batch_mode_window_8"] = {"us_per_frame": dtw * 1e6, "predicted_job_value": args.channels * frames / dtw / 1e6,
+                                                               "predicted_realtime_factor": frames / sr / dtw}
             extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
                                                    "(channels are independent: the job's step time is the slowest shard's step time)",
                                            "legs": legs}
