@@ -4,7 +4,8 @@
     their index (first / last workgroup, different XCDs), and differ from their neighbours;
   * determinism: a second context fed the same stream reproduces the output bit for bit (checksum of checksums);
   * linearity of the convolution stage: FIR(a x + b y) = a FIR(x) + b FIR(y) to rounding;
-  * a sample of channels is followed by the oracle at the 1e-9 RMS bar.
+  * a sample of channels is followed by the oracle at the 1e-9 RMS bar;
+  * batch mode (windows of 8 frames, time-blocked convolution) gives the samples of the per-frame calls.
 Configs 3 and 5 are small enough for the oracle to follow every channel.  Run with `pytest -m gpu`."""
 import hashlib
 
@@ -81,6 +82,37 @@ def test_config4_512_channels_192k_two_64k_irs(pkg, oracle):
         assert rms(got[c] - want) <= TOL_RMS, c
     ctx.close()
     ctx2.close()
+
+
+def test_config4_time_blocked_windows_at_full_size(pkg, oracle):
+    """Batch mode at config 4's full size: windows of 8 frames per call (time-blocked convolution, two free-running channel groups)
+    against one frame per call on a second context -- the same samples to 1e-14 -- and against the oracle on three channels."""
+    nch, frames, sr, taps, blocks, n_distinct, W = 512, 8192, 192000, 65536, 16, 8, 8
+    followed = {0, 300, 511}
+    ctx, pairs = build_config4(pkg, oracle, nch, frames, taps, n_distinct, followed)
+    ctx1, _ = build_config4(pkg, oracle, nch, frames, taps, n_distinct, set())
+    ctx.set_window(W)
+    sig = np.stack([synth_signal(s, frames * blocks, sr) for s in range(16)])
+    x = sig[np.arange(nch) % 16]
+    d_in, d_out = ctx.alloc(nch, blocks * frames), ctx.alloc(nch, blocks * frames)
+    d_in.upload(x)
+    for b in range(0, blocks, W):
+        ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, blocks * frames, W, sr)
+    got = d_out.download()
+    d1_in, d1_out = ctx1.alloc(nch, frames), ctx1.alloc(nch, frames)
+    worst = 0.0
+    for b in range(blocks):
+        d1_in.upload(np.ascontiguousarray(x[:, b * frames:(b + 1) * frames]))
+        ctx1.process_device(d1_in, d1_out, frames, sr)
+        worst = max(worst, float(np.max(np.abs(d1_out.download() - got[:, b * frames:(b + 1) * frames]))))
+    assert worst <= 1e-14, worst
+    for c in range(16, nch):                                   # twins stay bit-identical in window mode too
+        np.testing.assert_array_equal(got[c], got[c % 16])
+    for c, p in pairs.items():
+        want = np.concatenate([p.ref.process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+        assert rms(got[c] - want) <= TOL_RMS, c
+    ctx.close()
+    ctx1.close()
 
 
 def test_config4_convolution_is_linear_at_full_size(pkg):
