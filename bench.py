@@ -199,7 +199,7 @@ def leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, channel0=0, chain=
     return dt
 
 
-def window_leg_on_one_gpu(pkg, nch, frames, sr, taps, device, W=8, windows=4, channel0=0):
+def window_leg_on_one_gpu(pkg, nch, frames, sr, taps, device, W=16, windows=2, channel0=0):
     """Seconds per frame with W consecutive frames per call (batch mode, time blocked) over `windows` windows resident in HBM."""
     ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0)
     ctx.set_window(W)
@@ -246,9 +246,9 @@ def end_to_end(pkg, ctx, nch, frames, sr, steps=6):
     return res
 
 
-def batch_run(pkg, ctx, nch, sr, blocks=32):
+def batch_run(pkg, ctx, nch, sr, blocks=64):
     """gdg_batch_run on the SAME context: 16-bit files in, 24-bit files out (N + 3 of them), everything between in HBM;
-    per window size W of the block loop (1 = the reference's loop, 8 = time blocked)."""
+    per window size W of the block loop (1 = the reference's loop, 16 = time blocked)."""
     frames = 8192
     n = blocks * frames
     rng = np.random.default_rng(5)
@@ -257,7 +257,7 @@ def batch_run(pkg, ctx, nch, sr, blocks=32):
            "what": "controller.processFiles between 'files read' and 'files written' in one call: H2D of the file bytes, decode, the block "
                    "loop in steps of W blocks (N chains + metronome + spatializer + encode, the encoded step going down while the next one "
                    "runs); caller's buffers are pageable, already touched"}
-    for W in (1, 8):
+    for W in (1, 16):
         ctx.set_window(W)
         outs = ctx.batch_run(files, sr, "lpcm24")               # also touches the output pages once
         t0 = time.perf_counter()
@@ -265,7 +265,7 @@ def batch_run(pkg, ctx, nch, sr, blocks=32):
         dt = time.perf_counter() - t0
         res["window_%d" % W] = {"value": nch * n / dt / 1e6, "ms": dt * 1e3}
         res["host_bytes_in_plus_out"] = sum(f[0].nbytes for f in files) + sum(o.nbytes for o in outs)
-    res["value"] = res["window_8"]["value"]
+    res["value"] = res["window_16"]["value"]
     ctx.set_window(1)
     return res
 
@@ -277,7 +277,7 @@ def time_blocked(pkg, ctx, nch, frames, sr, blocks=32):
     d_in.upload(np.tile(synth_block(nch, frames, sr), (1, blocks)))
     res = {"unit": "Msamples/s", "frames_per_channel": blocks,
            "what": "device-resident, W consecutive 8192-sample frames per channel and call; W = 1 is the headline's per-frame call"}
-    for W in (1, 2, 4, 8):
+    for W in (1, 2, 4, 8, 16):
         ctx.set_window(W)
 
         def run():
@@ -473,8 +473,8 @@ def main():
                 "ms_per_step": s_elapsed / args.steps * 1e3, "realtime_factor": frames * args.steps / s_elapsed / sr,
             }
             if frames == 8192:
-                # the same split in batch mode: 8 consecutive frames per call, time blocked (every rank walks 4 windows of its shard)
-                W, windows = 8, 4
+                # the same split in batch mode: 16 consecutive frames per call, time blocked (every rank walks 2 windows of its shard)
+                W, windows = 16, 2
                 sctx.set_window(W)
                 wx = sx.repeat(1, W * windows).contiguous()
                 wy = torch.empty_like(wx)
@@ -484,7 +484,7 @@ def main():
                         sctx.process_window_device(wx.data_ptr() + 8 * b * frames, wy.data_ptr() + 8 * b * frames, W * windows * frames, W, sr)
                 wstep()
                 w_elapsed = shard.timed_steps(wstep, 1, ssync, dist, None) / (W * windows)
-                extras["strong_split"]["batch_mode_window_8"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
+                extras["strong_split"]["batch_mode_window_16"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
                                                                  "realtime_factor": frames / sr / w_elapsed}
                 del wx, wy
             sctx.close()
@@ -498,7 +498,7 @@ def main():
                                     "predicted_realtime_factor": frames / sr / dt}
                 if frames == 8192:
                     dtw = window_leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank)
-                    legs[str(n_loc)]["batch_mode_window_8"] = {"us_per_frame": dtw * 1e6, "predicted_job_value": args.channels * frames / dtw / 1e6,
+                    legs[str(n_loc)]["batch_mode_window_16"] = {"us_per_frame": dtw * 1e6, "predicted_job_value": args.channels * frames / dtw / 1e6,
                                                                "predicted_realtime_factor": frames / sr / dtw}
             extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
                                                    "(channels are independent: the job's step time is the slowest shard's step time)",

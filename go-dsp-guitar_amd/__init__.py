@@ -470,7 +470,7 @@ class Context:
         self._check(lib().gdg_metronome_configure(self._h, beats_per_period, bpm_speed, sample_rate))
 
     def set_window(self, frames_per_call):
-        """Time blocking: up to `frames_per_call` (1, 2, 4, 8) consecutive 8192-sample frames per channel and call."""
+        """Time blocking: up to `frames_per_call` (1, 2, 4, 8, 16) consecutive 8192-sample frames per channel and call."""
         self._check(lib().gdg_ctx_set_window(self._h, frames_per_call))
 
     def set_overlap(self, groups):

@@ -1271,7 +1271,7 @@ int gdg_ctx_set_overlap(gdg_ctx *ctx, int groups) {
 int gdg_ctx_set_window(gdg_ctx *ctx, int frames_per_call) {
     if (!ctx) return GDG_ERR_INVALID;
     const int W = frames_per_call;
-    if (W != 1 && W != 2 && W != 4 && W != 8) return fail(ctx, GDG_ERR_INVALID, "window of %d frames: 1, 2, 4 or 8", W);
+    if (W != 1 && W != 2 && W != 4 && W != 8 && W != 16) return fail(ctx, GDG_ERR_INVALID, "window of %d frames: 1, 2, 4, 8 or 16", W);
     if (W > 1 && ctx->max_frames != GDG_MAX_FRAMES)
         return fail(ctx, GDG_ERR_UNSUPPORTED, "windows are made of %d-sample frames, the context allows %d", GDG_MAX_FRAMES, ctx->max_frames);
     if (W == ctx->window) return GDG_OK;
@@ -1295,7 +1295,7 @@ int gdg_process_window_device(gdg_ctx *ctx, const double *d_in, double *d_out, s
     if (!ctx || !d_in || !d_out) return GDG_ERR_INVALID;
     const int W = frames_in_window;
     if (W < 1 || W > ctx->window) return fail(ctx, GDG_ERR_INVALID, "window of %d frames, the context is set up for %d (gdg_ctx_set_window)", W, ctx->window);
-    if (W != 1 && W != 2 && W != 4 && W != 8) return fail(ctx, GDG_ERR_INVALID, "window of %d frames: 1, 2, 4 or 8", W);
+    if (W != 1 && W != 2 && W != 4 && W != 8 && W != 16) return fail(ctx, GDG_ERR_INVALID, "window of %d frames: 1, 2, 4, 8 or 16", W);
     if (row_stride < (size_t)W * (size_t)ctx->max_frames || row_stride > 0x7fffffff)
         return fail(ctx, GDG_ERR_INVALID, "row stride %zu is shorter than the window (%d x %d)", row_stride, W, ctx->max_frames);
     if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);

@@ -703,12 +703,12 @@ fir_raw_inv_kernel(const gdg_fir_rawjob *__restrict__ jobs, double scale, const 
  * line slots they touch: (2 K + W - 1) spectrum reads for W frames instead of 2 K W.  The ring has R >= K + W - 1 slots so the
  * W new spectra do not overwrite what the early frames of the window still need.
  *
- * One thread per bin.  Partitions are walked in chunks of W: chunk c needs H[cW .. cW + W - 1] and the 2 W - 1 slots
- * X[t0 - cW + d], d = -(W - 1) .. W - 1, all loaded before the W x W multiply-adds, whose indices are compile-time constants.
+ * One thread per bin.  Partitions are walked in chunks of C (= W up to 8, 8 for W = 16): a chunk needs C IR partitions and the
+ * W + C - 1 delay-line slots they meet, all loaded before the C x W multiply-adds, whose indices are compile-time constants.
  * Every Y_j accumulates its terms in ascending k -- the order of the per-frame kernels; the results differ from W single-frame
  * calls only where the compiler contracts a multiply-add differently (last bit).
  * ---------------------------------------------------------------------------------------------- */
-template <int W, bool HNT>
+template <int W, int C, bool HNT>
 __global__ void __launch_bounds__(256)
 fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     gdg_fir_chan ch = chans[blockIdx.y];
@@ -718,38 +718,64 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     const int pos0 = (*ch.pos) % R;                       /* slot of X[t0] (frame 0 of the window) */
     const cplx *__restrict__ fdl = ch.fdl + b;
     const cplx *__restrict__ H = ch.H + b;
-    double ar[W], ai[W], br[W], bi[W];
+    double ar[W], ai[W];
 #pragma unroll
-    for (int j = 0; j < W; j++) { ar[j] = 0.0; ai[j] = 0.0; br[j] = 0.0; bi[j] = 0.0; }
-    for (int c = 0; c * W < K; c++) {
-        cplx x[2 * W - 1], h[W];
+    for (int j = 0; j < W; j++) { ar[j] = 0.0; ai[j] = 0.0; }
+    /* partitions in chunks of C: chunk c0 needs H[c0 .. c0 + C - 1] and the W + C - 1 slots X[t0 - c0 + d - (C - 1)], d = 0 .. W + C - 2 */
+    for (int c0 = 0; c0 < K; c0 += C) {
+        cplx x[W + C - 1], h[C];
 #pragma unroll
-        for (int d = 0; d < 2 * W - 1; d++) {
-            int slot = (pos0 + (d - (W - 1)) - c * W) % R;      /* |argument| < 3 R: one correction is not enough for the remainder's sign */
+        for (int d = 0; d < W + C - 1; d++) {
+            int slot = (pos0 + (d - (C - 1)) - c0) % R;      /* the remainder has the argument's sign: one correction */
             if (slot < 0) slot += R;
             x[d] = mac_load<true>(fdl + (size_t)slot * P);
         }
 #pragma unroll
-        for (int i = 0; i < W; i++) {
-            const int k = c * W + i;
+        for (int i = 0; i < C; i++) {
+            const int k = c0 + i;
             h[i] = (k < K) ? mac_load<HNT>(H + (size_t)k * P) : make_double2(0.0, 0.0);
         }
 #pragma unroll
-        for (int i = 0; i < W; i++) {
-            if (c * W + i < K) {
+        for (int i = 0; i < C; i++) {
+            if (c0 + i < K) {
 #pragma unroll
                 for (int j = 0; j < W; j++) {
-                    const cplx xv = x[j - i + W - 1];
+                    const cplx xv = x[j - i + C - 1];
                     ar[j] += xv.x * h[i].x - xv.y * h[i].y;
                     ai[j] += xv.x * h[i].y + xv.y * h[i].x;
-                    br[j] += xv.x * h[i].x;              /* bin 0 = (DC, Nyquist) as two reals: component-wise */
-                    bi[j] += xv.y * h[i].y;
                 }
             }
         }
     }
+    if (b != 0) {
 #pragma unroll
-    for (int j = 0; j < W; j++) gstore(ch.Y + (size_t)j * P + b, (b == 0) ? make_double2(br[j], bi[j]) : make_double2(ar[j], ai[j]));
+        for (int j = 0; j < W; j++) gstore(ch.Y + (size_t)j * P + b, make_double2(ar[j], ai[j]));
+    }
+    /* bin 0 = (DC, Nyquist) as two reals: component-wise products, the same ascending order.  Lane j of the channel's first workgroup
+     * takes frame j: its operands were loaded a moment ago (cache), eight partitions' worth are issued before they are consumed */
+    if (blockIdx.x == 0 && threadIdx.x < W) {
+        const int j = threadIdx.x;
+        double br = 0.0, bi = 0.0;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            cplx xv[8], hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = min(k0 + u, K - 1);
+                int slot = (pos0 + j - k) % R;
+                if (slot < 0) slot += R;
+                xv[u] = gload(ch.fdl + (size_t)slot * P);
+                hv[u] = gload(ch.H + (size_t)k * P);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (k0 + u < K) {
+                    br += xv[u].x * hv[u].x;
+                    bi += xv[u].y * hv[u].y;
+                }
+            }
+        }
+        gstore(ch.Y + (size_t)j * P, make_double2(br, bi));
+    }
 }
 
 /* after a window of W frames: the last frame becomes the overlap-save history of the next call, the frame counter moves on */
@@ -824,19 +850,20 @@ template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, con
 }
 
 /* a window of W frames of 8192 samples per channel (W in {2, 4, 8}); the four launches of one power-amp step */
-template <int W> static void launch_mac_tb(const gdg_fir_chan *d_chans, int n, bool shared, hipStream_t s) {
-    if (shared) fir_mac_tb_kernel<W, false><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
-    else fir_mac_tb_kernel<W, true><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
+template <int W, int C> static void launch_mac_tb(const gdg_fir_chan *d_chans, int n, bool shared, hipStream_t s) {
+    if (shared) fir_mac_tb_kernel<W, C, false><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
+    else fir_mac_tb_kernel<W, C, true><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
 }
 hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const cplx *d_tw, const cplx *d_tw2, int what,
                                  gdg_shift shift, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
-    if (W != 2 && W != 4 && W != 8) return hipErrorInvalidValue;
+    if (W != 2 && W != 4 && W != 8 && W != 16) return hipErrorInvalidValue;
     if (what == 0) fir_fwd13w_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
     else if (what == 1) {
-        if (W == 2) launch_mac_tb<2>(d_chans, n_chans, shared_spectra != 0, s);
-        else if (W == 4) launch_mac_tb<4>(d_chans, n_chans, shared_spectra != 0, s);
-        else launch_mac_tb<8>(d_chans, n_chans, shared_spectra != 0, s);
+        if (W == 2) launch_mac_tb<2, 2>(d_chans, n_chans, shared_spectra != 0, s);
+        else if (W == 4) launch_mac_tb<4, 4>(d_chans, n_chans, shared_spectra != 0, s);
+        else if (W == 8) launch_mac_tb<8, 8>(d_chans, n_chans, shared_spectra != 0, s);
+        else launch_mac_tb<16, 8>(d_chans, n_chans, shared_spectra != 0, s);
     } else if (what == 2) fir_inv_kernel<13, 3><<<dim3(n_chans * W), dim3(FftCfg<13>::T), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
     else fir_tb_finish_kernel<<<dim3(n_chans), dim3(256), 0, s>>>(d_chans, W, shift);
     return hipGetLastError();

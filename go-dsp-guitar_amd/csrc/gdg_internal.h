@@ -65,7 +65,7 @@ struct gdg_fir_rawjob {
 hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
 hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, gdg_shift shift, hipStream_t s);
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s);
-/* time blocking: a window of W (2, 4 or 8) consecutive 8192-sample frames per channel; what = 0 forward transforms, 1 multiply-accumulate
+/* time blocking: a window of W (2, 4, 8 or 16) consecutive 8192-sample frames per channel; what = 0 forward transforms, 1 multiply-accumulate
  * (reads every spectrum once for the W frames), 2 inverse transforms, 3 history + frame counter.  chans[].src / dst: frame 0 of the
  * window, frame j at + j * 8192; chans[].Y holds W spectra; chans[].R >= K + W - 1. */
 hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const double2 *d_tw, const double2 *d_tw2,

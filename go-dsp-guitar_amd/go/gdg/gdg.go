@@ -456,7 +456,7 @@ func (this *Context) MetronomeProcess(out []float64) error {
 	return this.err(C.gdg_metronome_process(this.ctx, (*C.double)(unsafe.Pointer(&out[0])), C.int(len(out))))
 }
 
-// SetWindow: the batch run steps through the files `frames` (1, 2, 4 or 8) blocks at a time; every power amp then reads its IR
+// SetWindow: the batch run steps through the files `frames` (1, 2, 4, 8 or 16) blocks at a time; every power amp then reads its IR
 // spectra and its delay line once per step instead of once per block (gdg_ctx_set_window).
 func (this *Context) SetWindow(frames int) error {
 	return this.err(C.gdg_ctx_set_window(this.ctx, C.int(frames)))

@@ -10,7 +10,7 @@ nch = int(os.environ.get("SWEEP_CHANNELS", "512"))
 sr, frames, taps, blocks = 192000, 8192, 65536, 32
 x = np.tile(bench.synth_block(nch, frames, sr), (1, blocks))
 print("W,us_per_block,Msamples_s,realtime_x,fir_fwd_us,fir_mac_us,fir_inv_us,segment_us")
-for W in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
+for W in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8, 16)):
     ctx = bench.make_context(pkg, nch, frames, 0, taps)
     ctx.set_window(W)
     d_in, d_out = ctx.alloc(nch, blocks * frames), ctx.alloc(nch, blocks * frames)

@@ -54,7 +54,7 @@ def per_frame(pkg, irs, x):
     return out
 
 
-@pytest.mark.parametrize("W", [2, 4, 8])
+@pytest.mark.parametrize("W", [2, 4, 8, 16])
 def test_window_equals_single_frames(W):
     pkg = package()
     irs = impulse_responses()
@@ -135,7 +135,7 @@ def test_window_rejections():
     pkg = package()
     ctx = pkg.Context(2, B)
     d_in, d_out = ctx.alloc(2, 8 * B), ctx.alloc(2, 8 * B)
-    with pytest.raises(pkg.GdgError, match="window of 3 frames: 1, 2, 4 or 8"):
+    with pytest.raises(pkg.GdgError, match="window of 3 frames: 1, 2, 4, 8 or 16"):
         ctx.set_window(3)
     with pytest.raises(pkg.GdgError, match="window of 2 frames, the context is set up for 1"):
         ctx.process_window_device(d_in, d_out, 8 * B, 2, RATE)
