@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
     "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
-    "gdg_batch_length", "gdg_batch_run", "gdg_ctx_set_window", "gdg_process_window_device", "gdg_ctx_set_overlap",
+    "gdg_batch_length", "gdg_batch_run", "gdg_batch_release", "gdg_ctx_set_window", "gdg_process_window_device", "gdg_ctx_set_overlap",
 ]
 
 
@@ -153,6 +153,7 @@ def lib():
             "gdg_process_window_device": (i32, [vp, vp, vp, C.c_size_t, i32, u32]),
             "gdg_batch_length": (i32, [vp, vp, i32, u32, C.POINTER(C.c_size_t)]),
             "gdg_batch_run": (i32, [vp, vp, i32, vp, vp]),
+            "gdg_batch_release": (i32, [vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -510,6 +511,9 @@ class Context:
         ptrs = (C.c_void_p * (n + 3))(*[(o.ctypes.data if o.size else None) for o in outs])
         self._check(lib().gdg_batch_run(self._h, arr, n, C.byref(opt), ptrs))
         return outs
+
+    def batch_release(self):
+        self._check(lib().gdg_batch_release(self._h))
 
     def metronome_process(self, frames):
         out = np.empty(frames, dtype=np.float64)

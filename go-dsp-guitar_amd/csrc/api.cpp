@@ -156,6 +156,10 @@ struct gdg_ctx {
     size_t h_up_cap = 0;
     hipStream_t batch_up_stream = nullptr;
     hipEvent_t batch_up_ready[2] = { nullptr, nullptr }, batch_begin = nullptr;
+    /* the batch run's device buffers (inputs, window, encoded steps, arena, upload halves, planar scratch): kept from call to call,
+     * grown when a batch needs more -- allocating and mapping gigabytes per call cost more than the run (gdg_batch_release frees them) */
+    void *batch_dev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t batch_dev_cap[6] = { 0, 0, 0, 0, 0, 0 };
     /* channel groups of the host-buffer paths: group g's upload, kernels and download run on stream g, so one group's
      * PCIe transfers overlap the other groups' kernels (channels are independent) */
     int plan_groups = 1;
@@ -323,6 +327,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
         if (ctx->batch_up_ready[h]) hipEventDestroy(ctx->batch_up_ready[h]);
     }
     if (ctx->batch_begin) hipEventDestroy(ctx->batch_begin);
+    for (int i = 0; i < 6; i++) hipFree(ctx->batch_dev[i]);
     if (ctx->batch_up_stream) hipStreamDestroy(ctx->batch_up_stream);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
@@ -2245,6 +2250,27 @@ int gdg_batch_length(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, 
     return GDG_OK;
 }
 
+/* slot i of the batch run's device buffers with at least `bytes` */
+static int batch_buffer(gdg_ctx *ctx, int i, size_t bytes, void **out) {
+    if (bytes > ctx->batch_dev_cap[i]) {
+        hipFree(ctx->batch_dev[i]);
+        ctx->batch_dev[i] = nullptr;
+        ctx->batch_dev_cap[i] = 0;
+        if (hipMalloc(&ctx->batch_dev[i], bytes) != hipSuccess) return fail(ctx, GDG_ERR_NOMEM, "the batch run cannot allocate %zu bytes on the device", bytes);
+        ctx->batch_dev_cap[i] = bytes;
+    }
+    *out = ctx->batch_dev[i];
+    return GDG_OK;
+}
+
+int gdg_batch_release(gdg_ctx *ctx) {
+    if (!ctx) return GDG_ERR_INVALID;
+    enter(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 6; i++) { hipFree(ctx->batch_dev[i]); ctx->batch_dev[i] = nullptr; ctx->batch_dev_cap[i] = 0; }
+    return GDG_OK;
+}
+
 static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes, size_t up_half_bytes) {
     if (!ctx->batch_stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->batch_stream, hipStreamNonBlocking));
@@ -2347,14 +2373,14 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     unsigned char *d_arena = nullptr, *d_enc = nullptr, *d_up = nullptr;
     auto body = [&]() -> int {
         int r;
-        HIP_TRY(ctx, hipMalloc((void **)&d_inputs, (size_t)N * length * sizeof(double)));
+        if ((r = batch_buffer(ctx, 0, (size_t)N * length * sizeof(double), (void **)&d_inputs)) != GDG_OK) return r;
         /* one window of the N + 3 outputs, rows in the output files' order (out_0 .. out_{N-1}, master left, master right, metronome,
          * controller.go:3123-3219); the inputs are read where they lie */
-        HIP_TRY(ctx, hipMalloc((void **)&d_win, (size_t)NO * W * B * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc((void **)&d_enc, 2 * enc_bytes));
-        if (arena_bytes) HIP_TRY(ctx, hipMalloc((void **)&d_arena, arena_bytes));
-        if (up_half) HIP_TRY(ctx, hipMalloc((void **)&d_up, 2 * up_half));
-        if (src_cap) HIP_TRY(ctx, hipMalloc((void **)&d_src, src_cap * sizeof(double)));
+        if ((r = batch_buffer(ctx, 1, (size_t)NO * W * B * sizeof(double), (void **)&d_win)) != GDG_OK) return r;
+        if ((r = batch_buffer(ctx, 2, 2 * enc_bytes, (void **)&d_enc)) != GDG_OK) return r;
+        if (arena_bytes && (r = batch_buffer(ctx, 3, arena_bytes, (void **)&d_arena)) != GDG_OK) return r;
+        if (up_half && (r = batch_buffer(ctx, 4, 2 * up_half, (void **)&d_up)) != GDG_OK) return r;
+        if (src_cap && (r = batch_buffer(ctx, 5, src_cap * sizeof(double), (void **)&d_src)) != GDG_OK) return r;
         HIP_TRY(ctx, hipMemsetAsync(d_inputs, 0, (size_t)N * length * sizeof(double), ctx->stream));     /* the zero padding, :3018-3045 */
 
         /* 1a. the arena goes up */
@@ -2494,7 +2520,7 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     hipStreamSynchronize(ctx->batch_up_stream);
     hipStreamSynchronize(ctx->batch_stream);
     hipStreamSynchronize(ctx->stream);
-    hipFree(d_inputs); hipFree(d_win); hipFree(d_src); hipFree(d_arena); hipFree(d_enc); hipFree(d_up);
+    /* the device buffers stay with the context for the next batch (gdg_batch_release) */
     return rc;
 }
 

@@ -339,6 +339,9 @@ int gdg_batch_length(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, 
  * are whatever was configured on the context; their state carries on from earlier calls, like the reference's.
  */
 int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *options, void *const *out_bytes);
+/* The device buffers of a batch run (the decoded inputs are the large part: N x length x 8 bytes) stay with the context for the next
+ * run of the same or a smaller size; this frees them. */
+int gdg_batch_release(gdg_ctx *ctx);
 
 #ifdef __cplusplus
 

@@ -7,7 +7,7 @@ from importlib import import_module
 pkg = import_module("go-dsp-guitar_amd")
 nch, sr, frames, taps = 512, 192000, 8192, 65536
 ctx = bench.make_context(pkg, nch, frames, 0, taps)
-for blocks, W in ((4, 1), (16, 1), (64, 1), (16, 8), (32, 8), (64, 8)):
+for blocks, W in ((4, 1), (16, 1), (64, 1), (16, 8), (64, 8), (32, 16), (64, 16), (128, 16)):
     ctx.set_window(W)
     n = blocks * frames
     rng = np.random.default_rng(5)

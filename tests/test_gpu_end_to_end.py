@@ -300,3 +300,22 @@ def test_batch_run_streams_every_format_bit_exact(oracle):
             assert got.size == total
             assert np.array_equal(got[:lengths[c]], want[c]), (W, FORMATS[c])
             assert not got[lengths[c]:].any(), (W, FORMATS[c])
+
+
+def test_batch_release_and_reuse():
+    """The batch run keeps its device buffers between runs (larger, then smaller batches reuse them); gdg_batch_release frees them and the
+    next run allocates again.  Same bytes every time."""
+    pkg = package()
+    ctx = pkg.Context(2, BLOCK)
+    rng = np.random.default_rng(8)
+    long_file = rng.integers(-9000, 9000, 3 * BLOCK, dtype=np.int16).view(np.uint8)
+    short_file = long_file[:2 * 5000].copy()
+    a = ctx.batch_run([(long_file, "lpcm16", 48000), None], 48000, "lpcm16")
+    b = ctx.batch_run([(short_file, "lpcm16", 48000), None], 48000, "lpcm16")
+    ctx.batch_release()
+    c = ctx.batch_run([(long_file, "lpcm16", 48000), None], 48000, "lpcm16")
+    ctx.close()
+    assert a[0].size == long_file.size and a[0].any()
+    np.testing.assert_array_equal(c[0], a[0])                      # after the release: the same bytes
+    np.testing.assert_array_equal(b[0][:short_file.size], a[0][:short_file.size])      # the smaller batch in the larger buffers
+    assert b[0].size == 2 * BLOCK and not b[0][short_file.size:].any()
