@@ -246,7 +246,7 @@ def end_to_end(pkg, ctx, nch, frames, sr, steps=6):
     return res
 
 
-def batch_run(pkg, ctx, nch, sr, blocks=64):
+def batch_run(pkg, ctx, nch, sr, blocks=128):
     """gdg_batch_run on the SAME context: 16-bit files in, 24-bit files out (N + 3 of them), everything between in HBM;
     per window size W of the block loop (1 = the reference's loop, 16 = time blocked)."""
     frames = 8192
