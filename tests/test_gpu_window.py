@@ -171,3 +171,48 @@ def test_window_with_shared_ir_spectra():
         outs.append(d_out.download())
         ctx.close()
     assert np.max(np.abs(outs[0] - outs[1])) <= 1e-14
+
+
+ALL_UNITS = [
+    ("noise_gate", [-30, -20, 50]), ("compressor", [1, 12, -6]), ("overdrive", [0, 20, 100, 0, 1, 2]), ("distortion", [0, 20, -3, 1]),
+    ("excess", [12, -6, 2]), ("fuzz", [1, 50, 0, 20, 100, 0, 1]), ("fuzz", [0, 30, 10, 10, 70, -6, 2]), ("octaver", [0, -6, -12, -3, 0, -6, -30]),
+    ("tone_stack", [-10, 0, -3, -20]), ("auto_wah", [0, -5, -45, 200, 9000]), ("auto_yoy", [0, -10, -50, 40]), ("bandpass", [3, 5000, 100]),
+    ("chorus", [35, 77]), ("flanger", [40, 100]), ("phaser", [70, 33, -60]), ("delay", [3, -10, 0]), ("ring_modulator", [7]),
+    ("tremolo", [10, 0, -60]), ("signal_generator", [50, -6, 1, 1000, 80, -3]), ("cabinet", None), ("reverb", [100]),
+]
+
+
+def test_every_unit_type_in_windows():
+    """All 21 unit types (oversampled shapers, FSM scans, delay rings, the noise generator's jump-ahead) frame after frame inside windows:
+    the segments' state runs through the W launches of a window exactly as through W calls -- the same bits (no convolution in between
+    whose contraction could differ)."""
+    pkg = package()
+    blocks, W = 8, 4
+    third = len(ALL_UNITS) // 3
+    chains = [ALL_UNITS[:third], ALL_UNITS[third:2 * third], ALL_UNITS[2 * third:]]
+    x = np.stack([0.7 * synth_signal(20 + c, blocks * B, RATE) for c in range(len(chains))])
+
+    def make():
+        ctx = pkg.Context(len(chains), B)
+        for c, chain in enumerate(chains):
+            for name, p in chain:
+                ctx.append_unit(c, name, params=p)
+        return ctx
+    ctx = make()
+    d_in, d_out = ctx.alloc(len(chains), B), ctx.alloc(len(chains), B)
+    want = np.zeros_like(x)
+    for b in range(blocks):
+        d_in.upload(np.ascontiguousarray(x[:, b * B:(b + 1) * B]))
+        ctx.process_device(d_in, d_out, B, RATE)
+        want[:, b * B:(b + 1) * B] = d_out.download()
+    ctx.close()
+    ctx = make()
+    ctx.set_window(W)
+    d_in, d_out = ctx.alloc(len(chains), blocks * B), ctx.alloc(len(chains), blocks * B)
+    d_in.upload(x)
+    for b in range(0, blocks, W):
+        ctx.process_window_device(d_in.ptr + 8 * b * B, d_out.ptr + 8 * b * B, blocks * B, W, RATE)
+    got = d_out.download()
+    ctx.close()
+    for c in range(len(chains)):
+        assert np.array_equal(got[c], want[c]), "chain %d: max diff %.3e" % (c, np.max(np.abs(got[c] - want[c])))
