@@ -456,6 +456,7 @@ __device__ __forceinline__ cplx mac_load(const cplx *p) {
 template <int UNROLL, int BPT, bool NT, bool SWAP = false, bool HNT = NT>
 __global__ void __launch_bounds__(1024)
 fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
+#pragma clang fp contract(off)      /* the sums of products as the reference forms them (no fused multiply-add): all three multiply-accumulate kernels give the same bits */
     gdg_fir_chan ch = chans[SWAP ? blockIdx.x : blockIdx.y];
     const int b0 = ((SWAP ? blockIdx.y : blockIdx.x) * blockDim.x + threadIdx.x) * BPT;
     if (b0 >= P) return;
@@ -536,6 +537,7 @@ __device__ __forceinline__ void inv_head_store(int k, cplx yk, cplx yn, double *
  * bandwidth to DRAM page conflicts (profiles/experiments/README.md). */
 template <int LOGN, bool HNT>
 __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int tid, double *sre, double *sim, const cplx *__restrict__ tw2) {
+#pragma clang fp contract(off)
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
     const int K = ch.K;
     double kr[ITER], ki[ITER], nr[ITER], ni[ITER], br = 0.0, bi = 0.0;
@@ -705,12 +707,13 @@ fir_raw_inv_kernel(const gdg_fir_rawjob *__restrict__ jobs, double scale, const 
  *
  * One thread per bin.  Partitions are walked in chunks of C (= W up to 8, 8 for W = 16): a chunk needs C IR partitions and the
  * W + C - 1 delay-line slots they meet, all loaded before the C x W multiply-adds, whose indices are compile-time constants.
- * Every Y_j accumulates its terms in ascending k -- the order of the per-frame kernels; the results differ from W single-frame
- * calls only where the compiler contracts a multiply-add differently (last bit).
+ * Every Y_j accumulates its terms in ascending k -- the order of the per-frame kernels -- and, like them, without fused
+ * multiply-adds (`fp contract(off)` in all three multiply-accumulate kernels): the results are bit-identical to W single-frame calls.
  * ---------------------------------------------------------------------------------------------- */
 template <int W, int C, bool HNT>
 __global__ void __launch_bounds__(256)
 fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
+#pragma clang fp contract(off)
     gdg_fir_chan ch = chans[blockIdx.y];
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= P) return;

@@ -163,8 +163,8 @@ int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int fram
  * Time blocking for callers that hold several consecutive frames of every channel -- the batch run, whose files live in HBM
  * (controller.go:3076-3107 walks them 8192 samples at a time only because its buffers are that long).  A window of W frames per
  * channel and call: the units' state runs through the W frames in order, and every power amp reads its IR spectra and delay line
- * ONCE for all W frames (2 K + W - 1 spectrum reads instead of 2 K W; the sums keep their order, the output agrees with W calls
- * of gdg_process_device to the last bit or two).
+ * ONCE for all W frames (2 K + W - 1 spectrum reads instead of 2 K W; the sums keep their order and their arithmetic: the output is
+ * bit-identical to W calls of gdg_process_device).
  * gdg_ctx_set_window: W in {1, 2, 4, 8, 16}; needs max_frames == 8192; may be called at any time, live convolution state moves into
  * the larger delay-line ring (K + W - 1 slots) like on a frame-size change.
  * gdg_process_window_device: d_in / d_out = [n_channels][row_stride] float64, frame j of channel c at c * row_stride + j * 8192;

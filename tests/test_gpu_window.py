@@ -1,7 +1,7 @@
 """Time blocking (gdg_ctx_set_window / gdg_process_window_device): W consecutive 8192-sample frames per channel and call, every power
-amp reading its IR spectra and its delay line once for all W frames.  The sums keep the order of the per-frame kernels (the
-compiler contracts the multiply-adds differently from kernel to kernel, so the last bit may differ): the output must agree with W
-calls of gdg_process_device to 1e-14 per sample; against the oracle the usual 1e-9 RMS applies."""
+amp reading its IR spectra and its delay line once for all W frames.  The sums keep the order of the per-frame kernels and, like
+them, are formed without fused multiply-adds: the output must be BIT-IDENTICAL to W calls of gdg_process_device; against the oracle
+the usual 1e-9 RMS applies."""
 import numpy as np
 import pytest
 
@@ -76,7 +76,7 @@ def test_window_equals_single_frames(W):
     got = d_out.download()
     ctx.close()
     for c in range(nch):
-        assert np.max(np.abs(got[c] - want[c])) <= 1e-14, "channel %d: max diff %.3e" % (c, np.max(np.abs(got[c] - want[c])))
+        assert np.array_equal(got[c], want[c]), "channel %d: max diff %.3e" % (c, np.max(np.abs(got[c] - want[c])))
 
 
 def test_window_against_the_oracle(oracle):
@@ -170,7 +170,7 @@ def test_window_with_shared_ir_spectra():
             ctx.process_window_device(d_in.ptr + 8 * b * B, d_out.ptr + 8 * b * B, blocks * B, W, RATE)
         outs.append(d_out.download())
         ctx.close()
-    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-14
+    assert np.array_equal(outs[0], outs[1])
 
 
 ALL_UNITS = [
