@@ -1224,8 +1224,8 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);
-                for (int j = 0; j < window; j++)           /* the units' state runs through the frames in order */
-                    HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, (size_t)j * (size_t)frames, shift, ctx->os, ctx->d_error, s));
+                /* one launch per window: a channel's workgroup walks its frames in order, the units' state runs through them */
+                HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s));
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));

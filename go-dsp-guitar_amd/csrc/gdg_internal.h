@@ -128,7 +128,7 @@ struct gdg_os_tables {
 #define GDG_OS_PADLO(F) (GDG_OS_NC - 1 - GDG_OS_BACK(F))
 #define GDG_OS_NE(F) (GDG_OS_NC + GDG_OS_R(F) - 1 + 1)              /* table entries per phase (+1: even) */
 
-hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, size_t frame_off, gdg_shift shift,
+hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
                           gdg_os_tables os, int *d_error, hipStream_t s);
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);

@@ -2134,12 +2134,13 @@ UNIT_FN unit_noisegate(UNIT_ARGS) {
 }
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
+/* MULTI = false: one frame per launch (the loop below disappears: this is the kernel of the per-frame calls, and a loop around its
+ * body costs it 8 us in scalar register spills).  MULTI = true: a window of n_frames frames per launch. */
+template <bool MULTI>
 __global__ void __launch_bounds__(SEG_T)
-seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, size_t frame_off, gdg_shift shift,
+seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
            gdg_os_tables os, int *d_error) {
     gdg_seg_chan ch = chans[blockIdx.x];
-    ch.src += frame_off;                    /* frame j of a window (gdg_process_window_device); 0 otherwise */
-    ch.dst += frame_off;
     if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
     const int tid = threadIdx.x;
@@ -2147,6 +2148,9 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
     int *s_types = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32);       /* 16 ints behind the stash cells */
     int my_type = 0;
     if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
+    /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
+     * through global memory from one frame to the next exactly as from one launch to the next (same CU, same L1; a barrier between) */
+  for (int wf = 0; wf < (MULTI ? n_frames : 1); wf++, ch.src += N, ch.dst += N) {
     const bool aligned = ((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0;
     if (aligned && N == CHK * SEG_T) {
         /* the batch block size: every load of the thread is in flight before the first one is consumed (a loop waits for
@@ -2211,6 +2215,8 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
     } else {
         for (int i = tid; i < N; i += SEG_T) as_global(ch.dst)[i] = fin[LX(i)];
     }
+    if (MULTI && wf + 1 < n_frames) { __threadfence_block(); __syncthreads(); }      /* state and LDS frames before the next frame touches them */
+  }
 }
 
 int gdg_seg_supported(int unit_type) {
@@ -2226,9 +2232,10 @@ int gdg_seg_supported(int unit_type) {
     }
 }
 
-hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, size_t frame_off, gdg_shift shift,
+hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
                           gdg_os_tables os, int *d_error, hipStream_t s) {
-    if (n_chans <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_kernel, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, frame_off, shift, os, d_error);
+    if (n_chans <= 0 || n_frames <= 0) return hipSuccess;
+    if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<true>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error);
+    else hipLaunchKernelGGL(seg_kernel<false>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, 1, shift, os, d_error);
     return hipGetLastError();
 }
