@@ -439,6 +439,102 @@ fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift
     }
 }
 
+/* The window's forward transforms, one workgroup per CHANNEL walking its W frames: the second half of a transform's input (the
+ * current frame) is the first half of the next one's (the previous frame) and stays in the registers of the very threads that need it
+ * -- element e = n1 + 1024 n2 of the packed sequence: n2 >= 4 now, n2 - 4 next time -- so every frame is read from HBM once instead of
+ * twice (the per-frame workgroups of fir_fwd13w_kernel<1> read 1.07 GB per launch where 0.81 suffice, profiles/r02_window8_pmc.txt). */
+__global__ void __launch_bounds__(512)
+fir_fwd13w_chan_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int N = 8192, T = 512;
+    __shared__ double sre[GDG_W_LDS];
+    __shared__ double sim[GDG_W_LDS];
+    const int tid = threadIdx.x;
+    gdg_fir_chan ch = chans[blockIdx.x];
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
+    const int pos = *ch.pos;
+    /* `fresh()` hides the thread index from the optimiser: otherwise every address of the loop body is loop-invariant, gets hoisted in
+     * front of the loop and spills (profiles/experiments/README.md) */
+    auto fresh = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    cplx wa[2], pv[2][4];
+    {
+        const double *a = ch.prev + (size_t)((pos + 1) & 1) * N;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int n1 = tid + T * b;
+            wa[b] = tw[n1];
+#pragma unroll
+            for (int m = 0; m < 4; m++) pv[b][m] = gload(reinterpret_cast<const cplx *>(a + 2 * (n1 + 1024 * m)));
+        }
+    }
+    for (int jw = 0; jw < W; jw++) {
+        const double *bsrc = ch.src + (size_t)jw * N;
+        cplx *out = ch.fdl + (size_t)((pos + jw) % ch.R) * N;
+        cplx ua[2][8];
+        {
+            const int t0 = fresh();
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int n1 = t0 + T * b;
+#pragma unroll
+                for (int m = 0; m < 4; m++) ua[b][4 + m] = gload(reinterpret_cast<const cplx *>(bsrc + 2 * (n1 + 1024 * m)));
+            }
+        }
+        /* step A: radix-8 across the workgroup */
+        {
+            const int ta = fresh();
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int n1 = ta + T * b;
+#pragma unroll
+                for (int m = 0; m < 4; m++) { ua[b][m] = pv[b][m]; pv[b][m] = ua[b][4 + m]; }
+                Dft<8, false>::run(ua[b]);
+                twiddle_powers8(ua[b], wa[b]);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) { sre[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].x; sim[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].y; }
+            }
+        }
+        __syncthreads();
+        /* step B: wave w transforms region w; X[8 k1 + w] back into the region in natural k1 order */
+        {
+            const int tb = fresh(), wv = tb >> 6, ln = tb & 63;
+            double *rre = sre + wv * GDG_W_RL, *rim = sim + wv * GDG_W_RL;
+            cplx v[16];
+            wave_fft1024<false>(v, rre, rim, tw, ln);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const int k1 = (ln + 64 * b) + 128 * t;
+                    rre[GDG_PAD(k1)] = v[b * 8 + t].x;
+                    rim[GDG_PAD(k1)] = v[b * 8 + t].y;
+                }
+        }
+        __syncthreads();
+        /* un-pack: X[k] and X[N-k] from Z[k], Z[N-k]; Z[k] = region[k & 7][k >> 3] */
+        auto Z = [&](int k) { return make_double2(sre[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)], sim[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)]); };
+        const int tu = fresh();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = tu + T * i;
+            if (k == 0) {
+                cplx z0 = Z(0), zh = Z(N / 2);
+                gstore(out, make_double2(z0.x + z0.y, z0.x - z0.y));
+                gstore(out + N / 2, make_double2(zh.x, -zh.y));
+            } else {
+                const int n = N - k;
+                cplx zk = Z(k), zn = Z(n);
+                cplx A = make_double2(zk.x + zn.x, zk.y - zn.y);
+                cplx Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+                cplx cw = cmul(tw2[k], Bv);
+                gstore(out + k, make_double2((A.x + cw.y) * 0.5, (A.y - cw.x) * 0.5));
+                gstore(out + n, make_double2((A.x - cw.y) * 0.5, (-A.y - cw.x) * 0.5));
+            }
+        }
+        __syncthreads();                                             /* the regions are rewritten by the next frame's step A */
+    }
+}
+
 /* Y[b] = sum_k FDL[(pos - k) mod K][b] * H[k][b]; bin 0 is the (DC, Nyquist) pair of reals.
  * UNROLL partitions are loaded before any is used (2 * UNROLL * BPT 16-byte loads in flight per lane);
  * BPT adjacent bins per lane; NT: non-temporal loads (each spectrum is read exactly once per launch). */
@@ -852,7 +948,17 @@ template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, con
     else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
 }
 
-/* a window of W frames of 8192 samples per channel (W in {2, 4, 8}); the four launches of one power-amp step */
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
+/* a window of W frames of 8192 samples per channel (W in {2, 4, 8, 16}); the four launches of one power-amp step */
 template <int W, int C> static void launch_mac_tb(const gdg_fir_chan *d_chans, int n, bool shared, hipStream_t s) {
     if (shared) fir_mac_tb_kernel<W, C, false><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
     else fir_mac_tb_kernel<W, C, true><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
@@ -861,8 +967,14 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
                                  gdg_shift shift, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
     if (W != 2 && W != 4 && W != 8 && W != 16) return hipErrorInvalidValue;
-    if (what == 0) fir_fwd13w_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
-    else if (what == 1) {
+    static int per_channel = -1;
+    if (per_channel < 0) { const char *e = getenv("GDG_FWD_PER_CHANNEL"); per_channel = e ? atoi(e) : 1; }
+    if (what == 0) {
+        /* one workgroup per channel needs a chip's worth of channels; below that the (channel, frame) grid fills the CUs better
+         * (64 channels: 9.7 vs 18.8 us per frame) */
+        if (per_channel && n_chans >= cu_count()) fir_fwd13w_chan_kernel<<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
+        else fir_fwd13w_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
+    } else if (what == 1) {
         if (W == 2) launch_mac_tb<2, 2>(d_chans, n_chans, shared_spectra != 0, s);
         else if (W == 4) launch_mac_tb<4, 4>(d_chans, n_chans, shared_spectra != 0, s);
         else if (W == 8) launch_mac_tb<8, 8>(d_chans, n_chans, shared_spectra != 0, s);
