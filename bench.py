@@ -50,24 +50,27 @@ CHAIN = [
     ("cabinet", None),
     ("reverb", [50]),
 ]
-IR_SEED = {"cab": 4242, "rev": 5242}
+
+
+def _synth():
+    """go-dsp-guitar_amd/synth.py: SURVEY 8(d)'s inputs and IRs on the reference's LCG (random/random.go), ONE seed table for the HIP
+    legs, the parity gate and the CPU baseline (inputs 1337 + channel; cabinet IR 4242 + 2 channel, reverb IR 4243 + 2 channel)."""
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    return importlib.import_module("go_dsp_guitar_amd.synth")
 
 
 def synth_ir(n_taps, seed):
-    rng = np.random.default_rng(seed)
-    k = np.arange(n_taps)
-    h = (1.0 - 2.0 * rng.random(n_taps)) * np.exp(-6.9 * k / float(n_taps))
-    return h / np.sqrt(np.sum(h * h))
+    return _synth().synth_ir(n_taps, seed)
 
 
 def synth_block(n_channels, frames, sample_rate, channel0=0):
-    t = np.arange(frames) / float(sample_rate)
-    x = np.empty((n_channels, frames))
-    for c in range(n_channels):
-        f = 82.4069 * 2.0 ** (((channel0 + c) % 48) / 12.0)
-        rng = np.random.default_rng(1337 + channel0 + c)
-        x[c] = 0.5 * np.sin(2 * np.pi * f * t) + 0.25 * np.sin(2 * np.pi * 3 * f * t) + 0.05 * (1.0 - 2.0 * rng.random(frames))
-    return x
+    return _synth().synth_block(n_channels, frames, sample_rate, channel0=channel0)
+
+
+def ir_for(kind, index, taps):
+    return synth_ir(taps, _synth().ir_seed(kind, index))
 
 
 def make_context(pkg, nch, frames, device, taps, channel0=0, n_distinct=0, chain=CHAIN, second_amp=True):
@@ -84,10 +87,10 @@ def make_context(pkg, nch, frames, device, taps, channel0=0, n_distinct=0, chain
                 key = (p, g % n_distinct if n_distinct > 0 else g)
                 if n_distinct > 0:
                     if key not in cache:
-                        cache[key] = synth_ir(taps, IR_SEED[p] + key[1])
+                        cache[key] = ir_for(p, key[1], taps)
                     ir = cache[key]
                 else:
-                    ir = synth_ir(taps, IR_SEED[p] + key[1])
+                    ir = ir_for(p, key[1], taps)
                 ctx.append_unit(c, name, fir=ir)
             else:
                 ctx.append_unit(c, name, params=p)
@@ -108,7 +111,7 @@ def cpu_baseline(sample_rate, frames, taps, target_seconds=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    irs = {"cab": synth_ir(taps, 4242), "rev": synth_ir(taps, 4243)}
+    irs = {"cab": ir_for("cab", 0, taps), "rev": ir_for("rev", 0, taps)}          # channel 0's pair: SURVEY 8(d)'s seeds 4242 / 4243
 
     def make_chain():
         ch = orc.Chain()
@@ -179,24 +182,48 @@ def cpu_baseline(sample_rate, frames, taps, target_seconds=12.0):
 
 # ---- helpers for the extra legs ------------------------------------------------------------------------------------------------
 
-def time_ctx_steps(ctx, d_in, d_out, frames, sr, steps, warmup=3):
-    for _ in range(max(warmup, 1)):
-        ctx.process_device(d_in, d_out, frames, sr)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.process_device(d_in, d_out, frames, sr)
-    ctx.synchronize()
-    return (time.perf_counter() - t0) / steps
+def robust_time(run, sync, units=1, reps=5, settle=6):
+    """Seconds per unit of `run()` (which enqueues `units` steps), measured the way every leg of this file is: warm-up calls until
+    two consecutive timings agree within 5 % (at most `settle`), then `reps` timed calls, each bracketed by a synchronize.  Returns
+    the MEDIAN with min / max and every repetition, so one slow repetition cannot pass for the leg's rate (and cannot hide either)."""
+    def once():
+        sync()
+        t0 = time.perf_counter()
+        run()
+        sync()
+        return (time.perf_counter() - t0) / units
+
+    prev = once()
+    settled = 0
+    for settled in range(1, settle + 1):
+        cur = once()
+        ok = abs(cur - prev) <= 0.05 * min(cur, prev)
+        prev = cur
+        if ok:
+            break
+    ts = sorted(once() for _ in range(reps))
+    return {"median": ts[len(ts) // 2], "min": ts[0], "max": ts[-1], "reps": ts, "warmup_calls": settled + 1}
+
+
+def us_stats(st):
+    return {"us_median": st["median"] * 1e6, "us_min": st["min"] * 1e6, "us_max": st["max"] * 1e6, "repetitions": len(st["reps"]),
+            "warmup_calls": st["warmup_calls"]}
 
 
 def leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, channel0=0, chain=CHAIN, second_amp=True):
+    """Per-frame calls of a fresh `nch`-channel context: `steps` steps per timed call (robust_time)."""
     ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0, chain=chain, second_amp=second_amp)
     d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
     d_in.upload(synth_block(nch, frames, sr, channel0=channel0))
-    dt = time_ctx_steps(ctx, d_in, d_out, frames, sr, steps)
+
+    def run():
+        for _ in range(steps):
+            ctx.process_device(d_in, d_out, frames, sr)
+    st = robust_time(run, ctx.synchronize, units=steps)
+    d_in.free()
+    d_out.free()
     ctx.close()
-    return dt
+    return st
 
 
 def window_leg_on_one_gpu(pkg, nch, frames, sr, taps, device, W=16, windows=2, channel0=0):
@@ -210,14 +237,11 @@ def window_leg_on_one_gpu(pkg, nch, frames, sr, taps, device, W=16, windows=2, c
     def run():
         for b in range(0, W * windows, W):
             ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, n, W, sr)
-    run()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    run()
-    ctx.synchronize()
-    dt = (time.perf_counter() - t0) / (W * windows)
+    st = robust_time(run, ctx.synchronize, units=W * windows, reps=3)
+    d_in.free()
+    d_out.free()
     ctx.close()
-    return dt
+    return st
 
 
 def end_to_end(pkg, ctx, nch, frames, sr, steps=6):
@@ -233,13 +257,10 @@ def end_to_end(pkg, ctx, nch, frames, sr, steps=6):
     res = {}
     for key, fn in (("staged", lambda: ctx._check(lib.gdg_process_staged(ctx._h, carr, nch, frames, sr))),
                     ("pageable", lambda: ctx._check(lib.gdg_process(ctx._h, ins, outs, frames, sr)))):
-        for _ in range(2):
-            fn()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        dt = (time.perf_counter() - t0) / steps
+        st = robust_time(lambda: [fn() for _ in range(steps)], ctx.synchronize, units=steps, reps=3)
+        dt = st["median"]
         res[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "ms_per_block": dt * 1e3,
+                    "ms_per_block_min_max": [st["min"] * 1e3, st["max"] * 1e3],
                     "pcie_gbs_in_plus_out": 2 * nch * frames * 8 / dt / 1e9}
     res["what"] = ("gdg_process_staged: frames already in the pinned slab (what the Go workers fill), H2D + chain + D2H inside the call; "
                    "gdg_process: caller's pageable rows staged through the pinned slab by the library's copy threads")
@@ -251,8 +272,7 @@ def batch_run(pkg, ctx, nch, sr, blocks=128):
     per window size W of the block loop (1 = the reference's loop, 16 = time blocked)."""
     frames = 8192
     n = blocks * frames
-    rng = np.random.default_rng(5)
-    files = [(rng.integers(-20000, 20000, n, dtype=np.int16).view(np.uint8), "lpcm16", sr) for _ in range(nch)]
+    files = batch_files(nch, sr, blocks)
     res = {"blocks": blocks, "files_in": "lpcm16 x %d" % nch, "files_out": "lpcm24 x %d" % (nch + 3), "unit": "Msamples/s",
            "what": "controller.processFiles between 'files read' and 'files written' in one call: H2D of the file bytes, decode, the block "
                    "loop in steps of W blocks (N chains + metronome + spatializer + encode, the encoded step going down while the next one "
@@ -260,13 +280,63 @@ def batch_run(pkg, ctx, nch, sr, blocks=128):
     for W in (1, 16):
         ctx.set_window(W)
         outs = ctx.batch_run(files, sr, "lpcm24")               # also touches the output pages once
-        t0 = time.perf_counter()
-        ctx.batch_run(files, sr, "lpcm24", outs=outs)
-        dt = time.perf_counter() - t0
-        res["window_%d" % W] = {"value": nch * n / dt / 1e6, "ms": dt * 1e3}
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctx.batch_run(files, sr, "lpcm24", outs=outs)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        dt = ts[1]
+        res["window_%d" % W] = {"value": nch * n / dt / 1e6, "ms": dt * 1e3, "ms_min_max": [ts[0] * 1e3, ts[2] * 1e3]}
         res["host_bytes_in_plus_out"] = sum(f[0].nbytes for f in files) + sum(o.nbytes for o in outs)
     res["value"] = res["window_16"]["value"]
     ctx.set_window(1)
+    return res
+
+
+def batch_files(nch, sr, blocks, channel0=0):
+    """16-bit files of `blocks` x 8192 samples: wave.go's 16-bit export of the synthetic block of global channels channel0 .., tiled"""
+    blk = np.trunc(32767.5 * synth_block(nch, 8192, sr, channel0=channel0)).astype(np.int16)
+    return [(np.tile(blk[c], blocks).view(np.uint8), "lpcm16", sr) for c in range(nch)]
+
+
+def sharded_batch_one_gpu(pkg, device, total, shards, sr, taps, blocks=32, W=16):
+    """The batch job the way N GPUs run it -- one context per contiguous channel block, gdg_batch_run_shard on each (float64 partial
+    master mixes), gdg_batch_finish_master once -- with all `shards` contexts on THIS GPU, one after the other: exercises and times
+    the path (the shards run concurrently on N GPUs: the job takes the slowest shard + the finish)."""
+    from go_dsp_guitar_amd import shard as sh
+    res = {"shards": shards, "total_channels": total, "blocks": blocks, "window": W, "files_in": "lpcm16", "files_out": "lpcm24",
+           "what": "gdg_batch_run_shard per contiguous channel block + gdg_batch_finish_master (shard partials added in shard order, "
+                   "then encoded); shards run one after the other on the one GPU"}
+    lefts, rights, t_shard = [], [], []
+    n = blocks * 8192
+    for g in range(shards):
+        c0, cnt = sh.channel_shard(total, shards, g)
+        ctx = make_context(pkg, cnt, 8192, device, taps, channel0=c0)
+        ctx.set_window(W)
+        for c in range(cnt):
+            ctx.spatializer_set_position(c, -90.0 + 180.0 * (c0 + c) / max(total - 1, 1), 1.0 + 0.01 * (c0 + c), 0.5)
+        files = batch_files(cnt, sr, blocks, channel0=c0)
+        outs, l, r, mb, mf = ctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(g == 0))     # touches pages, builds plans
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            outs, l, r, mb, mf = ctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(g == 0), outs=outs)
+            ts.append(time.perf_counter() - t0)
+        t_shard.append(min(ts))
+        lefts.append(l)
+        rights.append(r)
+        if g == shards - 1:
+            t0 = time.perf_counter()
+            ml, mr = ctx.batch_finish_master("lpcm24", lefts, rights, aux=None)
+            res["finish_master_ms"] = (time.perf_counter() - t0) * 1e3
+            res["master_nonzero"] = bool(ml.any() and mr.any())
+        ctx.close()
+    res["shard_ms"] = [t * 1e3 for t in t_shard]
+    slowest = max(t_shard)
+    res["predicted_job_ms_on_%d_gpus" % shards] = slowest * 1e3 + res["finish_master_ms"]
+    res["predicted_job_value"] = total * n / (slowest + res["finish_master_ms"] * 1e-3) / 1e6
+    res["unit"] = "Msamples/s"
     return res
 
 
@@ -283,13 +353,10 @@ def time_blocked(pkg, ctx, nch, frames, sr, blocks=32):
         def run():
             for b in range(0, blocks, W):
                 ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, blocks * frames, W, sr)
-        run()
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        run()
-        ctx.synchronize()
-        dt = (time.perf_counter() - t0) / blocks
-        res["window_%d" % W] = {"value": nch * frames / dt / 1e6, "us_per_frame": dt * 1e6, "realtime_factor": frames / sr / dt}
+        st = robust_time(run, ctx.synchronize, units=blocks, reps=3)
+        dt = st["median"]
+        res["window_%d" % W] = {"value": nch * frames / dt / 1e6, "us_per_frame": dt * 1e6, "us_per_frame_min_max": [st["min"] * 1e6, st["max"] * 1e6],
+                                "realtime_factor": frames / sr / dt}
     ctx.set_window(1)
     d_in.free()
     d_out.free()
@@ -303,8 +370,10 @@ def other_configs(pkg, device):
     for key, nch, frames, sr, taps, chain, steps in (("config2_1ch_48k_8ktaps_1024frames", 1, 1024, 48000, 8192, CHAIN, 200),
                                                     ("config2_1ch_48k_8ktaps_8192frames", 1, 8192, 48000, 8192, CHAIN, 100),
                                                     ("config3_64ch_96k_4xOS_32ktaps", 64, 8192, 96000, 32768, chain3, 30)):
-        dt = leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, chain=chain, second_amp=False)
-        out[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "us_per_block": dt * 1e6, "realtime_factor": frames / sr / dt}
+        st = leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, chain=chain, second_amp=False)
+        dt = st["median"]
+        out[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "us_per_block": dt * 1e6, "realtime_factor": frames / sr / dt,
+                    "timing": us_stats(st)}
     # config 5: 256 tuners (96000-sample windows, 262144-point autocorrelation each) + spatializer 256 -> 2 at 192 kHz
     nch, frames, sr = 256, 8192, 192000
     ctx = pkg.Context(nch, frames, device)
@@ -318,20 +387,72 @@ def other_configs(pkg, device):
         ctx.tuner_enqueue_device(d_x, frames, sr)
     ctx.spatialize_device(d_x, d_lr, frames)
     ctx.tuner_analyze()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        ctx.spatialize_device(d_x, d_lr, frames)
-    ctx.synchronize()
-    t_sp = (time.perf_counter() - t0) / 20
-    t0 = time.perf_counter()
-    for _ in range(5):
-        ctx.tuner_analyze()
-    t_an = (time.perf_counter() - t0) / 5
+    st_sp = robust_time(lambda: [ctx.spatialize_device(d_x, d_lr, frames) for _ in range(20)], ctx.synchronize, units=20)
+    st_an = robust_time(lambda: [ctx.tuner_analyze() for _ in range(5)], ctx.synchronize, units=5)
+    t_sp, t_an = st_sp["median"], st_an["median"]
+    d_x.free()
+    d_lr.free()
     ctx.close()
-    out["config5_256_tuners"] = {"value": nch / t_an, "unit": "analyses/s", "ms_per_256_analyses": t_an * 1e3}
-    out["config5_spatializer_256_to_2"] = {"value": nch * frames / t_sp / 1e6, "unit": "Msamples/s", "us_per_block": t_sp * 1e6}
+    out["config5_256_tuners"] = {"value": nch / t_an, "unit": "analyses/s", "ms_per_256_analyses": t_an * 1e3, "timing": us_stats(st_an)}
+    out["config5_spatializer_256_to_2"] = {"value": nch * frames / t_sp / 1e6, "unit": "Msamples/s", "us_per_block": t_sp * 1e6,
+                                           "timing": us_stats(st_sp)}
     return out
+
+
+# ---- parity gate (in the same run) ---------------------------------------------------------------------------------
+
+PARITY_TOL_RMS = 1e-9          # north_star: output matches the float64 reference within 1e-9 RMS
+
+
+def parity_gate(ctx_step, read_output, x_block, n_calls, nch, channel0, frames, sr, taps, n_distinct=0, extra_blocks=2):
+    """The oracle (CHECKER only, never timed, never on the product path) follows the first, the middle and the last channel of the
+    SAME context that was just timed: every call so far processed the block `x_block`, so the oracle replays `n_calls` blocks per
+    channel, compares the last one with what the device holds, then follows `extra_blocks` more steps.  Returns the worst per-channel
+    RMS and the max-abs difference over the compared blocks."""
+    import __graft_entry__ as entry
+    orc = entry.load_oracle()
+    orc.build()
+    channels = sorted({0, nch // 2, nch - 1})
+    chains = {}
+    for c in channels:
+        g = channel0 + c
+        ch = orc.Chain()
+        for name, p in CHAIN:
+            if isinstance(p, str):
+                ch.append_unit(name, fir=ir_for(p, (g % n_distinct) if n_distinct > 0 else g, taps))
+            else:
+                ch.append_unit(name, params=p)
+        chains[c] = ch
+    want = {c: None for c in channels}
+
+    def replay(c, blocks):
+        for _ in range(blocks):
+            want[c] = chains[c].process(x_block[c], sr)
+
+    def all_channels(blocks):
+        ths = [threading.Thread(target=replay, args=(c, blocks)) for c in channels]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    all_channels(n_calls)
+    sq = {c: 0.0 for c in channels}
+    max_abs, compared = 0.0, 0
+    for b in range(1 + extra_blocks):
+        if b > 0:
+            ctx_step()
+            all_channels(1)
+        got = read_output()
+        for c in channels:
+            d = got[c] - want[c]
+            sq[c] += float(np.sum(d * d))
+            max_abs = max(max_abs, float(np.max(np.abs(d))))
+        compared += 1
+    rms_max = max(float(np.sqrt(sq[c] / (compared * frames))) for c in channels)
+    return {"channels": [channel0 + c for c in channels], "blocks_replayed_by_the_oracle": n_calls + extra_blocks, "blocks_compared": compared,
+            "rms_max": rms_max, "max_abs": max_abs, "tolerance_rms": PARITY_TOL_RMS, "ok": bool(rms_max <= PARITY_TOL_RMS),
+            "what": "oracle (C restatement of the Go reference) vs the device output of the timed context, per-channel RMS over the compared blocks"}
 
 
 # ---- main ----------------------------------------------------------------------------------------------------------------------
@@ -347,7 +468,10 @@ def main():
     ap.add_argument("--sample-rate", type=int, default=192000)
     ap.add_argument("--frames", type=int, default=8192)
     ap.add_argument("--taps", type=int, default=65536)
+    ap.add_argument("--channel-groups", type=int, default=0,
+                    help="free-running channel groups on the GPU (gdg_ctx_set_overlap); 0 = 2 from 384 channels on, else 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity gate (oracle follows 3 channels of the timed context)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (no end_to_end / configs / split legs)")
     ap.add_argument("--distinct-irs", type=int, default=0,
                     help="number of distinct IR tap sets (0 = one per channel = the metric's d = 1; fewer lets power amps share spectra)")
@@ -384,11 +508,18 @@ def main():
     # every channel has its OWN impulse responses (d = 1): identical filters would share one copy of the spectra
     n_distinct = args.distinct_irs
     ctx = make_context(pkg, nch, frames, local_rank, taps, channel0=channel0, n_distinct=n_distinct)
+    # channel groups on one GPU are an explicit choice of the caller (gdg_ctx_set_overlap; the library's default is one group, whose
+    # calls are ordered on the context's stream): two free-running groups from 384 channels on, as a batch caller would
+    headline_groups = args.channel_groups if args.channel_groups > 0 else (2 if nch >= 384 else 1)
+    ctx.set_overlap(headline_groups)
     x = torch.from_numpy(synth_block(nch, frames, sr, channel0=channel0)).to(dev)
     y = torch.empty_like(x)
 
+    calls = [0]
+
     def step():
         ctx.process_device(x.data_ptr(), y.data_ptr(), frames, sr)
+        calls[0] += 1
 
     for _ in range(max(args.warmup, 1)):      # the first step also builds the plan and the IR spectra
         step()
@@ -404,6 +535,15 @@ def main():
     # barrier + synchronize | exactly K steps | synchronize; MAX over ranks (tested on CPU with gloo)
     elapsed = shard.timed_steps(step, args.steps, synchronize, dist if distributed else None, None)
     ctx.profile_enable(False)
+    # the timed region twice more (same K steps, same bracketing, rank-local): how far one run of it can be off
+    repeats = []
+    for _ in range(2):
+        synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        synchronize()
+        repeats.append((time.perf_counter() - t0) / args.steps * 1e3)
     kernels = {}
     ms, n = ctx.profile_read(pkg.K_FIR_MAC)
     timed_mac = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None}
@@ -438,8 +578,20 @@ def main():
             kernels["fir_mac"]["avg_ms_untimed_pass"] = (ms / n) if n else None
             continue
         kernels[name] = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None, "pass": "untimed, all launches bracketed, channel groups off"}
-    ctx.set_overlap(0)
+    ctx.set_overlap(headline_groups)
     finite = bool(torch.isfinite(y).all().item())
+    # parity gate on the context that was just timed (after the timed region; the oracle is the checker, nothing else)
+    parity = None
+    if not args.no_parity:
+        def read_output():
+            synchronize()
+            return y.cpu().numpy()
+        parity = parity_gate(step, read_output, x.cpu().numpy(), calls[0], nch, channel0, frames, sr, taps, n_distinct=n_distinct)
+        if distributed:
+            t = torch.tensor([parity["rms_max"], parity["max_abs"]], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            parity["rms_max_all_ranks"], parity["max_abs_all_ranks"] = float(t[0]), float(t[1])
+            parity["ok"] = bool(float(t[0]) <= PARITY_TOL_RMS)
 
     extras = {}
     if not args.no_extras and not strong:
@@ -489,22 +641,57 @@ def main():
                 extras["strong_split"]["batch_mode_window_16"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
                                                                  "realtime_factor": frames / sr / w_elapsed}
                 del wx, wy
+                # ... and as the batch run proper: file bytes in, file bytes out, every rank its shard (gdg_batch_run_shard), the float64
+                # partial master mixes gathered on rank 0's HOST over gloo ("the host adds the partials") and finished there
+                blocks = 32
+                n = blocks * frames
+                for c in range(n_loc):
+                    sctx.spatializer_set_position(c, -90.0 + 180.0 * (c0 + c) / max(T - 1, 1), 1.0 + 0.01 * (c0 + c), 0.5)
+                files = batch_files(n_loc, sr, blocks, channel0=c0)
+                held = {"r": sctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0))}
+
+                def bstep():
+                    held["r"] = sctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0), outs=held["r"][0])
+                b_elapsed = shard.timed_steps(bstep, 1, ssync, dist, None)
+                lt, rt = torch.from_numpy(held["r"][1]), torch.from_numpy(held["r"][2])
+                gl = [torch.empty_like(lt) for _ in range(world)] if rank == 0 else None
+                gr = [torch.empty_like(rt) for _ in range(world)] if rank == 0 else None
+                dist.barrier()
+                t0 = time.perf_counter()
+                dist.gather(lt, gl, dst=0)
+                dist.gather(rt, gr, dst=0)
+                master_ok = None
+                if rank == 0:
+                    ml, mr = sctx.batch_finish_master("lpcm24", [g.numpy() for g in gl], [g.numpy() for g in gr], aux=None)
+                    master_ok = bool(ml.any() and mr.any())
+                t_finish = time.perf_counter() - t0
+                extras["strong_split"]["batch_run_sharded"] = {
+                    "blocks": blocks, "window": W, "files_in": "lpcm16", "files_out": "lpcm24", "shard_ms_max_over_ranks": b_elapsed * 1e3,
+                    "gather_and_finish_master_ms": t_finish * 1e3, "value": T * n / (b_elapsed + t_finish) / 1e6, "unit": "Msamples/s",
+                    "realtime_factor": n / sr / (b_elapsed + t_finish), "master_nonzero": master_ok,
+                    "what": "gdg_batch_run_shard on every rank (file bytes to file bytes, PCIe inside), partial master mixes gathered on "
+                            "rank 0's host over gloo, gdg_batch_finish_master there"}
             sctx.close()
         elif rank == 0:
             legs = {}
             for n_loc in (64, 128, 256):
-                dt = leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank, 30)
-                legs[str(n_loc)] = {"n_gpus_of_the_split": args.channels // n_loc, "us_per_step": dt * 1e6,
+                st = leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank, 30)
+                dt = st["median"]
+                legs[str(n_loc)] = {"n_gpus_of_the_split": args.channels // n_loc, "us_per_step": dt * 1e6, "timing": us_stats(st),
                                     "value_this_gpu": n_loc * frames / dt / 1e6,
                                     "predicted_job_value": args.channels * frames / dt / 1e6, "unit": "Msamples/s",
                                     "predicted_realtime_factor": frames / sr / dt}
                 if frames == 8192:
-                    dtw = window_leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank)
-                    legs[str(n_loc)]["batch_mode_window_16"] = {"us_per_frame": dtw * 1e6, "predicted_job_value": args.channels * frames / dtw / 1e6,
+                    stw = window_leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank)
+                    dtw = stw["median"]
+                    legs[str(n_loc)]["batch_mode_window_16"] = {"us_per_frame": dtw * 1e6, "timing": us_stats(stw),
+                                                               "predicted_job_value": args.channels * frames / dtw / 1e6,
                                                                "predicted_realtime_factor": frames / sr / dtw}
             extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
                                                    "(channels are independent: the job's step time is the slowest shard's step time)",
                                            "legs": legs}
+            if frames == 8192:
+                extras["sharded_batch"] = sharded_batch_one_gpu(pkg, local_rank, args.channels, 2, sr, taps)
             extras["configs"] = other_configs(pkg, local_rank)
 
     if rank == 0:
@@ -546,6 +733,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_repeats": repeats,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -559,7 +747,10 @@ def main():
                 "channels_per_gpu": nch, "total_channels": total_channels, "sample_rate": sr, "frames": frames, "ir_taps": taps, "partitions": K,
                 "realtime_factor": value * 1e6 / (total_channels * sr),
                 "output_finite": finite,
-                "channel_groups": groups,
+                "inputs": "SURVEY 8(d): two sines + 0.05 x the reference LCG (random/random.go) seeded 1337 + channel; IRs (1 - 2 r) exp(-6.9 k / L) on the "
+                          "LCG seeded 4242 + 2 channel (cabinet) / 4243 + 2 channel (reverb), unit energy",
+                "channel_groups": headline_groups,
+                "channel_groups_note": "opt-in through gdg_ctx_set_overlap (free-running groups; the library's default is 1, ordered on the context's stream)",
                 "control_plane": "gloo barrier + max of one scalar; no RCCL, no data-path collective",
             },
             "roofline": {
@@ -586,6 +777,8 @@ def main():
                                    "achieved_incl_state": (seg_traffic / (seg["avg_ms"] * 1e-3) / 1e9) if (seg_traffic and seg["avg_ms"]) else None},
             },
         }
+        if parity is not None:
+            out["parity"] = parity
         out.update(extras)
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: it is a property of the host, not of the GPU count
             out["cpu_baseline"] = cpu_baseline(sr, frames, taps)
@@ -593,6 +786,9 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        sys.stderr.write("bench.py: PARITY GATE FAILED: per-channel RMS %.3e > %.1e\n" % (parity["rms_max"], PARITY_TOL_RMS))
+        sys.exit(1)
 
 
 if __name__ == "__main__":

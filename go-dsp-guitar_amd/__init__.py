@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "gdg_resample_time_length", "gdg_resample_time", "gdg_resample_time_device",
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
     "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
-    "gdg_batch_length", "gdg_batch_run", "gdg_batch_release", "gdg_ctx_set_window", "gdg_process_window_device", "gdg_ctx_set_overlap",
+    "gdg_batch_length", "gdg_batch_run", "gdg_batch_run_shard", "gdg_batch_finish_master", "gdg_batch_release", "gdg_profile_sample", "gdg_ctx_set_window", "gdg_process_window_device", "gdg_ctx_set_overlap",
 ]
 
 
@@ -59,6 +59,11 @@ class TunerResult(C.Structure):
 class BatchInput(C.Structure):          # gdg_batch_input
     _fields_ = [("bytes", C.c_void_p), ("samples_per_channel", C.c_size_t), ("format", C.c_int), ("sample_rate", C.c_uint32),
                 ("channels", C.c_uint), ("channel", C.c_uint)]
+
+
+class BatchShardOut(C.Structure):       # gdg_batch_shard_out
+    _fields_ = [("master_left", C.c_void_p), ("master_right", C.c_void_p), ("metronome_bytes", C.c_void_p), ("metronome", C.c_void_p),
+                ("job_samples", C.c_size_t)]
 
 
 class BatchOptions(C.Structure):        # gdg_batch_options
@@ -154,6 +159,9 @@ def lib():
             "gdg_batch_length": (i32, [vp, vp, i32, u32, C.POINTER(C.c_size_t)]),
             "gdg_batch_run": (i32, [vp, vp, i32, vp, vp]),
             "gdg_batch_release": (i32, [vp]),
+            "gdg_batch_run_shard": (i32, [vp, vp, i32, vp, vp, vp]),
+            "gdg_batch_finish_master": (i32, [vp, i32, vp, vp, i32, vp, C.c_size_t, u32, i32, vp, vp]),
+            "gdg_profile_sample": (i32, [vp, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -347,6 +355,9 @@ class Context:
         mask = sum(1 << (k + 1) for k in kinds) if kinds else (1 if on else 0)
         self._check(lib().gdg_profile_enable(self._h, mask))
 
+    def profile_sample(self, every):
+        self._check(lib().gdg_profile_sample(self._h, every))
+
     def profile_read(self, kind):
         ms, n = C.c_double(0.0), C.c_int(0)
         self._check(lib().gdg_profile_read(self._h, kind, C.byref(ms), C.byref(n)))
@@ -483,10 +494,7 @@ class Context:
         po = d_out.ptr if isinstance(d_out, DeviceBuffer) else d_out
         self._check(lib().gdg_process_window_device(self._h, pi, po, row_stride, frames_in_window, sample_rate))
 
-    def batch_run(self, inputs, target_rate, out_format, metronome_to_master=False, run_meters=False, tuner_enqueue=False, outs=None):
-        """controller.processFiles on the device (controller/controller.go:2809-3219 without prompts and file I/O).
-        inputs: per channel None ("leaving channel empty") or (data-section bytes, format, sample_rate[, channels, channel]);
-        returns the N + 3 output data sections (uint8 arrays): out_0 .. out_{N-1}, master left, master right, metronome."""
+    def _batch_inputs(self, inputs):
         n = len(inputs)
         arr = (BatchInput * n)()
         keep = []
@@ -500,6 +508,20 @@ class Context:
             keep.append(data)
             w = max(lib().gdg_wave_bytes_per_sample(f), 1)
             arr[i] = BatchInput(data.ctypes.data if data.size else None, data.size // (w * max(channels, 1)), f, rate, channels, channel)
+        return arr, keep
+
+    def batch_length(self, inputs, target_rate):
+        arr, _keep = self._batch_inputs(inputs)
+        length = C.c_size_t(0)
+        self._check(lib().gdg_batch_length(self._h, arr, len(inputs), target_rate, C.byref(length)))
+        return length.value
+
+    def batch_run(self, inputs, target_rate, out_format, metronome_to_master=False, run_meters=False, tuner_enqueue=False, outs=None):
+        """controller.processFiles on the device (controller/controller.go:2809-3219 without prompts and file I/O).
+        inputs: per channel None ("leaving channel empty") or (data-section bytes, format, sample_rate[, channels, channel]);
+        returns the N + 3 output data sections (uint8 arrays): out_0 .. out_{N-1}, master left, master right, metronome."""
+        n = len(inputs)
+        arr, _keep = self._batch_inputs(inputs)
         fo = WAVE_FORMATS[out_format] if isinstance(out_format, str) else out_format
         opt = BatchOptions(target_rate, fo, int(bool(metronome_to_master)), int(bool(run_meters)), int(bool(tuner_enqueue)))
         length = C.c_size_t(0)
@@ -511,6 +533,44 @@ class Context:
         ptrs = (C.c_void_p * (n + 3))(*[(o.ctypes.data if o.size else None) for o in outs])
         self._check(lib().gdg_batch_run(self._h, arr, n, C.byref(opt), ptrs))
         return outs
+
+    def batch_run_shard(self, inputs, target_rate, out_format, job_samples=0, metronome=False, run_meters=False, tuner_enqueue=False, outs=None):
+        """One shard of a batch split over several contexts (gdg_batch_run_shard): returns (outs, left, right, metronome_bytes,
+        metronome_f64): the shard's n encoded chain outputs, its float64 partial master mix, and -- on the shard that runs the
+        metronome -- the encoded metronome track and its float64 samples (the master's aux input)."""
+        n = len(inputs)
+        arr, _keep = self._batch_inputs(inputs)
+        fo = WAVE_FORMATS[out_format] if isinstance(out_format, str) else out_format
+        opt = BatchOptions(target_rate, fo, 0, int(bool(run_meters)), int(bool(tuner_enqueue)))
+        length = job_samples or self.batch_length(inputs, target_rate)
+        wo = lib().gdg_wave_bytes_per_sample(fo)
+        if outs is None:
+            outs = [np.zeros(length * wo, dtype=np.uint8) for _ in range(n)]
+        left, right = np.zeros(length), np.zeros(length)
+        mb = np.zeros(length * wo, dtype=np.uint8) if metronome else None
+        mf = np.zeros(length) if metronome else None
+        ptrs = (C.c_void_p * n)(*[(o.ctypes.data if o.size else None) for o in outs])
+        so = BatchShardOut(left.ctypes.data if length else None, right.ctypes.data if length else None,
+                           mb.ctypes.data if (metronome and length) else None, mf.ctypes.data if (metronome and length) else None, job_samples)
+        if length == 0:
+            so = BatchShardOut(left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), None, None, job_samples)
+        self._check(lib().gdg_batch_run_shard(self._h, arr, n, C.byref(opt), ptrs, C.byref(so)))
+        return outs, left, right, mb, mf
+
+    def batch_finish_master(self, out_format, lefts, rights, aux=None, sample_rate=0, run_meters=False):
+        """master = sum of the shards' partial mixes (in shard order) + aux, encoded on this context's device."""
+        G, n = len(lefts), lefts[0].size
+        fo = WAVE_FORMATS[out_format] if isinstance(out_format, str) else out_format
+        wo = lib().gdg_wave_bytes_per_sample(fo)
+        lefts = [_f64(a) for a in lefts]
+        rights = [_f64(a) for a in rights]
+        lp = (C.c_void_p * G)(*[a.ctypes.data for a in lefts])
+        rp = (C.c_void_p * G)(*[a.ctypes.data for a in rights])
+        ml, mr = np.zeros(n * wo, dtype=np.uint8), np.zeros(n * wo, dtype=np.uint8)
+        a = _f64(aux) if aux is not None else None
+        self._check(lib().gdg_batch_finish_master(self._h, fo, lp, rp, G, a.ctypes.data if a is not None else None, n, sample_rate,
+                                                  int(bool(run_meters)), ml.ctypes.data if n else None, mr.ctypes.data if n else None))
+        return ml, mr
 
     def batch_release(self):
         self._check(lib().gdg_batch_release(self._h))

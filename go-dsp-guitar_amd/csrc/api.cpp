@@ -37,13 +37,90 @@ static const int32_t g_param_default[GDG_UNIT_COUNT][GDG_MAX_PARAMS] = {
     { 100, 30 }, { 100, 10 }, { 100, 10, 45 }, { 100, 50, -10 }, { 100 }, { 200, -5, -5 }, { 50 }, { 14 }, { 0 },
 };
 
+/* Device memory of the per-unit state.  A 512-channel context owns ~17 000 blocks (per unit: small state, history ring, and per
+ * power amp the overlap-save history, delay line, product spectra, frame counter, IR spectra); as one hipMalloc / hipFree each they
+ * cost ~1 s to release and scatter the state over the address space.  They come out of a few large chunks instead (geometric growth
+ * up to 1 GiB, 288 GB of HBM to draw on), sub-allocated on the host: first fit over an address-ordered free list that coalesces on
+ * free.  No implicit synchronisation: whoever frees a block has already waited for the work that used it (every call site does).
+ * Blocks are NOT zeroed (neither is hipMalloc'ed memory by contract): every site that needs zeros sets them. */
+struct DevArena {
+    struct Chunk { char *base; size_t size; std::map<size_t, size_t> holes; };       /* holes: offset -> bytes */
+    std::vector<Chunk> chunks;
+    std::map<const void *, std::pair<size_t, size_t>> live;                           /* block -> (chunk index, bytes) */
+    size_t total = 0;
+    /* Blocks of a page or more start on `big_align` (env GDG_ARENA_ALIGN, default 4 KiB like a hipMalloc of their own would): the
+     * streaming kernels read delay lines and spectra front to back, and packing those at 256-byte offsets behind the small state
+     * blocks cost the convolution 5-13 % (profiles/arena_ab_r03.txt).  GDG_ARENA=0: one hipMalloc per block (A/B measurements). */
+    size_t big_align = 4096;
+    bool direct = false;
+    DevArena() {
+        if (const char *e = getenv("GDG_ARENA_ALIGN")) { size_t a = (size_t)atoll(e); if (a >= 256 && (a & (a - 1)) == 0) big_align = a; }
+        if (const char *e = getenv("GDG_ARENA")) direct = atoi(e) == 0;
+    }
+    static size_t round_up(size_t b, size_t a) { return (b + a - 1) & ~(a - 1); }
+    hipError_t alloc(void **out, size_t bytes) {
+        if (direct) return hipMalloc(out, bytes ? bytes : 1);
+        const size_t need = round_up(bytes ? bytes : 1, 256);
+        const size_t align = need >= 4096 ? big_align : 256;
+        for (size_t c = 0; c < chunks.size(); c++) {
+            auto &h = chunks[c].holes;
+            const uintptr_t base = (uintptr_t)chunks[c].base;
+            for (auto it = h.begin(); it != h.end(); ++it) {
+                const size_t off = it->first, end = off + it->second;
+                const size_t at = (size_t)(round_up(base + off, align) - base);
+                if (at + need > end) continue;
+                h.erase(it);
+                if (at > off) h.emplace(off, at - off);
+                if (end > at + need) h.emplace(at + need, end - (at + need));
+                *out = chunks[c].base + at;
+                live.emplace(*out, std::make_pair(c, need));
+                return hipSuccess;
+            }
+        }
+        size_t size = std::max(need, std::min((size_t)1 << 30, std::max((size_t)64 << 20, total)));
+        void *base = nullptr;
+        hipError_t e = hipMalloc(&base, size);
+        if (e != hipSuccess && size > need) { size = need; e = hipMalloc(&base, size); }
+        if (e != hipSuccess) { *out = nullptr; return e; }
+        total += size;
+        chunks.push_back(Chunk{ static_cast<char *>(base), size, {} });        /* hipMalloc'ed chunks of >= 64 MiB start on 2 MiB */
+        if (size > need) chunks.back().holes.emplace(need, size - need);
+        *out = base;
+        live.emplace(*out, std::make_pair(chunks.size() - 1, need));
+        return hipSuccess;
+    }
+    void release(const void *p) {
+        if (!p) return;
+        if (direct) { hipFree(const_cast<void *>(p)); return; }
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        Chunk &ch = chunks[it->second.first];
+        size_t off = (size_t)(static_cast<const char *>(p) - ch.base), n = it->second.second;
+        live.erase(it);
+        auto next = ch.holes.lower_bound(off);
+        if (next != ch.holes.end() && off + n == next->first) { n += next->second; next = ch.holes.erase(next); }
+        if (next != ch.holes.begin()) {
+            auto prev = std::prev(next);
+            if (prev->first + prev->second == off) { prev->second += n; return; }
+        }
+        ch.holes.emplace(off, n);
+    }
+    void destroy() {
+        for (auto &c : chunks) hipFree(c.base);
+        chunks.clear();
+        live.clear();
+        total = 0;
+    }
+};
+
 /* IR spectra of one (taps, partition size) pair; power amps with identical composite filters share one copy in HBM
  * (the MAC then streams it from L2 / MALL for all but the first channel: SURVEY.md 8d, d < 1) */
 struct SharedSpectra {
     std::vector<double> taps;
     int P = 0, K = 0, hop = 0;
     double2 *d_H = nullptr;
-    ~SharedSpectra() { if (d_H) hipFree(d_H); }
+    DevArena *arena = nullptr;
+    ~SharedSpectra() { if (d_H && arena) arena->release(d_H); }
 };
 
 struct Unit {
@@ -110,7 +187,10 @@ struct gdg_ctx {
     double *d_stage_in = nullptr, *d_stage_out = nullptr;
     double *h_stage_in = nullptr, *h_stage_out = nullptr;
     int stage_out_stride = 0;         /* > 0: d_stage_out holds one complete block of chain outputs, row c = channel c, this stride */
+    int stage_out_frames = 0;         /* ... of this many frames per row */
     int *d_error = nullptr;
+    DevArena arena;                   /* per-unit state (see DevArena) */
+    std::vector<void *> user_allocs;  /* gdg_device_alloc blocks the caller has not freed (released with the context) */
     /* tables */
     std::map<int, std::pair<double2 *, double2 *>> fir_tables;
     std::multimap<uint64_t, std::weak_ptr<SharedSpectra>> spectra;     /* content hash -> live IR spectra */
@@ -125,6 +205,9 @@ struct gdg_ctx {
     gdg_os_tables os;
     /* profiling */
     unsigned profiling = 0;                  /* bit 0: everything; bit k+1: kernel kind k */
+    int prof_every = 1;                      /* gdg_profile_sample: bracket every n-th process call only */
+    unsigned long long prof_calls = 0;
+    bool prof_now = true;
     std::vector<ProfEvent> prof;
     std::vector<hipEvent_t> event_pool;
     /* tuner / spatializer */
@@ -294,9 +377,11 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     return GDG_OK;
 }
 
-static void free_unit(Unit &u) {
-    hipFree(u.d_ds); hipFree(u.d_is); hipFree(u.d_hist);
-    hipFree(u.d_prev); hipFree(u.d_fdl); hipFree(u.d_Y); hipFree(u.d_pos);
+/* the caller has waited for every launch that used the unit */
+static void free_unit(gdg_ctx *ctx, Unit &u) {
+    DevArena &a = ctx->arena;
+    a.release(u.d_ds); a.release(u.d_is); a.release(u.d_hist);
+    a.release(u.d_prev); a.release(u.d_fdl); a.release(u.d_Y); a.release(u.d_pos);
     u = Unit();                     /* drops the unit's reference to its (possibly shared) IR spectra */
 }
 
@@ -304,7 +389,10 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     if (!ctx) return GDG_ERR_INVALID;
     enter(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    for (auto &u : ctx->units) if (u.alive) free_unit(u);
+    for (auto &u : ctx->units) if (u.alive) free_unit(ctx, u);
+    ctx->spectra.clear();
+    ctx->arena.destroy();
+    for (void *p : ctx->user_allocs) hipFree(p);
     for (auto &kv : ctx->fir_tables) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &p : ctx->prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
@@ -371,12 +459,13 @@ int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle) {
     u.type = unit_type;
     u.channel = channel;
     memcpy(u.params, g_param_default[unit_type], sizeof(u.params));
-    hipError_t e = hipMalloc((void **)&u.d_ds, GDG_DS_LEN * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&u.d_is, GDG_IS_LEN * sizeof(int));
+    hipError_t e = ctx->arena.alloc((void **)&u.d_ds, GDG_DS_LEN * sizeof(double));
+    if (e == hipSuccess) e = ctx->arena.alloc((void **)&u.d_is, GDG_IS_LEN * sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(u.d_ds, 0, GDG_DS_LEN * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(u.d_is, 0, GDG_IS_LEN * sizeof(int), ctx->stream);
     if (e != hipSuccess) {
-        free_unit(u);               /* the slot goes back to "not alive"; nothing leaks */
+        hipStreamSynchronize(ctx->stream);
+        free_unit(ctx, u);          /* the slot goes back to "not alive"; nothing leaks */
         return fail(ctx, GDG_ERR_HIP, "gdg_unit_create: %s", hipGetErrorString(e));
     }
     *handle = (int)h;
@@ -390,7 +479,7 @@ int gdg_unit_destroy(gdg_ctx *ctx, int handle) {
     hipStreamSynchronize(ctx->stream);
     for (auto &chain : ctx->chains)
         chain.erase(std::remove_if(chain.begin(), chain.end(), [&](const Slot &s) { return s.handle == handle; }), chain.end());
-    free_unit(*u);
+    free_unit(ctx, *u);
     ctx->dirty = true;
     return GDG_OK;
 }
@@ -464,11 +553,11 @@ int gdg_chain_set(gdg_ctx *ctx, int channel, const int *handles, const uint8_t *
 
 static int ensure_hist(gdg_ctx *ctx, Unit &u, size_t len, long long key) {
     if (u.hist_key == key && u.hist_len == len) return GDG_OK;
-    if (u.d_hist) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(u.d_hist); u.d_hist = nullptr; }
+    if (u.d_hist) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); ctx->arena.release(u.d_hist); u.d_hist = nullptr; }
     u.hist_len = len;
     u.hist_key = key;
     if (len > 0) {
-        HIP_TRY(ctx, hipMalloc((void **)&u.d_hist, len * sizeof(double)));
+        HIP_TRY(ctx, ctx->arena.alloc((void **)&u.d_hist, len * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(u.d_hist, 0, len * sizeof(double), ctx->stream));
     }
     return GDG_OK;
@@ -803,7 +892,8 @@ static int fir_spectra(gdg_ctx *ctx, Unit &u, int hop, int P, int K) {
     sp->P = P;
     sp->K = K;
     sp->hop = hop;
-    HIP_TRY(ctx, hipMalloc((void **)&sp->d_H, spec));
+    sp->arena = &ctx->arena;
+    HIP_TRY(ctx, ctx->arena.alloc((void **)&sp->d_H, spec));
     HIP_TRY(ctx, hipMemsetAsync(sp->d_H, 0, spec, ctx->stream));
     if (L > 0) {
         double2 *tw, *tw2;
@@ -815,19 +905,21 @@ static int fir_spectra(gdg_ctx *ctx, Unit &u, int hop, int P, int K) {
             int n = std::min(hop, L - k * hop);
             memcpy(padded.data() + (size_t)k * P, u.taps.data() + (size_t)k * hop, (size_t)n * sizeof(double));
         }
-        double *d_taps = nullptr;
-        gdg_fir_irjob *d_jobs = nullptr;
+        /* two temporaries out of the arena, released on every way out once the stream is idle */
+        struct Temps {
+            DevArena &a; hipStream_t st; void *p = nullptr, *q = nullptr;
+            ~Temps() { hipStreamSynchronize(st); a.release(p); a.release(q); }
+        } tmp{ ctx->arena, ctx->stream };
         std::vector<gdg_fir_irjob> jobs((size_t)K);
-        HIP_TRY(ctx, hipMalloc((void **)&d_taps, padded.size() * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc((void **)&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
+        HIP_TRY(ctx, ctx->arena.alloc(&tmp.p, padded.size() * sizeof(double)));
+        HIP_TRY(ctx, ctx->arena.alloc(&tmp.q, jobs.size() * sizeof(gdg_fir_irjob)));
+        double *d_taps = static_cast<double *>(tmp.p);
+        gdg_fir_irjob *d_jobs = static_cast<gdg_fir_irjob *>(tmp.q);
         for (int k = 0; k < K; k++) { jobs[(size_t)k].a = d_taps + (size_t)k * P; jobs[(size_t)k].out = sp->d_H + (size_t)k * P; }
         HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
         /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
         HIP_TRY(ctx, gdg_launch_fir_ir(P, d_jobs, K, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        hipFree(d_taps);
-        hipFree(d_jobs);
     }
     u.H = sp;
     if (ctx->share_spectra) ctx->spectra.emplace(key, sp);
@@ -865,7 +957,8 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
     /* the old state, kept until the new delay line is built */
     double *o_prev = u.d_prev; double2 *o_fdl = u.d_fdl, *o_Y = u.d_Y; int *o_pos = u.d_pos;
     const int K1 = u.fir_K, P1 = u.fir_P, hop1 = u.fir_hop, R1 = u.fir_R;
-    auto free_old = [&]() { hipFree(o_prev); hipFree(o_fdl); hipFree(o_Y); hipFree(o_pos); };
+    DevArena &arena = ctx->arena;
+    auto free_old = [&]() { arena.release(o_prev); arena.release(o_fdl); arena.release(o_Y); arena.release(o_pos); };
     u.d_prev = nullptr; u.d_fdl = nullptr; u.d_Y = nullptr; u.d_pos = nullptr;
     double *d_old_hist = nullptr, *d_new_hist = nullptr;
     void *d_jobs = nullptr;
@@ -878,7 +971,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
             int pos = 0;
             HIP_TRY(ctx, hipMemcpy(&pos, o_pos, sizeof(int), hipMemcpyDeviceToHost));
             old_len = (size_t)(K1 + 1) * (size_t)hop1;
-            HIP_TRY(ctx, hipMalloc((void **)&d_old_hist, old_len * sizeof(double)));
+            HIP_TRY(ctx, arena.alloc((void **)&d_old_hist, old_len * sizeof(double)));
             std::vector<gdg_fir_rawjob> jobs((size_t)K1);
             for (int j = 0; j < K1; j++) {
                 int m = K1 - 1 - j;                                   /* frame t - m, t = the latest one, sits in slot (pos - 1 - m) mod R1 */
@@ -888,19 +981,19 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
                 jobs[(size_t)j].second = d_old_hist + (size_t)(j + 1) * hop1;
                 jobs[(size_t)j].hop = hop1;
             }
-            HIP_TRY(ctx, hipMalloc(&d_jobs, jobs.size() * sizeof(gdg_fir_rawjob)));
+            HIP_TRY(ctx, arena.alloc(&d_jobs, jobs.size() * sizeof(gdg_fir_rawjob)));
             HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_rawjob), hipMemcpyHostToDevice, ctx->stream));
             int r = fir_tables(ctx, P1, &tw, &tw2);
             if (r != GDG_OK) return r;
             HIP_TRY(ctx, gdg_launch_fir_raw_inv(P1, (const gdg_fir_rawjob *)d_jobs, K1, 1.0 / (2.0 * (double)P1), tw, tw2, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            hipFree(d_jobs); d_jobs = nullptr;
+            arena.release(d_jobs); d_jobs = nullptr;
         }
         size_t spec = (size_t)R * (size_t)P * sizeof(double2);
-        HIP_TRY(ctx, hipMalloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc((void **)&u.d_fdl, spec));
-        HIP_TRY(ctx, hipMalloc((void **)&u.d_Y, (size_t)W * (size_t)P * sizeof(double2)));
-        HIP_TRY(ctx, hipMalloc((void **)&u.d_pos, sizeof(int)));
+        HIP_TRY(ctx, arena.alloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
+        HIP_TRY(ctx, arena.alloc((void **)&u.d_fdl, spec));
+        HIP_TRY(ctx, arena.alloc((void **)&u.d_Y, (size_t)W * (size_t)P * sizeof(double2)));
+        HIP_TRY(ctx, arena.alloc((void **)&u.d_pos, sizeof(int)));
         HIP_TRY(ctx, hipMemsetAsync(u.d_prev, 0, 2 * (size_t)P * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(u.d_fdl, 0, spec, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(u.d_pos, 0, sizeof(int), ctx->stream));
@@ -909,7 +1002,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
         if (carry) {
             /* 2. the newest K hop samples, re-cut into K frames of the new size (zeros where the old line does not reach) */
             size_t new_len = (size_t)K * (size_t)hop;
-            HIP_TRY(ctx, hipMalloc((void **)&d_new_hist, new_len * sizeof(double)));
+            HIP_TRY(ctx, arena.alloc((void **)&d_new_hist, new_len * sizeof(double)));
             HIP_TRY(ctx, hipMemsetAsync(d_new_hist, 0, new_len * sizeof(double), ctx->stream));
             size_t n = std::min(old_len, new_len);
             HIP_TRY(ctx, hipMemcpyAsync(d_new_hist + (new_len - n), d_old_hist + (old_len - n), n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -922,7 +1015,7 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
                     jobs[(size_t)(f - 1)].hop = hop;
                     jobs[(size_t)(f - 1)].out = u.d_fdl + (size_t)f * P;
                 }
-                HIP_TRY(ctx, hipMalloc(&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
+                HIP_TRY(ctx, arena.alloc(&d_jobs, jobs.size() * sizeof(gdg_fir_irjob)));
                 HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
                 r = fir_tables(ctx, P, &tw, &tw2);
                 if (r != GDG_OK) return r;
@@ -937,7 +1030,8 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
         return GDG_OK;
     };
     rc = body();
-    hipFree(d_old_hist); hipFree(d_new_hist); hipFree(d_jobs);
+    if (rc != GDG_OK || carry) hipStreamSynchronize(ctx->stream);          /* nothing in flight reads what is released below */
+    arena.release(d_old_hist); arena.release(d_new_hist); arena.release(d_jobs);
     free_old();
     if (rc != GDG_OK) { u.fir_dirty = true; u.fir_live = false; return rc; }
     u.fir_P = P;
@@ -1107,7 +1201,7 @@ static hipEvent_t take_event(gdg_ctx *ctx) {
 struct ProfScope {
     gdg_ctx *ctx; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on = false;
     ProfScope(gdg_ctx *c, int k, hipStream_t s = nullptr) : ctx(c), kind(k), st(s ? s : c->stream) {
-        on = (ctx->profiling & 1u) || (ctx->profiling & (1u << (k + 1)));
+        on = ctx->prof_now && ((ctx->profiling & 1u) || (ctx->profiling & (1u << (k + 1))));
         if (on) { a = take_event(ctx); b = take_event(ctx); hipEventRecord(a, st); }
     }
     ~ProfScope() {
@@ -1118,6 +1212,13 @@ struct ProfScope {
 int gdg_profile_enable(gdg_ctx *ctx, int enable) {
     if (!ctx) return GDG_ERR_INVALID;
     ctx->profiling = enable < 0 ? 0u : (unsigned)enable;
+    return GDG_OK;
+}
+
+int gdg_profile_sample(gdg_ctx *ctx, int every) {
+    if (!ctx || every < 1) return GDG_ERR_INVALID;
+    ctx->prof_every = every;
+    ctx->prof_calls = 0;
     return GDG_OK;
 }
 
@@ -1158,6 +1259,11 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
     if (sample_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     hipSetDevice(ctx->device);
+    struct ProfPhase {          /* this call's launches are bracketed or not as a whole (gdg_profile_sample) */
+        gdg_ctx *c;
+        explicit ProfPhase(gdg_ctx *ctx_) : c(ctx_) { c->prof_now = c->prof_every <= 1 || !c->profiling || (c->prof_calls++ % (unsigned)c->prof_every) == 0; }
+        ~ProfPhase() { c->prof_now = true; }
+    } prof_phase(ctx);
     const int G = groups < 1 ? 1 : groups;
     /* device-resident calls: the groups are not joined at the end of the call, so one group's kernels overlap the other's across calls
      * (the join happens when anything else touches the context: enter()) */
@@ -1247,14 +1353,16 @@ static int pcie_groups(int n) {
     return g < 1 ? 1 : (g > 16 ? 16 : g);
 }
 
-/* channel groups of the device-resident calls: the groups' kernels run on streams of their own and overlap (one group's
- * latency-bound segment kernel with the other's HBM-bound convolution); env GDG_DEVICE_GROUPS overrides */
+/* channel groups of the device-resident calls: the groups' kernels run on streams of their own, are NOT joined at the end of the call
+ * and overlap (one group's latency-bound segment kernel with the other's HBM-bound convolution).  Opt-in only -- gdg_ctx_set_overlap(G > 1)
+ * or env GDG_DEVICE_GROUPS -- because a caller that caches gdg_ctx_stream() and enqueues its own work behind a process call is only
+ * ordered after the call's kernels when they run on that stream: the default is ONE group on the context's stream.
+ * Measured (profiles/device_groups_r02.txt): two groups gain 7-10 % from 512 channels on, nothing below, four lose. */
 static int device_groups(const gdg_ctx *ctx) {
     static int forced = -1;
     if (forced < 0) { const char *e = getenv("GDG_DEVICE_GROUPS"); forced = e ? atoi(e) : 0; }
     const int n = ctx->nch;
-    /* measured (profiles/device_groups_r02.txt): two groups gain 7-10 % from 512 channels on, nothing below, four lose */
-    int g = ctx->overlap_groups > 0 ? ctx->overlap_groups : (forced > 0 ? forced : (n >= 384 ? 2 : 1));
+    int g = ctx->overlap_groups > 0 ? ctx->overlap_groups : (forced > 0 ? forced : 1);
     if (g > n) g = n;
     return g < 1 ? 1 : (g > 16 ? 16 : g);
 }
@@ -1391,7 +1499,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     {   /* all channels, in order: the compact rows are a complete block (gdg_spatialize_staged may mix it without an upload) */
         bool complete = n == ctx->nch;
         for (int i = 0; complete && i < n; i++) complete = active[(size_t)i] == i;
-        if (complete) ctx->stage_out_stride = frames;
+        if (complete) { ctx->stage_out_stride = frames; ctx->stage_out_frames = frames; }
     }
     for (int g = 0; g < G; g++) {
         if (G > 1) HIP_TRY(ctx, hipStreamSynchronize(ctx->gstreams[(size_t)g]));
@@ -1454,7 +1562,7 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
     ctx->stage_out_stride = 0;
     rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true, G, &before, &after);
     if (rc != GDG_OK) return rc;
-    if (n == ctx->nch) ctx->stage_out_stride = ctx->max_frames;          /* rows by channel: every channel took part */
+    if (n == ctx->nch) { ctx->stage_out_stride = ctx->max_frames; ctx->stage_out_frames = frames; }     /* rows by channel: every channel took part */
     return check_device_error(ctx);
 }
 
@@ -1464,6 +1572,7 @@ int gdg_device_alloc(gdg_ctx *ctx, size_t bytes, void **d_ptr) {
     if (!ctx || !d_ptr) return GDG_ERR_INVALID;
     enter(ctx);
     HIP_TRY(ctx, hipMalloc(d_ptr, bytes));
+    ctx->user_allocs.push_back(*d_ptr);
     return GDG_OK;
 }
 
@@ -1471,6 +1580,8 @@ int gdg_device_free(gdg_ctx *ctx, void *d_ptr) {
     if (!ctx) return GDG_ERR_INVALID;
     enter(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    auto it = std::find(ctx->user_allocs.begin(), ctx->user_allocs.end(), d_ptr);
+    if (it != ctx->user_allocs.end()) ctx->user_allocs.erase(it);
     HIP_TRY(ctx, hipFree(d_ptr));
     return GDG_OK;
 }
@@ -1836,6 +1947,8 @@ int gdg_spatialize_staged(gdg_ctx *ctx, int from_outputs, double *out_left, doub
     int stride = ctx->stage_out_stride;
     if (from_outputs && stride <= 0)
         return fail(ctx, GDG_ERR_INVALID, "no complete block of chain outputs on the device (the last host-buffer call did not cover all %d channels)", ctx->nch);
+    if (from_outputs && frames != ctx->stage_out_frames)
+        return fail(ctx, GDG_ERR_INVALID, "the chain outputs on the device are blocks of %d frames, %d were asked for", ctx->stage_out_frames, frames);
     if (!from_outputs) {
         stride = ctx->max_frames;
         HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_stage_in, (size_t)ctx->max_frames * sizeof(double), ctx->h_stage_in, (size_t)ctx->max_frames * sizeof(double),
@@ -2320,7 +2433,8 @@ static void move_pieces(const std::vector<BatchPiece> &pieces) {
  *      the encoded block (N + 3 rows x 8192 x width bytes) goes down on the copy stream while the next block computes, and the
  *      copy threads scatter it into the caller's N + 3 buffers.
  */
-int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *opt, void *const *out_bytes) {
+static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *opt, void *const *out_bytes,
+                          const gdg_batch_shard_out *shard) {
     if (!ctx || !inputs || !opt || !out_bytes) return GDG_ERR_INVALID;
     if (n_inputs != ctx->nch) return fail(ctx, GDG_ERR_INVALID, "the batch has %d inputs, the context %d channels", n_inputs, ctx->nch);
     if (ctx->max_frames < GDG_BLOCK_SIZE)
@@ -2329,6 +2443,15 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     if (!out_width) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", opt->out_format);
     if (opt->target_rate == 0) return fail(ctx, GDG_ERR_INVALID, "sample rate must be positive");
     const int N = n_inputs, NO = N + 3, B = GDG_BLOCK_SIZE, ports = 2 * N + 3;
+    /* One shard of a job split over several contexts: the master mix is the sum over ALL channels, then the aux input,
+     * then the encoder's clip (spatializer.go:300-310, controller.go:3123-3219) -- so a shard hands out its PARTIAL sums as float64
+     * and gdg_batch_finish_master adds the shards' partials in shard order, then aux, then encodes.  The metronome runs on the shard
+     * that is given somewhere to put it. */
+    const bool sharded = shard != nullptr;
+    if (sharded && (!shard->master_left || !shard->master_right)) return fail(ctx, GDG_ERR_INVALID, "a shard needs buffers for its partial master mix");
+    const bool run_metro = !sharded || shard->metronome_bytes || shard->metronome;
+    const int enc_rows = sharded ? N + (shard->metronome_bytes ? 1 : 0) : NO;      /* rows that leave the device encoded */
+    const int f64_rows = sharded ? 2 + (shard->metronome ? 1 : 0) : 0;             /* rows that leave it as float64 */
     /* inputs that are mono and already at the target rate are STREAMED: their bytes go up step by step while the block loop runs;
      * the others (a channel picked out of an interleaved file, resample.Time over the whole file) go up before the loop */
     std::vector<size_t> arena_off((size_t)N, 0);
@@ -2356,12 +2479,19 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     size_t length = 0;
     int rc = gdg_batch_length(ctx, inputs, n_inputs, opt->target_rate, &length);
     if (rc != GDG_OK) return rc;
+    if (sharded && shard->job_samples) {
+        if (shard->job_samples < length || shard->job_samples % GDG_BLOCK_SIZE)
+            return fail(ctx, GDG_ERR_INVALID, "the job's %zu samples: at least this shard's %zu and a multiple of %d", shard->job_samples, length, GDG_BLOCK_SIZE);
+        length = shard->job_samples;
+    }
     if (length == 0) return GDG_OK;                                            /* every output has 0 samples */
     if (opt->run_meters && ctx->n_meter != ports)
-        return fail(ctx, GDG_ERR_INVALID, "level meters: %d ports configured, the batch needs 2 N + 3 = %d", ctx->n_meter, ports);
+        return fail(ctx, GDG_ERR_INVALID, "level meters: %d ports configured, the batch needs 2 N + 3 = %d (a shard: its N inputs, its N outputs, metronome, left, right)",
+                    ctx->n_meter, ports);
     enter(ctx);
     const int W = ctx->window;                                                 /* frames per step (gdg_ctx_set_window; 1 = the reference's loop) */
-    const size_t enc_bytes = (size_t)NO * W * B * (size_t)out_width;           /* one encoded window */
+    const size_t ws = (size_t)W * B;                                           /* row stride of the window, the same for every step */
+    const size_t enc_bytes = (((size_t)enc_rows * ws * (size_t)out_width + 15) & ~(size_t)15) + (size_t)f64_rows * ws * sizeof(double);   /* one window on its way down */
     const size_t half = std::max(enc_bytes, (size_t)8 << 20);
     if (length > 0x7fffffff) return fail(ctx, GDG_ERR_INVALID, "files of %zu samples are too long", length);
     /* one step of the streamed inputs: the piece descriptors, then every piece on a 16-byte boundary */
@@ -2376,7 +2506,7 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         if ((r = batch_buffer(ctx, 0, (size_t)N * length * sizeof(double), (void **)&d_inputs)) != GDG_OK) return r;
         /* one window of the N + 3 outputs, rows in the output files' order (out_0 .. out_{N-1}, master left, master right, metronome,
          * controller.go:3123-3219); the inputs are read where they lie */
-        if ((r = batch_buffer(ctx, 1, (size_t)NO * W * B * sizeof(double), (void **)&d_win)) != GDG_OK) return r;
+        if ((r = batch_buffer(ctx, 1, (size_t)NO * ws * sizeof(double), (void **)&d_win)) != GDG_OK) return r;
         if ((r = batch_buffer(ctx, 2, 2 * enc_bytes, (void **)&d_enc)) != GDG_OK) return r;
         if (arena_bytes && (r = batch_buffer(ctx, 3, arena_bytes, (void **)&d_arena)) != GDG_OK) return r;
         if (up_half && (r = batch_buffer(ctx, 4, 2 * up_half, (void **)&d_up)) != GDG_OK) return r;
@@ -2438,9 +2568,18 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         }
         auto scatter = [&](size_t i) {                                           /* step i's bytes from its pinned half into the files */
             const unsigned char *src = ctx->h_batch[i & 1];
-            const size_t row_bytes = (size_t)steps[i].w * B * out_width, at = steps[i].off * out_width;
-            copy_rows_parallel(0, (size_t)NO, [&](size_t o) {
-                if (out_bytes[o]) memcpy(static_cast<unsigned char *>(out_bytes[o]) + at, src + o * row_bytes, row_bytes);   /* NULL: "skipping output" (:3143) */
+            const size_t wb = (size_t)steps[i].w * B, row_bytes = wb * out_width, at = steps[i].off * out_width;
+            const size_t f64_at = ((size_t)enc_rows * row_bytes + 15) & ~(size_t)15;
+            copy_rows_parallel(0, (size_t)enc_rows + (size_t)f64_rows, [&](size_t o) {
+                if (o < (size_t)enc_rows) {
+                    /* NULL: "skipping output" (:3143); a shard's row N is the metronome track */
+                    void *dst = (sharded && o == (size_t)N) ? shard->metronome_bytes : out_bytes[o];
+                    if (dst) memcpy(static_cast<unsigned char *>(dst) + at, src + o * row_bytes, row_bytes);
+                } else {
+                    const size_t k = o - (size_t)enc_rows;
+                    double *dst = k == 0 ? shard->master_left : (k == 1 ? shard->master_right : shard->metronome);
+                    memcpy(dst + steps[i].off, src + f64_at + k * wb * sizeof(double), wb * sizeof(double));
+                }
             }, row_bytes);
         };
         /* the streamed inputs of step i: gathered into a pinned half by the copy threads, moved and decoded on the upload stream while
@@ -2483,28 +2622,44 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
         if ((r = stage(0)) != GDG_OK) return r;
         for (size_t i = 0; i < steps.size(); i++) {
             const size_t off = steps[i].off;
-            const int w = steps[i].w, h = (int)(i & 1), wb = w * B;               /* the window's rows are wb long */
+            const int w = steps[i].w, h = (int)(i & 1), wb = w * B;               /* this step fills the first wb samples of the window's rows */
             if (n_streamed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_up_ready[h], 0));
             const double *d_in = d_inputs + off;
-            double *d_master = d_win + (size_t)N * wb, *d_metro = d_master + 2 * (size_t)wb;
+            double *d_master = d_win + (size_t)N * ws, *d_metro = d_master + 2 * ws;
             unsigned char *enc = d_enc + h * enc_bytes;
             if (opt->tuner_enqueue)
                 for (int j = 0; j < w; j++) if ((r = tuner_enqueue_rows(ctx, d_in + (size_t)j * B, length, B, opt->target_rate)) != GDG_OK) return r;
-            if ((r = process_rows(ctx, ctx->all_channels, d_in, d_win, B, opt->target_rate, (int)length, false, 1, nullptr, nullptr, w, wb)) != GDG_OK) return r;
-            if ((r = gdg_metronome_process_device(ctx, d_metro, wb)) != GDG_OK) return r;
-            for (int j = 0; j < w; j++) if ((r = spatialize_rows(ctx, d_win + (size_t)j * B, wb, d_master + (size_t)j * B, wb, B)) != GDG_OK) return r;
-            if (opt->metronome_to_master) HIP_TRY(ctx, gdg_launch_add_aux(d_master, d_master + wb, d_metro, wb, ctx->stream));
+            if ((r = process_rows(ctx, ctx->all_channels, d_in, d_win, B, opt->target_rate, (int)length, false, 1, nullptr, nullptr, w, (int)ws)) != GDG_OK) return r;
+            if (run_metro && (r = gdg_metronome_process_device(ctx, d_metro, wb)) != GDG_OK) return r;
+            for (int j = 0; j < w; j++) if ((r = spatialize_rows(ctx, d_win + (size_t)j * B, (int)ws, d_master + (size_t)j * B, (int)ws, B)) != GDG_OK) return r;
+            /* a shard's master rows stay partial sums: the aux input is added once, after the shards' sums (gdg_batch_finish_master) */
+            if (opt->metronome_to_master && !sharded) HIP_TRY(ctx, gdg_launch_add_aux(d_master, d_master + ws, d_metro, wb, ctx->stream));
             if (opt->run_meters) {                                               /* ports: inputs | outputs | metronome | left, right (:2707-2777) */
                 if ((r = meter_rows(ctx, d_in, length, 0, N, wb, opt->target_rate)) != GDG_OK) return r;
-                if ((r = meter_rows(ctx, d_win, (size_t)wb, N, N, wb, opt->target_rate)) != GDG_OK) return r;
-                if ((r = meter_rows(ctx, d_metro, (size_t)wb, 2 * N, 1, wb, opt->target_rate)) != GDG_OK) return r;
-                if ((r = meter_rows(ctx, d_master, (size_t)wb, 2 * N + 1, 2, wb, opt->target_rate)) != GDG_OK) return r;
+                if ((r = meter_rows(ctx, d_win, ws, N, N, wb, opt->target_rate)) != GDG_OK) return r;
+                if (run_metro && (r = meter_rows(ctx, d_metro, ws, 2 * N, 1, wb, opt->target_rate)) != GDG_OK) return r;
+                if (!sharded && (r = meter_rows(ctx, d_master, ws, 2 * N + 1, 2, wb, opt->target_rate)) != GDG_OK) return r;     /* a shard's master ports: gdg_batch_finish_master */
             }
             if (i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_moved[h], 0));     /* step i - 2 has left enc */
-            if ((r = gdg_wave_encode_device(ctx, opt->out_format, d_win, (size_t)NO * wb, 1, enc)) != GDG_OK) return r;
+            {
+                ProfScope ps(ctx, GDG_K_WAVE);
+                const size_t row_bytes = (size_t)wb * out_width;
+                if (!sharded) HIP_TRY(ctx, gdg_launch_wave_encode_rows(opt->out_format, d_win, ws, (size_t)wb, (unsigned)NO, enc, ctx->stream));
+                else {
+                    HIP_TRY(ctx, gdg_launch_wave_encode_rows(opt->out_format, d_win, ws, (size_t)wb, (unsigned)N, enc, ctx->stream));
+                    if (shard->metronome_bytes)
+                        HIP_TRY(ctx, gdg_launch_wave_encode_rows(opt->out_format, d_metro, ws, (size_t)wb, 1u, enc + (size_t)N * row_bytes, ctx->stream));
+                    unsigned char *f64 = enc + (((size_t)enc_rows * row_bytes + 15) & ~(size_t)15);
+                    HIP_TRY(ctx, hipMemcpy2DAsync(f64, (size_t)wb * sizeof(double), d_master, ws * sizeof(double), (size_t)wb * sizeof(double), 2,
+                                                  hipMemcpyDeviceToDevice, ctx->stream));
+                    if (shard->metronome)
+                        HIP_TRY(ctx, hipMemcpyAsync(f64 + 2 * (size_t)wb * sizeof(double), d_metro, (size_t)wb * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                }
+            }
             HIP_TRY(ctx, hipEventRecord(ctx->batch_ready[h], ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_stream, ctx->batch_ready[h], 0));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, (size_t)NO * wb * out_width, hipMemcpyDeviceToHost, ctx->batch_stream));
+            const size_t down = (((size_t)enc_rows * wb * out_width + 15) & ~(size_t)15) + (size_t)f64_rows * wb * sizeof(double);
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, sharded ? down : (size_t)NO * wb * out_width, hipMemcpyDeviceToHost, ctx->batch_stream));
             HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
             if ((r = stage(i + 1)) != GDG_OK) return r;                          /* while step i runs: the next step's inputs go up ... */
             if (i >= 1) {                                                        /* ... and step i - 1 goes into the files */
@@ -2522,6 +2677,60 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
     hipStreamSynchronize(ctx->stream);
     /* the device buffers stay with the context for the next batch (gdg_batch_release) */
     return rc;
+}
+
+int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *opt, void *const *out_bytes) {
+    return batch_run_impl(ctx, inputs, n_inputs, opt, out_bytes, nullptr);
+}
+
+int gdg_batch_run_shard(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *opt, void *const *out_bytes,
+                        const gdg_batch_shard_out *shard) {
+    if (!shard) return GDG_ERR_INVALID;
+    return batch_run_impl(ctx, inputs, n_inputs, opt, out_bytes, shard);
+}
+
+/* master = ((p_0 + p_1) + ... + p_{G-1}) + aux per side, then the encoder (its clip included) -- all on this context's device; the host
+ * only moves the G partial pairs up and the two encoded rows down, in pieces of <= 2^20 samples through the context's io scratch */
+int gdg_batch_finish_master(gdg_ctx *ctx, int out_format, const double *const *left, const double *const *right, int n_shards, const double *aux,
+                            size_t samples, uint32_t sample_rate, int run_meters, void *left_bytes, void *right_bytes) {
+    if (!ctx || !left || !right || n_shards <= 0) return GDG_ERR_INVALID;
+    const int width = gdg_wave_bytes_per_sample(out_format);
+    if (!width) return fail(ctx, GDG_ERR_UNSUPPORTED, "unknown sample format %d", out_format);
+    for (int g = 0; g < n_shards; g++) if (!left[g] || !right[g]) return fail(ctx, GDG_ERR_INVALID, "shard %d has no partial master mix", g);
+    if (run_meters && (ctx->n_meter < 2 || sample_rate == 0)) return fail(ctx, GDG_ERR_INVALID, "master meters: the context's last two ports, at a positive rate");
+    if (samples == 0) return GDG_OK;
+    enter(ctx);
+    const size_t piece = (size_t)1 << 20;
+    int rc = ensure_io(ctx, 1, 3 * piece * sizeof(double));                     /* [left | right | incoming partial or aux] */
+    if (rc == GDG_OK) rc = ensure_io(ctx, 0, 2 * piece * (size_t)width);
+    if (rc != GDG_OK) return rc;
+    double *d_l = static_cast<double *>(ctx->d_io[1]), *d_r = d_l + piece, *d_p = d_r + piece;
+    unsigned char *d_enc = static_cast<unsigned char *>(ctx->d_io[0]);
+    for (size_t at = 0; at < samples; at += piece) {
+        const size_t n = std::min(piece, samples - at);
+        HIP_TRY(ctx, hipMemcpyAsync(d_l, left[0] + at, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_r, right[0] + at, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        for (int g = 1; g < n_shards; g++) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_p, left[g] + at, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, gdg_launch_accumulate(d_l, d_p, (int)n, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(d_p, right[g] + at, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, gdg_launch_accumulate(d_r, d_p, (int)n, ctx->stream));
+        }
+        if (aux) {                                                               /* spatializer.go:300-310 */
+            HIP_TRY(ctx, hipMemcpyAsync(d_p, aux + at, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, gdg_launch_add_aux(d_l, d_r, d_p, (int)n, ctx->stream));
+        }
+        if (run_meters) {
+            for (size_t o = 0; o < n; o += GDG_BLOCK_SIZE)                       /* block by block, like the loop that fed the other ports */
+                if ((rc = meter_rows(ctx, d_l + o, piece, ctx->n_meter - 2, 2, (int)std::min((size_t)GDG_BLOCK_SIZE, n - o), sample_rate)) != GDG_OK) return rc;
+        }
+        HIP_TRY(ctx, gdg_launch_wave_encode(out_format, d_l, n, 1, d_enc, ctx->stream));
+        HIP_TRY(ctx, gdg_launch_wave_encode(out_format, d_r, n, 1, d_enc + piece * (size_t)width, ctx->stream));
+        if (left_bytes) HIP_TRY(ctx, hipMemcpyAsync(static_cast<unsigned char *>(left_bytes) + at * width, d_enc, n * width, hipMemcpyDeviceToHost, ctx->stream));
+        if (right_bytes) HIP_TRY(ctx, hipMemcpyAsync(static_cast<unsigned char *>(right_bytes) + at * width, d_enc + piece * (size_t)width, n * width, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return GDG_OK;
 }
 
 }  /* extern "C" */

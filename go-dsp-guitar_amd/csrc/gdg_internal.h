@@ -170,6 +170,8 @@ hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, doub
 struct gdg_meter_rec { double current, peak; unsigned long long counter; int enabled, pad; };
 hipError_t gdg_launch_wave_decode(int fmt, const void *d_bytes, size_t per, unsigned channels, double *d_out, hipStream_t s);
 hipError_t gdg_launch_wave_encode(int fmt, const double *d_in, size_t per, unsigned channels, void *d_bytes, hipStream_t s);
+/* rows of one strided array -> compact encoded rows (row_len % 4 == 0) */
+hipError_t gdg_launch_wave_encode_rows(int fmt, const double *d_in, size_t row_stride, size_t row_len, unsigned n_rows, void *d_bytes, hipStream_t s);
 /* many mono pieces in one launch (the batch run's streamed upload): piece r = `count` samples of format `fmt` at `src` -> dst */
 struct gdg_decode_row { const unsigned char *src; double *dst; unsigned count; int fmt; };
 hipError_t gdg_launch_wave_decode_rows(const gdg_decode_row *d_rows, int n_rows, unsigned max_count, hipStream_t s);
@@ -179,6 +181,7 @@ hipError_t gdg_launch_meter(const double *d_rows, size_t stride, int n_ports, in
 
 /* dst_a[i] += src[i]; dst_b[i] += src[i]  (the aux input of the spatializer, spatializer.go:300-310) */
 hipError_t gdg_launch_add_aux(double *d_a, double *d_b, const double *d_src, int n, hipStream_t s);
+hipError_t gdg_launch_accumulate(double *d_dst, const double *d_src, int n, hipStream_t s);      /* dst[i] += src[i] */
 hipError_t gdg_launch_metronome(const double *d_tick, unsigned n_tick, const double *d_tock, unsigned n_tock, double *d_out, int n,
                                 unsigned sc0, unsigned tc0, unsigned spb, unsigned beats, unsigned j0, hipStream_t s);
 

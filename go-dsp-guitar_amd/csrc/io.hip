@@ -254,6 +254,17 @@ hipError_t gdg_launch_add_aux(double *d_a, double *d_b, const double *d_src, int
     return hipGetLastError();
 }
 
+/* dst[i] += src[i]: the shards' partial master sums, added in shard order (gdg_batch_finish_master) */
+__global__ void __launch_bounds__(256) accumulate_kernel(double *__restrict__ dst, const double *__restrict__ src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+hipError_t gdg_launch_accumulate(double *d_dst, const double *d_src, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    accumulate_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_dst, d_src, n);
+    return hipGetLastError();
+}
+
 hipError_t gdg_launch_metronome(const double *d_tick, unsigned n_tick, const double *d_tock, unsigned n_tock, double *d_out, int n,
                                 unsigned sc0, unsigned tc0, unsigned spb, unsigned beats, unsigned j0, hipStream_t s) {
     if (n <= 0) return hipSuccess;
@@ -455,6 +466,59 @@ hipError_t gdg_launch_wave_encode(int fmt, const double *d_in, size_t per, unsig
     case GDG_FMT_LPCM32: launch_encode<GDG_FMT_LPCM32>(d_in, per, channels, p, s); break;
     case GDG_FMT_IEEE32: launch_encode<GDG_FMT_IEEE32>(d_in, per, channels, p, s); break;
     case GDG_FMT_IEEE64: launch_encode<GDG_FMT_IEEE64>(d_in, per, channels, p, s); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+/* n_rows rows of row_len samples each, row r at d_in + r * row_stride, encoded into COMPACT rows of row_len * width bytes: the batch
+ * run's window keeps one row stride for every step (full windows and the tail), so one plan serves the whole batch; blockIdx.y = row.
+ * row_len a multiple of 4, rows 16-byte aligned (the batch run's rows are multiples of 8192 samples). */
+template <int FMT>
+__global__ void __launch_bounds__(256)
+wave_encode4_rows_kernel(const double *__restrict__ in, size_t row_stride, size_t groups_per_row, unsigned *__restrict__ words) {
+    constexpr int W = fmt_width<FMT>::W;
+    const v2d *row = reinterpret_cast<const v2d *>(in + (size_t)blockIdx.y * row_stride);
+    unsigned *dst = words + (size_t)blockIdx.y * groups_per_row * W;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < groups_per_row; g += (size_t)gridDim.x * 256) {
+        v2d a = __builtin_nontemporal_load(row + 2 * g), b = __builtin_nontemporal_load(row + 2 * g + 1);
+        double r[4] = { a.x, a.y, b.x, b.y };
+        unsigned w[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) w[k] = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            unsigned code = encode_code<FMT>(r[s]);
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                int byte = s * W + k;
+                w[byte >> 2] |= ((code >> (8 * k)) & 0xffu) << ((byte & 3) * 8);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; k++) __builtin_nontemporal_store(w[k], dst + g * W + k);
+    }
+}
+
+template <int FMT>
+static void launch_encode_rows(const double *d_in, size_t row_stride, size_t row_len, unsigned n_rows, unsigned char *p, hipStream_t s) {
+    size_t groups = row_len / 4;
+    unsigned tiles = (unsigned)((groups + 255) / 256);
+    wave_encode4_rows_kernel<FMT><<<dim3(tiles, n_rows), dim3(256), 0, s>>>(d_in, row_stride, groups, reinterpret_cast<unsigned *>(p));
+}
+
+hipError_t gdg_launch_wave_encode_rows(int fmt, const double *d_in, size_t row_stride, size_t row_len, unsigned n_rows, void *d_bytes, hipStream_t s) {
+    if (n_rows == 0 || row_len == 0) return hipSuccess;
+    if ((row_len & 3) || (row_stride & 1) || ((uintptr_t)d_in & 15) || ((uintptr_t)d_bytes & 3)) return hipErrorInvalidValue;
+    unsigned char *p = static_cast<unsigned char *>(d_bytes);
+    switch (fmt) {
+    case GDG_FMT_LPCM8: launch_encode_rows<GDG_FMT_LPCM8>(d_in, row_stride, row_len, n_rows, p, s); break;
+    case GDG_FMT_LPCM16: launch_encode_rows<GDG_FMT_LPCM16>(d_in, row_stride, row_len, n_rows, p, s); break;
+    case GDG_FMT_LPCM24: launch_encode_rows<GDG_FMT_LPCM24>(d_in, row_stride, row_len, n_rows, p, s); break;
+    case GDG_FMT_LPCM32: launch_encode_rows<GDG_FMT_LPCM32>(d_in, row_stride, row_len, n_rows, p, s); break;
+    case GDG_FMT_IEEE32: launch_encode_rows<GDG_FMT_IEEE32>(d_in, row_stride, row_len, n_rows, p, s); break;
+    case GDG_FMT_IEEE64:                                       /* wave.go:694-709: the sample's bytes, no clipping */
+        return hipMemcpy2DAsync(p, row_len * sizeof(double), d_in, row_stride * sizeof(double), row_len * sizeof(double), n_rows, hipMemcpyDeviceToDevice, s);
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

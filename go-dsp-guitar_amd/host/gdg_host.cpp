@@ -891,7 +891,13 @@ void Spatializer::Process(const double *const *inputBuffers, const double *auxIn
     auto one = [&](int g) {
         int first = 0, count = 0;
         engine_->shardRange(g, &first, &count);
-        if (count <= 0 || (uint32_t)first >= inputCount_) return;
+        if (count <= 0) return;
+        /* gdg_spatialize reads `count` row pointers: a spatializer with fewer inputs than the engine has channels cannot feed this
+         * shard (the reference creates it with the engine's channel count, controller.go:3281-3287) */
+        if ((uint64_t)first + (uint64_t)count > (uint64_t)inputCount_) {
+            engine_->setError(format("spatializer with %u inputs cannot feed shard %d (channels %d to %d)", inputCount_, g, first, first + count - 1));
+            return;
+        }
         std::lock_guard<std::mutex> lk(engine_->shardMutex(g));
         gdg_ctx *ctx = engine_->context(g);
         if (!ctx) return;
@@ -899,7 +905,11 @@ void Spatializer::Process(const double *const *inputBuffers, const double *auxIn
         int rc;
         if (reuseChainOutputs) rc = gdg_spatialize_staged(ctx, 1, pl, pr, (int)n);
         else rc = gdg_spatialize(ctx, inputBuffers + first, pl, pr, (int)n);
-        if (rc != GDG_OK) { std::fill(pl, pl + n, 0.0); std::fill(pr, pr + n, 0.0); }
+        if (rc != GDG_OK) {
+            engine_->setError(format("spatializer, shard %d: %s", g, gdg_last_error(ctx)));
+            std::fill(pl, pl + n, 0.0);
+            std::fill(pr, pr + n, 0.0);
+        }
     };
     for (int g = 1; g < G; g++) workers.emplace_back(one, g);
     one(0);

@@ -205,6 +205,7 @@ public:
     void shardRange(int shard, int *first, int *count) const;
     gdg_ctx *context(int shard = 0);                       /* creates the device context on first use */
     std::mutex &shardMutex(int shard);                     /* a context takes one call at a time (include/gdg.h) */
+    void setError(const Error &e);                         /* what lastError() returns; also used by the spatializer / tuner twins for per-shard failures */
 
 private:
     friend class signal::Chain;
@@ -214,7 +215,6 @@ private:
     void runBatch(std::vector<Pending> batch);
     Error runShard(int shard, std::vector<Pending> &group, int frames, uint32_t sampleRate);
     Error sync(int shard, const std::vector<signal::Chain *> &chains, uint32_t sampleRate);
-    void setError(const Error &e);
     int nChannels_, maxFrames_;
     std::vector<std::unique_ptr<Shard>> shards_;
     std::vector<std::shared_ptr<signal::Chain>> chains_;

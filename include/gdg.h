@@ -172,12 +172,14 @@ int gdg_process_device(gdg_ctx *ctx, const double *d_in, double *d_out, int fram
  */
 int gdg_ctx_set_window(gdg_ctx *ctx, int frames_per_call);
 /*
- * Channel groups of the device-resident calls (gdg_process_device, gdg_process_window_device): the channels are cut into `groups`
- * contiguous groups whose kernels run on streams of their own and are NOT joined at the end of the call, so one group's
- * latency-bound segment kernel overlaps another group's HBM-bound convolution, also across calls.  The context's stream is ordered
- * after them by the next library call of any other kind (including gdg_ctx_stream() and gdg_ctx_synchronize()): fetch the stream
- * AFTER the process call if you enqueue your own work behind it.  0 = automatic (two groups from 384 channels on, else one; env
- * GDG_DEVICE_GROUPS overrides), 1 = off.
+ * Channel groups of the device-resident calls (gdg_process_device, gdg_process_window_device) -- OPT-IN.  By default every call's
+ * kernels run on gdg_ctx_stream(): work a caller enqueues on that stream after the call is ordered after them.  With groups > 1 the
+ * channels are cut into `groups` contiguous groups whose kernels run on streams of their own and are NOT joined at the end of the
+ * call, so one group's latency-bound segment kernel overlaps another group's HBM-bound convolution, also across calls (+7-10 % at 512
+ * channels with two groups).  The price is the ordering contract: the context's stream is ordered after the groups only by the next
+ * library call of any other kind (including gdg_ctx_stream() and gdg_ctx_synchronize()) -- fetch the stream AFTER the process call if
+ * you enqueue your own work behind it.  groups: 1 ... 16; 0 = back to the default (one group, unless env GDG_DEVICE_GROUPS names a
+ * count).
  */
 int gdg_ctx_set_overlap(gdg_ctx *ctx, int groups);
 int gdg_process_window_device(gdg_ctx *ctx, const double *d_in, double *d_out, size_t row_stride, int frames_in_window, uint32_t sample_rate);
@@ -220,6 +222,10 @@ enum gdg_kernel_kind {
 /* enable == 1: bracket every kernel launch with a HIP event pair from now on (costs a few microseconds per launch);
  * enable == 1 << (kind + 1) (or-able): only the launches of those kernel kinds; 0: off. */
 int gdg_profile_enable(gdg_ctx *ctx, int enable);
+/* Bracket only every `every`-th process call (gdg_process_device / _window_device / host-buffer calls) while profiling is on: an event
+ * pair costs a few microseconds AND keeps the bracketed kernel from overlapping its neighbours' ramp-up and tail, which is 5 % of a
+ * 0.6 ms step when the dominant kernel of every step is bracketed.  1 = every call (default). */
+int gdg_profile_sample(gdg_ctx *ctx, int every);
 /* Drain the recorded pairs: total milliseconds and launch count of one kernel kind; resets it. */
 int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches);
 
@@ -339,6 +345,34 @@ int gdg_batch_length(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, 
  * are whatever was configured on the context; their state carries on from earlier calls, like the reference's.
  */
 int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *options, void *const *out_bytes);
+/*
+ * The batch run of ONE SHARD of a job whose channels are split over several contexts / GPUs (contiguous channel blocks,
+ * no collective).  The master mix is the sum over ALL channels, then the aux input, then the encoder's clip
+ * (spatializer/spatializer.go:300-310, controller/controller.go:3123-3219); encoding a shard's partial mix would clip and truncate
+ * before the sum.  So a shard hands out its partial sums as float64 and the caller finishes the master on any one context:
+ *   for every shard g (in parallel, one context each):  gdg_batch_run_shard(ctx_g, inputs of g's channels, ..., out_bytes_g, &shard_g)
+ *   then once:  gdg_batch_finish_master(ctx_0, fmt, {left_g}, {right_g}, G, aux, samples, rate, meters, master_left, master_right)
+ * gdg_batch_run_shard = gdg_batch_run except: out_bytes holds the shard's n_inputs chain outputs only; master_left / master_right
+ * receive gdg_batch_length() float64 samples each (this shard's channels mixed, NO aux, not clipped); the metronome runs on the
+ * shard that passes metronome_bytes (its encoded track, the N + 3rd file) and / or metronome (the float64 track = the master's aux
+ * input when metrMasterOutput is set) -- exactly one shard should; with run_meters the context carries 2 n + 3 ports of which a
+ * shard feeds its inputs, its outputs and, if it runs it, the metronome.
+ * gdg_batch_finish_master: master = ((p_0 + p_1) + ... + p_{G-1}) + aux per side, summed and encoded on ctx's device (aux may be
+ * NULL; left_bytes / right_bytes NULL = "skipping output"); run_meters != 0 feeds the two LAST ports of ctx's meters with the
+ * finished master, block by block.
+ */
+typedef struct {
+    double *master_left, *master_right;   /* host, gdg_batch_length() float64 each */
+    void *metronome_bytes;                /* host, gdg_batch_length() encoded samples, or NULL */
+    double *metronome;                    /* host, gdg_batch_length() float64, or NULL */
+    size_t job_samples;                   /* samples of every output of the JOB (the longest gdg_batch_length over the shards: the
+                                           * reference pads every channel to the longest input, controller.go:3005-3045); 0 = this
+                                           * shard's own length */
+} gdg_batch_shard_out;
+int gdg_batch_run_shard(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *options, void *const *out_bytes,
+                        const gdg_batch_shard_out *shard);
+int gdg_batch_finish_master(gdg_ctx *ctx, int out_format, const double *const *left, const double *const *right, int n_shards, const double *aux,
+                            size_t samples, uint32_t sample_rate, int run_meters, void *left_bytes, void *right_bytes);
 /* The device buffers of a batch run (the decoded inputs are the large part: N x length x 8 bytes) stay with the context for the next
  * run of the same or a smaller size; this frees them. */
 int gdg_batch_release(gdg_ctx *ctx);

@@ -7,32 +7,29 @@ import __graft_entry__ as entry
 TOL_RMS = 1e-9          # north_star: output matches the float64 reference within 1e-9 RMS
 
 
+def _synth():
+    import importlib
+    entry.load_package()
+    return importlib.import_module("go_dsp_guitar_amd.synth")
+
+
 def lcg_floats(seed, n):
-    """random/random.go LCG, vectorised: x0 = (64979 seed + 83) mod (2^31-1); x <- 16807 x mod (2^31-1)."""
-    mod = (1 << 31) - 1
-    x = (64979 * seed + 83) % mod
-    out = np.empty(n)
-    for i in range(n):
-        x = (16807 * x) % mod
-        out[i] = x / (mod - 1)
-    return out
+    """random/random.go LCG (go-dsp-guitar_amd/synth.py; known answers: tests/test_synth.py)."""
+    return _synth().lcg_floats(seed, n)
 
 
 def synth_signal(channel, n, sample_rate, seed_base=1337):
-    """x_c[n] = 0.5 sin(2 pi f_c n/sr) + 0.25 sin(2 pi 3 f_c n/sr) + 0.05 u_c[n], f_c = 82.4069 * 2^((c mod 48)/12)."""
+    """x_c[n] = 0.5 sin(2 pi f_c n/sr) + 0.25 sin(2 pi 3 f_c n/sr) + 0.05 u_c[n], f_c = 82.4069 * 2^((c mod 48)/12), u_c = the
+    reference LCG seeded seed_base + c."""
     f = 82.4069 * 2.0 ** ((channel % 48) / 12.0)
     t = np.arange(n) / float(sample_rate)
-    rng = np.random.default_rng(seed_base + channel)
-    u = 1.0 - 2.0 * rng.random(n)
+    u = 1.0 - 2.0 * lcg_floats(seed_base + channel, n)
     return 0.5 * np.sin(2 * np.pi * f * t) + 0.25 * np.sin(2 * np.pi * 3 * f * t) + 0.05 * u
 
 
 def synth_ir(n_taps, seed=4242):
-    """h[k] = (1 - 2 r_k) exp(-6.9 k / L), scaled to unit energy (Normalize with 0 dB compensation)."""
-    rng = np.random.default_rng(seed)
-    k = np.arange(n_taps)
-    h = (1.0 - 2.0 * rng.random(n_taps)) * np.exp(-6.9 * k / float(n_taps))
-    return h / np.sqrt(np.sum(h * h))
+    """h[k] = (1 - 2 r_k) exp(-6.9 k / L), r = the reference LCG, scaled to unit energy (Normalize with 0 dB compensation)."""
+    return _synth().synth_ir(n_taps, seed)
 
 
 def rms(a):

@@ -154,11 +154,10 @@ def _interleave(rows):
     return np.ascontiguousarray(np.stack(rows, axis=1)).reshape(-1)
 
 
-def test_batch_run_one_call_matches_oracle(oracle):
-    """gdg_batch_run: the same batch in ONE call of the C-ABI (controller.go:2809-3219): a stereo file whose second channel is
-    taken and whose rate already is the target (no resampling, :2993), an empty input (:2935), inputs at two other rates, the
-    metronome in the master mix (metrMasterOutput), meters on, tuner fed."""
-    pkg = package()
+def _batch_case(oracle, pkg):
+    """A small batch with every special case of controller.processFiles (controller.go:2809-3219) and its oracle result: a stereo file
+    whose second channel is taken and whose rate already is the target (no resampling, :2993), an empty input (:2935), inputs at two
+    other rates, the metronome in the master mix (metrMasterOutput), meters on, tuner fed."""
     rate, nch = 48000, 5
     rng = np.random.default_rng(11)
     irs = [synth_ir(2000, seed=40 + c) for c in range(nch)]
@@ -212,22 +211,33 @@ def test_batch_run_one_call_matches_oracle(oracle):
         for m, r in zip(ref_meters, rows):
             m.process(r, rate)
 
-    # ---- device: one call -------------------------------------------------------------------------------------------------
-    def configured():
-        ctx = pkg.Context(nch, BLOCK)
-        for c in range(nch):
+    def configured(first=0, count=nch):
+        """a context carrying channels first .. first + count - 1 of the job (the whole job by default)"""
+        ctx = pkg.Context(count, BLOCK)
+        for c in range(count):
             for name, p in CHAIN:
-                ctx.append_unit(c, name, fir=irs[c]) if p == "ir" else ctx.append_unit(c, name, params=p)
+                ctx.append_unit(c, name, fir=irs[first + c]) if p == "ir" else ctx.append_unit(c, name, params=p)
         ctx.spatializer_set_sample_rate(rate)
-        for c, (a, d, l) in enumerate(positions):
-            ctx.spatializer_set_position(c, a, d, l)
+        for c in range(count):
+            ctx.spatializer_set_position(c, *positions[first + c])
         ctx.metronome_set_sounds(tick, tock)
         ctx.metronome_configure(3, 200, rate)
-        ctx.meter_configure(ports)
+        ctx.meter_configure(2 * count + 3)
         ctx.meter_set_enabled(True)
         return ctx
 
     assert length == 9 * BLOCK
+    from types import SimpleNamespace
+    return SimpleNamespace(rate=rate, nch=nch, inputs=inputs, length=length, ref_out=ref_out, ref_meters=ref_meters, ref_tuners=ref_tuners,
+                           configured=configured)
+
+
+def test_batch_run_one_call_matches_oracle(oracle):
+    """gdg_batch_run: the batch of _batch_case in ONE call of the C-ABI."""
+    pkg = package()
+    case = _batch_case(oracle, pkg)
+    rate, nch, inputs, length, ref_out, ref_meters, ref_tuners, configured = (case.rate, case.nch, case.inputs, case.length, case.ref_out,
+                                                                              case.ref_meters, case.ref_tuners, case.configured)
     # W: frames per step (time blocking, gdg_ctx_set_window): 9 blocks = 8 + 1 at W = 8, 2 + 2 + 2 + 2 + 1 at W = 2
     for out_fmt, W in (("ieee64", 1), ("lpcm24", 8), ("ieee64", 2)):
         ctx = configured()
@@ -254,6 +264,77 @@ def test_batch_run_one_call_matches_oracle(oracle):
                 assert np.isnan(tuned[c]["frequency"])
             else:
                 assert abs(tuned[c]["frequency"] - want["frequency"]) <= 1e-9 * max(1.0, abs(want["frequency"]))
+
+
+@pytest.mark.parametrize("W", [1, 4])
+def test_batch_run_sharded_over_three_contexts_matches_oracle(oracle, W):
+    """The same job split over THREE contexts in contiguous channel blocks (here all on one GPU): every shard runs
+    gdg_batch_run_shard on its channels -- in windows of W frames -- and hands out its PARTIAL master mix as float64; the master is
+    finished once (gdg_batch_finish_master): shard partials added in shard order, then the metronome as the aux input, then the
+    encoder with its clip -- spatializer/spatializer.go:300-310, controller/controller.go:3123-3219.  Encoding each shard's partial
+    mix instead would clip and truncate before the sum."""
+    import importlib
+    pkg = package()
+    shard = importlib.import_module("go_dsp_guitar_amd.shard")
+    case = _batch_case(oracle, pkg)
+    rate, nch, length, ref_out = case.rate, case.nch, case.length, case.ref_out
+    G = 3
+    blocks = [shard.channel_shard(nch, G, g) for g in range(G)]
+    assert [b[1] for b in blocks] == [1, 2, 2]
+    ctxs = [case.configured(first, count) for first, count in blocks]
+    for ctx in ctxs:
+        ctx.set_window(W)
+    job = max(ctx.batch_length(case.inputs[f:f + n], rate) for ctx, (f, n) in zip(ctxs, blocks))
+    assert job == length
+    for out_fmt in ("lpcm24", "ieee64"):
+        if out_fmt == "ieee64":                      # a second job on fresh state
+            for ctx in ctxs:
+                ctx.close()
+            ctxs = [case.configured(first, count) for first, count in blocks]
+            for ctx in ctxs:
+                ctx.set_window(W)
+        lefts, rights, outs, metro_bytes, metro = [], [], [], None, None
+        for g, (ctx, (first, count)) in enumerate(zip(ctxs, blocks)):
+            o, l, r, mb, mf = ctx.batch_run_shard(case.inputs[first:first + count], rate, out_fmt, job_samples=job, metronome=(g == 0),
+                                                  run_meters=True, tuner_enqueue=True)
+            outs += o
+            lefts.append(l)
+            rights.append(r)
+            if g == 0:
+                metro_bytes, metro = mb, mf
+        ml, mr = ctxs[0].batch_finish_master(out_fmt, lefts, rights, aux=metro, sample_rate=rate, run_meters=True)
+        got = outs + [ml, mr, metro_bytes]
+        for r in range(nch + 3):
+            want = oracle.wave_encode(out_fmt, ref_out[r])
+            assert got[r].size == want.size
+            if out_fmt == "ieee64":
+                err = rms(got[r].view(np.float64) - ref_out[r])
+                assert err <= TOL_RMS, "output %d: RMS %.3e" % (r, err)
+            else:
+                np.testing.assert_array_equal(got[r], want, err_msg="output %d" % r)
+        # a partial mix is NOT the master: the shards' partial sums add up to the mix before the aux input
+        assert rms(sum(lefts) + metro - ref_out[nch]) <= TOL_RMS and rms(sum(rights) + metro - ref_out[nch + 1]) <= TOL_RMS
+        if out_fmt == "lpcm24":
+            # meters: every shard fed its inputs and outputs, shard 0 the metronome, the finishing context the master
+            for g, (ctx, (first, count)) in enumerate(zip(ctxs, blocks)):
+                lv, pk = ctx.meter_analyze()
+                for c in range(count):
+                    assert (lv[c], pk[c]) == case.ref_meters[first + c].analyze(), "input meter of channel %d" % (first + c)
+                    assert (lv[count + c], pk[count + c]) == case.ref_meters[nch + first + c].analyze(), "output meter of channel %d" % (first + c)
+                if g == 0:
+                    assert (lv[2 * count], pk[2 * count]) == case.ref_meters[2 * nch].analyze(), "metronome meter"
+                    for k in (1, 2):
+                        assert (lv[2 * count + k], pk[2 * count + k]) == case.ref_meters[2 * nch + k].analyze(), "master meter %d" % k
+            for g, (ctx, (first, count)) in enumerate(zip(ctxs, blocks)):
+                tuned = ctx.tuner_analyze()
+                for c in range(count):
+                    want = case.ref_tuners[first + c].analyze()
+                    assert tuned[c]["note_index"] == want["note_index"] and tuned[c]["cents"] == want["cents"]
+    # rejections
+    with pytest.raises(pkg.GdgError, match="at least this shard's"):
+        ctxs[1].batch_run_shard(case.inputs[1:3], rate, "lpcm16", job_samples=BLOCK)
+    for ctx in ctxs:
+        ctx.close()
 
 
 def test_batch_run_rejections_and_empty_batch():

@@ -115,6 +115,109 @@ def test_config4_time_blocked_windows_at_full_size(pkg, oracle):
     ctx1.close()
 
 
+def build_private(pkg, oracle, nch, frames, taps, channel0, followed):
+    """bench.py's headline context: every channel its OWN pair of 65536-tap IRs (d = 1: private spectra, 2.3 GiB of state at
+    512 channels), seeded by GLOBAL channel number like bench.py (go-dsp-guitar_amd/synth.py)."""
+    import importlib
+    synth = importlib.import_module("go_dsp_guitar_amd.synth")
+    ctx = pkg.Context(nch, frames)
+    pairs = {}
+    for c in range(nch):
+        g = channel0 + c
+        cab, rev = synth.synth_ir(taps, synth.ir_seed("cab", g)), synth.synth_ir(taps, synth.ir_seed("rev", g))
+        if c in followed:
+            p = ChainPair(ctx, c, oracle)
+            full_chain(p, 0, cab, rev)
+            pairs[c] = p
+        else:
+            for name, params, fir in (("compressor", [1, 30, -20], None), ("overdrive", [0, 20, 100, 0, 1, 0], None), ("tone_stack", None, None),
+                                      ("chorus", None, None), ("power_amp", None, cab), ("power_amp", None, rev), ("cabinet", None, None),
+                                      ("reverb", [50], None)):
+                ctx.append_unit(c, name, params=params, fir=fir)
+    return ctx, pairs
+
+
+@pytest.mark.parametrize("nch,channel0,groups", [(512, 0, 2), (64, 448, 1)], ids=["headline_512ch_fused_private_spectra", "per_gpu_shard_64ch_split_mac"])
+def test_config4_private_irs_device_calls_follow_the_oracle(pkg, oracle, nch, channel0, groups):
+    """The EXACT launch shapes bench.py times, followed by the oracle at full size:
+      * 512 channels, d = 1: `fir_inv_kernel<13, 1>` (multiply-accumulate fused into the inverse transform, private spectra through
+        non-temporal loads), two free-running channel groups, device-resident per-frame calls -- the headline;
+      * 64 channels (the last shard of the 512-channel job over 8 GPUs, BASELINE config 4's per-GPU shape): the split path,
+        `fir_mac_kernel` (bin-tiled) + `fir_inv_kernel<13, 0>`.
+    16 blocks, so the whole 8-partition delay line is live and wraps; a second context runs the same stream as ONE window of 16
+    frames (`fir_mac_tb_kernel<16, 8>` on private spectra) and must give the same bits; the oracle follows the first, a middle and
+    the last channel of the context over all 16 blocks."""
+    import importlib
+    synth = importlib.import_module("go_dsp_guitar_amd.synth")
+    frames, sr, taps, blocks, W = 8192, 192000, 65536, 16, 16
+    followed = {0, nch // 2 - 1, nch - 1}
+    ctx, pairs = build_private(pkg, oracle, nch, frames, taps, channel0, followed)
+    ctxw, _ = build_private(pkg, oracle, nch, frames, taps, channel0, set())
+    ctx.set_overlap(groups)
+    ctxw.set_window(W)
+    x = synth.synth_rows(nch, frames * blocks, sr, channel0=channel0)
+    d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
+    got = np.empty_like(x)
+    for b in range(blocks):
+        d_in.upload(np.ascontiguousarray(x[:, b * frames:(b + 1) * frames]))
+        ctx.process_device(d_in, d_out, frames, sr)
+        got[:, b * frames:(b + 1) * frames] = d_out.download()
+    assert np.isfinite(got).all()
+    w_in, w_out = ctxw.alloc(nch, blocks * frames), ctxw.alloc(nch, blocks * frames)
+    w_in.upload(x)
+    ctxw.process_window_device(w_in.ptr, w_out.ptr, blocks * frames, W, sr)
+    gotw = w_out.download()
+    assert np.array_equal(got, gotw), float(np.max(np.abs(got - gotw)))
+    # every channel has its own filters and its own noise: no two rows coincide
+    assert len({hashlib.sha256(np.ascontiguousarray(r).tobytes()).digest() for r in got}) == nch
+    for c, p in pairs.items():
+        want = np.concatenate([p.ref.process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+        err = rms(got[c] - want)
+        assert err <= TOL_RMS, (c, err)
+    for b in (d_in, d_out, w_in, w_out):
+        b.free()
+    ctx.close()
+    ctxw.close()
+
+
+def test_small_context_right_after_a_large_one_is_released(pkg):
+    """a 64-channel context created right after a ~15 GB 512-channel context was destroyed ran 26-36x slow in two bench
+    runs (never reproduced since, 12 attempts in round 3).  gdg_ctx_destroy must leave the device quiet: the large context's state
+    comes out of a few arena chunks (released in milliseconds), and a fresh small context steps at its normal rate at once -- no
+    repetition of 30 steps may take more than 3x the median."""
+    import time
+    import importlib
+    synth = importlib.import_module("go_dsp_guitar_amd.synth")
+    frames, sr, taps = 8192, 192000, 65536
+    big, _ = build_private(pkg, None, 512, frames, taps, 0, set())
+    big.set_window(16)
+    d_in, d_out = big.alloc(512, 16 * frames), big.alloc(512, 16 * frames)
+    d_in.upload(np.tile(synth.synth_rows(512, frames, sr), (1, 16)))
+    big.process_window_device(d_in.ptr, d_out.ptr, 16 * frames, 16, sr)
+    big.synchronize()
+    t0 = time.perf_counter()
+    big.close()                                             # frees d_in / d_out too (the context owns what gdg_device_alloc handed out)
+    t_close = time.perf_counter() - t0
+    small, _ = build_private(pkg, None, 64, frames, taps, 0, set())
+    s_in, s_out = small.alloc(64, frames), small.alloc(64, frames)
+    s_in.upload(synth.synth_rows(64, frames, sr))
+    for _ in range(3):
+        small.process_device(s_in, s_out, frames, sr)
+    small.synchronize()
+    reps = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        for _ in range(30):
+            small.process_device(s_in, s_out, frames, sr)
+        small.synchronize()
+        reps.append((time.perf_counter() - t0) / 30)
+    small.close()
+    med = sorted(reps)[len(reps) // 2]
+    assert t_close < 0.5, "destroying the large context took %.0f ms" % (t_close * 1e3)
+    assert max(reps) <= 3.0 * med, ["%.0f us" % (t * 1e6) for t in reps]
+    assert med < 1e-3, "64 channels: %.0f us per step" % (med * 1e6)
+
+
 def test_config4_convolution_is_linear_at_full_size(pkg):
     nch, frames, sr, taps, blocks = 512, 8192, 192000, 65536, 10            # 10 blocks: the whole 8-partition delay line is live
     irs = [synth_ir(taps, seed=777 + i) * 0.05 for i in range(4)]           # small gain: the output clip stays inactive
