@@ -367,7 +367,7 @@ class Context:
     def fft_real(self, x):
         """fft.RealFourier: n reals -> n / 2 + 1 complex bins."""
         x = _f64(x)
-        out = np.empty(x.size + 2, dtype=np.float64)
+        out = np.empty(2 * (x.size // 2 + 1), dtype=np.float64)
         self._check(lib().gdg_fft_real(self._h, x.ctypes.data, x.size, out.ctypes.data))
         return out.view(np.complex128)
 

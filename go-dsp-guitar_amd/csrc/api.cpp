@@ -19,7 +19,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <memory>
 #include <map>
 #include <string>
@@ -155,6 +157,8 @@ struct StepDesc {
     int n;
     size_t offset;                    /* byte offset of its descriptor array inside the plan blob */
     bool shared_spectra = false;      /* FIR step: some channels read the same IR spectra */
+    bool chain_next = false;          /* FIR step whose every channel feeds another power amp next (the following step): that amp's forward
+                                       * transform rides on this step's inverse (fir_inv_kernel CHAIN) in per-frame calls */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
 
@@ -190,6 +194,7 @@ struct gdg_ctx {
     int stage_out_frames = 0;         /* ... of this many frames per row */
     int *d_error = nullptr;
     DevArena arena;                   /* per-unit state (see DevArena) */
+    std::map<std::vector<double>, double *> scan_tabs;     /* scan tables by their coefficients: one copy per distinct set (scan_tables) */
     std::vector<void *> user_allocs;  /* gdg_device_alloc blocks the caller has not freed (released with the context) */
     /* tables */
     std::map<int, std::pair<double2 *, double2 *>> fir_tables;
@@ -201,6 +206,7 @@ struct gdg_ctx {
      * GDG_FIR_FUSED=0 / 1 forces one shape (A/B measurements). */
     int fir_fused = -1;
     int fir_split_max = 96;           /* GDG_FIR_SPLIT_MAX: largest launch (channels) that takes the split shape */
+    bool fir_chain = true;            /* GDG_FIR_CHAIN=0: adjacent power amps keep separate launches (A/B measurements, bit-identity tests) */
     double *d_os = nullptr;
     gdg_os_tables os;
     /* profiling */
@@ -246,6 +252,7 @@ struct gdg_ctx {
     /* channel groups of the host-buffer paths: group g's upload, kernels and download run on stream g, so one group's
      * PCIe transfers overlap the other groups' kernels (channels are independent) */
     int plan_groups = 1;
+    std::vector<size_t> plan_bounds;           /* first active index of every channel group (+ the end) the plan was built for */
     int overlap_groups = 0;                    /* 0: automatic (device_groups) */
     bool groups_pending = false;               /* group streams hold work the context's stream has not been ordered after */
     std::vector<hipStream_t> gstreams;
@@ -336,6 +343,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     { const char *e = getenv("GDG_SHARE_IR_SPECTRA"); if (e) ctx->share_spectra = atoi(e) != 0; }
     { const char *e = getenv("GDG_FIR_FUSED"); if (e) ctx->fir_fused = atoi(e) != 0 ? 1 : 0; }
     { const char *e = getenv("GDG_FIR_SPLIT_MAX"); if (e) ctx->fir_split_max = atoi(e); }
+    { const char *e = getenv("GDG_FIR_CHAIN"); if (e) ctx->fir_chain = atoi(e) != 0; }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -568,6 +576,72 @@ static int zero_is(gdg_ctx *ctx, Unit &u, int first, int count) {
     return GDG_OK;
 }
 
+/* ---- scan tables of the constant-coefficient recurrences (seg.hip: lin_scan, lin2_scan) ----------------------------------------------
+ * Powers of the 8-sample chunk map of a one-pole section / follower (scalar A = keep^8) or of a high-pass feeding a low-pass (2 x 2
+ * lower-triangular P = M^8), by binary exponentiation in plain FP64 multiplications -- the arithmetic the kernel itself used while
+ * it still built them on every call.  They depend on the coefficients only, i.e. on parameters and the sample rate: built when a plan
+ * is built, one copy in HBM per distinct coefficient set (512 channels with the same tone-stack settings share one). */
+static double pow_u(double A, int e) {
+    double r = 1.0, b = A;
+    for (int k = 0; k < 10; k++) { if (e & (1 << k)) r *= b; b *= b; }
+    return r;
+}
+static void lin_tab_host(bool maxop, double a, double keep, double *tab) {
+    const double k2 = keep * keep, k4 = k2 * k2, A = k4 * k4;
+    for (int lane = 0; lane < 64; lane++) {
+        tab[LT_PC + lane] = pow_u(A, lane);
+        if (lane < 16) tab[LT_PA + lane] = pow_u(A, lane + 1);
+        if (lane >= 32) tab[LT_PB + lane - 32] = pow_u(A, lane - 31);
+        if (lane < 10) tab[LT_ST + lane] = pow_u(A, 1 << lane);
+        if (lane < GDG_CHK) tab[LT_W + lane] = (maxop ? 1.0 : a) * pow_u(keep, GDG_CHK - 1 - lane);
+    }
+}
+struct Tri { double a, b, c; };                                /* [[a, 0], [b, c]] */
+static Tri tri_mul(const Tri &x, const Tri &y) { Tri r = { x.a * y.a, (x.b * y.a) + (x.c * y.b), x.c * y.c }; return r; }
+static Tri tri_pow(Tri M, int e) {
+    Tri r = { 1.0, 0.0, 1.0 };
+    for (int k = 0; k < 10; k++) { if (e & (1 << k)) r = tri_mul(r, M); M = tri_mul(M, M); }
+    return r;
+}
+static void tri_store(double *p, const Tri &t) { p[0] = t.a; p[1] = t.b; p[2] = t.c; }
+/* per sample (h, l) <- M (h, l) + (aH, aL) x, M = [[1-aH, 0], [-aL, 1-aL]] */
+static void lin2_tab_host(double aH, double aL, double *tab) {
+    const Tri M = { 1.0 - aH, -aL, 1.0 - aL };
+    const Tri P = tri_pow(M, GDG_CHK);
+    for (int lane = 0; lane < 64; lane++) {
+        tri_store(tab + L2_PC + 3 * lane, tri_pow(P, lane));
+        if (lane < 16) tri_store(tab + L2_PA + 3 * lane, tri_pow(P, lane + 1));
+        if (lane >= 32) tri_store(tab + L2_PB + 3 * (lane - 32), tri_pow(P, lane - 31));
+        if (lane < 10) tri_store(tab + L2_ST + 3 * lane, tri_pow(P, 1 << lane));
+        if (lane < GDG_CHK) {
+            Tri G = tri_pow(M, GDG_CHK - 1 - lane);
+            tab[L2_W + 2 * lane] = G.a * aH;
+            tab[L2_W + 2 * lane + 1] = (G.b * aH) + (G.c * aL);
+        }
+    }
+}
+/* `tab` built for `key` (a tag + the coefficients): the device copy, made on first use */
+static int scan_tables(gdg_ctx *ctx, const std::vector<double> &key, const std::vector<double> &tab, const double **out) {
+    auto it = ctx->scan_tabs.find(key);
+    if (it == ctx->scan_tabs.end()) {
+        double *d = nullptr;
+        HIP_TRY(ctx, ctx->arena.alloc((void **)&d, tab.size() * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = ctx->scan_tabs.emplace(key, d).first;
+    }
+    *out = it->second;
+    return GDG_OK;
+}
+/* [follower | coupling capacitor] of fuzz / octaver, or the follower alone (compressor): follow 0 = peak (max-affine), 1 = level */
+static int follower_tables(gdg_ctx *ctx, int follow, double d_inv, double d, bool with_cap, const double **out) {
+    std::vector<double> key = { 1.0, (double)follow, d_inv, d, with_cap ? 1.0 : 0.0 };
+    std::vector<double> tab((with_cap ? 2 : 1) * LT_SIZE, 0.0);
+    if (follow == 0) lin_tab_host(true, 0.0, d_inv, tab.data());
+    else lin_tab_host(false, d, d_inv, tab.data());
+    if (with_cap) lin_tab_host(false, d, 1.0 - d, tab.data() + LT_SIZE);
+    return scan_tables(ctx, key, tab, out);
+}
+
 /* Fill the device-side description of one non-FIR unit; (re)build its history for this rate / frame size. */
 static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate, gdg_seg_unit &d) {
     memset(&d, 0, sizeof(d));
@@ -582,6 +656,7 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         d.dp[1] = decibels_to_factor(p[2]);
         d.dp[2] = exp(-20.0 / sr);
         d.dp[3] = 1.0 - d.dp[2];
+        rc = follower_tables(ctx, p[0], d.dp[2], d.dp[3], false, &d.tab);
         break;
     }
     case GDG_UNIT_OVERDRIVE:
@@ -630,12 +705,18 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
             d.dp[4 + j] = 1.0 - exp(m2pi_sr * freqs[j]);
             d.dp[8 + j] = 1.0 - exp(m2pi_sr * freqs[j + 1]);
         }
+        std::vector<double> key = { 2.0 }, tab(4 * L2_SIZE, 0.0);
+        for (int j = 0; j < 4; j++) { key.push_back(d.dp[4 + j]); key.push_back(d.dp[8 + j]); lin2_tab_host(d.dp[4 + j], d.dp[8 + j], tab.data() + j * L2_SIZE); }
+        rc = scan_tables(ctx, key, tab, &d.tab);
         break;
     }
     case GDG_UNIT_CABINET: {
         static const double f[7] = { 300.0, 120.0, 80.0, 3000.0, 4000.0, 5000.0, 6000.0 };
         double m2pi_sr = -GO_MATH_TWO_PI / sr;
         for (int j = 0; j < 7; j++) d.dp[j] = 1.0 - exp(m2pi_sr * f[j]);
+        std::vector<double> key = { 3.0 }, tab(7 * LT_SIZE, 0.0);
+        for (int j = 0; j < 7; j++) { key.push_back(d.dp[j]); lin_tab_host(false, d.dp[j], 1.0 - d.dp[j], tab.data() + j * LT_SIZE); }
+        rc = scan_tables(ctx, key, tab, &d.tab);
         break;
     }
     case GDG_UNIT_CHORUS: {
@@ -751,6 +832,8 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         double inner_rate = (double)((uint32_t)f * sample_rate);
         d.dp[5] = exp(-20.0 / inner_rate);
         d.dp[6] = 1.0 - d.dp[5];
+        rc = follower_tables(ctx, p[0], d.dp[5], d.dp[6], true, &d.tab);
+        if (rc != GDG_OK) return rc;
         if (f > 1) {
             const size_t len2 = 8 + 76, len4 = 8 + 154;
             rc = ensure_hist(ctx, u, len2 + len4, 1);
@@ -802,6 +885,12 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         double m2pi_sr = -GO_MATH_TWO_PI / sr;
         d.dp[0] = 1.0 - exp(m2pi_sr * (double)fa);
         d.dp[1] = 1.0 - exp(m2pi_sr * (double)fb);
+        {
+            std::vector<double> key = { 4.0, d.dp[0], d.dp[1] }, tab(L2_SIZE, 0.0);
+            lin2_tab_host(d.dp[0], d.dp[1], tab.data());
+            rc = scan_tables(ctx, key, tab, &d.tab);
+            if (rc != GDG_OK) return rc;
+        }
         d.jp[0] = half;
         if (u.bp_half_order != half) {
             /* bandpass.go:40-49: both capacitor slices are re-made when the order changes */
@@ -814,6 +903,7 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         for (int i = 0; i < 6; i++) d.dp[i] = decibels_to_factor(p[1 + i]);
         d.dp[6] = exp(-20.0 / sr);
         d.dp[7] = 1.0 - d.dp[6];
+        rc = follower_tables(ctx, p[0], d.dp[6], d.dp[7], true, &d.tab);
         break;
     }
     case GDG_UNIT_NOISEGATE: {
@@ -1047,12 +1137,13 @@ struct Op { bool is_fir; std::vector<int> handles; };
 
 /* `active`: the channels taking part in this call; row i of d_in / d_out belongs to channel active[i] */
 static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
-                      int stride, int stride_out, bool rows_by_channel, int G) {
+                      int stride, int stride_out, bool rows_by_channel, int G, const std::vector<size_t> &bounds) {
     const int nch = ctx->nch;
     join_groups(ctx);                 /* a new plan replaces descriptors (and possibly unit state) the group streams may still be reading */
-    /* channel groups: group of the i-th active channel = floor(i G / |active|), i.e. contiguous runs of `active` */
+    /* channel groups: contiguous runs of `active`, group g = [bounds[g], bounds[g + 1]) (equal shares unless the caller weights them) */
     std::vector<int> group_of((size_t)nch, 0);
-    for (size_t i = 0; i < active.size(); i++) group_of[(size_t)active[i]] = (int)(i * (size_t)G / active.size());
+    for (int g = 0; g < G; g++)
+        for (size_t i = bounds[(size_t)g]; i < bounds[(size_t)g + 1]; i++) group_of[(size_t)active[i]] = g;
     ctx->plan_groups = G;
     /* per channel: ops placed on a common grid of slots: 2k = segment k, 2k+1 = FIR k */
     std::map<int, std::vector<std::pair<int, Op>>> by_slot;           /* slot -> (channel, op) */
@@ -1156,6 +1247,19 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         seg_descs.push_back(sd);
         fir_descs.push_back(fd);
     }
+    /* adjacent power amps (the benchmark chain: cabinet IR, then reverb IR): when EVERY channel of a FIR step hands its frame to the
+     * next FIR step, that step's forward transform is produced by this step's inverse kernel -- no launch, no round trip of the frame */
+    if (ctx->fir_chain && frames == GDG_MAX_FRAMES) {
+        for (size_t i = 0; i + 1 < ctx->steps.size(); i++) {
+            if (!ctx->steps[i].is_fir || !ctx->steps[i + 1].is_fir) continue;
+            auto &a = fir_descs[i], &b = fir_descs[i + 1];
+            bool ok = !a.empty() && a.size() == b.size() && ctx->steps[i].group_range == ctx->steps[i + 1].group_range;
+            for (size_t k = 0; ok && k < a.size(); k++) ok = a[k].dst == b[k].src && !(a[k].flags & GDG_DST_IS_OUTPUT) && a[k].hop == frames && b[k].hop == frames;
+            if (!ok) continue;
+            ctx->steps[i].chain_next = true;
+            for (auto &f : a) f.flags |= GDG_DST_UNUSED;      /* only the chained transform reads the frame (window-mode kernels ignore the flag) */
+        }
+    }
     /* serialise */
     ctx->blob.clear();
     auto append = [&](const void *p, size_t bytes) {
@@ -1250,9 +1354,45 @@ static int check_device_error(gdg_ctx *ctx);
 /* what a host-buffer entry point does around group g's kernels, on group g's stream (upload before, download after) */
 typedef std::function<hipError_t(int g, hipStream_t s)> GroupHook;
 
+/* group g of G over n active channels = [b[g], b[g + 1]): equal shares (first i with floor(i G / n) == g) */
+static std::vector<size_t> equal_group_bounds(size_t n, int G) {
+    std::vector<size_t> b((size_t)G + 1);
+    for (int g = 0; g <= G; g++) b[(size_t)g] = ((size_t)g * n + (size_t)G - 1) / (size_t)G;
+    return b;
+}
+
+/* Groups of the host-buffer calls.  The first group's upload and the last group's download are the two transfers nothing overlaps,
+ * so the outer groups are SMALL and the inner ones large: weights 1 : 2 : 1 ... (env GDG_PCIE_WEIGHTS, e.g. "1,3,3,1", also sets the
+ * group count).  Measured: profiles/host_path_groups_r03.txt. */
+static std::vector<size_t> pcie_group_bounds(size_t n, int *G_io) {
+    static std::vector<int> forced = []() {
+        std::vector<int> w;
+        if (const char *e = getenv("GDG_PCIE_WEIGHTS")) {
+            for (const char *p = e; *p;) { int v = atoi(p); if (v > 0) w.push_back(v); while (*p && *p != ',') p++; if (*p == ',') p++; }
+        }
+        return w;
+    }();
+    int G = *G_io;
+    std::vector<int> w = forced;
+    if (!w.empty()) G = (int)w.size();
+    if ((size_t)G > n) { G = (int)n; w.clear(); }
+    if (G < 1) G = 1;
+    *G_io = G;
+    if (w.empty()) return equal_group_bounds(n, G);
+    size_t total = 0, acc = 0;
+    for (int v : w) total += (size_t)v;
+    std::vector<size_t> b((size_t)G + 1, 0);
+    for (int g = 0; g < G; g++) {
+        acc += (size_t)w[(size_t)g];
+        b[(size_t)g + 1] = std::max(b[(size_t)g] + 1, std::min(n - (size_t)(G - 1 - g), (acc * n + total / 2) / total));      /* never empty */
+    }
+    b[(size_t)G] = n;
+    return b;
+}
+
 static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
                         int stride = 0, bool rows_by_channel = false, int groups = 1, const GroupHook *before = nullptr, const GroupHook *after = nullptr,
-                        int window = 1, int stride_out = 0) {
+                        int window = 1, int stride_out = 0, const std::vector<size_t> *group_bounds_in = nullptr) {
     if (stride == 0) stride = frames;
     if (stride_out == 0) stride_out = stride;
     if (d_in == d_out) return fail(ctx, GDG_ERR_INVALID, "in-place processing is not supported");
@@ -1270,11 +1410,15 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     const bool free_run = G > 1 && !before && !after;
     if (!free_run || (int)ctx->gstreams.size() > G) join_groups(ctx);
     const int P2 = fir_transform_size(frames);
+    std::vector<size_t> bounds;
+    if (group_bounds_in && (int)group_bounds_in->size() == G + 1) bounds = *group_bounds_in;
+    else bounds = equal_group_bounds(active.size(), G);
     /* the plan holds pointers into the buffers it was built on; other buffers of the same shape are reached by a shift */
     if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate ||
         ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_stride_out != stride_out || ctx->plan_by_channel != rows_by_channel ||
-        ctx->plan_groups != G) {
-        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, stride_out, rows_by_channel, G);
+        ctx->plan_groups != G || ctx->plan_bounds != bounds) {
+        int rc = build_plan(ctx, active, d_in, d_out, frames, sample_rate, stride, stride_out, rows_by_channel, G, bounds);
+        ctx->plan_bounds = bounds;
         ctx->plan_stride = stride;
         ctx->plan_stride_out = stride_out;
         ctx->plan_by_channel = rows_by_channel;
@@ -1303,7 +1447,8 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
         hipStream_t s = G > 1 ? ctx->gstreams[(size_t)g] : ctx->stream;
         if (G > 1) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->gfork, 0));
         if (before) HIP_TRY(ctx, (*before)(g, s));
-        for (auto &st : ctx->steps) {
+        for (size_t si = 0; si < ctx->steps.size(); si++) {
+            const StepDesc &st = ctx->steps[si];
             int first = st.group_range[(size_t)g].first, n = st.group_range[(size_t)g].second;
             if (n == 0) continue;
             if (st.is_fir) {
@@ -1317,15 +1462,17 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                       HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 3, shift, s)); }
                     continue;
                 }
-                { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, shift, s)); }
+                const bool chained = si > 0 && ctx->steps[si - 1].chain_next;      /* the previous power amp's inverse made this one's spectrum */
+                if (!chained) { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, shift, s)); }
+                const gdg_fir_chan *d_next = st.chain_next ? reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + ctx->steps[si + 1].offset) + first : nullptr;
                 const bool fused = ctx->fir_fused < 0 ? (n > ctx->fir_split_max) : (ctx->fir_fused != 0);
                 if (fused) {
                     /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel) */
                     ProfScope ps(ctx, GDG_K_FIR_MAC, s);
-                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, shift, s));
+                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, shift, s, d_next));
                 } else {
                     { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(P2, d, n, st.shared_spectra ? 1 : 0, s)); }
-                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, shift, s)); }
+                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, shift, s, d_next)); }
                 }
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
@@ -1442,25 +1589,78 @@ static int ensure_staging(gdg_ctx *ctx) {
     return GDG_OK;
 }
 
-/* rows [a, b) of a host-side staging copy, spread over a few threads: one core moves pageable memory at ~10 GB/s, which made
- * the 2 x 32 MiB of a 512-channel block cost 3 ms -- more than the whole chain (env GDG_COPY_THREADS, default 8) */
-static void copy_rows_parallel(size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes) {
-    static int threads = -1;
-    if (threads < 0) {
+/* Host copy workers.  One core moves pageable memory at ~10 GB/s, which made the 2 x 32 MiB of a 512-channel block cost 3 ms -- more
+ * than the whole chain -- so staging copies are spread over a few threads (env GDG_COPY_THREADS, default 8).  The workers are
+ * PERSISTENT: a pool created on first use and parked on a condition variable between jobs (spawning and joining std::threads on
+ * every call cost 60-100 us per call, twice per block).  One job at a time; a caller that finds the pool busy (another shard's
+ * thread is copying) runs its slices itself -- the shards' copies are parallel with each other anyway.  The pool is never
+ * destroyed: its threads are parked when the process exits. */
+class CopyPool {
+public:
+    explicit CopyPool(int workers) {
+        for (int i = 0; i < workers; i++) threads_.emplace_back([this, i]() { loop((size_t)i + 1); });
+    }
+    size_t slots() const { return threads_.size() + 1; }
+    /* slice t of T runs fn(t); the caller takes slice 0 and returns when all slices are done */
+    void run(size_t T, const std::function<void(size_t)> &fn) {
+        if (T <= 1) { fn(0); return; }
+        std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+        if (!job.owns_lock()) { for (size_t t = 0; t < T; t++) fn(t); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; T_ = T; pending_ = T - 1; gen_++;
+        }
+        cv_work_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void loop(size_t slot) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)> *fn = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&]() { return gen_ != seen; });
+                seen = gen_;
+                if (slot < T_) fn = fn_;
+            }
+            if (!fn) continue;
+            (*fn)(slot);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) cv_done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t T_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
+static CopyPool &copy_pool() {
+    static CopyPool *pool = []() {
         const char *e = getenv("GDG_COPY_THREADS");
-        threads = e ? atoi(e) : 8;
+        int threads = e ? atoi(e) : 8;
         unsigned hw = std::thread::hardware_concurrency();
         if (hw > 0 && threads > (int)hw) threads = (int)hw;
         if (threads < 1) threads = 1;
-    }
+        return new CopyPool(threads - 1);
+    }();
+    return *pool;
+}
+
+/* rows [a, b) of a host-side staging copy, spread over the copy workers (at least ~1 MiB per thread) */
+static void copy_rows_parallel(size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes) {
     size_t n = b > a ? b - a : 0;
-    size_t T = std::min((size_t)threads, n * row_bytes / (1u << 20) + 1);      /* at least ~1 MiB per thread */
+    if (n == 0) return;
+    CopyPool &pool = copy_pool();
+    size_t T = std::min(pool.slots(), n * row_bytes / (1u << 20) + 1);
     if (T <= 1 || n < 2) { for (size_t i = a; i < b; i++) copy_row(i); return; }
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < T; t++)
-        pool.emplace_back([=, &copy_row]() { for (size_t i = a + n * t / T; i < a + n * (t + 1) / T; i++) copy_row(i); });
-    for (size_t i = a; i < a + n / T; i++) copy_row(i);
-    for (auto &th : pool) th.join();
+    pool.run(T, [&](size_t t) { for (size_t i = a + n * t / T; i < a + n * (t + 1) / T; i++) copy_row(i); });
 }
 
 int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *const *in, double *const *out, int frames, uint32_t sample_rate) {
@@ -1478,9 +1678,10 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     if (rc != GDG_OK) return rc;
     /* rows travel compactly ([i][frames]); G channel groups: group g's rows are staged and uploaded on stream g while the
      * earlier groups already compute, and copied back to the caller while the later groups still run */
-    const int G = pcie_groups(n);
+    int G = pcie_groups(n);
+    const std::vector<size_t> gb = pcie_group_bounds((size_t)n, &G);
     const size_t row = (size_t)frames;
-    auto lo = [&](int g) { return (size_t)(((size_t)g * (size_t)n + (size_t)G - 1) / (size_t)G); };     /* first i with floor(i G / n) == g */
+    auto lo = [&](int g) { return gb[(size_t)g]; };
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           /* the staging slabs may still be in use */
     GroupHook before = [&](int g, hipStream_t s) -> hipError_t {
         size_t a = lo(g), b = lo(g + 1);
@@ -1494,7 +1695,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
         return hipMemcpyAsync(ctx->h_stage_out + a * row, ctx->d_stage_out + a * row, (b - a) * row * sizeof(double), hipMemcpyDeviceToHost, s);
     };
     ctx->stage_out_stride = 0;
-    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, 0, false, G, &before, &after);
+    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, 0, false, G, &before, &after, 1, 0, &gb);
     if (rc != GDG_OK) return rc;
     {   /* all channels, in order: the compact rows are a complete block (gdg_spatialize_staged may mix it without an upload) */
         bool complete = n == ctx->nch;
@@ -1543,8 +1744,9 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
     const size_t stride = (size_t)ctx->max_frames;
     /* G channel groups on their own streams: uploads, kernels and downloads of different groups overlap.  One strided copy
      * per run of consecutive channels inside a group (512 single-row copies would cost ~10 us each). */
-    const int G = pcie_groups(n);
-    auto lo = [&](int g) { return (size_t)(((size_t)g * (size_t)n + (size_t)G - 1) / (size_t)G); };
+    int G = pcie_groups(n);
+    const std::vector<size_t> gb = pcie_group_bounds((size_t)n, &G);
+    auto lo = [&](int g) { return gb[(size_t)g]; };
     auto copy_runs = [&](int g, double *dst, const double *src, hipMemcpyKind kind, hipStream_t s) -> hipError_t {
         for (size_t i = lo(g); i < lo(g + 1);) {
             size_t j = i + 1;
@@ -1560,7 +1762,7 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
     GroupHook before = [&](int g, hipStream_t s) { return copy_runs(g, ctx->d_stage_in, ctx->h_stage_in, hipMemcpyHostToDevice, s); };
     GroupHook after = [&](int g, hipStream_t s) { return copy_runs(g, ctx->h_stage_out, ctx->d_stage_out, hipMemcpyDeviceToHost, s); };
     ctx->stage_out_stride = 0;
-    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true, G, &before, &after);
+    rc = process_rows(ctx, active, ctx->d_stage_in, ctx->d_stage_out, frames, sample_rate, ctx->max_frames, true, G, &before, &after, 1, 0, &gb);
     if (rc != GDG_OK) return rc;
     if (n == ctx->nch) { ctx->stage_out_stride = ctx->max_frames; ctx->stage_out_frames = frames; }     /* rows by channel: every channel took part */
     return check_device_error(ctx);
@@ -1604,18 +1806,17 @@ int gdg_copy_to_host(gdg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 
 /* fft.RealFourier / fft.RealInverseFourier (fft/fft.go:744-856, :863-990) as the FIR path computes them: the packed-real transforms
  * of fir.hip, stand-alone, so that the HIP FFT has known-answer tests of its own.  n real samples <->
- * n / 2 + 1 complex bins (re, im interleaved), n = 128 ... 16384 a power of two.  Forward unscaled, inverse scaled by 1 / n, the
+ * n / 2 + 1 complex bins (re, im interleaved), n = 1 or a power of two from 2 to 16384.  Forward unscaled, inverse scaled by 1 / n, the
  * reference's SCALING_DEFAULT. */
 static int fft_size_ok(gdg_ctx *ctx, int n) {
-    int P = n / 2;
-    if (n < 2 * GDG_MIN_FIR_FRAMES || n > 2 * GDG_MAX_FRAMES || (n & (n - 1)) != 0)
-        return fail(ctx, GDG_ERR_INVALID, "transform size %d: a power of two from %d to %d", n, 2 * GDG_MIN_FIR_FRAMES, 2 * GDG_MAX_FRAMES);
-    (void)P;
+    if (n < 2 || n > 2 * GDG_MAX_FRAMES || (n & (n - 1)) != 0)
+        return fail(ctx, GDG_ERR_INVALID, "transform size %d: a power of two from 2 to %d", n, 2 * GDG_MAX_FRAMES);
     return GDG_OK;
 }
 
 int gdg_fft_real(gdg_ctx *ctx, const double *samples, int n, double *spectrum) {
     if (!ctx || !samples || !spectrum) return GDG_ERR_INVALID;
+    if (n == 1) { spectrum[0] = samples[0]; spectrum[1] = 0.0; return GDG_OK; }          /* fft.go:765-768: one element is its own transform */
     int rc = fft_size_ok(ctx, n);
     if (rc != GDG_OK) return rc;
     enter(ctx);
@@ -1652,6 +1853,7 @@ int gdg_fft_real(gdg_ctx *ctx, const double *samples, int n, double *spectrum) {
 
 int gdg_fft_real_inverse(gdg_ctx *ctx, const double *spectrum, int n, double *samples) {
     if (!ctx || !samples || !spectrum) return GDG_ERR_INVALID;
+    if (n == 1) { samples[0] = spectrum[0]; return GDG_OK; }
     int rc = fft_size_ok(ctx, n);
     if (rc != GDG_OK) return rc;
     enter(ctx);

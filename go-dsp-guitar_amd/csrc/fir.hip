@@ -679,12 +679,21 @@ __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int ti
 /* FUSED 0: Y comes from fir_mac_kernel.  FUSED 1 / 2: the multiply-accumulate runs here, straight into the inverse's
  * first stage (no Y round trip through HBM: the 6 % of extra bytes cost the separate MAC 20 % of its time, see
  * profiles/probes/); 2 = the IR spectra are shared between channels and read with cacheable loads. */
-template <int LOGN, int FUSED>
+/* CHAIN (8192-point frames only): the NEXT unit of every channel is a power amp too (the benchmark chain: cabinet IR, then reverb IR).
+ * The inverse's last pass leaves the clipped output frame in exactly the registers the next amp's forward transform (fir_fwd13w_kernel,
+ * 8 x 1024) wants as its "current" half -- packed element n1 + 1024 m of the frame sits in thread n1 mod 512, slot (n1 div 512, 4 + m) on
+ * both sides -- so that transform runs right here: the frame goes to the next amp's overlap-save history and, transformed together
+ * with the previous one, into its delay line, without the round trip through the intermediate frame buffer and without a launch.
+ * Same arithmetic in the same order as the stand-alone forward kernel: the delay line gets the same bits. */
+template <int LOGN, int FUSED, bool CHAIN = false>
 __global__ void __launch_bounds__(FftCfg<LOGN>::T)
-fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
+               const gdg_fir_chan *__restrict__ next_chans = nullptr) {
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T;
-    __shared__ double sre[FftCfg<LOGN>::LDS];
-    __shared__ double sim[FftCfg<LOGN>::LDS];
+    static_assert(!CHAIN || (LOGN == 13 && FUSED != 3), "the chained forward transform is the 8 x 1024 one of the batch block size");
+    constexpr int LDS_WORDS = (CHAIN && GDG_W_LDS > FftCfg<LOGN>::LDS) ? GDG_W_LDS : FftCfg<LOGN>::LDS;
+    __shared__ double sre[LDS_WORDS];
+    __shared__ double sim[LDS_WORDS];
     const int tid = threadIdx.x;
     /* FUSED 3: frame j of a window of W frames (blockIdx.x = channel * W + j): Y holds W spectra, dst W frames, the frame
      * counter stays (fir_tb_finish_kernel) */
@@ -706,6 +715,25 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, c
     }
     __syncthreads();
 
+    /* CHAIN: the next amp's previous frame and the radix-8 step's twiddles, requested now, consumed after the inverse's passes */
+    cplx nx_prev[2][4], nx_w[2];
+    cplx *nx_out = nullptr;
+    double *nx_keep = nullptr;
+    if constexpr (CHAIN) {
+        const gdg_fir_chan nx = next_chans[blockIdx.x];
+        const int pos2 = *nx.pos;
+        const double *a2 = nx.prev + (size_t)((pos2 + 1) & 1) * N;
+        nx_keep = nx.prev + (size_t)(pos2 & 1) * N;
+        nx_out = nx.fdl + (size_t)(pos2 % nx.R) * N;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int n1 = tid + T * b;
+            nx_w[b] = tw[n1];
+#pragma unroll
+            for (int m = 0; m < 4; m++) nx_prev[b][m] = gload(reinterpret_cast<const cplx *>(a2 + 2 * (n1 + 1024 * m)));
+        }
+    }
+
     cplx v[16];
     constexpr int NP = sched_npass(LOGN);
     run_lds_passes<LOGN, 0, NP - 1, true>(v, sre, sim, tw, tid);
@@ -716,7 +744,69 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, c
     pass_compute<LOGN, LR, LNS, true>(v, tw, tid);
     const int hop = ch.hop;
     double *__restrict__ dst = ch.dst + (size_t)jw * hop + ((ch.flags & GDG_DST_IS_OUTPUT) ? shift.out : 0);
-    if (hop == N) {
+    if constexpr (CHAIN) {
+        static_assert(R == 8 && B == 2, "last pass of the 8192-point inverse: radix 8, two butterflies per thread");
+        /* frame -> next amp's history; [previous | frame] -> radix-8 step of its forward transform (fir_fwd13w_kernel, step A) */
+        cplx ua[2][8];
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int n1 = tid + T * b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                cplx z = v[b * R + 4 + m];
+                z.x = fmin(1.0, fmax(-1.0, z.x));           /* filter/filter.go:487-493 */
+                z.y = fmin(1.0, fmax(-1.0, z.y));
+                ua[b][m] = nx_prev[b][m];
+                ua[b][4 + m] = z;
+                gstore(reinterpret_cast<cplx *>(nx_keep + 2 * (n1 + 1024 * m)), z);
+                if (!(ch.flags & GDG_DST_UNUSED)) gstore(reinterpret_cast<cplx *>(dst + 2 * (n1 + 1024 * m)), z);
+            }
+        }
+        __syncthreads();                                    /* the inverse's last pass has been read by everybody */
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int n1 = tid + T * b;
+            Dft<8, false>::run(ua[b]);
+            twiddle_powers8(ua[b], nx_w[b]);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) { sre[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].x; sim[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].y; }
+        }
+        __syncthreads();
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            double *rre = sre + wave * GDG_W_RL, *rim = sim + wave * GDG_W_RL;
+            cplx f[16];
+            wave_fft1024<false>(f, rre, rim, tw, lane);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const int k1 = (lane + 64 * b) + 128 * t;
+                    rre[GDG_PAD(k1)] = f[b * 8 + t].x;
+                    rim[GDG_PAD(k1)] = f[b * 8 + t].y;
+                }
+        }
+        __syncthreads();
+        auto Z = [&](int k) { return make_double2(sre[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)], sim[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)]); };
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = tid + T * i;
+            if (k == 0) {
+                cplx z0 = Z(0), zh = Z(N / 2);
+                gstore(nx_out, make_double2(z0.x + z0.y, z0.x - z0.y));
+                gstore(nx_out + N / 2, make_double2(zh.x, -zh.y));
+            } else {
+                const int n = N - k;
+                cplx zk = Z(k), zn = Z(n);
+                cplx A = make_double2(zk.x + zn.x, zk.y - zn.y);
+                cplx Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+                cplx cw = cmul(tw2[k], Bv);
+                gstore(nx_out + k, make_double2((A.x + cw.y) * 0.5, (A.y - cw.x) * 0.5));
+                gstore(nx_out + n, make_double2((A.x - cw.y) * 0.5, (-A.y - cw.x) * 0.5));
+            }
+        }
+    } else if (hop == N) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
             int j = tid + T * b;
@@ -893,6 +983,96 @@ fir_tb_finish_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift sh
 
 /* ---- host side ------------------------------------------------------------------------------- */
 
+/* ------------------------------------------------------------------------------------------------
+ * Small transforms, P = 1 ... 32 packed points (n = 2 ... 64 real samples): below the FIR path's smallest frame, here so that the
+ * stand-alone gdg_fft_real / gdg_fft_real_inverse cover the sizes of the reference's own known answers (fft/fft_test.go:237-271:
+ * eight points).  Same algorithm as the large kernels -- packed-real transform: P complex points z[e] = (r[2e], r[2e+1]), one
+ * complex FFT, the un-packing / re-packing stage with tw2[k] = exp(-i pi k / P) -- as a plain radix-2 decimation-in-time in LDS,
+ * one wave per job, one butterfly per lane and stage.
+ * ---------------------------------------------------------------------------------------------- */
+template <bool INV>
+__device__ __forceinline__ void small_fft(cplx *z, int P, int logp, const cplx *__restrict__ tw, int lane) {
+    /* z holds the input in bit-reversed order; stage s joins transforms of length 2^s */
+    for (int s = 0; s < logp; s++) {
+        const int half = 1 << s;
+        if (lane < P / 2) {
+            const int j = lane & (half - 1), base = ((lane >> s) << (s + 1)) + j;
+            cplx w = tw[j * (P >> (s + 1))];                  /* exp(-2 pi i j / 2^(s+1)) */
+            if (INV) w.y = -w.y;
+            const cplx a = z[base], b = cmul(z[base + half], w);
+            z[base] = cadd(a, b);
+            z[base + half] = csub(a, b);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__device__ __forceinline__ int bitrev(int v, int bits) { return bits ? (int)(__brev((unsigned)v) >> (32 - bits)) : 0; }
+
+__global__ void __launch_bounds__(64)
+fft_small_fwd_kernel(const gdg_fir_irjob *__restrict__ jobs, int P, int logp, double scale, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    __shared__ cplx z[32];
+    const int lane = threadIdx.x;
+    const gdg_fir_irjob jb = jobs[blockIdx.x];
+    if (lane < P) {
+        /* r = [a (P) | b (P)] (hop == P) or [a (P) | zeros] (hop == 0) */
+        double r2[2];
+        for (int h = 0; h < 2; h++) {
+            const int i = 2 * lane + h;
+            r2[h] = (i < P) ? gload1(jb.a + i) : ((jb.hop > 0 && jb.b) ? gload1(jb.b + (i - P)) : 0.0);
+        }
+        z[bitrev(lane, logp)] = make_double2(r2[0], r2[1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    small_fft<false>(z, P, logp, tw, lane);
+    if (lane <= P / 2) {
+        const int k = lane;
+        if (k == 0) {
+            gstore(jb.out, make_double2((z[0].x + z[0].y) * scale, (z[0].x - z[0].y) * scale));
+        } else {
+            const int n = P - k;
+            const cplx zk = z[k], zn = z[n];
+            const cplx A = make_double2(zk.x + zn.x, zk.y - zn.y), Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+            const cplx cw = cmul(tw2[k], Bv);
+            const double hs = 0.5 * scale;
+            gstore(jb.out + k, make_double2((A.x + cw.y) * hs, (A.y - cw.x) * hs));
+            if (n != k) gstore(jb.out + n, make_double2((A.x - cw.y) * hs, (-A.y - cw.x) * hs));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+fft_small_inv_kernel(const gdg_fir_rawjob *__restrict__ jobs, int P, int logp, double scale, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    __shared__ cplx z[32];
+    const int lane = threadIdx.x;
+    const gdg_fir_rawjob jb = jobs[blockIdx.x];
+    if (lane <= P / 2) {
+        const int k = lane;
+        if (k == 0) {
+            const cplx y0 = gload(jb.Y);
+            z[0] = make_double2(y0.x + y0.y, y0.x - y0.y);
+        } else {
+            const int n = P - k;
+            const cplx yk = gload(jb.Y + k), yn = gload(jb.Y + n);
+            const cplx A = make_double2(yk.x + yn.x, yk.y - yn.y), Bv = make_double2(yk.x - yn.x, yk.y + yn.y);
+            cplx w = tw2[k];
+            w.y = -w.y;
+            const cplx O = cmul(Bv, w);
+            z[bitrev(k, logp)] = make_double2(A.x - O.y, A.y + O.x);
+            if (n != k) z[bitrev(n, logp)] = make_double2(A.x + O.y, -A.y + O.x);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    small_fft<true>(z, P, logp, tw, lane);
+    if (lane < P) {
+        for (int h = 0; h < 2; h++) {
+            const int i = 2 * lane + h;
+            const double x = (h ? z[lane].y : z[lane].x) * scale;
+            if (i < jb.hop) { if (jb.first) gstore1(jb.first + i, x); }
+            else if (i < 2 * jb.hop) gstore1(jb.second + (i - jb.hop), x);
+        }
+    }
+}
+
 static int ilog2_exact(int P) {
     int l = 0;
     while ((1 << l) < P) l++;
@@ -942,7 +1122,16 @@ template <int LG> static void launch_ir(const gdg_fir_irjob *d_jobs, int n, doub
 template <int LG> static void launch_raw_inv(const gdg_fir_rawjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
     fir_raw_inv_kernel<LG><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_jobs, scale, tw, tw2);
 }
-template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, gdg_shift shift, hipStream_t s) {
+template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, gdg_shift shift, hipStream_t s,
+                                         const gdg_fir_chan *d_next) {
+    if constexpr (LG == 13) {
+        if (d_next) {       /* the next unit of every channel is a power amp: its forward transform rides along */
+            if (fused == 0) fir_inv_kernel<13, 0, true><<<dim3(n), dim3(FftCfg<13>::T), 0, s>>>(d_chans, 1, shift, tw, tw2, d_next);
+            else if (fused == 1) fir_inv_kernel<13, 1, true><<<dim3(n), dim3(FftCfg<13>::T), 0, s>>>(d_chans, 1, shift, tw, tw2, d_next);
+            else fir_inv_kernel<13, 2, true><<<dim3(n), dim3(FftCfg<13>::T), 0, s>>>(d_chans, 1, shift, tw, tw2, d_next);
+            return;
+        }
+    }
     if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
     else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
     else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
@@ -1000,6 +1189,10 @@ hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n
 hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
     if (n_jobs <= 0) return hipSuccess;
     int L = ilog2_exact(P);
+    if (L >= 0 && L <= 5) {
+        fft_small_fwd_kernel<<<dim3(n_jobs), dim3(64), 0, s>>>(d_jobs, P, L, scale, d_tw, d_tw2);
+        return hipGetLastError();
+    }
     GDG_DISPATCH_LOGN(L, launch_ir<LG>(d_jobs, n_jobs, scale, d_tw, d_tw2, s));
     return hipGetLastError();
 }
@@ -1007,6 +1200,10 @@ hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, dou
 hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_jobs, double scale, const cplx *d_tw, const cplx *d_tw2, hipStream_t s) {
     if (n_jobs <= 0) return hipSuccess;
     int L = ilog2_exact(P);
+    if (L >= 0 && L <= 5) {
+        fft_small_inv_kernel<<<dim3(n_jobs), dim3(64), 0, s>>>(d_jobs, P, L, scale, d_tw, d_tw2);
+        return hipGetLastError();
+    }
     GDG_DISPATCH_LOGN(L, launch_raw_inv<LG>(d_jobs, n_jobs, scale, d_tw, d_tw2, s));
     return hipGetLastError();
 }
@@ -1050,10 +1247,12 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, i
 }
 
 /* fused: 0 = inverse only (Y from gdg_launch_fir_mac), 1 = MAC + inverse, 2 = MAC + inverse with shared (cacheable) IR spectra */
-hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, int fused, gdg_shift shift, hipStream_t s) {
+hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, int fused, gdg_shift shift, hipStream_t s,
+                              const gdg_fir_chan *d_next_chans) {
     if (n_chans <= 0) return hipSuccess;
     int L = ilog2_exact(P);
-    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, shift, s));
+    if (d_next_chans && L != 13) return hipErrorInvalidValue;
+    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, shift, s, d_next_chans));
     return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@
  * (in samples) from the buffers the plan was built on to the ones of this call -- walking through a file does not rebuild the plan. */
 #define GDG_SRC_IS_INPUT 1
 #define GDG_DST_IS_OUTPUT 2
+#define GDG_DST_UNUSED 4             /* FIR unit whose output frame is consumed by a chained forward transform only (fir_inv_kernel, CHAIN) */
 struct gdg_shift { long long in, out; };
 
 struct gdg_fir_chan {
@@ -70,7 +71,10 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, i
  * window, frame j at + j * 8192; chans[].Y holds W spectra; chans[].R >= K + W - 1. */
 hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, const double2 *d_tw, const double2 *d_tw2,
                                  int what, gdg_shift shift, hipStream_t s);
-hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, gdg_shift shift, hipStream_t s);
+/* d_next_chans != NULL (P == 8192, frames of 8192): descriptor i is the power amp that follows chans[i] in the same channel's chain; its
+ * forward transform (history + delay-line slot) is produced by this launch and gdg_launch_fir_fwd is NOT called for it */
+hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, gdg_shift shift, hipStream_t s,
+                              const gdg_fir_chan *d_next_chans = nullptr);
 hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 
@@ -98,7 +102,24 @@ struct gdg_seg_unit {
     double *ds;
     int *is;
     double *hist;
+    const double *tab;        /* scan tables of the unit's constant-coefficient recurrences (powers of the 8-sample chunk map), built on the
+                               * host at plan time -- they depend on the coefficients only -- and shared by all units with the same ones */
 };
+
+/* scan tables (seg.hip: lin_scan / lin2_scan); layouts shared with the host builder in api.cpp */
+#define GDG_CHK 8                 /* samples per thread at the batch block size (8192 / 1024) */
+#define LT_W 0                    /* [8]  dot weights */
+#define LT_ST 8                   /* [10] A^(2^k), k = 0..9 */
+#define LT_PA 18                  /* [16] A^(q + 1), q = lane & 15 */
+#define LT_PB 34                  /* [32] A^(lane - 31), lane = 32..63, at index lane - 32 */
+#define LT_PC 66                  /* [64] A^lane */
+#define LT_SIZE 130
+#define L2_W 0                    /* [8][2]  dot weights (gH_i, gL_i) */
+#define L2_ST 16                  /* [10][3] P^(2^k) */
+#define L2_PA 46                  /* [16][3] */
+#define L2_PB 94                  /* [32][3] */
+#define L2_PC 190                 /* [64][3] */
+#define L2_SIZE 382
 
 struct gdg_seg_chan {
     const double *src;

@@ -179,18 +179,14 @@ __device__ __forceinline__ double apply_map(double A, double B, double s) {
  *   - the 16 wave totals are scanned by lanes 0..15 of every wave with the A^64 ladder, seeded with the state before the
  *     frame in lane 0, so lane w holds the state entering wave w;
  *   - start state of the thread's chunk = exclusive in-wave value (wave_shr:1) + A^lane * (state entering the wave).
- * One workgroup barrier per scan (the exchange slots alternate).  The tables are built once per unit call by one wave per
- * section (binary exponentiation, ~100 instructions).  The exact replay from the start state is unchanged, so only that
- * start state carries the scan's rounding (~1e-16 relative), as before.
+ * One workgroup barrier per scan (the exchange slots alternate).  The tables depend on the coefficient only: the host builds them at
+ * plan time (api.cpp: scan_tables) and the unit copies them from HBM into LDS.  The exact replay from the start state is unchanged,
+ * so only that start state carries the scan's rounding (~1e-16 relative), as before.
  * 2 x 2 variant (tone stack band = high-pass feeding a low-pass): the pair (h, l) evolves linearly with the constant
  * lower-triangular matrix [[1-aH, 0], [-aL, 1-aL]] per sample, so ONE scan of vectors replaces two scans and one of the
  * three passes. */
-#define LT_W 0                    /* [8]  dot weights */
-#define LT_ST 8                   /* [10] A^(2^k), k = 0..9 */
-#define LT_PA 18                  /* [16] A^(q + 1), q = lane & 15 */
-#define LT_PB 34                  /* [32] A^(lane - 31), lane = 32..63, at index lane - 32 */
-#define LT_PC 66                  /* [64] A^lane */
-#define LT_SIZE 130
+/* table layout (LT_*, L2_*): gdg_internal.h -- the tables are built on the host at plan time (api.cpp scan_tables) */
+static_assert(GDG_CHK == CHK, "chunk size of the scan tables");
 #define LX_SLOT 17                /* exchange slot: [state before the frame | 16 wave totals] */
 
 template <int CTRL, int ROWMASK>
@@ -204,23 +200,12 @@ __device__ __forceinline__ double dpp0(double v) {       /* DPP move, lanes with
 #define DPP_ROW_BCAST31 0x143
 #define DPP_WAVE_SHR1 0x138
 
-__device__ __forceinline__ double pow_u(double A, int e) {     /* A^e, 0 <= e < 1024 */
-    double r = 1.0, b = A;
-#pragma unroll
-    for (int k = 0; k < 10; k++) { if (e & (1 << k)) r *= b; b *= b; }
-    return r;
-}
-
-/* built by ONE wave (all 64 lanes call it); a = per-sample coefficient, keep = 1 - a (the follower passes its own pair) */
-template <bool MAXOP>
-__device__ __forceinline__ void lin_tab_build(double *tab, double a, double keep) {
-    const int lane = threadIdx.x & 63;
-    const double k2 = keep * keep, k4 = k2 * k2, A = k4 * k4;
-    tab[LT_PC + lane] = pow_u(A, lane);
-    if (lane < 16) tab[LT_PA + lane] = pow_u(A, lane + 1);
-    if (lane >= 32) tab[LT_PB + lane - 32] = pow_u(A, lane - 31);
-    if (lane < 10) tab[LT_ST + lane] = pow_u(A, 1 << lane);
-    if (lane < CHK) tab[LT_W + lane] = (MAXOP ? 1.0 : a) * pow_u(keep, CHK - 1 - lane);
+/* the unit's tables: HBM (shared by every unit with the same coefficients, so usually L2 hits) -> LDS, all threads, issued together with
+ * the frame chunk.  Round 2 built them here on every call, one wave per section: a dependent chain of ~400 FP64 operations (4 000 of the
+ * tone stack's 24 000 cycles) for values that only change with the sample rate or a parameter. */
+__device__ __forceinline__ void tab_fetch(double *dst, const double *src_generic, int n) {
+    const double *src = src_generic;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = *(const __attribute__((address_space(1))) double *)(src + i);
 }
 
 template <bool MAXOP>
@@ -259,37 +244,6 @@ __device__ __forceinline__ double lin_scan(double B, const double *tab, const do
 }
 
 /* ---- 2 x 2: lower-triangular matrices (m00, m10, m11) --------------------------------------------------------------- */
-struct Tri { double a, b, c; };                                /* [[a, 0], [b, c]] */
-__device__ __forceinline__ Tri tri_mul(const Tri &x, const Tri &y) { Tri r = { x.a * y.a, (x.b * y.a) + (x.c * y.b), x.c * y.c }; return r; }
-__device__ __forceinline__ Tri tri_pow(Tri M, int e) {
-    Tri r = { 1.0, 0.0, 1.0 };
-#pragma unroll
-    for (int k = 0; k < 10; k++) { if (e & (1 << k)) r = tri_mul(r, M); M = tri_mul(M, M); }
-    return r;
-}
-#define L2_W 0                    /* [8][2]  dot weights (gH_i, gL_i) */
-#define L2_ST 16                  /* [10][3] P^(2^k) */
-#define L2_PA 46                  /* [16][3] */
-#define L2_PB 94                  /* [32][3] */
-#define L2_PC 190                 /* [64][3] */
-#define L2_SIZE 382
-__device__ __forceinline__ void tri_store(double *p, const Tri &t) { p[0] = t.a; p[1] = t.b; p[2] = t.c; }
-
-/* one wave builds the tables of one band: per sample (h, l) <- M (h, l) + (aH, aL) x, M = [[1-aH, 0], [-aL, 1-aL]] */
-__device__ __forceinline__ void lin2_tab_build(double *tab, double aH, double aL) {
-    const int lane = threadIdx.x & 63;
-    const Tri M = { 1.0 - aH, -aL, 1.0 - aL };
-    const Tri P = tri_pow(M, CHK);
-    tri_store(tab + L2_PC + 3 * lane, tri_pow(P, lane));
-    if (lane < 16) tri_store(tab + L2_PA + 3 * lane, tri_pow(P, lane + 1));
-    if (lane >= 32) tri_store(tab + L2_PB + 3 * (lane - 32), tri_pow(P, lane - 31));
-    if (lane < 10) tri_store(tab + L2_ST + 3 * lane, tri_pow(P, 1 << lane));
-    if (lane < CHK) {
-        Tri G = tri_pow(M, CHK - 1 - lane);
-        tab[L2_W + 2 * lane] = G.a * aH;
-        tab[L2_W + 2 * lane + 1] = (G.b * aH) + (G.c * aL);
-    }
-}
 __device__ __forceinline__ void lin2_comb(double &h, double &l, const double *m, double sh, double sl) {
     h = fma(m[0], sh, h);
     l = fma(m[2], sl, fma(m[1], sh, l));
@@ -578,7 +532,7 @@ __device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip
     const double d_inv = U->dp[2], d = U->dp[3], limit = U->dp[0], target = U->dp[1];
     GDG_GLOBAL double *ds = as_global(U->ds);
     if (tid == 0) st[0] = ds[0];
-    if (tid < 64) { if (follow == 0) lin_tab_build<true>(scr, 0.0, d_inv); else lin_tab_build<false>(scr, d, d_inv); }
+    tab_fetch(scr, U->tab, LT_SIZE);
     const ChunkT<true> c = full_chunk();
     double x[CHK], e[CHK];
     chunk_load(in, c, x);
@@ -879,11 +833,11 @@ __device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip)
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;                    /* [0..7] the capacitor voltages, [16..27] factors and coefficients */
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x;
     GDG_GLOBAL double *ds = as_global(U->ds);
     if (tid < 8) st[tid] = ds[tid];
     if (tid < 12) st[16 + tid] = U->dp[tid];
-    if (wave < 4) lin2_tab_build(scr + wave * L2_SIZE, U->dp[4 + wave], U->dp[8 + wave]);
+    tab_fetch(scr, U->tab, 4 * L2_SIZE);
     const ChunkT<true> c = full_chunk();
     double x[CHK], sum[CHK];
     chunk_load(in, c, x);
@@ -946,10 +900,10 @@ __device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;                    /* [0..6] the capacitor voltages, [16..22] the coefficients */
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x;
     GDG_GLOBAL double *ds = as_global(U->ds);
     if (tid < 7) { st[tid] = ds[tid]; st[16 + tid] = U->dp[tid]; }
-    if (wave < 7) { const double a = U->dp[wave]; lin_tab_build<false>(scr + wave * LT_SIZE, a, 1.0 - a); }
+    tab_fetch(scr, U->tab, 7 * LT_SIZE);
     const ChunkT<true> c = full_chunk();
     double v[CHK];
     chunk_load(in, c, v);
@@ -1595,8 +1549,7 @@ __device__ __forceinline__ void fuzz_os_tiles(const gdg_seg_unit *Ug, double *in
      * slow one has read the old state inside the same scan */
     double *st = tmp + SEG_STASH + 16;               /* [2 * (tile & 1) + {0: envelope, 1: coupling capacitor}] */
     if (tid == 0) { st[0] = ds[0]; st[1] = ds[1]; }
-    if (tid < 64) { if (follow == 0) lin_tab_build<true>(tab_env, 0.0, d_inv); else lin_tab_build<false>(tab_env, d, d_inv); }
-    else if (tid < 128) lin_tab_build<false>(tab_cap, d, 1.0 - d);
+    tab_fetch(tab_env, U->tab, 2 * LT_SIZE);                    /* [follower | coupling capacitor]; tab_cap = tab_env + LT_SIZE */
     for (int q = tid; q < TAPS - 1 + 8; q += SEG_T) { if (q < 8) carry8[q] = hist[q]; else old_tail[q - 8] = hist[q]; }
     __syncthreads();
     int parity = 0, tile = 0;
@@ -1881,7 +1834,7 @@ __device__ __forceinline__ void bandpass_full(const gdg_seg_unit *Ug, int flip) 
     const double aH = U->dp[0], aL = U->dp[1];
     const int half = U->jp[0];
     if (threadIdx.x < 8) st[threadIdx.x] = ds[threadIdx.x];
-    if (threadIdx.x < 64) lin2_tab_build(scr, aH, aL);
+    tab_fetch(scr, U->tab, L2_SIZE);
     const ChunkT<true> c = full_chunk();
     double v[CHK];
     chunk_load(in, c, v);
@@ -1937,8 +1890,7 @@ __device__ __forceinline__ void octaver_full(const gdg_seg_unit *Ug, int flip) {
     const double d_inv = U->dp[6], d = U->dp[7];
     double *tab_env = scr, *tab_cap = scr + LT_SIZE;
     if (tid < 2) st[tid] = ds[tid];
-    if (tid < 64) { if (follow == 0) lin_tab_build<true>(tab_env, 0.0, d_inv); else lin_tab_build<false>(tab_env, d, d_inv); }
-    else if (tid < 128) lin_tab_build<false>(tab_cap, d, 1.0 - d);
+    tab_fetch(tab_env, U->tab, 2 * LT_SIZE);                    /* [follower | coupling capacitor] */
     const int pp0 = is[0], reg0 = is[1];
     const ChunkT<true> c = full_chunk();
     double x[CHK], e[CHK];

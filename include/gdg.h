@@ -199,7 +199,9 @@ int gdg_copy_rows_device(gdg_ctx *ctx, double *d_dst, size_t dst_stride, const d
 /*
  * fft.RealFourier / fft.RealInverseFourier (fft/fft.go:744-856, :863-990) as fir.hip computes them (packed-real Stockham
  * transforms in registers + LDS): n real samples <-> n / 2 + 1 complex bins (re, im interleaved; the other half is the
- * conjugate mirror the reference also stores).  n = 128 ... 16384, a power of two.  Forward unscaled, inverse scaled by 1 / n
+ * conjugate mirror the reference also stores).  n = 1 (the identity, fft/fft.go:765-768) or a power of two from 2 to 16384 (n <= 64: a small radix-2 kernel of
+ * the same packed-real scheme, which is what lets the reference's own eight-point known answers, fft/fft_test.go:237-271, run on the
+ * HIP transforms).  Forward unscaled, inverse scaled by 1 / n
  * (SCALING_DEFAULT); like the reference the inverse reads only the real parts of bins 0 and n / 2.  Host buffers, blocking.
  */
 int gdg_fft_real(gdg_ctx *ctx, const double *samples, int n, double *spectrum);

@@ -198,3 +198,59 @@ def test_fir_launch_shapes_agree(pkg, oracle, nch, frames, taps):
         ref.append_unit("power_amp", fir=irs[c])
         want = np.concatenate([ref.process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
         assert rms(outs["0"][c] - want) <= TOL_RMS and rms(outs["1"][c] - want) <= TOL_RMS
+
+
+@pytest.mark.parametrize("nch,fused,share", [(3, "0", True), (3, "1", False), (130, None, True), (130, None, False)],
+                         ids=["split_inverse", "fused_private", "auto_fused_shared", "auto_fused_private"])
+def test_adjacent_power_amps_chain_their_transforms(pkg, oracle, nch, fused, share):
+    """Two (and three) power amps in a row at the batch block size: the inverse transform of one produces the forward transform of the
+    next inside the same launch (fir_inv_kernel CHAIN: the clipped frame goes from the inverse's registers into the next amp's history
+    and delay line).  GDG_FIR_CHAIN=0 keeps the launches separate: both ways give the same bits, in every launch shape (split inverse,
+    fused with private / shared spectra), across a change of the chain in mid-stream, and they follow the oracle."""
+    import os
+    frames, sr, blocks, taps = 8192, 96000, 6, 20000
+    x = np.stack([synth_signal(c, frames * blocks, sr) for c in range(nch)])
+    n_irs = 2 if share else nch
+    irs = [[synth_ir(taps, seed=900 + 10 * k + j) * 0.9 for j in range(3)] for k in range(n_irs)]
+    outs = {}
+    for chain in ("1", "0"):
+        os.environ["GDG_FIR_CHAIN"] = chain
+        if fused is not None:
+            os.environ["GDG_FIR_FUSED"] = fused
+        try:
+            ctx = pkg.Context(nch, frames)
+        finally:
+            del os.environ["GDG_FIR_CHAIN"]
+            os.environ.pop("GDG_FIR_FUSED", None)
+        ctx.share_ir_spectra(share)
+        third = []
+        for c in range(nch):
+            ctx.append_unit(c, "compressor", params=[1, 30, -20])
+            ctx.append_unit(c, "power_amp", fir=irs[c % n_irs][0])
+            ctx.append_unit(c, "power_amp", fir=irs[c % n_irs][1])
+            third.append(ctx.append_unit(c, "power_amp", fir=irs[c % n_irs][2], bypass=True))
+            ctx.append_unit(c, "cabinet")
+        d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
+        got = []
+        for b in range(blocks):
+            if b == 3:                                           # the third amp joins: amp 2 now chains into amp 3 as well
+                for c in range(nch):
+                    ctx.chain_set(c, [h for h, _ in ctx._chains[c]], [False] * 5)
+            d_in.upload(np.ascontiguousarray(x[:, b * frames:(b + 1) * frames]))
+            ctx.process_device(d_in, d_out, frames, sr)
+            got.append(d_out.download())
+        outs[chain] = np.concatenate(got, axis=1)
+        ctx.close()
+    assert np.array_equal(outs["1"], outs["0"]), float(np.max(np.abs(outs["1"] - outs["0"])))
+    for c in (0, nch - 1):
+        ref = oracle.Chain()
+        ref.append_unit("compressor", params=[1, 30, -20])
+        for j in range(3):
+            ref.append_unit("power_amp", fir=irs[c % n_irs][j], bypass=(j == 2))
+        ref.append_unit("cabinet")
+        want = []
+        for b in range(blocks):
+            if b == 3:
+                ref.set_bypass(3, False)
+            want.append(ref.process(x[c, b * frames:(b + 1) * frames], sr))
+        assert rms(outs["1"][c] - np.concatenate(want)) <= TOL_RMS, c

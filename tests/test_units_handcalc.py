@@ -100,7 +100,54 @@ def test_hip_fft_known_answers(n):
 def test_hip_fft_rejects_sizes_outside_the_lds_resident_range():
     pkg = package()
     ctx = pkg.Context(1, 64)
-    for n in (64, 100, 32768):
+    for n in (0, 3, 100, 32768):
         with pytest.raises(pkg.GdgError):
             ctx.fft_real(np.zeros(n))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_fft_reproduces_the_reference_tests_own_vectors(golden):
+    """fft/fft_test.go on the HIP transforms: TestRealFFT's seven vectors (:237-271, tolerance 1e-8 as there), the orthonormal
+    scaling vector (:547-570; the scale 1/sqrt(n) is applied by the test, the library's forward transform is unscaled like
+    SCALING_DEFAULT), the single-element transform (:639-746) and the all-zero inputs (:194).  The reference stores the full
+    spectrum (n bins, conjugate mirror); the library returns bins 0 .. n/2, which determine the rest."""
+    pkg = package()
+    ctx = pkg.Context(1, 64)
+    t = golden("fft")["tests"]
+    real = t["TestRealFFT"]
+    for x, re, im in zip(real["in"]["value"], real["outRealExpected"]["value"], real["outImagExpected"]["value"]):
+        n = len(x)
+        got = ctx.fft_real(np.array(x))
+        want = np.array(re) + 1j * np.array(im)
+        assert got.size == n // 2 + 1
+        assert np.max(np.abs(got - want[:n // 2 + 1])) <= 1e-8, (x, got)
+        # the mirror the reference stores: X[n - k] = conj(X[k])
+        assert np.max(np.abs(np.conj(got[1:n // 2][::-1]) - want[n // 2 + 1:])) <= 1e-8
+        back = ctx.fft_real_inverse(got, n)
+        assert np.max(np.abs(back - np.array(x))) <= 1e-14
+    o = t["TestOrthonormalScaling"]
+    x = np.array(o["in"]["value"])
+    got = ctx.fft_real(x) / np.sqrt(x.size)
+    want = np.array(o["expectedReal"]["value"]) + 1j * np.array(o["expectedImag"]["value"])
+    assert np.max(np.abs(got - want[:x.size // 2 + 1])) <= 1e-8
+    one = t["TestSingleElementFFT"]["inReal"]["value"]
+    assert ctx.fft_real(np.array(one))[0] == one[0] and ctx.fft_real_inverse(np.array([one[0] + 0j]), 1)[0] == one[0]
+    for n in t["TestZeroFloat"]["sizes"]["value"]:
+        if n & (n - 1) == 0:
+            assert not ctx.fft_real(np.zeros(n)).any()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64])
+def test_hip_fft_small_sizes_against_numpy(n):
+    pkg = package()
+    ctx = pkg.Context(1, 64)
+    rng = np.random.default_rng(100 + n)
+    for _ in range(4):
+        x = rng.standard_normal(n)
+        got, ref = ctx.fft_real(x), np.fft.rfft(x)
+        assert np.max(np.abs(got - ref)) <= 1e-14 * max(1.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(ctx.fft_real_inverse(ref, n) - x)) <= 1e-14
     ctx.close()
