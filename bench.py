@@ -530,7 +530,8 @@ def main():
     # Every PROFILE_EVERY-th step's launches of that kernel are bracketed (gdg_profile_sample): an event pair also keeps the bracketed kernel
     # from overlapping its neighbours' ramp-up and tail -- with every step bracketed the timed region is 5 % slower than unobserved.
     ctx.profile_sample(PROFILE_EVERY)
-    ctx.profile_enable(kinds=[pkg.K_FIR_MAC])
+    if os.environ.get("GDG_BENCH_TIMED_PROFILE", "1") != "0":       # experiment knob: what the events in the timed region cost
+        ctx.profile_enable(kinds=[pkg.K_FIR_MAC])
 
     def synchronize():
         ctx.synchronize()

@@ -1454,12 +1454,22 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             if (st.is_fir) {
                 const gdg_fir_chan *d = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + st.offset) + first;
                 if (window > 1) {
-                    /* `window` frames per channel: every spectrum is read once for all of them (fir.hip, "Time blocking") */
+                    /* `window` frames per channel: every spectrum is read once for all of them (fir.hip, "Time blocking"); with adjacent
+                     * power amps the inverse transforms of one make the forward transforms of the next (one launch, no frame round trip) */
                     const int sh = st.shared_spectra ? 1 : 0;
-                    { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 0, shift, s)); }
+                    const bool chain_ok = gdg_fir_window_chain_ok(n) != 0;
+                    const bool chained_w = chain_ok && si > 0 && ctx->steps[si - 1].chain_next;
+                    const bool chains_w = chain_ok && st.chain_next;
+                    if (!chained_w) { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 0, shift, s)); }
                     { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 1, shift, s)); }
-                    { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 2, shift, s));
-                      HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 3, shift, s)); }
+                    {
+                        ProfScope ps(ctx, GDG_K_FIR_INV, s);
+                        if (chains_w) {
+                            const gdg_fir_chan *d_next = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + ctx->steps[si + 1].offset) + first;
+                            HIP_TRY(ctx, gdg_launch_fir_window_chain(window, d, d_next, n, tw, tw2, shift, s));
+                        } else HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 2, shift, s));
+                        HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 3, shift, s));
+                    }
                     continue;
                 }
                 const bool chained = si > 0 && ctx->steps[si - 1].chain_next;      /* the previous power amp's inverse made this one's spectrum */

@@ -967,6 +967,133 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     }
 }
 
+/* Time blocking + adjacent power amps: one workgroup per CHANNEL walks the W frames of the window; per frame the inverse transform of
+ * amp 1 (product spectrum Y_j -> clipped frame) runs straight into the forward transform of amp 2 ([previous | frame] -> delay-line
+ * slot), the frame staying in registers as in fir_inv_kernel<.., CHAIN> and the previous frame as in fir_fwd13w_chan_kernel.  Against
+ * the two separate launches (inverse: 128 KiB in, 64 out per channel-frame; forward: 64 in, 128 out) the frame's round trip through
+ * HBM is gone: 256 KiB instead of 384.  Only the LAST frame of the window is also written to amp 1's output buffer: amp 2's
+ * fir_tb_finish_kernel takes its overlap-save history from there.  Same arithmetic in the same order as the separate kernels. */
+__global__ void __launch_bounds__(512)
+fir_inv_fwd_chain_chan_kernel(const gdg_fir_chan *__restrict__ chans, const gdg_fir_chan *__restrict__ next_chans, int W, gdg_shift shift,
+                              const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int LOGN = 13, N = 8192, T = 512;
+    constexpr int LDS_WORDS = GDG_W_LDS > FftCfg<LOGN>::LDS ? GDG_W_LDS : FftCfg<LOGN>::LDS;
+    __shared__ double sre[LDS_WORDS];
+    __shared__ double sim[LDS_WORDS];
+    const int tid = threadIdx.x;
+    const gdg_fir_chan ch = chans[blockIdx.x], nx = next_chans[blockIdx.x];
+    const int pos2 = *nx.pos;
+    double *dst_last = ch.dst + (size_t)(W - 1) * N + ((ch.flags & GDG_DST_IS_OUTPUT) ? shift.out : 0);
+    /* hides the thread index from the optimiser (see fir_fwd13w_chan_kernel): otherwise the loop body's addresses are hoisted and spill */
+    auto fresh = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    cplx wa[2], pv[2][4];
+    {
+        const double *a2 = nx.prev + (size_t)((pos2 + 1) & 1) * N;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int n1 = tid + T * b;
+            wa[b] = tw[n1];
+#pragma unroll
+            for (int m = 0; m < 4; m++) pv[b][m] = gload(reinterpret_cast<const cplx *>(a2 + 2 * (n1 + 1024 * m)));
+        }
+    }
+    for (int jw = 0; jw < W; jw++) {
+        const cplx *__restrict__ Y = ch.Y + (size_t)jw * N;
+        cplx *nx_out = nx.fdl + (size_t)((pos2 + jw) % nx.R) * N;
+        /* inverse of amp 1 (fir_inv_kernel<13, 3>) */
+        {
+            const int t0 = fresh();
+            constexpr int ITER = (N / 2) / T;
+            cplx yk[ITER], yn[ITER];
+#pragma unroll
+            for (int i = 0; i < ITER; i++) {
+                const int k = t0 + T * i, n = (k == 0) ? N / 2 : N - k;
+                yk[i] = gload(Y + k);
+                yn[i] = gload(Y + n);
+            }
+#pragma unroll
+            for (int i = 0; i < ITER; i++) inv_head_store<LOGN>(t0 + T * i, yk[i], yn[i], sre, sim, tw2);
+        }
+        __syncthreads();
+        cplx ua[2][8];
+        {
+            const int t1 = fresh();
+            cplx v[16];
+            constexpr int NP = sched_npass(LOGN);
+            run_lds_passes<LOGN, 0, NP - 1, true>(v, sre, sim, tw, t1);
+            constexpr int LR = sched_lr(LOGN, NP - 1), LNS = sched_lns(LOGN, NP - 1), R = 1 << LR;
+            static_assert(R == 8, "last pass of the 8192-point inverse: radix 8");
+            pass_load<LOGN, LR>(v, sre, sim, t1);
+            pass_compute<LOGN, LR, LNS, true>(v, tw, t1);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int n1 = t1 + T * b;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    cplx z = v[b * R + 4 + m];
+                    z.x = fmin(1.0, fmax(-1.0, z.x));           /* filter/filter.go:487-493 */
+                    z.y = fmin(1.0, fmax(-1.0, z.y));
+                    ua[b][m] = pv[b][m];
+                    ua[b][4 + m] = z;
+                    pv[b][m] = z;
+                    if (jw == W - 1 || !(ch.flags & GDG_DST_UNUSED))
+                        gstore(reinterpret_cast<cplx *>((jw == W - 1 ? dst_last : dst_last - (size_t)(W - 1 - jw) * N) + 2 * (n1 + 1024 * m)), z);
+                }
+            }
+        }
+        __syncthreads();                                        /* the inverse's last pass has been read by everybody */
+        /* forward of amp 2 (fir_fwd13w_chan_kernel) */
+        {
+            const int ta = fresh();
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int n1 = ta + T * b;
+                Dft<8, false>::run(ua[b]);
+                twiddle_powers8(ua[b], wa[b]);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) { sre[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].x; sim[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].y; }
+            }
+        }
+        __syncthreads();
+        {
+            const int tb = fresh(), wv = tb >> 6, ln = tb & 63;
+            double *rre = sre + wv * GDG_W_RL, *rim = sim + wv * GDG_W_RL;
+            cplx f[16];
+            wave_fft1024<false>(f, rre, rim, tw, ln);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const int k1 = (ln + 64 * b) + 128 * t;
+                    rre[GDG_PAD(k1)] = f[b * 8 + t].x;
+                    rim[GDG_PAD(k1)] = f[b * 8 + t].y;
+                }
+        }
+        __syncthreads();
+        auto Z = [&](int k) { return make_double2(sre[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)], sim[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)]); };
+        const int tu = fresh();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = tu + T * i;
+            if (k == 0) {
+                cplx z0 = Z(0), zh = Z(N / 2);
+                gstore(nx_out, make_double2(z0.x + z0.y, z0.x - z0.y));
+                gstore(nx_out + N / 2, make_double2(zh.x, -zh.y));
+            } else {
+                const int n = N - k;
+                cplx zk = Z(k), zn = Z(n);
+                cplx A = make_double2(zk.x + zn.x, zk.y - zn.y);
+                cplx Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+                cplx cw = cmul(tw2[k], Bv);
+                gstore(nx_out + k, make_double2((A.x + cw.y) * 0.5, (A.y - cw.x) * 0.5));
+                gstore(nx_out + n, make_double2((A.x - cw.y) * 0.5, (-A.y - cw.x) * 0.5));
+            }
+        }
+        __syncthreads();                                        /* the regions are rewritten by the next frame's inverse head */
+    }
+}
+
 /* after a window of W frames: the last frame becomes the overlap-save history of the next call, the frame counter moves on */
 __global__ void __launch_bounds__(256)
 fir_tb_finish_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift) {
@@ -1170,6 +1297,23 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
         else launch_mac_tb<16, 8>(d_chans, n_chans, shared_spectra != 0, s);
     } else if (what == 2) fir_inv_kernel<13, 3><<<dim3(n_chans * W), dim3(FftCfg<13>::T), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
     else fir_tb_finish_kernel<<<dim3(n_chans), dim3(256), 0, s>>>(d_chans, W, shift);
+    return hipGetLastError();
+}
+
+/* 1 when a window's inverse transforms of one power amp can produce the forward transforms of the next (one workgroup per channel
+ * walking the frames: needs a chip's worth of channels, like the per-channel forward kernel) */
+int gdg_fir_window_chain_ok(int n_chans) {
+    static int per_channel = -1;
+    if (per_channel < 0) { const char *e = getenv("GDG_FWD_PER_CHANNEL"); per_channel = e ? atoi(e) : 1; }
+    return per_channel && n_chans >= cu_count();
+}
+
+/* the window's inverse transforms of d_chans and the forward transforms of d_next_chans (the power amp that follows in every channel) */
+hipError_t gdg_launch_fir_window_chain(int W, const gdg_fir_chan *d_chans, const gdg_fir_chan *d_next_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2,
+                                       gdg_shift shift, hipStream_t s) {
+    if (n_chans <= 0) return hipSuccess;
+    if (W != 2 && W != 4 && W != 8 && W != 16) return hipErrorInvalidValue;
+    fir_inv_fwd_chain_chan_kernel<<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, d_next_chans, W, shift, d_tw, d_tw2);
     return hipGetLastError();
 }
 

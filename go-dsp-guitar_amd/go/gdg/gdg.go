@@ -462,7 +462,8 @@ func (this *Context) SetWindow(frames int) error {
 	return this.err(C.gdg_ctx_set_window(this.ctx, C.int(frames)))
 }
 
-// SetOverlap: channel groups of the device-resident calls (0 = automatic, 1 = off; gdg_ctx_set_overlap).
+// SetOverlap: free-running channel groups of the device-resident calls, opt-in (gdg_ctx_set_overlap: 0 or 1 = one group on the
+// context's stream, the default; > 1: groups on streams of their own, joined by the next call of any other kind).
 func (this *Context) SetOverlap(groups int) error {
 	return this.err(C.gdg_ctx_set_overlap(this.ctx, C.int(groups)))
 }
@@ -501,28 +502,17 @@ func (this *Context) BatchRun(inputs []BatchInput, opt BatchOptions) ([][]byte, 
 	if n == 0 {
 		return nil, fmt.Errorf("gdg: no inputs")
 	}
-	arr := (*[1 << 20]C.gdg_batch_input)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.gdg_batch_input{}))))
-	defer C.free(unsafe.Pointer(arr))
+	arr, release, err := batchInputs(inputs)
+	if err != nil {
+		return nil, err
+	}
+	defer release()
 	var owned []unsafe.Pointer
 	defer func() {
 		for _, p := range owned {
 			C.free(p)
 		}
 	}()
-	for i, in := range inputs {
-		width := int(C.gdg_wave_bytes_per_sample(C.int(in.Format)))
-		if len(in.Data) == 0 || width == 0 || in.Channels <= 0 {
-			continue
-		}
-		p := C.CBytes(in.Data)
-		owned = append(owned, p)
-		arr[i].bytes = p
-		arr[i].samples_per_channel = C.size_t(len(in.Data) / (width * in.Channels))
-		arr[i].format = C.int(in.Format)
-		arr[i].sample_rate = C.uint32_t(in.SampleRate)
-		arr[i].channels = C.uint(in.Channels)
-		arr[i].channel = C.uint(in.Channel)
-	}
 	o := C.gdg_batch_options{target_rate: C.uint32_t(opt.TargetRate), out_format: C.int(opt.OutFormat),
 		metronome_to_master: cbool(opt.MetronomeToMaster), run_meters: cbool(opt.RunMeters), tuner_enqueue: cbool(opt.TunerEnqueue)}
 	var samples C.size_t
@@ -538,16 +528,235 @@ func (this *Context) BatchRun(inputs []BatchInput, opt BatchOptions) ([][]byte, 
 		return outs, nil
 	}
 	ptrs := (*[1 << 20]unsafe.Pointer)(C.calloc(C.size_t(n+3), C.size_t(unsafe.Sizeof(uintptr(0)))))
+	if ptrs == nil {
+		return nil, fmt.Errorf("gdg: out of memory")
+	}
 	defer C.free(unsafe.Pointer(ptrs))
 	for i := 0; i < n+3; i++ {
 		ptrs[i] = C.malloc(C.size_t(each))
+		if ptrs[i] == nil {
+			return nil, fmt.Errorf("gdg: out of memory (%d bytes per output)", each)
+		}
 		owned = append(owned, ptrs[i])
 	}
 	if e := this.err(C.gdg_batch_run(this.ctx, &arr[0], C.int(n), &o, (*unsafe.Pointer)(unsafe.Pointer(ptrs)))); e != nil {
 		return nil, e
 	}
 	for i := range outs {
-		outs[i] = C.GoBytes(ptrs[i], C.int(each))
+		outs[i] = goBytes(ptrs[i], each)
 	}
 	return outs, nil
+}
+
+// goBytes copies n bytes of C memory into a fresh slice.  C.GoBytes takes a C.int length and overflows from 2 GiB on
+// (46 minutes of float64 at 96 kHz); this goes through a slice header over the C memory instead.
+func goBytes(p unsafe.Pointer, n int) []byte {
+	out := make([]byte, n)
+	if n > 0 {
+		copy(out, (*[1 << 40]byte)(p)[:n:n])
+	}
+	return out
+}
+
+func goFloats(p unsafe.Pointer, n int) []float64 {
+	out := make([]float64, n)
+	if n > 0 {
+		copy(out, (*[1 << 37]float64)(p)[:n:n])
+	}
+	return out
+}
+
+// batchInputs builds the C array of gdg_batch_input; the file bytes live in C memory until release() is called.
+func batchInputs(inputs []BatchInput) (arr *[1 << 20]C.gdg_batch_input, release func(), err error) {
+	n := len(inputs)
+	arr = (*[1 << 20]C.gdg_batch_input)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.gdg_batch_input{}))))
+	if arr == nil {
+		return nil, func() {}, fmt.Errorf("gdg: out of memory")
+	}
+	owned := []unsafe.Pointer{unsafe.Pointer(arr)}
+	release = func() {
+		for _, p := range owned {
+			C.free(p)
+		}
+	}
+	for i, in := range inputs {
+		width := int(C.gdg_wave_bytes_per_sample(C.int(in.Format)))
+		if len(in.Data) == 0 || width == 0 || in.Channels <= 0 {
+			continue
+		}
+		p := C.CBytes(in.Data)
+		if p == nil {
+			release()
+			return nil, func() {}, fmt.Errorf("gdg: out of memory")
+		}
+		owned = append(owned, p)
+		arr[i].bytes = p
+		arr[i].samples_per_channel = C.size_t(len(in.Data) / (width * in.Channels))
+		arr[i].format = C.int(in.Format)
+		arr[i].sample_rate = C.uint32_t(in.SampleRate)
+		arr[i].channels = C.uint(in.Channels)
+		arr[i].channel = C.uint(in.Channel)
+	}
+	return arr, release, nil
+}
+
+// BatchLength: samples of every output for these inputs (gdg_batch_length): the longest resampled input, rounded up to 8192.
+func (this *Context) BatchLength(inputs []BatchInput, targetRate uint32) (int, error) {
+	if len(inputs) == 0 {
+		return 0, fmt.Errorf("gdg: no inputs")
+	}
+	arr, release, err := batchInputs(inputs)
+	if err != nil {
+		return 0, err
+	}
+	defer release()
+	var samples C.size_t
+	if e := this.err(C.gdg_batch_length(this.ctx, &arr[0], C.int(len(inputs)), C.uint32_t(targetRate), &samples)); e != nil {
+		return 0, e
+	}
+	return int(samples), nil
+}
+
+// ShardResult: what one shard of a split job hands back (gdg_batch_run_shard).
+type ShardResult struct {
+	Outputs        [][]byte  // the shard's n encoded chain outputs
+	Left, Right    []float64 // its PARTIAL master mix (no aux input, not clipped)
+	MetronomeBytes []byte    // only on the shard that runs the metronome
+	Metronome      []float64 // its float64 samples (the master's aux input when metrMasterOutput is set)
+}
+
+// BatchRunShard: the batch run of ONE shard of a job whose channels are split over several contexts / GPUs (contiguous channel
+// blocks, gdg.Shards).  jobSamples = the longest BatchLength over all shards (every output of the job has that length,
+// controller.go:3005-3045); exactly one shard passes runMetronome.  The master is finished once with FinishMaster.
+func (this *Context) BatchRunShard(inputs []BatchInput, opt BatchOptions, jobSamples int, runMetronome bool) (*ShardResult, error) {
+	n := len(inputs)
+	if n == 0 {
+		return nil, fmt.Errorf("gdg: no inputs")
+	}
+	arr, release, err := batchInputs(inputs)
+	if err != nil {
+		return nil, err
+	}
+	defer release()
+	o := C.gdg_batch_options{target_rate: C.uint32_t(opt.TargetRate), out_format: C.int(opt.OutFormat),
+		metronome_to_master: 0, run_meters: cbool(opt.RunMeters), tuner_enqueue: cbool(opt.TunerEnqueue)}
+	width := int(C.gdg_wave_bytes_per_sample(o.out_format))
+	res := &ShardResult{Outputs: make([][]byte, n)}
+	if jobSamples == 0 || width == 0 {
+		return res, nil
+	}
+	var owned []unsafe.Pointer
+	defer func() {
+		for _, p := range owned {
+			C.free(p)
+		}
+	}()
+	alloc := func(bytes int) unsafe.Pointer {
+		p := C.malloc(C.size_t(bytes))
+		if p != nil {
+			owned = append(owned, p)
+		}
+		return p
+	}
+	ptrs := (*[1 << 20]unsafe.Pointer)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(uintptr(0)))))
+	if ptrs == nil {
+		return nil, fmt.Errorf("gdg: out of memory")
+	}
+	owned = append(owned, unsafe.Pointer(ptrs))
+	for i := 0; i < n; i++ {
+		if ptrs[i] = alloc(jobSamples * width); ptrs[i] == nil {
+			return nil, fmt.Errorf("gdg: out of memory")
+		}
+	}
+	var so C.gdg_batch_shard_out
+	so.master_left = (*C.double)(alloc(jobSamples * 8))
+	so.master_right = (*C.double)(alloc(jobSamples * 8))
+	so.job_samples = C.size_t(jobSamples)
+	if so.master_left == nil || so.master_right == nil {
+		return nil, fmt.Errorf("gdg: out of memory")
+	}
+	if runMetronome {
+		so.metronome_bytes = alloc(jobSamples * width)
+		so.metronome = (*C.double)(alloc(jobSamples * 8))
+		if so.metronome_bytes == nil || so.metronome == nil {
+			return nil, fmt.Errorf("gdg: out of memory")
+		}
+	}
+	if e := this.err(C.gdg_batch_run_shard(this.ctx, &arr[0], C.int(n), &o, (*unsafe.Pointer)(unsafe.Pointer(ptrs)), &so)); e != nil {
+		return nil, e
+	}
+	for i := range res.Outputs {
+		res.Outputs[i] = goBytes(ptrs[i], jobSamples*width)
+	}
+	res.Left = goFloats(unsafe.Pointer(so.master_left), jobSamples)
+	res.Right = goFloats(unsafe.Pointer(so.master_right), jobSamples)
+	if runMetronome {
+		res.MetronomeBytes = goBytes(so.metronome_bytes, jobSamples*width)
+		res.Metronome = goFloats(unsafe.Pointer(so.metronome), jobSamples)
+	}
+	return res, nil
+}
+
+// FinishMaster: master = ((p_0 + p_1) + ... + p_{G-1}) + aux per side, summed and encoded on this context's device
+// (gdg_batch_finish_master; spatializer/spatializer.go:300-310, controller/controller.go:3123-3219).  aux == nil: no aux input.
+func (this *Context) FinishMaster(outFormat int, shards []*ShardResult, aux []float64, sampleRate uint32, runMeters bool) (left []byte, right []byte, err error) {
+	g := len(shards)
+	if g == 0 {
+		return nil, nil, fmt.Errorf("gdg: no shards")
+	}
+	samples := len(shards[0].Left)
+	width := int(C.gdg_wave_bytes_per_sample(C.int(outFormat)))
+	if samples == 0 || width == 0 {
+		return []byte{}, []byte{}, nil
+	}
+	var owned []unsafe.Pointer
+	defer func() {
+		for _, p := range owned {
+			C.free(p)
+		}
+	}()
+	cFloats := func(v []float64) *C.double {
+		p := C.malloc(C.size_t(len(v) * 8))
+		if p == nil {
+			return nil
+		}
+		owned = append(owned, p)
+		copy((*[1 << 37]float64)(p)[:len(v):len(v)], v)
+		return (*C.double)(p)
+	}
+	lp := (*[1 << 20]*C.double)(C.calloc(C.size_t(2*g), C.size_t(unsafe.Sizeof(uintptr(0)))))
+	if lp == nil {
+		return nil, nil, fmt.Errorf("gdg: out of memory")
+	}
+	owned = append(owned, unsafe.Pointer(lp))
+	for i, s := range shards {
+		if len(s.Left) != samples || len(s.Right) != samples {
+			return nil, nil, fmt.Errorf("gdg: shard %d has %d samples, shard 0 has %d", i, len(s.Left), samples)
+		}
+		lp[i], lp[g+i] = cFloats(s.Left), cFloats(s.Right)
+		if lp[i] == nil || lp[g+i] == nil {
+			return nil, nil, fmt.Errorf("gdg: out of memory")
+		}
+	}
+	var cAux *C.double
+	if aux != nil {
+		if len(aux) != samples {
+			return nil, nil, fmt.Errorf("gdg: the aux input has %d samples, the job %d", len(aux), samples)
+		}
+		if cAux = cFloats(aux); cAux == nil {
+			return nil, nil, fmt.Errorf("gdg: out of memory")
+		}
+	}
+	lb, rb := C.malloc(C.size_t(samples*width)), C.malloc(C.size_t(samples*width))
+	if lb == nil || rb == nil {
+		C.free(lb)
+		C.free(rb)
+		return nil, nil, fmt.Errorf("gdg: out of memory")
+	}
+	owned = append(owned, lb, rb)
+	if e := this.err(C.gdg_batch_finish_master(this.ctx, C.int(outFormat), &lp[0], &lp[g], C.int(g), cAux, C.size_t(samples), C.uint32_t(sampleRate),
+		cbool(runMeters), lb, rb)); e != nil {
+		return nil, nil, e
+	}
+	return goBytes(lb, samples*width), goBytes(rb, samples*width), nil
 }

@@ -29,7 +29,7 @@ import (
 	"github.com/andrepxx/go-dsp-guitar/effects"
 	"github.com/andrepxx/go-dsp-guitar/filter"
 
-	"gdg" // ../gdg, the cgo binding
+	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding, added to the reference module by the overlay (go/overlay.json)
 )
 
 const blockSize = 8192 // controller/controller.go:36 BLOCK_SIZE

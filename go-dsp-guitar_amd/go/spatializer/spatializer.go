@@ -22,7 +22,7 @@ import (
 	"os"
 	"sync"
 
-	"gdg" // ../gdg, the cgo binding
+	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding, added to the reference module by the overlay (go/overlay.json)
 )
 
 const (

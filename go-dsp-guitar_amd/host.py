@@ -38,6 +38,8 @@ def lib():
             "gdgh_engine_create": (vp, [i32, i32, i32]), "gdgh_engine_destroy": (None, [vp]),
             "gdgh_engine_set_rendezvous": (None, [vp, i32, i32]), "gdgh_engine_last_error": (cs, [vp]),
             "gdgh_engine_process_all": (cs, [vp, vp, vp, i32, C.c_uint32]),
+            "gdgh_engine_batch_run": (cs, [vp, vp, i32, vp, i32, vp, C.POINTER(C.c_size_t)]),
+            "gdgh_engine_context": (vp, [vp, i32]), "gdgh_engine_shard_range": (None, [vp, i32, C.POINTER(i32), C.POINTER(i32)]),
             "gdgh_engine_create_sharded": (vp, [i32, i32, vp, i32]), "gdgh_engine_shards": (i32, [vp]), "gdgh_engine_shard_of": (i32, [vp, i32]),
             "gdgh_spatializer_create": (vp, [vp, C.c_uint32]), "gdgh_spatializer_destroy": (None, [vp]),
             "gdgh_spatializer_set": (cs, [vp, i32, C.c_uint32, C.c_double]), "gdgh_spatializer_get": (cs, [vp, i32, C.c_uint32, C.POINTER(C.c_double)]),
@@ -140,6 +142,56 @@ class Engine:
         _err(lib().gdgh_engine_process_all(self._h, ins, outs, x.shape[1], sample_rate))
         return out
 
+
+    def shard_range(self, shard):
+        first, count = C.c_int(0), C.c_int(0)
+        lib().gdgh_engine_shard_range(self._h, shard, C.byref(first), C.byref(count))
+        return first.value, count.value
+
+    def raw_context(self, shard=0):
+        """the shard's gdg_ctx handle (for configuring what the twin has no class for: metronome, meters) wrapped as a package Context
+        that does NOT own it"""
+        import __graft_entry__ as entry
+        pkg = entry.load_package()
+        ctx = pkg.Context.__new__(pkg.Context)
+        ctx._h = C.c_void_p(lib().gdgh_engine_context(self._h, shard))
+        ctx.n_channels = self.shard_range(shard)[1]
+        ctx.max_frames, ctx.device, ctx._chains = 8192, 0, []
+        ctx.close = lambda: None                      # the engine owns the context
+        return ctx
+
+    def batch_run(self, inputs, target_rate, out_format, window=16, metronome_to_master=False, run_meters=False, tuner_enqueue=False):
+        """Engine::BatchRun: controller.processFiles' data path over all shards; returns the N + 3 output data sections."""
+        import __graft_entry__ as entry
+        pkg = entry.load_package()
+        n = len(inputs)
+        arr = (pkg.BatchInput * n)()
+        keep = []
+        for i, it in enumerate(inputs):
+            if it is None:
+                continue
+            data, fmt, rate = it[0], it[1], it[2]
+            channels, channel = (it[3], it[4]) if len(it) > 3 else (1, 0)
+            f = pkg.WAVE_FORMATS[fmt] if isinstance(fmt, str) else fmt
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            keep.append(data)
+            w = max(pkg.lib().gdg_wave_bytes_per_sample(f), 1)
+            arr[i] = pkg.BatchInput(data.ctypes.data if data.size else None, data.size // (w * max(channels, 1)), f, rate, channels, channel)
+        fo = pkg.WAVE_FORMATS[out_format] if isinstance(out_format, str) else out_format
+        opt = pkg.BatchOptions(target_rate, fo, int(bool(metronome_to_master)), int(bool(run_meters)), int(bool(tuner_enqueue)))
+        wo = pkg.lib().gdg_wave_bytes_per_sample(fo)
+        # the job's length: the longest shard's (asked from the shards' own contexts)
+        length = 0
+        for g in range(self.shards()):
+            first, count = self.shard_range(g)
+            if count > 0:
+                length = max(length, self.raw_context(g).batch_length(inputs[first:first + count], target_rate))
+        outs = [np.zeros(length * wo, dtype=np.uint8) for _ in range(n + 3)]
+        ptrs = (C.c_void_p * (n + 3))(*[(o.ctypes.data if o.size else None) for o in outs])
+        samples = C.c_size_t(0)
+        _err(lib().gdgh_engine_batch_run(self._h, arr, n, C.byref(opt), window, ptrs, C.byref(samples)))
+        assert samples.value == length
+        return outs
 
 class Chain:
     """signal.Chain: the 14 methods of signal/signal.go:21-36."""

@@ -811,6 +811,80 @@ Error Engine::ProcessAll(const double *const *in, double *const *out, int frames
     return LastError();
 }
 
+Error Engine::BatchRun(const gdg_batch_input *inputs, int nInputs, const gdg_batch_options &options, int window, void *const *outs, size_t *samples) {
+    if (!inputs || !outs) return "BatchRun: no inputs or no outputs";
+    if (nInputs != nChannels_) return format("BatchRun: %d inputs for %d channels", nInputs, nChannels_);
+    const int G = shards();
+    const int N = nChannels_;
+    setError("");
+    std::vector<std::shared_ptr<signal::Chain>> chains;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        chains = chains_;
+    }
+    /* 1. per shard: the device follows the chains (units, parameters, filters, layout) as before a Process call; the job's length is
+     *    the longest shard's (the reference pads every channel to the longest input, controller.go:3005-3045) */
+    size_t job = 0;
+    for (int g = 0; g < G; g++) {
+        int first = 0, count = 0;
+        shardRange(g, &first, &count);
+        if (count <= 0) continue;
+        std::lock_guard<std::mutex> lk(shards_[(size_t)g]->mu);
+        gdg_ctx *ctx = context(g);
+        if (!ctx) return LastError();
+        std::vector<signal::Chain *> mine;
+        for (auto &c : chains) if (c->channel() >= first && c->channel() < first + count) mine.push_back(c.get());
+        Error e = sync(g, mine, options.target_rate);
+        if (!e.empty()) { setError(e); return e; }
+        if (gdg_ctx_set_window(ctx, window) != GDG_OK) { setError(gdg_last_error(ctx)); return LastError(); }
+        size_t len = 0;
+        if (gdg_batch_length(ctx, inputs + first, count, options.target_rate, &len) != GDG_OK) { setError(gdg_last_error(ctx)); return LastError(); }
+        job = std::max(job, len);
+    }
+    if (samples) *samples = job;
+    if (job == 0) return "";
+    /* 2. the shards, concurrently: encoded chain outputs straight into the caller's buffers, partial master mixes as float64 */
+    std::vector<std::vector<double>> left((size_t)G), right((size_t)G);
+    std::vector<double> metronome(job, 0.0);
+    std::vector<Error> errs((size_t)G);
+    auto one = [&](int g) {
+        int first = 0, count = 0;
+        shardRange(g, &first, &count);
+        if (count <= 0) return;
+        std::lock_guard<std::mutex> lk(shards_[(size_t)g]->mu);
+        gdg_ctx *ctx = shards_[(size_t)g]->ctx;
+        left[(size_t)g].assign(job, 0.0);
+        right[(size_t)g].assign(job, 0.0);
+        gdg_batch_shard_out so;
+        memset(&so, 0, sizeof(so));
+        so.master_left = left[(size_t)g].data();
+        so.master_right = right[(size_t)g].data();
+        so.job_samples = job;
+        if (g == 0) { so.metronome_bytes = outs[N + 2]; so.metronome = metronome.data(); }      /* shard 0 runs the metronome */
+        gdg_batch_options o = options;
+        o.metronome_to_master = 0;                       /* the aux input joins the master once, after the shards' sums */
+        if (gdg_batch_run_shard(ctx, inputs + first, count, &o, outs + first, &so) != GDG_OK) errs[(size_t)g] = gdg_last_error(ctx);
+    };
+    {
+        std::vector<std::thread> workers;
+        for (int g = 1; g < G; g++) workers.emplace_back(one, g);
+        one(0);
+        for (auto &w : workers) w.join();
+    }
+    for (int g = 0; g < G; g++) if (!errs[(size_t)g].empty()) { setError(format("shard %d: %s", g, errs[(size_t)g].c_str())); return LastError(); }
+    /* 3. the master mix, finished on shard 0's device */
+    std::vector<const double *> lp, rp;
+    for (int g = 0; g < G; g++) if (!left[(size_t)g].empty()) { lp.push_back(left[(size_t)g].data()); rp.push_back(right[(size_t)g].data()); }
+    std::lock_guard<std::mutex> lk(shards_[0]->mu);
+    gdg_ctx *ctx0 = shards_[0]->ctx;
+    if (gdg_batch_finish_master(ctx0, options.out_format, lp.data(), rp.data(), (int)lp.size(), options.metronome_to_master ? metronome.data() : nullptr, job,
+                                options.target_rate, options.run_meters, outs[N], outs[N + 1]) != GDG_OK) {
+        setError(gdg_last_error(ctx0));
+        return LastError();
+    }
+    return "";
+}
+
 /* ================================ spatializer ============================================= */
 namespace spatializer {
 
@@ -983,6 +1057,11 @@ const char *gdgh_engine_process_all(void *e, const double *const *in, double *co
     return ret(((Engine *)e)->ProcessAll(in, out, frames, sr));
 }
 
+const char *gdgh_engine_batch_run(void *e, const gdg_batch_input *inputs, int n, const gdg_batch_options *opt, int window, void *const *outs, size_t *samples) {
+    return ret(((Engine *)e)->BatchRun(inputs, n, *opt, window, outs, samples));
+}
+void *gdgh_engine_context(void *e, int shard) { return ((Engine *)e)->context(shard); }
+void gdgh_engine_shard_range(void *e, int shard, int *first, int *count) { ((Engine *)e)->shardRange(shard, first, count); }
 void *gdgh_engine_create_sharded(int n_channels, int max_frames, const int *devices, int n_devices) {
     return new Engine(n_channels, max_frames, std::vector<int>(devices, devices + n_devices));
 }

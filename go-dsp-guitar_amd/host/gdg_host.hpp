@@ -25,7 +25,7 @@
 #include <utility>
 #include <vector>
 
-struct gdg_ctx;
+#include "../../include/gdg.h"      /* the C-ABI the twin is written against (gdg_ctx, gdg_batch_input, gdg_batch_options ...) */
 
 #define GDG_HOST_MAX_FRAMES 8192      /* controller/controller.go:36 BLOCK_SIZE */
 
@@ -197,6 +197,14 @@ public:
     void SetRendezvous(int expected, int timeoutMs) { expected_ = expected; timeoutMs_ = timeoutMs; }
     /* direct batch call for callers that already hold all channels' buffers (bench, tests) */
     Error ProcessAll(const double *const *in, double *const *out, int frames, uint32_t sampleRate);
+    /* controller.processFiles between "the files are read" and "the files are written" (controller.go:2884-3219) over ALL shards:
+     * the chains are synchronised to the devices, every shard runs its block of channels on its own thread, `window` blocks per step
+     * (gdg_batch_run_shard; shard 0 also runs the metronome), and the master is finished once on shard 0's device: the shards'
+     * float64 partial mixes added in shard order, then the metronome as aux input (options.metronome_to_master), then the encoder
+     * (gdg_batch_finish_master) -- the reference's sum over all channels -> + aux -> encode (spatializer.go:300-310,
+     * controller.go:3123-3219).  inputs: one per channel of the engine; outs: N + 3 host buffers as for gdg_batch_run
+     * (NULL = "skipping output"); `samples` receives the length of every output. */
+    Error BatchRun(const gdg_batch_input *inputs, int nInputs, const gdg_batch_options &options, int window, void *const *outs, size_t *samples);
     std::string LastError() const;
     int channels() const { return nChannels_; }
     int shards() const { return (int)shards_.size(); }

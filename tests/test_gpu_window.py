@@ -216,3 +216,40 @@ def test_every_unit_type_in_windows():
     ctx.close()
     for c in range(len(chains)):
         assert np.array_equal(got[c], want[c]), "chain %d: max diff %.3e" % (c, np.max(np.abs(got[c] - want[c])))
+
+
+def test_window_chain_of_adjacent_power_amps_gives_the_same_bits():
+    """Time blocking with two power amps in a row, a chip's worth of channels: one workgroup per channel walks the window, the inverse
+    transform of amp 1 running into the forward transform of amp 2 (fir_inv_fwd_chain_chan_kernel).  GDG_FIR_CHAIN=0 keeps the launches
+    separate; per-frame calls are the third way.  All three: identical samples."""
+    import os
+    pkg = package()
+    nch, frames, sr, taps, W, blocks = 256, 8192, 96000, 20000, 4, 8
+    x = np.stack([synth_signal(c % 7, frames * blocks, sr) * (0.5 + 0.001 * c) for c in range(nch)])
+    irs = [[synth_ir(taps, seed=70 + 2 * k + j) * 0.9 for j in range(2)] for k in range(3)]
+    outs = {}
+    for mode in ("window_chain", "window_separate", "per_frame"):
+        os.environ["GDG_FIR_CHAIN"] = "0" if mode == "window_separate" else "1"
+        try:
+            ctx = pkg.Context(nch, frames)
+        finally:
+            del os.environ["GDG_FIR_CHAIN"]
+        for c in range(nch):
+            ctx.append_unit(c, "tone_stack")
+            ctx.append_unit(c, "power_amp", fir=irs[c % 3][0])
+            ctx.append_unit(c, "power_amp", fir=irs[c % 3][1])
+            ctx.append_unit(c, "cabinet")
+        d_in, d_out = ctx.alloc(nch, blocks * frames), ctx.alloc(nch, blocks * frames)
+        d_in.upload(x)
+        if mode == "per_frame":
+            for b in range(blocks):
+                ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, blocks * frames, 1, sr)
+        else:
+            ctx.set_window(W)
+            for b in range(0, blocks, W):
+                ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, blocks * frames, W, sr)
+        outs[mode] = d_out.download()
+        ctx.close()
+    assert np.array_equal(outs["window_chain"], outs["window_separate"])
+    assert np.array_equal(outs["window_chain"], outs["per_frame"])
+    assert np.abs(outs["per_frame"]).max() > 0.01

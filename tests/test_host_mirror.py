@@ -502,3 +502,72 @@ def test_control_plane_setters_race_with_processing(host, oracle):
         tail = slice(28 * frames, None)                        # the level follower forgets with exp(-t / 2400 samples): e^-12 by then
         assert rms(got[c, tail] - want[tail]) <= 1e-6, "channel %d" % c
     eng.close()
+
+
+@pytest.mark.gpu
+def test_engine_batch_run_over_three_shards_matches_the_oracle_pipeline(host, oracle):
+    """Engine::BatchRun (= what the Go shim's patched controller.processFiles calls): file bytes in, file bytes out, seven channels over
+    THREE shards (three contexts on device 0), windows of 4 blocks, the master finished once from the shards' float64 partial mixes +
+    the metronome as aux input (spatializer.go:300-310, controller.go:3123-3219).  Against the oracle's pipeline: decode ->
+    resample.Time -> pad -> per block N chains, metronome, spatializer(+aux) -> encode; 24-bit files byte for byte."""
+    BLOCK = 8192
+    sr, nch = 48000, 7
+    rng = np.random.default_rng(21)
+    taps = {"Cab": synth_ir(2000, seed=3), "Room": synth_ir(5000, seed=4)}
+    irs = host.ImpulseResponses()
+    irs.add("Cab", sr, -20, taps["Cab"])
+    irs.add("Room", sr, -10, taps["Room"])
+    eng = host.Engine(nch, BLOCK, devices=[0, 0, 0])
+    chains, refs = [], []
+    for c in range(nch):
+        ch, ref = eng.create_chain(irs), oracle.Chain()
+        _full_chain(ch, ref, oracle, sr, taps)
+        chains.append(ch)
+        refs.append(ref)
+    sp = host.Spatializer(eng, nch)
+    sp.SetSampleRate(sr)
+    ref_sp = oracle.Spatializer(nch)
+    ref_sp.set_sample_rate(sr)
+    for c in range(nch):
+        a, d, l = float(rng.uniform(-90, 90)), float(rng.uniform(0.3, 5)), float(rng.uniform(0.2, 1))
+        sp.SetAzimuth(c, a); sp.SetDistance(c, d); sp.SetLevel(c, l)
+        ref_sp.set_azimuth(c, a); ref_sp.set_distance(c, d); ref_sp.set_level(c, l)
+    tick, tock = rng.uniform(-0.5, 0.5, 900), rng.uniform(-0.5, 0.5, 500)
+    m0 = eng.raw_context(0)                                   # the metronome lives on shard 0
+    m0.metronome_set_sounds(tick, tock)
+    m0.metronome_configure(3, 200, sr)
+    ref_met = oracle.Metronome()
+    ref_met.tick, ref_met.tock = tick, tock
+    ref_met.s.beats_per_period, ref_met.s.bpm_speed, ref_met.s.sample_rate = 3, 200, sr
+    # the files: 16-bit at the target rate, one at 44.1 kHz (resampled), one empty; different lengths
+    lengths = [30000, 70000, 41000, 0, 20000, 65000, 9000]
+    inputs, ref_in = [], []
+    for c, n in enumerate(lengths):
+        if n == 0:
+            inputs.append(None)
+            ref_in.append(np.zeros(0))
+            continue
+        rate = 44100 if c == 2 else sr
+        data = oracle.wave_encode("lpcm16", 0.7 * synth_signal(c, n, rate))
+        inputs.append((data, "lpcm16", rate))
+        xd = oracle.wave_decode("lpcm16", data)
+        ref_in.append(xd if rate == sr else oracle.resample_time(xd, rate, sr))
+    longest = max(len(v) for v in ref_in)
+    length = BLOCK * ((longest + BLOCK - 1) // BLOCK)
+    xin = np.zeros((nch, length))
+    for c, v in enumerate(ref_in):
+        xin[c, :len(v)] = v
+    ref_out = np.zeros((nch + 3, length))
+    for b in range(length // BLOCK):
+        sl = slice(b * BLOCK, (b + 1) * BLOCK)
+        for c in range(nch):
+            ref_out[c, sl] = refs[c].process(xin[c, sl], sr)
+        ref_out[nch + 2, sl] = ref_met.process(BLOCK)
+        ref_out[nch, sl], ref_out[nch + 1, sl] = ref_sp.process(ref_out[:nch, sl], aux=ref_out[nch + 2, sl])
+    outs = eng.batch_run(inputs, sr, "lpcm24", window=4, metronome_to_master=True)
+    assert eng.last_error() == ""
+    assert len(outs) == nch + 3 and all(o.size == 3 * length for o in outs)
+    for r in range(nch + 3):
+        np.testing.assert_array_equal(outs[r], oracle.wave_encode("lpcm24", ref_out[r]), err_msg="output %d" % r)
+    del sp
+    eng.close()
