@@ -221,14 +221,14 @@ struct gdg_ctx {
     int tuner_wp = 0;
     uint32_t tuner_sr = 0;
     double *d_note_freqs = nullptr;
-    gdg_tuner_out *d_tuner_out = nullptr;
+    gdg_tuner_out *d_tuner_out = nullptr, *h_tuner_out = nullptr;      /* results on the device / in pinned host memory */
     double2 *d_tuner_work = nullptr, *d_tuner_twn = nullptr, *d_tuner_twm = nullptr;
     std::vector<double> sp_az, sp_dist, sp_level;
     uint32_t sp_hist_sr = 96000;
-    double *d_sp_hist = nullptr;
-    int sp_hist_len = 0;
+    double *d_sp_hist = nullptr;               /* [2][nch][sp_hist_len]: read this block / written for the next (sp_hist_cur) */
+    int sp_hist_len = 0, sp_hist_cur = 0;
     gdg_spat_chan *d_sp_chan = nullptr;
-    double *d_sp_partial = nullptr, *d_sp_out = nullptr;
+    double *d_sp_out = nullptr;
     bool sp_dirty = true;
     /* io (wave codecs, resample.Time, level meters) */
     void *d_io[2] = { nullptr, nullptr };
@@ -408,7 +408,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
     hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
-    hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_partial); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter); hipFree(ctx->d_tick); hipFree(ctx->d_tock);
+    hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter); hipFree(ctx->d_tick); hipFree(ctx->d_tock);
     for (auto st : ctx->gstreams) hipStreamDestroy(st);
     for (auto e : ctx->gjoin) hipEventDestroy(e);
     if (ctx->gfork) hipEventDestroy(ctx->gfork);
@@ -425,6 +425,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     if (ctx->batch_begin) hipEventDestroy(ctx->batch_begin);
     for (int i = 0; i < 6; i++) hipFree(ctx->batch_dev[i]);
     if (ctx->batch_up_stream) hipStreamDestroy(ctx->batch_up_stream);
+    if (ctx->h_tuner_out) hipHostFree(ctx->h_tuner_out);
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1919,6 +1920,7 @@ static int ensure_tuner(gdg_ctx *ctx) {
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_note_freqs, GDG_NOTE_COUNT * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_note_freqs, GDG_NOTE_FREQS, GDG_NOTE_COUNT * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_out, (size_t)ctx->nch * sizeof(gdg_tuner_out)));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_tuner_out, (size_t)ctx->nch * sizeof(gdg_tuner_out), hipHostMallocDefault));
     ctx->tuner_wp = 0;
     return GDG_OK;
 }
@@ -2003,13 +2005,14 @@ int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
                                               ctx->d_tuner_twn, ctx->d_tuner_twm, tw512, tw256, ctx->d_note_freqs, GDG_NOTE_COUNT,
                                               ctx->d_tuner_out, ctx->stream));
     }
-    std::vector<gdg_tuner_out> host((size_t)ctx->nch);
-    HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->d_tuner_out, host.size() * sizeof(gdg_tuner_out), hipMemcpyDeviceToHost, ctx->stream));
+    /* pinned destination: the copy is a plain DMA behind the kernel (a pageable one goes through the runtime's staging path) */
+    gdg_tuner_out *host = ctx->h_tuner_out;
+    HIP_TRY(ctx, hipMemcpyAsync(host, ctx->d_tuner_out, (size_t)ctx->nch * sizeof(gdg_tuner_out), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < ctx->nch; c++) {
-        results[c].frequency = host[(size_t)c].frequency;
-        results[c].note_index = host[(size_t)c].note_index;
-        results[c].cents = (int8_t)host[(size_t)c].cents;
+        results[c].frequency = host[c].frequency;
+        results[c].note_index = host[c].note_index;
+        results[c].cents = (int8_t)host[c].cents;
     }
     return GDG_OK;
 }
@@ -2024,12 +2027,12 @@ const char *gdg_tuner_note_name(int note_index) { return (note_index >= 0 && not
 static int ensure_spatializer(gdg_ctx *ctx) {
     if (ctx->d_sp_hist) return GDG_OK;
     ctx->sp_hist_len = (int)ceil((double)ctx->sp_hist_sr * SPAT_GROUP_DELAY);
-    size_t hist_bytes = (size_t)ctx->nch * (size_t)ctx->sp_hist_len * sizeof(double);
+    size_t hist_bytes = 2 * (size_t)ctx->nch * (size_t)ctx->sp_hist_len * sizeof(double);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_hist, hist_bytes));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_sp_hist, 0, hist_bytes, ctx->stream));
+    ctx->sp_hist_cur = 0;
     if (!ctx->d_sp_chan) {
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_chan, (size_t)ctx->nch * sizeof(gdg_spat_chan)));
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_partial, (size_t)gdg_spat_groups(ctx->nch) * 2 * (size_t)ctx->max_frames * sizeof(double)));
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_out, 2 * (size_t)ctx->max_frames * sizeof(double)));
     }
     ctx->sp_dirty = true;
@@ -2104,6 +2107,17 @@ static int upload_spat_chans(gdg_ctx *ctx) {
     return GDG_OK;
 }
 
+/* the one launch of a block: mix + history for the next block (the two history buffers swap) */
+static int launch_spatializer(gdg_ctx *ctx, const double *d_in, int in_stride, double *d_left, int out_stride, int frames) {
+    const size_t one = (size_t)ctx->nch * (size_t)ctx->sp_hist_len;
+    const double *rd = ctx->d_sp_hist + (size_t)ctx->sp_hist_cur * one;
+    double *wr = ctx->d_sp_hist + (size_t)(ctx->sp_hist_cur ^ 1) * one;
+    ProfScope ps(ctx, GDG_K_SPATIALIZER);
+    HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_in, in_stride, rd, wr, ctx->sp_hist_len, d_left, out_stride, frames, ctx->stream));
+    ctx->sp_hist_cur ^= 1;
+    return GDG_OK;
+}
+
 int gdg_spatialize_device(gdg_ctx *ctx, const double *d_in, double *d_out_lr, int frames) {
     if (!ctx || !d_in || !d_out_lr) return GDG_ERR_INVALID;
     if (frames <= 0 || frames > ctx->max_frames) return fail(ctx, GDG_ERR_INVALID, "frames %d out of range (max %d)", frames, ctx->max_frames);
@@ -2111,10 +2125,7 @@ int gdg_spatialize_device(gdg_ctx *ctx, const double *d_in, double *d_out_lr, in
     int rc = ensure_spatializer(ctx);
     if (rc != GDG_OK) return rc;
     if (ctx->sp_dirty) { rc = upload_spat_chans(ctx); if (rc != GDG_OK) return rc; }
-    ProfScope ps(ctx, GDG_K_SPATIALIZER);
-    HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_in, frames, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
-                                        d_out_lr, frames, frames, ctx->max_frames, ctx->stream));
-    return GDG_OK;
+    return launch_spatializer(ctx, d_in, frames, d_out_lr, frames, frames);
 }
 
 /* one frame out of rows of any stride (the batch run's windows): left to d_left, right to d_left + out_stride */
@@ -2122,10 +2133,7 @@ static int spatialize_rows(gdg_ctx *ctx, const double *d_in, int in_stride, doub
     int rc = ensure_spatializer(ctx);
     if (rc != GDG_OK) return rc;
     if (ctx->sp_dirty) { rc = upload_spat_chans(ctx); if (rc != GDG_OK) return rc; }
-    ProfScope ps(ctx, GDG_K_SPATIALIZER);
-    HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_in, in_stride, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
-                                        d_left, out_stride, frames, ctx->max_frames, ctx->stream));
-    return GDG_OK;
+    return launch_spatializer(ctx, d_in, in_stride, d_left, out_stride, frames);
 }
 
 int gdg_spatialize(gdg_ctx *ctx, const double *const *in, double *out_left, double *out_right, int frames) {
@@ -2167,11 +2175,8 @@ int gdg_spatialize_staged(gdg_ctx *ctx, int from_outputs, double *out_left, doub
                                       (size_t)frames * sizeof(double), (size_t)ctx->nch, hipMemcpyHostToDevice, ctx->stream));
         d_rows = ctx->d_stage_in;
     }
-    {
-        ProfScope ps(ctx, GDG_K_SPATIALIZER);
-        HIP_TRY(ctx, gdg_launch_spatializer(ctx->d_sp_chan, ctx->nch, d_rows, stride, ctx->d_sp_hist, ctx->sp_hist_len, ctx->d_sp_partial,
-                                            ctx->d_sp_out, frames, frames, ctx->max_frames, ctx->stream));
-    }
+    rc = launch_spatializer(ctx, d_rows, stride, ctx->d_sp_out, frames, frames);
+    if (rc != GDG_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_left, ctx->d_sp_out, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(out_right, ctx->d_sp_out + frames, (size_t)frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -166,9 +166,10 @@ struct gdg_spat_chan {
     double fac_left, fac_right, w_early, w_late;
     int mode, early, late, pad;
 };
-hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, double *d_hist, int H,
-                                  double *d_partial, double *d_out_lr, int out_stride, int frames, int max_frames, hipStream_t s);   /* right = left + out_stride */
-int gdg_spat_groups(int nch);
+/* one launch: mix of `frames` samples (right = left + out_stride) reading the history d_hist_read, and the new history (last H inputs of
+ * every channel) into d_hist_write -- two different buffers, swapped by the caller from block to block */
+hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, const double *d_hist_read,
+                                  double *d_hist_write, int H, double *d_out_lr, int out_stride, int frames, hipStream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Tuner (tuner.hip): one 96000-sample ring per channel; analysis = 262144-point real FFT

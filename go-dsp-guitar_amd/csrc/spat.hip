@@ -2,88 +2,104 @@
  * spat.hip -- spatializer.Process (spatializer/spatializer.go:140-335): the partial N -> 2 stereo
  * mixdown of one shard of channels.  Memory bound (8 B per channel-sample in, 16 B per sample out).
  *
- * Two levels so that the launch fills the chip: each workgroup sums a group of 32 channels for a
- * tile of 256 samples in channel order, a second tiny kernel adds the group partials in group
- * order.  (The reference adds all channels in index order; the different association changes the
- * result by ~1e-16 * N, far inside the 1e-9 RMS bar.  Across shards the host adds the partial
- * pairs and the aux buffer, spatializer.go:300-310.)
+ * Two levels so that the launch fills the chip: groups of 32 channels are summed in channel order, the
+ * group partials in group order.  (The reference adds all channels in index order; the different
+ * association changes the result by ~1e-16 * N, far inside the 1e-9 RMS bar.  Across shards the host adds
+ * the partial pairs and the aux buffer, spatializer.go:300-310.)
  * Per-channel gains, delays and interpolation weights are computed on the host in the reference's
  * arithmetic (api.cpp), including its quirk that the delay is always computed for 96 kHz.
  */
 #include "gdg_internal.h"
 
-#define SPAT_GROUP 32
+#define SPAT_GROUP 32                    /* channels summed in index order by one lane */
+#define SPAT_TILE 32                     /* samples per workgroup */
+#define SPAT_SUB 8                       /* channel groups a workgroup works on at the same time (256 threads = 32 samples x 8) */
+#define SPAT_UNROLL 16                   /* channels whose loads are in flight together */
+#define SPAT_MAX_GROUPS 256              /* 8192 channels per shard */
 
+/* ONE launch per block (round 2: partial sums, reduce and history update were three launches, 23 us per 8192-frame block of 256
+ * channels, all latency).  Workgroup t < tiles mixes samples [32 t, 32 t + 32): lane (s, q) sums channel groups q, q + 8, ... of 32
+ * channels each in channel order, the group partials meet in LDS and are added in group order -- the same association as before, so
+ * the same bits.  The history (last H inputs of every channel, spatializer.go:313-331) is double buffered: this block reads
+ * `hist_read` and the workgroups t >= tiles write `hist_write`, so nobody waits for anybody inside the launch. */
 __global__ void __launch_bounds__(256)
-spat_partial_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__restrict__ in, int in_stride,
-                    const double *__restrict__ hist, int H, double *__restrict__ partial, int frames, int max_frames) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int g = blockIdx.y;
-    if (j >= frames) return;
-    const int c_begin = g * SPAT_GROUP, c_end = min(nch, c_begin + SPAT_GROUP);
-    double L = 0.0, R = 0.0;
-    for (int c = c_begin; c < c_end; c++) {
-        const gdg_spat_chan ch = chans[c];
-        const double *x = in + (size_t)c * in_stride;
-        const double cur = x[j];
-        if (ch.mode == 0) {
-            L += ch.fac_left * cur;
-            R += ch.fac_right * cur;
-        } else {
-            const double *hb = hist + (size_t)c * H;
-            int ie = j - ch.early, il = j - ch.late;
-            double se = (ie >= 0) ? x[ie] : hb[H + ie];
-            double sl = (il >= 0) ? x[il] : hb[H + il];
-            double early_sample = ch.w_early * se;
-            double late_sample = ch.w_late * sl;
-            double delayed = early_sample + late_sample;
-            if (ch.mode == 1) { L += ch.fac_left * delayed; R += ch.fac_right * cur; }
-            else { L += ch.fac_left * cur; R += ch.fac_right * delayed; }
+spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__restrict__ in, int in_stride,
+            const double *__restrict__ hist_read, double *__restrict__ hist_write, int H, double *__restrict__ out_lr, int out_stride,
+            int frames, int tiles) {
+    extern __shared__ double part[];                 /* [groups][2][SPAT_TILE] doubles, then nch channel descriptors */
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= tiles) {
+        /* history: entry k of channel c = element k + frames - H of [old history | frame] shifted by H */
+        const int total = nch * H;
+        for (int e = ((int)blockIdx.x - tiles) * 256 + tid; e < total; e += ((int)gridDim.x - tiles) * 256) {
+            const int c = e / H, k = e - c * H, src = k + frames - H;
+            hist_write[e] = (src >= 0) ? in[(size_t)c * in_stride + src] : hist_read[(size_t)c * H + k + frames];
         }
+        return;
     }
-    partial[((size_t)g * 2 + 0) * max_frames + j] = L;
-    partial[((size_t)g * 2 + 1) * max_frames + j] = R;
-}
-
-__global__ void __launch_bounds__(256)
-spat_reduce_kernel(const double *__restrict__ partial, int groups, double *__restrict__ out_lr, int out_stride, int frames, int max_frames) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= frames) return;
-    double L = 0.0, R = 0.0;
-    for (int g = 0; g < groups; g++) {
-        L += partial[((size_t)g * 2 + 0) * max_frames + j];
-        R += partial[((size_t)g * 2 + 1) * max_frames + j];
-    }
-    out_lr[j] = L;
-    out_lr[(size_t)out_stride + j] = R;
-}
-
-/* history = the last H inputs of every channel (spatializer.go:313-331); one workgroup per channel */
-__global__ void __launch_bounds__(256)
-spat_hist_kernel(const double *__restrict__ in, int in_stride, double *__restrict__ hist, int H, int frames) {
-    const int c = blockIdx.x;
-    double *hb = hist + (size_t)c * H;
-    const double *x = in + (size_t)c * in_stride;
-    double keep[4];
-    int cnt = 0;
-    for (int k = threadIdx.x; k < H && cnt < 4; k += 256, cnt++) {
-        int src = k + frames - H;                    /* index into the concatenation [old history | frame] shifted by H */
-        keep[cnt] = (src >= 0) ? x[src] : hb[k + frames];
+    const int s = tid & (SPAT_TILE - 1), q = tid / SPAT_TILE;
+    const int j = min((int)blockIdx.x * SPAT_TILE + s, frames - 1);      /* lanes past the end repeat the last sample and are not stored */
+    const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
+    /* the channel descriptors, once per workgroup, into LDS (behind the partials) */
+    gdg_spat_chan *s_ch = reinterpret_cast<gdg_spat_chan *>(part + (size_t)groups * 2 * SPAT_TILE);
+    for (int c = tid; c < nch; c += 256) s_ch[c] = chans[c];
+    __syncthreads();
+    for (int g = q; g < groups; g += SPAT_SUB) {
+        const int c_begin = g * SPAT_GROUP, c_end = min(nch, c_begin + SPAT_GROUP);
+        double L = 0.0, R = 0.0;
+        /* SPAT_UNROLL channels at a time: all their loads (current sample, the two neighbours of the delayed one -- from the block or from
+         * the history, one address either way) are issued before the first is consumed; the sums keep the channel order */
+        for (int c0 = c_begin; c0 < c_end; c0 += SPAT_UNROLL) {
+            double cur[SPAT_UNROLL], se[SPAT_UNROLL], sl[SPAT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SPAT_UNROLL; u++) {
+                const int c = min(c0 + u, c_end - 1);
+                const double *x = in + (size_t)c * in_stride;
+                const double *hb = hist_read + (size_t)c * H;
+                const int delayed = s_ch[c].mode != 0;
+                const int ie = delayed ? j - s_ch[c].early : j, il = delayed ? j - s_ch[c].late : j;
+                cur[u] = x[j];
+                se[u] = *((ie >= 0) ? x + ie : hb + (H + ie));
+                sl[u] = *((il >= 0) ? x + il : hb + (H + il));
+            }
+#pragma unroll
+            for (int u = 0; u < SPAT_UNROLL; u++) {
+                if (c0 + u < c_end) {
+                    const gdg_spat_chan ch = s_ch[c0 + u];
+                    if (ch.mode == 0) {
+                        L += ch.fac_left * cur[u];
+                        R += ch.fac_right * cur[u];
+                    } else {
+                        double early_sample = ch.w_early * se[u];
+                        double late_sample = ch.w_late * sl[u];
+                        double delayed = early_sample + late_sample;
+                        if (ch.mode == 1) { L += ch.fac_left * delayed; R += ch.fac_right * cur[u]; }
+                        else { L += ch.fac_left * cur[u]; R += ch.fac_right * delayed; }
+                    }
+                }
+            }
+        }
+        part[(g * 2 + 0) * SPAT_TILE + s] = L;
+        part[(g * 2 + 1) * SPAT_TILE + s] = R;
     }
     __syncthreads();
-    cnt = 0;
-    for (int k = threadIdx.x; k < H && cnt < 4; k += 256, cnt++) hb[k] = keep[cnt];
+    if (tid < 2 * SPAT_TILE) {
+        const int side = tid / SPAT_TILE, jj = blockIdx.x * SPAT_TILE + s;
+        if (jj < frames) {
+            double acc = 0.0;
+            for (int g = 0; g < groups; g++) acc += part[(g * 2 + side) * SPAT_TILE + s];
+            out_lr[(size_t)side * out_stride + jj] = acc;
+        }
+    }
 }
 
-hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, double *d_hist, int H,
-                                  double *d_partial, double *d_out_lr, int out_stride, int frames, int max_frames, hipStream_t s) {
-    if (H > 1024) return hipErrorInvalidValue;
+hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, const double *d_hist_read,
+                                  double *d_hist_write, int H, double *d_out_lr, int out_stride, int frames, hipStream_t s) {
+    if (H > 1024 || nch > SPAT_MAX_GROUPS * SPAT_GROUP) return hipErrorInvalidValue;
+    const int tiles = (frames + SPAT_TILE - 1) / SPAT_TILE;
+    int hist_blocks = (nch * H + 2047) / 2048;                    /* eight entries per thread */
+    if (hist_blocks < 1) hist_blocks = 1;
     const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
-    const int tiles = (frames + 255) / 256;
-    spat_partial_kernel<<<dim3(tiles, groups), dim3(256), 0, s>>>(d_chans, nch, d_in, in_stride, d_hist, H, d_partial, frames, max_frames);
-    spat_reduce_kernel<<<dim3(tiles), dim3(256), 0, s>>>(d_partial, groups, d_out_lr, out_stride, frames, max_frames);
-    spat_hist_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_in, in_stride, d_hist, H, frames);
+    spat_kernel<<<dim3(tiles + hist_blocks), dim3(256), (size_t)groups * 2 * SPAT_TILE * sizeof(double) + (size_t)nch * sizeof(gdg_spat_chan), s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
     return hipGetLastError();
 }
-
-int gdg_spat_groups(int nch) { return (nch + SPAT_GROUP - 1) / SPAT_GROUP; }
