@@ -530,8 +530,9 @@ def main():
     # Every PROFILE_EVERY-th step's launches of that kernel are bracketed (gdg_profile_sample): an event pair also keeps the bracketed kernel
     # from overlapping its neighbours' ramp-up and tail -- with every step bracketed the timed region is 5 % slower than unobserved.
     ctx.profile_sample(PROFILE_EVERY)
+    MAC_KINDS = [pkg.K_FIR_MAC, pkg.K_FIR_MAC_CHAIN]     # the dominant kernel and its chained variant (adjacent power amps)
     if os.environ.get("GDG_BENCH_TIMED_PROFILE", "1") != "0":       # experiment knob: what the events in the timed region cost
-        ctx.profile_enable(kinds=[pkg.K_FIR_MAC])
+        ctx.profile_enable(kinds=MAC_KINDS)
 
     def synchronize():
         ctx.synchronize()
@@ -553,8 +554,11 @@ def main():
     kernels = {}
     ms, n = ctx.profile_read(pkg.K_FIR_MAC)
     timed_mac = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None}
+    ms_c, n_c = ctx.profile_read(pkg.K_FIR_MAC_CHAIN)
+    timed_chain = {"ms_total": ms_c, "launches": n_c, "avg_ms": (ms_c / n_c) if n_c else None}
+    plain_per_step = sum(1 for _, p in CHAIN if isinstance(p, str)) - (1 if n_c else 0)      # FIR units whose MAC kernel is the plain one
     sampled_steps = (args.steps + PROFILE_EVERY - 1) // PROFILE_EVERY
-    groups = max(1, n // max(1, sampled_steps * sum(1 for _, p in CHAIN if isinstance(p, str))))
+    groups = max(1, n // max(1, sampled_steps * max(plain_per_step, 1)))
     # Roofline pass.  From 384 channels on the library cuts the channels into two groups whose kernels run on streams of their own
     # and overlap (gdg_ctx_set_overlap): the timed region above is faster for it, but a launch's HIP-event duration then includes the
     # time it shares the chip with the other group's kernels.  The kernel's own bandwidth is measured here: the SAME steps with the
@@ -562,7 +566,7 @@ def main():
     ctx.set_overlap(1)
     step()
     synchronize()
-    ctx.profile_enable(kinds=[pkg.K_FIR_MAC])
+    ctx.profile_enable(kinds=MAC_KINDS)
     t_alone = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -572,6 +576,9 @@ def main():
     ms, n = ctx.profile_read(pkg.K_FIR_MAC)
     kernels["fir_mac"] = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None,
                           "pass": "timed region" if groups == 1 else "roofline pass: the timed region's steps again with the channel groups off (the kernel runs alone)"}
+    ms_c, n_c = ctx.profile_read(pkg.K_FIR_MAC_CHAIN)
+    kernels["fir_mac_chain"] = {"ms_total": ms_c, "launches": n_c, "avg_ms": (ms_c / n_c) if n_c else None,
+                                "what": "the same kernel when another power amp follows: it also makes that amp's forward transform (history + delay-line slot)"}
     if groups == 1:
         kernels["fir_mac"].update(timed_mac)
     ctx.profile_enable(True)                      # untimed pass: the same steps again with every launch bracketed
@@ -579,6 +586,7 @@ def main():
         step()
     synchronize()
     ctx.profile_enable(False)
+    ctx.profile_read(pkg.K_FIR_MAC_CHAIN)
     for kind, name in enumerate(pkg.KERNEL_KINDS[:4]):
         ms, n = ctx.profile_read(kind)
         if name == "fir_mac":
@@ -717,7 +725,11 @@ def main():
         mac_bytes = nch * ((1.0 + d_share) * K * spec_bytes + out_bytes)
         mac_gbs = mac_bytes / (mac["avg_ms"] * 1e-3) / 1e9 if mac["avg_ms"] else None
         fir_units = fir_per_chain * args.steps
-        fir_ms = sum((kernels[k]["avg_ms"] or 0.0) * fir_units for k in ("fir_fwd", "fir_mac", "fir_inv"))
+        chain = kernels["fir_mac_chain"]
+        # the chained variant: 2 K spectra in, the NEXT amp's new spectrum out (16 B per sample); the frame itself never leaves the chip
+        chain_bytes = nch * ((1.0 + d_share) * K * spec_bytes + spec_bytes)
+        chain_gbs = chain_bytes / (chain["avg_ms"] * 1e-3) / 1e9 if chain["avg_ms"] else None
+        fir_ms = sum((kernels[k]["ms_total"] or 0.0) for k in ("fir_fwd", "fir_mac", "fir_mac_chain", "fir_inv"))
         fir_bytes_per_sample = 16.0 + 16.0 * (1 + 2 * K)              # SURVEY 8d B_conv with (P+1)/P -> 1 (packed bin 0)
         fir_gbs = fir_units * samples_per_step * fir_bytes_per_sample / (fir_ms * 1e-3) / 1e9 if fir_ms else None
         seg = kernels["segment"]
@@ -768,6 +780,9 @@ def main():
                 "frac": (mac_gbs / HBM_PEAK_GBS) if mac_gbs else None,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": mac_bytes, "avg_launch_ms": mac["avg_ms"], "launches": mac["launches"],
+                "chained_variant": {"kernel": "fir_inv_kernel<13, 1, CHAIN> (amp 1 of two adjacent power amps: + the forward transform of amp 2)",
+                                    "algorithmic_bytes_per_launch": chain_bytes, "avg_launch_ms": chain["avg_ms"], "launches": chain["launches"],
+                                    "achieved": chain_gbs, "frac": (chain_gbs / HBM_PEAK_GBS) if chain_gbs else None},
                 "fir_unit_all_three_kernels": {"bytes_per_channel_sample": fir_bytes_per_sample, "achieved": fir_gbs,
                                                "frac": (fir_gbs / HBM_PEAK_GBS) if fir_gbs else None},
                 "kernels_ms": kernels,

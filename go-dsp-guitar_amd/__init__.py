@@ -26,7 +26,7 @@ UNIT_NAMES = [
 ]
 UNIT = {name: i for i, name in enumerate(UNIT_NAMES)}
 
-K_FIR_FWD, K_FIR_MAC, K_FIR_INV, K_SEGMENT, K_TUNER, K_SPATIALIZER, K_WAVE, K_RESAMPLE, K_METER = range(9)
+K_FIR_FWD, K_FIR_MAC, K_FIR_INV, K_SEGMENT, K_TUNER, K_SPATIALIZER, K_WAVE, K_RESAMPLE, K_METER, K_FIR_MAC_CHAIN = range(10)
 WAVE_FORMATS = {"lpcm8": 0, "lpcm16": 1, "lpcm24": 2, "lpcm32": 3, "ieee32": 4, "ieee64": 5}     # enum gdg_wave_format
 KERNEL_KINDS = ["fir_fwd", "fir_mac", "fir_inv", "segment", "tuner", "spatializer"]
 

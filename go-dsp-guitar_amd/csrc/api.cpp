@@ -1478,8 +1478,9 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                 const gdg_fir_chan *d_next = st.chain_next ? reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + ctx->steps[si + 1].offset) + first : nullptr;
                 const bool fused = ctx->fir_fused < 0 ? (n > ctx->fir_split_max) : (ctx->fir_fused != 0);
                 if (fused) {
-                    /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel) */
-                    ProfScope ps(ctx, GDG_K_FIR_MAC, s);
+                    /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel; its chained
+                     * variant, which also makes the next amp's forward transform, under a kind of its own) */
+                    ProfScope ps(ctx, d_next ? GDG_K_FIR_MAC_CHAIN : GDG_K_FIR_MAC, s);
                     HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, shift, s, d_next));
                 } else {
                     { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(P2, d, n, st.shared_spectra ? 1 : 0, s)); }

@@ -219,6 +219,8 @@ enum gdg_kernel_kind {
     GDG_K_WAVE,          /* wave sample codecs */
     GDG_K_RESAMPLE,      /* resample.Time */
     GDG_K_METER,         /* level meters */
+    GDG_K_FIR_MAC_CHAIN, /* GDG_K_FIR_MAC of a power amp that is followed by another one: the same kernel also makes the next amp's forward
+                          * transform (fir_inv_kernel CHAIN); kept apart so that GDG_K_FIR_MAC times the plain kernel only */
     GDG_K_COUNT
 };
 /* enable == 1: bracket every kernel launch with a HIP event pair from now on (costs a few microseconds per launch);

@@ -8,10 +8,10 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p "$REPO/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_g
-rocprofv3 --kernel-trace --stats -d /tmp/prof_g -o g -- python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras > /tmp/g.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_g -o g -- python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-parity > /tmp/g.log 2>&1
 G=$(find /tmp/prof_g -name '*.db' | head -1)
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras   (default: channel groups automatic)"
+  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras   (default: two free-running channel groups, opted into by bench.py)"
   echo "# bench line of the traced run:"; grep "^{" /tmp/g.log | tail -1
   python "$REPO/profiles/summarize_rocprof.py" "$G"
 } > "$REPO/gpurun_out/${TAG}_bench_512ch_groups_rocprof.txt" 2>&1
