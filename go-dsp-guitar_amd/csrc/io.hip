@@ -407,7 +407,31 @@ static void launch_encode(const double *d_in, size_t per, unsigned channels, uns
 template <int FMT>
 __device__ __forceinline__ void decode_piece(const gdg_decode_row &r) {
     constexpr int W = fmt_width<FMT>::W;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < r.count; i += gridDim.x * 256) {
+    unsigned done = 0;
+    if ((((uintptr_t)r.src) & 3) == 0 && (((uintptr_t)r.dst) & 15) == 0) {
+        /* word-sized loads, four samples per thread: byte loads fetch every line W times over (the batch run's pieces are 16-byte aligned) */
+        const unsigned *words = reinterpret_cast<const unsigned *>(r.src);
+        v2d *out = reinterpret_cast<v2d *>(r.dst);
+        const unsigned groups = r.count / 4;
+        for (unsigned g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
+            unsigned w[W];
+#pragma unroll
+            for (int k = 0; k < W; k++) w[k] = __builtin_nontemporal_load(words + (size_t)g * W + k);
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned code = 0;
+#pragma unroll
+                for (int k = 0; k < W; k++) code |= getb(w, q * W + k) << (8 * k);
+                v[q] = decode_code<FMT>(code);
+            }
+            v2d a = { v[0], v[1] }, b = { v[2], v[3] };
+            out[2 * (size_t)g] = a;
+            out[2 * (size_t)g + 1] = b;
+        }
+        done = groups * 4;
+    }
+    for (unsigned i = done + blockIdx.x * 256 + threadIdx.x; i < r.count; i += gridDim.x * 256) {
         unsigned code = 0;
 #pragma unroll
         for (int k = 0; k < W; k++) code |= (unsigned)r.src[(size_t)i * W + k] << (8 * k);
