@@ -1,6 +1,7 @@
 """Multi-GPU plumbing: channels are independent (controller/controller.go:3262-3269), so N GPUs are N
-shards with NO data-path collective.  torch.distributed (RCCL on the GPU box, gloo in the CPU tests) is
-used only for the barrier around the timed region and the max-over-ranks of the elapsed time.
+shards with NO data-path collective.  torch.distributed -- over gloo, on the GPU box as in the CPU tests: the job
+contains no RCCL / xGMI traffic -- is used only for the barrier around the timed region, the max-over-ranks of the
+elapsed time and, for the sharded batch run, the gather of the shards' partial master mixes on rank 0's host.
 """
 import time
 
