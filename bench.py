@@ -348,6 +348,8 @@ def time_blocked(pkg, ctx, nch, frames, sr, blocks=32):
     d_in.upload(np.tile(synth_block(nch, frames, sr), (1, blocks)))
     res = {"unit": "Msamples/s", "frames_per_channel": blocks,
            "what": "device-resident, W consecutive 8192-sample frames per channel and call; W = 1 is the headline's per-frame call"}
+    ctx.set_overlap(2 if nch >= 384 else 1)     # two free-running channel groups (W = 16: 323 -> 310 us)
+    res["channel_groups"] = 2 if nch >= 384 else 1
     for W in (1, 2, 4, 8, 16):
         ctx.set_window(W)
 
@@ -510,7 +512,8 @@ def main():
     n_distinct = args.distinct_irs
     ctx = make_context(pkg, nch, frames, local_rank, taps, channel0=channel0, n_distinct=n_distinct)
     # channel groups on one GPU are an explicit choice of the caller (gdg_ctx_set_overlap; the library's default is one group, whose
-    # calls are ordered on the context's stream): two free-running groups from 384 channels on, as a batch caller would
+    # calls are ordered on the context's stream): two free-running groups from 384 channels on (0.625 -> 0.565 ms per step on the
+    # same box, profiles/probes/bisect_g1.py), as a batch caller that only touches the results through the library would
     headline_groups = args.channel_groups if args.channel_groups > 0 else (2 if nch >= 384 else 1)
     ctx.set_overlap(headline_groups)
     x = torch.from_numpy(synth_block(nch, frames, sr, channel0=channel0)).to(dev)
@@ -532,7 +535,7 @@ def main():
     ctx.profile_sample(PROFILE_EVERY)
     MAC_KINDS = [pkg.K_FIR_MAC, pkg.K_FIR_MAC_CHAIN]     # the dominant kernel and its chained variant (adjacent power amps)
     if os.environ.get("GDG_BENCH_TIMED_PROFILE", "1") != "0":       # experiment knob: what the events in the timed region cost
-        ctx.profile_enable(kinds=MAC_KINDS)
+        ctx.profile_enable(kinds=[pkg.K_FIR_MAC])                  # the roofline kernel only (its chained variant: in the passes below)
 
     def synchronize():
         ctx.synchronize()
@@ -559,10 +562,9 @@ def main():
     plain_per_step = sum(1 for _, p in CHAIN if isinstance(p, str)) - (1 if n_c else 0)      # FIR units whose MAC kernel is the plain one
     sampled_steps = (args.steps + PROFILE_EVERY - 1) // PROFILE_EVERY
     groups = max(1, n // max(1, sampled_steps * max(plain_per_step, 1)))
-    # Roofline pass.  From 384 channels on the library cuts the channels into two groups whose kernels run on streams of their own
-    # and overlap (gdg_ctx_set_overlap): the timed region above is faster for it, but a launch's HIP-event duration then includes the
-    # time it shares the chip with the other group's kernels.  The kernel's own bandwidth is measured here: the SAME steps with the
-    # groups off, HIP events around the dominant kernel only, then once more with every launch bracketed.
+    # Second pass: the SAME steps with one channel group and the dominant kernel (both variants) bracketed on every step, then once more
+    # with every launch bracketed.  With --channel-groups > 1 a launch of the timed region shares the chip with the other group's kernels
+    # and its HIP-event duration says little about the kernel: the roofline then comes from this pass.
     ctx.set_overlap(1)
     step()
     synchronize()
@@ -579,8 +581,12 @@ def main():
     ms_c, n_c = ctx.profile_read(pkg.K_FIR_MAC_CHAIN)
     kernels["fir_mac_chain"] = {"ms_total": ms_c, "launches": n_c, "avg_ms": (ms_c / n_c) if n_c else None,
                                 "what": "the same kernel when another power amp follows: it also makes that amp's forward transform (history + delay-line slot)"}
-    if groups == 1:
-        kernels["fir_mac"].update(timed_mac)
+    if groups == 1 and timed_mac["avg_ms"]:
+        # one channel group: the timed region's own events time the kernel alone -- that average is the roofline's; the pass above (every
+        # step bracketed) stays as a cross-check and for the per-step totals
+        kernels["fir_mac"].update({"avg_ms_all_steps_bracketed": kernels["fir_mac"]["avg_ms"], "avg_ms": timed_mac["avg_ms"],
+                                   "launches_timed_region": timed_mac["launches"],
+                                   "pass": "timed region (HIP events on every %d-th step)" % PROFILE_EVERY})
     ctx.profile_enable(True)                      # untimed pass: the same steps again with every launch bracketed
     for _ in range(args.steps):
         step()
@@ -779,7 +785,7 @@ def main():
                 "achieved": mac_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (mac_gbs / HBM_PEAK_GBS) if mac_gbs else None,
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": mac_bytes, "avg_launch_ms": mac["avg_ms"], "launches": mac["launches"],
+                "algorithmic_bytes_per_launch": mac_bytes, "avg_launch_ms": mac["avg_ms"], "launches": mac.get("launches_timed_region", mac["launches"]),
                 "chained_variant": {"kernel": "fir_inv_kernel<13, 1, CHAIN> (amp 1 of two adjacent power amps: + the forward transform of amp 2)",
                                     "algorithmic_bytes_per_launch": chain_bytes, "avg_launch_ms": chain["avg_ms"], "launches": chain["launches"],
                                     "achieved": chain_gbs, "frac": (chain_gbs / HBM_PEAK_GBS) if chain_gbs else None},
