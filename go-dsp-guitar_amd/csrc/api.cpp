@@ -1409,7 +1409,7 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     /* device-resident calls: the groups are not joined at the end of the call, so one group's kernels overlap the other's across calls
      * (the join happens when anything else touches the context: enter()) */
     const bool free_run = G > 1 && !before && !after;
-    if (!free_run || (int)ctx->gstreams.size() > G) join_groups(ctx);
+    if (!free_run) join_groups(ctx);      /* (a change of the group count rebuilds the plan, and build_plan joins every stream there is) */
     const int P2 = fir_transform_size(frames);
     std::vector<size_t> bounds;
     if (group_bounds_in && (int)group_bounds_in->size() == G + 1) bounds = *group_bounds_in;
