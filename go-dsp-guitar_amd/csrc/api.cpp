@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -2719,6 +2720,10 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
     if (rc != GDG_OK) return rc;
     double *d_inputs = nullptr, *d_win = nullptr, *d_src = nullptr;
     unsigned char *d_arena = nullptr, *d_enc = nullptr, *d_up = nullptr;
+    static int trace = -1;
+    if (trace < 0) { const char *e = getenv("GDG_BATCH_TRACE"); trace = e ? atoi(e) : 0; }
+    auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_ms();
     auto body = [&]() -> int {
         int r;
         if ((r = batch_buffer(ctx, 0, (size_t)N * length * sizeof(double), (void **)&d_inputs)) != GDG_OK) return r;
@@ -2729,7 +2734,22 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
         if (arena_bytes && (r = batch_buffer(ctx, 3, arena_bytes, (void **)&d_arena)) != GDG_OK) return r;
         if (up_half && (r = batch_buffer(ctx, 4, 2 * up_half, (void **)&d_up)) != GDG_OK) return r;
         if (src_cap && (r = batch_buffer(ctx, 5, src_cap * sizeof(double), (void **)&d_src)) != GDG_OK) return r;
-        HIP_TRY(ctx, hipMemsetAsync(d_inputs, 0, (size_t)N * length * sizeof(double), ctx->stream));     /* the zero padding, :3018-3045 */
+        /* the zero padding (:3018-3045): only what no decode / resample will write -- the tail of every row behind its file's samples, the
+         * whole row of an empty input (zeroing all N x length samples first cost 1.5 ms of a 60 ms run at 512 x 1 Mi samples) */
+        for (int i = 0; i < N; i++) {
+            const gdg_batch_input &in = inputs[i];
+            size_t covered = 0;
+            if (in.bytes && in.samples_per_channel) {
+                covered = in.samples_per_channel;
+                if (in.sample_rate != opt->target_rate) {
+                    int n_out = gdg_resample_time_length((int)in.samples_per_channel, in.sample_rate, opt->target_rate);
+                    covered = n_out > 0 ? (size_t)n_out : 0;
+                }
+                if (covered > length) covered = length;
+            }
+            if (covered < length)
+                HIP_TRY(ctx, hipMemsetAsync(d_inputs + (size_t)i * length + covered, 0, (length - covered) * sizeof(double), ctx->stream));
+        }
 
         /* 1a. the arena goes up */
         int used[2] = { 0, 0 };
@@ -2837,8 +2857,11 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
             HIP_TRY(ctx, hipEventRecord(ctx->batch_up_ready[h], ctx->batch_up_stream));
             return GDG_OK;
         };
+        if (trace) fprintf(stderr, "[batch] set-up %.2f ms\n", now_ms() - t_begin);
         if ((r = stage(0)) != GDG_OK) return r;
+        if (trace) fprintf(stderr, "[batch] stage(0) done at %.2f ms\n", now_ms() - t_begin);
         for (size_t i = 0; i < steps.size(); i++) {
+            const double t_it = now_ms();
             const size_t off = steps[i].off;
             const int w = steps[i].w, h = (int)(i & 1), wb = w * B;               /* this step fills the first wb samples of the window's rows */
             if (n_streamed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_up_ready[h], 0));
@@ -2849,7 +2872,9 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
                 for (int j = 0; j < w; j++) if ((r = tuner_enqueue_rows(ctx, d_in + (size_t)j * B, length, B, opt->target_rate)) != GDG_OK) return r;
             if ((r = process_rows(ctx, ctx->all_channels, d_in, d_win, B, opt->target_rate, (int)length, false, 1, nullptr, nullptr, w, (int)ws)) != GDG_OK) return r;
             if (run_metro && (r = gdg_metronome_process_device(ctx, d_metro, wb)) != GDG_OK) return r;
-            for (int j = 0; j < w; j++) if ((r = spatialize_rows(ctx, d_win + (size_t)j * B, (int)ws, d_master + (size_t)j * B, (int)ws, B)) != GDG_OK) return r;
+            /* the step's w frames are consecutive in their rows: ONE mix over w x 8192 samples gives the samples of w calls (a frame's first
+             * samples find their delayed neighbours in the frame before instead of in the history, which holds the same values) */
+            if ((r = spatialize_rows(ctx, d_win, (int)ws, d_master, (int)ws, wb)) != GDG_OK) return r;
             /* a shard's master rows stay partial sums: the aux input is added once, after the shards' sums (gdg_batch_finish_master) */
             if (opt->metronome_to_master && !sharded) HIP_TRY(ctx, gdg_launch_add_aux(d_master, d_master + ws, d_metro, wb, ctx->stream));
             if (opt->run_meters) {                                               /* ports: inputs | outputs | metronome | left, right (:2707-2777) */
@@ -2879,14 +2904,23 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
             const size_t down = (((size_t)enc_rows * wb * out_width + 15) & ~(size_t)15) + (size_t)f64_rows * wb * sizeof(double);
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, sharded ? down : (size_t)NO * wb * out_width, hipMemcpyDeviceToHost, ctx->batch_stream));
             HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
+            const double t_enq = now_ms();
             if ((r = stage(i + 1)) != GDG_OK) return r;                          /* while step i runs: the next step's inputs go up ... */
+            const double t_st = now_ms();
+            double t_wait = t_st;
             if (i >= 1) {                                                        /* ... and step i - 1 goes into the files */
                 HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h ^ 1]));
+                t_wait = now_ms();
                 scatter(i - 1);
             }
+            if (trace) fprintf(stderr, "[batch] step %zu: enqueue %.2f | stage next %.2f | wait for step-1 download %.2f | scatter %.2f  (at %.2f ms)\n", i,
+                               t_enq - t_it, t_st - t_enq, t_wait - t_st, now_ms() - t_wait, now_ms() - t_begin);
         }
+        const double t_l0 = now_ms();
         HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[(steps.size() - 1) & 1]));
+        const double t_l1 = now_ms();
         scatter(steps.size() - 1);
+        if (trace) fprintf(stderr, "[batch] last: wait %.2f | scatter %.2f (at %.2f ms)\n", t_l1 - t_l0, now_ms() - t_l1, now_ms() - t_begin);
         return check_device_error(ctx);
     };
     rc = body();
