@@ -397,6 +397,18 @@ def other_configs(pkg, device):
     d_lr.free()
     ctx.close()
     out["config5_256_tuners"] = {"value": nch / t_an, "unit": "analyses/s", "ms_per_256_analyses": t_an * 1e3, "timing": us_stats(st_an)}
+    # config 5's per-GPU shape on 8 GPUs: 32 tuners (a channel's blocks then go over 8 workgroups: gdg_tuner_short_parts)
+    ctx32 = pkg.Context(32, frames, device)
+    d32 = ctx32.alloc(32, frames)
+    d32.upload(synth_block(32, frames, sr))
+    for _ in range(13):
+        ctx32.tuner_enqueue_device(d32, frames, sr)
+    ctx32.tuner_analyze()
+    st32 = robust_time(lambda: [ctx32.tuner_analyze() for _ in range(5)], ctx32.synchronize, units=5)
+    d32.free()
+    ctx32.close()
+    out["config5_32_tuners_per_gpu"] = {"value": 32 / st32["median"], "unit": "analyses/s", "us_per_32_analyses": st32["median"] * 1e6,
+                                        "predicted_256_tuners_on_8_gpus": 256 / st32["median"], "timing": us_stats(st32)}
     out["config5_spatializer_256_to_2"] = {"value": nch * frames / t_sp / 1e6, "unit": "Msamples/s", "us_per_block": t_sp * 1e6,
                                            "timing": us_stats(st_sp)}
     return out

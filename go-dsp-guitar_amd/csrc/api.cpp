@@ -224,6 +224,7 @@ struct gdg_ctx {
     double *d_note_freqs = nullptr;
     gdg_tuner_out *d_tuner_out = nullptr, *h_tuner_out = nullptr;      /* results on the device / in pinned host memory */
     double2 *d_tuner_work = nullptr, *d_tuner_twn = nullptr, *d_tuner_twm = nullptr;
+    double2 *d_tuner_part = nullptr;           /* partial sums of a short-lag analysis split over several workgroups per channel */
     std::vector<double> sp_az, sp_dist, sp_level;
     uint32_t sp_hist_sr = 96000;
     double *d_sp_hist = nullptr;               /* [2][nch][sp_hist_len]: read this block / written for the next (sp_hist_cur) */
@@ -408,7 +409,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error);
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
-    hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
+    hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_part); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
     hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter); hipFree(ctx->d_tick); hipFree(ctx->d_tock);
     for (auto st : ctx->gstreams) hipStreamDestroy(st);
     for (auto e : ctx->gjoin) hipEventDestroy(e);
@@ -1988,9 +1989,11 @@ int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
         double2 *tw4096, *tw2_4096;
         rc = fir_tables(ctx, 4096, &tw4096, &tw2_4096);
         if (rc != GDG_OK) return rc;
+        const int parts = gdg_tuner_short_parts(ctx->nch);
+        if (parts > 1 && !ctx->d_tuner_part) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_part, (size_t)ctx->nch * 8 * 4096 * sizeof(double2)));
         ProfScope ps(ctx, GDG_K_TUNER);
         HIP_TRY(ctx, gdg_launch_tuner_short(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, (double)ctx->tuner_sr, tw4096, tw2_4096,
-                                            ctx->d_note_freqs, GDG_NOTE_COUNT, ctx->d_tuner_out, ctx->stream));
+                                            ctx->d_note_freqs, GDG_NOTE_COUNT, ctx->d_tuner_out, ctx->d_tuner_part, parts, ctx->stream));
     } else {
         /* rates above ~252 kHz: the window reaches past lag 4096 -- the reference's own scheme, a 262144-point transform pair */
         if (!ctx->d_tuner_work) {

@@ -181,8 +181,10 @@ struct gdg_tuner_out { double frequency; int note_index; int cents; };
 hipError_t gdg_launch_tuner_enqueue(double *d_rings, int nch, int wp, const double *d_samples, int stride, int frames, hipStream_t s);
 hipError_t gdg_tuner_tables_create(double2 **d_tw_n, double2 **d_tw_m);
 int gdg_tuner_short_ok(double sample_rate, double lowest_note_frequency);
+/* parts > 1: a channel's blocks over `parts` workgroups, partial sums through d_partial ([nch][parts][4096] complex) */
+int gdg_tuner_short_parts(int nch);
 hipError_t gdg_launch_tuner_short(const double *d_rings, int nch, int wp, double sample_rate, const double2 *tw4096, const double2 *tw2_4096,
-                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s);
+                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, double2 *d_partial, int parts, hipStream_t s);
 hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, double sample_rate, double2 *d_work,
                                     const double2 *d_tw_n, const double2 *d_tw_m, const double2 *d_tw512, const double2 *d_tw256,
                                     const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s);

@@ -256,23 +256,21 @@ tuner_pick_kernel(const cplx *__restrict__ R, double sample_rate, const double *
 #define TUNER_BLK 4096
 #define TUNER_SHORT_MAX_LAG TUNER_BLK          /* r[0 .. 4096] are free of wrap-around */
 
-__global__ void __launch_bounds__(256)
-tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate, const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
-                   const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out) {
-    constexpr int LOGN = 12, N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;      /* 4096 complex points, 256 threads */
-    __shared__ double s_all[2 * FftCfg<LOGN>::LDS];
-    __shared__ double s_val[256];
-    __shared__ int s_idx[256];
-    double *sre = s_all, *sim = s_all + FftCfg<LOGN>::LDS;
-    const int tid = threadIdx.x, ch = blockIdx.x;
-    const double *ring = rings + (size_t)ch * GDG_TUNER_RING;
-    /* per thread: bins k = tid + T i and n = N - k (i = 0: thread 0 holds (X[0], X[N]) as two reals and X[N/2]) */
-    cplx pk[ITER], pn[ITER], sk[ITER], sn[ITER];
-#pragma unroll
-    for (int i = 0; i < ITER; i++) { pk[i] = pn[i] = sk[i] = sn[i] = make_double2(0.0, 0.0); }
-    constexpr int NBLK = (GDG_TUNER_RING + TUNER_BLK - 1) / TUNER_BLK;                          /* 24 */
+/* blocks [blk_begin, blk_end) of one channel's ring into the running sums (sk, sn); `lead`: block blk_begin - 1 is transformed first, only to
+ * serve as "previous block" of the first cross term (a part of a split analysis that does not start at block 0) */
+template <int LOGN>
+__device__ __forceinline__ void tuner_accumulate_blocks(const double *ring, int wp, int blk_begin, int blk_end, bool lead, double *sre, double *sim,
+                                                        const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
+                                                        cplx (&sk)[(FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T], cplx (&sn)[(FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T]) {
+    constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
     constexpr int LR0 = sched_lr(LOGN, 0), R0 = 1 << LR0, B0 = 16 / R0;
-    for (int blk = 0; blk < NBLK; blk++) {
+    const int tid = threadIdx.x;
+    /* per thread: bins k = tid + T i and n = N - k (i = 0: thread 0 holds (X[0], X[N]) as two reals and X[N/2]) */
+    cplx pk[ITER], pn[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; i++) { pk[i] = pn[i] = make_double2(0.0, 0.0); }
+    for (int blk = lead ? blk_begin - 1 : blk_begin; blk < blk_end; blk++) {
+        const bool count = blk >= blk_begin;
         /* pass 0 straight from the ring: packed element e = (a[2e], a[2e+1]), a = block `blk` then 4096 zeros */
         cplx v[16];
 #pragma unroll
@@ -303,10 +301,12 @@ tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate,
                 const double zx = sre[0], zy = sim[0];
                 ak = make_double2(zx + zy, zx - zy);                                            /* X[0], X[N]: two reals */
                 an = make_double2(sre[GDG_PAD(N / 2)], -sim[GDG_PAD(N / 2)]);                   /* X[N/2] */
-                sk[i].x += ak.x * ak.x + pk[i].x * ak.x;                                        /* bins 0 and N (= 4096) are even */
-                sk[i].y += ak.y * ak.y + pk[i].y * ak.y;
-                sn[i].x += an.x * an.x + an.y * an.y + (pn[i].x * an.x + pn[i].y * an.y);       /* N/2 = 2048 is even */
-                sn[i].y += pn[i].x * an.y - pn[i].y * an.x;
+                if (count) {
+                    sk[i].x += ak.x * ak.x + pk[i].x * ak.x;                                    /* bins 0 and N (= 4096) are even */
+                    sk[i].y += ak.y * ak.y + pk[i].y * ak.y;
+                    sn[i].x += an.x * an.x + an.y * an.y + (pn[i].x * an.x + pn[i].y * an.y);   /* N/2 = 2048 is even */
+                    sn[i].y += pn[i].x * an.y - pn[i].y * an.x;
+                }
             } else {
                 const int n = N - k;
                 const cplx zk = make_double2(sre[GDG_PAD(k)], sim[GDG_PAD(k)]), zn = make_double2(sre[GDG_PAD(n)], sim[GDG_PAD(n)]);
@@ -314,17 +314,28 @@ tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate,
                 const cplx cw = cmul(tw2[k], Bv);
                 ak = make_double2((A.x + cw.y) * 0.5, (A.y - cw.x) * 0.5);
                 an = make_double2((A.x - cw.y) * 0.5, (-A.y - cw.x) * 0.5);
-                const double sg = (k & 1) ? -1.0 : 1.0;                                         /* n = N - k has the parity of k */
-                sk[i].x += ak.x * ak.x + ak.y * ak.y + sg * (pk[i].x * ak.x + pk[i].y * ak.y);  /* conj(p) a */
-                sk[i].y += sg * (pk[i].x * ak.y - pk[i].y * ak.x);
-                sn[i].x += an.x * an.x + an.y * an.y + sg * (pn[i].x * an.x + pn[i].y * an.y);
-                sn[i].y += sg * (pn[i].x * an.y - pn[i].y * an.x);
+                if (count) {
+                    const double sg = (k & 1) ? -1.0 : 1.0;                                     /* n = N - k has the parity of k */
+                    sk[i].x += ak.x * ak.x + ak.y * ak.y + sg * (pk[i].x * ak.x + pk[i].y * ak.y);      /* conj(p) a */
+                    sk[i].y += sg * (pk[i].x * ak.y - pk[i].y * ak.x);
+                    sn[i].x += an.x * an.x + an.y * an.y + sg * (pn[i].x * an.x + pn[i].y * an.y);
+                    sn[i].y += sg * (pn[i].x * an.y - pn[i].y * an.x);
+                }
             }
             pk[i] = ak; pn[i] = an;
         }
         __syncthreads();                                                                        /* everyone is done reading Z */
     }
-    /* inverse packed-real transform of S: r[2n], r[2n + 1] = Re, Im of z[n] (unscaled: arg-max and parabola are scale free) */
+}
+
+/* the sums S -> r (inverse packed-real transform, unscaled: arg-max and parabola are scale free) -> the pick */
+template <int LOGN>
+__device__ __forceinline__ void tuner_finish(const cplx (&sk)[(FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T], const cplx (&sn)[(FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T],
+                                             double *s_all, double *s_val, int *s_idx, double sample_rate, const cplx *__restrict__ tw,
+                                             const cplx *__restrict__ tw2, const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *out_ch) {
+    constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
+    double *sre = s_all, *sim = s_all + FftCfg<LOGN>::LDS;
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < ITER; i++) inv_head_store<LOGN>(tid + T * i, sk[i], sn[i], sre, sim, tw2);
     __syncthreads();
@@ -346,7 +357,65 @@ tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate,
         }
     }
     __syncthreads();
-    tuner_pick([&](int lag) { return s_all[lag]; }, sample_rate, note_freqs, n_notes, out + ch, s_val, s_idx);
+    tuner_pick([&](int lag) { return s_all[lag]; }, sample_rate, note_freqs, n_notes, out_ch, s_val, s_idx);
+}
+
+#define TUNER_NBLK ((GDG_TUNER_RING + TUNER_BLK - 1) / TUNER_BLK)                                /* 24 */
+
+/* one workgroup per channel: all 24 blocks, then the finish (a chip's worth of channels) */
+__global__ void __launch_bounds__(256)
+tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate, const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
+                   const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out) {
+    constexpr int LOGN = 12, ITER = (FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T;                    /* 4096 complex points, 256 threads */
+    __shared__ double s_all[2 * FftCfg<LOGN>::LDS];
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    const int ch = blockIdx.x;
+    cplx sk[ITER], sn[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; i++) { sk[i] = sn[i] = make_double2(0.0, 0.0); }
+    tuner_accumulate_blocks<LOGN>(rings + (size_t)ch * GDG_TUNER_RING, wp, 0, TUNER_NBLK, false, s_all, s_all + FftCfg<LOGN>::LDS, tw, tw2, sk, sn);
+    tuner_finish<LOGN>(sk, sn, s_all, s_val, s_idx, sample_rate, tw, tw2, note_freqs, n_notes, out + ch);
+}
+
+/* Fewer channels than CUs (BASELINE config 5 on 8 GPUs: 32 tuners per GPU): a channel's 24 blocks are cut into `parts` runs, one workgroup
+ * each (blockIdx.x = channel * parts + part; a run that does not start at block 0 transforms its predecessor once more for the cross term);
+ * the partial sums S_p go to HBM (64 KiB each) and tuner_short_finish_kernel adds them in part order, inverts and picks. */
+__global__ void __launch_bounds__(256)
+tuner_short_part_kernel(const double *__restrict__ rings, int wp, int parts, const cplx *__restrict__ tw, const cplx *__restrict__ tw2, cplx *__restrict__ partial) {
+    constexpr int LOGN = 12, N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
+    __shared__ double s_all[2 * FftCfg<LOGN>::LDS];
+    const int ch = blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
+    const int b0 = part * TUNER_NBLK / parts, b1 = (part + 1) * TUNER_NBLK / parts;
+    cplx sk[ITER], sn[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; i++) { sk[i] = sn[i] = make_double2(0.0, 0.0); }
+    tuner_accumulate_blocks<LOGN>(rings + (size_t)ch * GDG_TUNER_RING, wp, b0, b1, b0 > 0, s_all, s_all + FftCfg<LOGN>::LDS, tw, tw2, sk, sn);
+    cplx *dst = partial + (size_t)blockIdx.x * N;                  /* [i][0 = k side, 1 = n side][tid] */
+#pragma unroll
+    for (int i = 0; i < ITER; i++) { gstore(dst + (2 * i) * T + tid, sk[i]); gstore(dst + (2 * i + 1) * T + tid, sn[i]); }
+}
+
+__global__ void __launch_bounds__(256)
+tuner_short_finish_kernel(const cplx *__restrict__ partial, int parts, double sample_rate, const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
+                          const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out) {
+    constexpr int LOGN = 12, N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
+    __shared__ double s_all[2 * FftCfg<LOGN>::LDS];
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    cplx sk[ITER], sn[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; i++) { sk[i] = sn[i] = make_double2(0.0, 0.0); }
+    for (int p = 0; p < parts; p++) {                              /* in part order */
+        const cplx *src = partial + ((size_t)ch * parts + p) * N;
+#pragma unroll
+        for (int i = 0; i < ITER; i++) {
+            const cplx a = gload(src + (2 * i) * T + tid), b = gload(src + (2 * i + 1) * T + tid);
+            sk[i].x += a.x; sk[i].y += a.y; sn[i].x += b.x; sn[i].y += b.y;
+        }
+    }
+    tuner_finish<LOGN>(sk, sn, s_all, s_val, s_idx, sample_rate, tw, tw2, note_freqs, n_notes, out + ch);
 }
 
 hipError_t gdg_launch_tuner_enqueue(double *d_rings, int nch, int wp, const double *d_samples, int stride, int frames, hipStream_t s) {
@@ -365,9 +434,24 @@ int gdg_tuner_short_ok(double sample_rate, double lowest_note_frequency) {
     return hi_f + 1.0 <= (double)TUNER_SHORT_MAX_LAG;
 }
 
+/* workgroups per channel of the short-lag analysis: one from a chip's worth of channels on, else enough runs of blocks to put a workgroup
+ * on every CU (at most 8: three blocks + the repeated predecessor each) */
+int gdg_tuner_short_parts(int nch) {
+    const char *e = getenv("GDG_TUNER_PARTS");                    /* read per call: a test walks through the part counts */
+    const int forced = e ? atoi(e) : 0;
+    int parts = forced > 0 ? forced : (nch >= cu_count() ? 1 : (cu_count() + nch - 1) / nch);
+    if (parts > 8) parts = 8;
+    return parts < 1 ? 1 : parts;
+}
+
 hipError_t gdg_launch_tuner_short(const double *d_rings, int nch, int wp, double sample_rate, const cplx *tw4096, const cplx *tw2_4096,
-                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s) {
-    tuner_short_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_rings, wp, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out);
+                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, cplx *d_partial, int parts, hipStream_t s) {
+    if (parts <= 1 || !d_partial) {
+        tuner_short_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_rings, wp, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out);
+        return hipGetLastError();
+    }
+    tuner_short_part_kernel<<<dim3(nch * parts), dim3(256), 0, s>>>(d_rings, wp, parts, tw4096, tw2_4096, d_partial);
+    tuner_short_finish_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_partial, parts, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out);
     return hipGetLastError();
 }
 

@@ -47,6 +47,39 @@ def test_tuner_matches_oracle_on_string_tones(pkg, oracle, sr, frames):
     ctx.close()
 
 
+def test_tuner_analysis_split_over_workgroups_agrees(pkg, oracle):
+    """Fewer channels than CUs: a channel's 24 blocks are transformed by up to 8 workgroups (runs of blocks, each repeating its predecessor
+    for the cross term), the partial sums added in part order.  Every split gives the note, the cents and -- to rounding -- the frequency of
+    the one-workgroup analysis and of the oracle (GDG_TUNER_PARTS forces the count; the default picks it from the channel count)."""
+    import os
+    sr, frames = 192000, 8192
+    nch = len(STRINGS)
+    total = 96000 + 5 * frames
+    x = np.stack([tone(f, total, sr, detune_cents=2.0 * (i - 3), phase=0.2 * i) + 0.01 * synth_signal(i, total, sr) for i, (_, f) in enumerate(STRINGS)])
+    ctx = pkg.Context(nch, frames)
+    refs = [oracle.Tuner() for _ in range(nch)]
+    for b in range(0, total, frames):
+        blk = x[:, b:b + frames]
+        ctx.tuner_enqueue(blk, sr)
+        for c in range(nch):
+            refs[c].process(blk[c], sr)
+    results = {}
+    try:
+        for parts in (1, 2, 3, 5, 8):
+            os.environ["GDG_TUNER_PARTS"] = str(parts)
+            results[parts] = ctx.tuner_analyze()
+    finally:
+        os.environ.pop("GDG_TUNER_PARTS", None)
+    results["auto"] = ctx.tuner_analyze()
+    ctx.close()
+    for c in range(nch):
+        want = refs[c].analyze()
+        for key, got in results.items():
+            assert got[c]["note"] == want["note"] and got[c]["cents"] == want["cents"], (key, c)
+            assert abs(got[c]["frequency"] - want["frequency"]) / want["frequency"] <= 1e-9, (key, c)
+            assert abs(got[c]["frequency"] - results[1][c]["frequency"]) / want["frequency"] <= 1e-12, (key, c)
+
+
 def test_tuner_noise_and_silence(pkg, oracle):
     sr, frames, nch = 48000, 4096, 3
     ctx = pkg.Context(nch, frames)
