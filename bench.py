@@ -571,9 +571,8 @@ def main():
     timed_mac = {"ms_total": ms, "launches": n, "avg_ms": (ms / n) if n else None}
     ms_c, n_c = ctx.profile_read(pkg.K_FIR_MAC_CHAIN)
     timed_chain = {"ms_total": ms_c, "launches": n_c, "avg_ms": (ms_c / n_c) if n_c else None}
-    plain_per_step = sum(1 for _, p in CHAIN if isinstance(p, str)) - (1 if n_c else 0)      # FIR units whose MAC kernel is the plain one
-    sampled_steps = (args.steps + PROFILE_EVERY - 1) // PROFILE_EVERY
-    groups = max(1, n // max(1, sampled_steps * max(plain_per_step, 1)))
+
+    groups = headline_groups
     # Second pass: the SAME steps with one channel group and the dominant kernel (both variants) bracketed on every step, then once more
     # with every launch bracketed.  With --channel-groups > 1 a launch of the timed region shares the chip with the other group's kernels
     # and its HIP-event duration says little about the kernel: the roofline then comes from this pass.
