@@ -685,16 +685,12 @@ def main():
                 def bstep():
                     held["r"] = sctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0), outs=held["r"][0])
                 b_elapsed = shard.timed_steps(bstep, 1, ssync, dist, None)
-                lt, rt = torch.from_numpy(held["r"][1]), torch.from_numpy(held["r"][2])
-                gl = [torch.empty_like(lt) for _ in range(world)] if rank == 0 else None
-                gr = [torch.empty_like(rt) for _ in range(world)] if rank == 0 else None
                 dist.barrier()
                 t0 = time.perf_counter()
-                dist.gather(lt, gl, dst=0)
-                dist.gather(rt, gr, dst=0)
+                lefts, rights = shard.gather_master_partials(held["r"][1], held["r"][2], dist, dst=0)
                 master_ok = None
                 if rank == 0:
-                    ml, mr = sctx.batch_finish_master("lpcm24", [g.numpy() for g in gl], [g.numpy() for g in gr], aux=None)
+                    ml, mr = sctx.batch_finish_master("lpcm24", lefts, rights, aux=None)
                     master_ok = bool(ml.any() and mr.any())
                 t_finish = time.perf_counter() - t0
                 extras["strong_split"]["batch_run_sharded"] = {

@@ -52,3 +52,19 @@ def combine_spatializer_partials(partials, aux=None):
         left += aux
         right += aux
     return left, right
+
+
+def gather_master_partials(left, right, dist, dst=0):
+    """The sharded batch run's only exchange: every rank's float64 partial master mix (left, right: numpy arrays of the job's length) to
+    rank `dst`'s HOST over the control-plane group (gloo) -- SURVEY.md 8e: "the host adds the partials".  Returns (lefts, rights) in rank order
+    on `dst` (to be handed to gdg_batch_finish_master, which adds them in that order, then the aux input, then encodes), (None, None) elsewhere."""
+    import torch
+    lt, rt = torch.from_numpy(np.ascontiguousarray(left)), torch.from_numpy(np.ascontiguousarray(right))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    gl = [torch.empty_like(lt) for _ in range(world)] if rank == dst else None
+    gr = [torch.empty_like(rt) for _ in range(world)] if rank == dst else None
+    dist.gather(lt, gl, dst=dst)
+    dist.gather(rt, gr, dst=dst)
+    if rank != dst:
+        return None, None
+    return [g.numpy() for g in gl], [g.numpy() for g in gr]

@@ -30,7 +30,17 @@ def _worker(rank, world, port, q):
     start, count = shard.channel_shard(512, world, rank)
     sleep = 0.01 * (1 + 2 * rank)                       # rank 1 is three times slower: the job time is ITS time
     elapsed = shard.timed_steps(lambda: time.sleep(sleep), 5, lambda: None, dist)
-    q.put((rank, start, count, elapsed))
+    # the sharded batch run's one exchange: float64 partial master mixes to rank 0's host, in rank order
+    n = 3 * 8192
+    left = np.full(n, 1.0 + rank) * np.linspace(0.0, 1.0, n)
+    right = -left
+    lefts, rights = shard.gather_master_partials(left, right, dist, dst=0)
+    if rank == 0:
+        gathered = bool(len(lefts) == world and all(np.array_equal(lefts[r], np.full(n, 1.0 + r) * np.linspace(0.0, 1.0, n)) for r in range(world))
+                        and all(np.array_equal(rights[r], -lefts[r]) for r in range(world)))
+    else:
+        gathered = lefts is None and rights is None
+    q.put((rank, start, count, elapsed, gathered))
     dist.destroy_process_group()
 
 
@@ -46,7 +56,8 @@ def test_two_rank_gloo_timing_and_sharding():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, c0, e0), (r1, s1, c1, e1) = res
+    (r0, s0, c0, e0, g0), (r1, s1, c1, e1, g1) = res
+    assert g0 and g1                                     # partial master mixes: gathered on rank 0 in rank order, nowhere else
     assert (s0, c0, s1, c1) == (0, 256, 256, 256)
     assert e0 == e1                                      # every rank reports the max over ranks
     assert 0.15 <= e0 < 1.0                              # >= 5 x 30 ms of the slow rank
