@@ -15,13 +15,15 @@
 #define SPAT_TILE 32                     /* samples per workgroup */
 #define SPAT_SUB 8                       /* channel groups a workgroup works on at the same time (256 threads = 32 samples x 8) */
 #define SPAT_UNROLL 16                   /* channels whose loads are in flight together */
-#define SPAT_MAX_GROUPS 256              /* 8192 channels per shard */
+#define SPAT_MAX_GROUPS 64               /* 2048 channels per shard (32 KiB of group partials in LDS) */
+#define SPAT_LDS_DESC_MAX 512             /* up to this many channels the descriptors are staged in LDS (24 KiB), beyond it read from HBM */
 
 /* ONE launch per block (round 2: partial sums, reduce and history update were three launches, 23 us per 8192-frame block of 256
  * channels, all latency).  Workgroup t < tiles mixes samples [32 t, 32 t + 32): lane (s, q) sums channel groups q, q + 8, ... of 32
  * channels each in channel order, the group partials meet in LDS and are added in group order -- the same association as before, so
  * the same bits.  The history (last H inputs of every channel, spatializer.go:313-331) is double buffered: this block reads
  * `hist_read` and the workgroups t >= tiles write `hist_write`, so nobody waits for anybody inside the launch. */
+template <bool LDS_DESC>
 __global__ void __launch_bounds__(256)
 spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__restrict__ in, int in_stride,
             const double *__restrict__ hist_read, double *__restrict__ hist_write, int H, double *__restrict__ out_lr, int out_stride,
@@ -40,10 +42,13 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
     const int s = tid & (SPAT_TILE - 1), q = tid / SPAT_TILE;
     const int j = min((int)blockIdx.x * SPAT_TILE + s, frames - 1);      /* lanes past the end repeat the last sample and are not stored */
     const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
-    /* the channel descriptors, once per workgroup, into LDS (behind the partials) */
-    gdg_spat_chan *s_ch = reinterpret_cast<gdg_spat_chan *>(part + (size_t)groups * 2 * SPAT_TILE);
-    for (int c = tid; c < nch; c += 256) s_ch[c] = chans[c];
-    __syncthreads();
+    /* the channel descriptors, once per workgroup, into LDS (behind the partials); very wide shards read them from HBM instead */
+    gdg_spat_chan *l_ch = reinterpret_cast<gdg_spat_chan *>(part + (size_t)groups * 2 * SPAT_TILE);
+    if constexpr (LDS_DESC) {
+        for (int c = tid; c < nch; c += 256) l_ch[c] = chans[c];
+        __syncthreads();
+    }
+#define s_ch (LDS_DESC ? (const gdg_spat_chan *)l_ch : chans)
     for (int g = q; g < groups; g += SPAT_SUB) {
         const int c_begin = g * SPAT_GROUP, c_end = min(nch, c_begin + SPAT_GROUP);
         double L = 0.0, R = 0.0;
@@ -93,6 +98,8 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
     }
 }
 
+#undef s_ch
+
 hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, const double *d_hist_read,
                                   double *d_hist_write, int H, double *d_out_lr, int out_stride, int frames, hipStream_t s) {
     if (H > 1024 || nch > SPAT_MAX_GROUPS * SPAT_GROUP) return hipErrorInvalidValue;
@@ -100,6 +107,10 @@ hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const d
     int hist_blocks = (nch * H + 2047) / 2048;                    /* eight entries per thread */
     if (hist_blocks < 1) hist_blocks = 1;
     const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
-    spat_kernel<<<dim3(tiles + hist_blocks), dim3(256), (size_t)groups * 2 * SPAT_TILE * sizeof(double) + (size_t)nch * sizeof(gdg_spat_chan), s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
+    const size_t part_bytes = (size_t)groups * 2 * SPAT_TILE * sizeof(double);
+    if (nch <= SPAT_LDS_DESC_MAX)
+        spat_kernel<true><<<dim3(tiles + hist_blocks), dim3(256), part_bytes + (size_t)nch * sizeof(gdg_spat_chan), s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
+    else
+        spat_kernel<false><<<dim3(tiles + hist_blocks), dim3(256), part_bytes, s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
     return hipGetLastError();
 }

@@ -130,3 +130,23 @@ def test_spatializer_rejects_out_of_range(pkg):
     with pytest.raises(pkg.GdgError):
         ctx.spatializer_set_position(2, 0.0, 1.0, 1.0)
     ctx.close()
+
+
+def test_spatializer_wide_shard(pkg, oracle):
+    """More channels than the spatializer stages descriptors for in LDS (512): 700 channels take the variant that reads them from HBM."""
+    nch, frames, sr = 700, 512, 48000
+    rng = np.random.default_rng(4)
+    ctx = pkg.Context(nch, frames)
+    ref = oracle.Spatializer(nch)
+    ctx.spatializer_set_sample_rate(sr)
+    ref.set_sample_rate(sr)
+    for c in range(nch):
+        a, d, l = float(rng.uniform(-180, 180)), float(rng.uniform(0, 10)), float(rng.uniform(0, 1))
+        ctx.spatializer_set_position(c, a, d, l)
+        ref.set_azimuth(c, a); ref.set_distance(c, d); ref.set_level(c, l)
+    for b in range(3):
+        x = rng.uniform(-0.5, 0.5, (nch, frames))
+        gl, gr = ctx.spatialize(x)
+        wl, wr = ref.process(x)
+        assert rms(gl - wl) <= TOL_RMS and rms(gr - wr) <= TOL_RMS, b
+    ctx.close()
