@@ -200,6 +200,7 @@ struct gdg_ctx {
     /* tables */
     std::map<int, std::pair<double2 *, double2 *>> fir_tables;
     std::multimap<uint64_t, std::weak_ptr<SharedSpectra>> spectra;     /* content hash -> live IR spectra */
+    std::vector<std::shared_ptr<SharedSpectra>> pending_ir;           /* spectra allocated by the plan being built, transformed together (flush_ir) */
     bool share_spectra = true;
     /* FIR launch shape.  -1 (default): by channel count -- the fused kernel (one workgroup per channel: multiply-accumulate
      * straight into the inverse transform) needs >= ~128 channels to fill the 256 CUs; below that the multiply-accumulate runs
@@ -961,10 +962,10 @@ static bool reference_panics(int frames, int taps) {
 static int fir_spectra(gdg_ctx *ctx, Unit &u, int hop, int P, int K) {
     const int L = (int)u.taps.size();
     size_t spec = (size_t)K * (size_t)P * sizeof(double2);
-    uint64_t key = 1469598103934665603ull;                              /* FNV-1a over the tap bytes, P and L */
+    uint64_t key = 1469598103934665603ull;                              /* FNV-1a style over the taps' 64-bit patterns, P, hop and L (byte-wise
+                                                                         * it cost 0.5 ms per 65536-tap filter: half a second for 1024 of them) */
     {
-        const unsigned char *b = reinterpret_cast<const unsigned char *>(u.taps.data());
-        for (size_t i = 0; i < u.taps.size() * sizeof(double); i++) { key ^= b[i]; key *= 1099511628211ull; }
+        for (size_t i = 0; i < u.taps.size(); i++) { uint64_t w; memcpy(&w, &u.taps[i], sizeof(w)); key ^= w; key *= 1099511628211ull; key ^= key >> 29; }
         key ^= (uint64_t)P; key *= 1099511628211ull;
         key ^= (uint64_t)hop; key *= 1099511628211ull;
         key ^= (uint64_t)L; key *= 1099511628211ull;
@@ -987,35 +988,65 @@ static int fir_spectra(gdg_ctx *ctx, Unit &u, int hop, int P, int K) {
     sp->hop = hop;
     sp->arena = &ctx->arena;
     HIP_TRY(ctx, ctx->arena.alloc((void **)&sp->d_H, spec));
-    HIP_TRY(ctx, hipMemsetAsync(sp->d_H, 0, spec, ctx->stream));
-    if (L > 0) {
+    if (L > 0) ctx->pending_ir.push_back(sp);                           /* transformed with the plan's other new filters: flush_ir */
+    else HIP_TRY(ctx, hipMemsetAsync(sp->d_H, 0, spec, ctx->stream));   /* filter.Empty: one all-zero partition */
+    u.H = sp;
+    if (ctx->share_spectra) ctx->spectra.emplace(key, sp);
+    return GDG_OK;
+}
+
+/* The IR spectra of every filter the plan under construction brought in, in a few large launches: a 512-channel context with private IRs
+ * has 1024 of them, and one upload + launch + synchronise + release each cost 1.1 ms a piece (1.2 s before the first frame).  Filters of
+ * the same transform size go together, at most ~256 MiB of zero-padded taps per round: partition k = taps [k hop, (k + 1) hop) padded to P. */
+static int flush_ir_body(gdg_ctx *ctx, const std::vector<std::shared_ptr<SharedSpectra>> &todo);
+static int flush_ir(gdg_ctx *ctx) {
+    if (ctx->pending_ir.empty()) return GDG_OK;
+    int rc = flush_ir_body(ctx, ctx->pending_ir);
+    if (rc == GDG_OK) ctx->pending_ir.clear();          /* on failure the list stays: the caller marks these filters for a fresh start */
+    return rc;
+}
+static int flush_ir_body(gdg_ctx *ctx, const std::vector<std::shared_ptr<SharedSpectra>> &todo) {
+    std::map<int, std::vector<SharedSpectra *>> by_P;
+    for (auto &sp : todo) by_P[sp->P].push_back(sp.get());
+    for (auto &kv : by_P) {
+        const int P = kv.first;
         double2 *tw, *tw2;
         int rc = fir_tables(ctx, P, &tw, &tw2);
         if (rc != GDG_OK) return rc;
-        /* partition k = taps [k hop, (k + 1) hop), zero-padded to the transform half */
-        std::vector<double> padded((size_t)K * (size_t)P, 0.0);
-        for (int k = 0; k < K; k++) {
-            int n = std::min(hop, L - k * hop);
-            memcpy(padded.data() + (size_t)k * P, u.taps.data() + (size_t)k * hop, (size_t)n * sizeof(double));
+        const size_t budget = ((size_t)256 << 20) / ((size_t)P * sizeof(double));       /* partitions per round */
+        size_t at = 0;
+        while (at < kv.second.size()) {
+            size_t end = at, parts = 0;
+            while (end < kv.second.size() && (parts == 0 || parts + (size_t)kv.second[end]->K <= budget)) parts += (size_t)kv.second[end++]->K;
+            std::vector<double> padded(parts * (size_t)P, 0.0);
+            std::vector<gdg_fir_irjob> jobs(parts);
+            struct Temps {
+                DevArena &a; hipStream_t st; void *p = nullptr, *q = nullptr;
+                ~Temps() { hipStreamSynchronize(st); a.release(p); a.release(q); }
+            } tmp{ ctx->arena, ctx->stream };
+            HIP_TRY(ctx, ctx->arena.alloc(&tmp.p, padded.size() * sizeof(double)));
+            HIP_TRY(ctx, ctx->arena.alloc(&tmp.q, jobs.size() * sizeof(gdg_fir_irjob)));
+            double *d_taps = static_cast<double *>(tmp.p);
+            size_t j = 0;
+            for (size_t i = at; i < end; i++) {
+                const SharedSpectra &sp = *kv.second[i];
+                const int L = (int)sp.taps.size();
+                for (int k = 0; k < sp.K; k++, j++) {
+                    const int n = std::min(sp.hop, L - k * sp.hop);
+                    if (n > 0) memcpy(padded.data() + j * (size_t)P, sp.taps.data() + (size_t)k * sp.hop, (size_t)n * sizeof(double));
+                    memset(&jobs[j], 0, sizeof(gdg_fir_irjob));
+                    jobs[j].a = d_taps + j * (size_t)P;
+                    jobs[j].out = sp.d_H + (size_t)k * P;
+                }
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(tmp.q, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
+            /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
+            HIP_TRY(ctx, gdg_launch_fir_ir(P, static_cast<const gdg_fir_irjob *>(tmp.q), (int)parts, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                     /* `padded` and `jobs` are locals */
+            at = end;
         }
-        /* two temporaries out of the arena, released on every way out once the stream is idle */
-        struct Temps {
-            DevArena &a; hipStream_t st; void *p = nullptr, *q = nullptr;
-            ~Temps() { hipStreamSynchronize(st); a.release(p); a.release(q); }
-        } tmp{ ctx->arena, ctx->stream };
-        std::vector<gdg_fir_irjob> jobs((size_t)K);
-        HIP_TRY(ctx, ctx->arena.alloc(&tmp.p, padded.size() * sizeof(double)));
-        HIP_TRY(ctx, ctx->arena.alloc(&tmp.q, jobs.size() * sizeof(gdg_fir_irjob)));
-        double *d_taps = static_cast<double *>(tmp.p);
-        gdg_fir_irjob *d_jobs = static_cast<gdg_fir_irjob *>(tmp.q);
-        for (int k = 0; k < K; k++) { jobs[(size_t)k].a = d_taps + (size_t)k * P; jobs[(size_t)k].out = sp->d_H + (size_t)k * P; }
-        HIP_TRY(ctx, hipMemcpyAsync(d_taps, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(gdg_fir_irjob), hipMemcpyHostToDevice, ctx->stream));
-        /* 1/(2P): the inverse real transform's scale, folded into the IR spectra */
-        HIP_TRY(ctx, gdg_launch_fir_ir(P, d_jobs, K, 1.0 / (2.0 * (double)P), tw, tw2, ctx->stream));
     }
-    u.H = sp;
-    if (ctx->share_spectra) ctx->spectra.emplace(key, sp);
     return GDG_OK;
 }
 
@@ -1142,6 +1173,11 @@ struct Op { bool is_fir; std::vector<int> handles; };
 static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
                       int stride, int stride_out, bool rows_by_channel, int G, const std::vector<size_t> &bounds) {
     const int nch = ctx->nch;
+    static int ptrace = -1;
+    if (ptrace < 0) { const char *e = getenv("GDG_PLAN_TRACE"); ptrace = e ? atoi(e) : 0; }
+    auto pnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_fir = 0.0, t_unit = 0.0;
+    const double t_plan0 = pnow();
     join_groups(ctx);                 /* a new plan replaces descriptors (and possibly unit state) the group streams may still be reading */
     /* channel groups: contiguous runs of `active`, group g = [bounds[g], bounds[g + 1]) (equal shares unless the caller weights them) */
     std::vector<int> group_of((size_t)nch, 0);
@@ -1197,7 +1233,9 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
             else dst = ((done[(size_t)c] & 1) ? ctx->d_w1 : ctx->d_w0) + (size_t)c * ctx->w_stride;
             if (is_fir) {
                 Unit &u = ctx->units[(size_t)op.handles[0]];
+                const double tq = pnow();
                 int rc = prepare_fir(ctx, u, frames, sample_rate);
+                t_fir += pnow() - tq;
                 if (rc != GDG_OK) return rc;
                 gdg_fir_chan f;
                 memset(&f, 0, sizeof(f));
@@ -1216,7 +1254,9 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 s.unit_count = (int)op.handles.size();
                 for (int h : op.handles) {
                     gdg_seg_unit du;
+                    const double tq = pnow();
                     int rc = prepare_unit(ctx, ctx->units[(size_t)h], frames, sample_rate, du);
+                    t_unit += pnow() - tq;
                     if (rc != GDG_OK) return rc;
                     seg_units.push_back(du);
                 }
@@ -1249,6 +1289,12 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         ctx->steps.push_back(st);
         seg_descs.push_back(sd);
         fir_descs.push_back(fd);
+    }
+    {   /* the new filters' spectra, all together */
+        const double tq = pnow();
+        int rc = flush_ir(ctx);
+        if (ptrace) fprintf(stderr, "[plan] prepare_fir %.1f ms, prepare_unit %.1f ms, flush_ir %.1f ms, so far %.1f ms\n", t_fir, t_unit, pnow() - tq, pnow() - t_plan0);
+        if (rc != GDG_OK) return rc;
     }
     /* adjacent power amps (the benchmark chain: cabinet IR, then reverb IR): when EVERY channel of a FIR step hands its frame to the
      * next FIR step, that step's forward transform is produced by this step's inverse kernel -- no launch, no round trip of the frame */
@@ -1425,7 +1471,13 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
         ctx->plan_stride = stride;
         ctx->plan_stride_out = stride_out;
         ctx->plan_by_channel = rows_by_channel;
-        if (rc != GDG_OK) { ctx->dirty = true; return rc; }
+        if (rc != GDG_OK) {
+            /* filters whose spectra were allocated but not transformed start over at the next plan */
+            for (auto &sp : ctx->pending_ir) for (auto &u : ctx->units) if (u.alive && u.H == sp) { u.H.reset(); u.fir_dirty = true; u.fir_live = false; }
+            ctx->pending_ir.clear();
+            ctx->dirty = true;
+            return rc;
+        }
         ctx->plan_active = active;
     }
     const gdg_seg_unit *d_units = reinterpret_cast<const gdg_seg_unit *>(ctx->d_blob + ctx->units_offset);
