@@ -32,6 +32,17 @@ def random_params(rng, unit_type, allow_oversampling):
     return out
 
 
+def reference_panics(frames, taps):
+    """filter.Process walks the frame in blocks of nextpow2(L) samples but counts them on nextpow2(N): with N not a power of two a block can
+    start beyond the frame and the reference panics on the slice bounds (filter/filter.go:370-382, :443-453); the library rejects such pairs"""
+    if taps <= 0 or frames <= 0:
+        return False
+    n_power = 1 << (frames - 1).bit_length()
+    block = 1 << (taps - 1).bit_length()
+    blocks = -(-n_power // block)
+    return (blocks - 1) * block > frames
+
+
 def _fft_computed(name, params):
     """units whose output the reference computes through an FFT convolution (filter.Process): the power amp, and every oversampled unit
     (its decimator, oversampling.go:126-184)"""
@@ -62,7 +73,7 @@ def _split_points(units):
     return cut
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(64))
 def test_random_chains_follow_the_oracle(oracle, seed):
     pkg = package()
     rng = np.random.default_rng(1000 + seed)
@@ -79,9 +90,8 @@ def test_random_chains_follow_the_oracle(oracle, seed):
             bypass = bool(rng.random() < 0.15)
             if name == "power_amp":
                 taps = int(rng.choice([1, 77, 500, 3000, 9000]))
-                # frame sizes that are not a power of two: keep away from the pairs the reference itself panics on (filter.go:443-453)
-                if frames & (frames - 1):
-                    taps = min(taps, frames)
+                while reference_panics(frames, taps):                # keep away from the pairs the reference itself panics on
+                    taps *= 2
                 fir = synth_ir(taps, seed=int(rng.integers(1, 10 ** 6))) * float(rng.choice([0.5, 1.0, 2.5]))
                 units.append((name, fir, bypass))
             else:
@@ -157,3 +167,141 @@ def test_octaver_behind_a_decimator_matches_on_the_same_input(oracle):
     assert lead > 0 and np.max(np.abs(w1[:lead])) > 0.0 and not np.array_equal(np.sign(g1[:lead]), np.sign(w1[:lead]))     # silence: noise of other signs
     g2, w2 = run([oc], w1)
     assert rms(g2 - w2) <= TOL_RMS                        # same input, same output
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_edits_in_mid_stream_follow_the_oracle(oracle, seed):
+    """A stream during which the chain keeps changing the way a user at the web UI changes it: parameters set to new values, units bypassed
+    and re-enabled, moved up and down, the block size switched between calls (power amps carry their convolution state across, like
+    filter.Process), the sample rate changed (the reference re-makes the rate-dependent buffers).  Every edit goes to the HIP context and
+    to the oracle's chain; every block is compared."""
+    pkg = package()
+    rng = np.random.default_rng(5000 + seed)
+    rates = [44100, 48000, 96000]
+    sr = int(rng.choice(rates))
+    max_frames = int(rng.choice([8192, 2048, 1024]))
+    nch = 2
+    ctx = pkg.Context(nch, max_frames)
+    pairs, types = [], []
+    for c in range(nch):
+        p = ChainPair(ctx, c, oracle)
+        ts = []
+        with_fft = bool(rng.random() < 0.6)
+        for _ in range(int(rng.integers(2, 7))):
+            while True:
+                t = int(rng.integers(0, 21))
+                name = pkg.UNIT_NAMES[t]
+                if name == "power_amp" and not with_fft:
+                    continue
+                if name == "octaver" and with_fft:          # ill-conditioned behind an FFT-computed stage (see above): not this test's subject
+                    continue
+                break
+            if name == "power_amp":
+                p.append(name, fir=synth_ir(int(rng.choice([33, 700, 2500])), seed=int(rng.integers(1, 10 ** 6))), bypass=bool(rng.random() < 0.2))
+            else:
+                p.append(name, params=random_params(rng, t, allow_oversampling=with_fft), bypass=bool(rng.random() < 0.2))
+            ts.append(t)
+        pairs.append(p)
+        types.append(ts)
+    bypass = [[b for _, b in ctx._chains[c]] for c in range(nch)]
+    order = [list(range(len(types[c]))) for c in range(nch)]          # order[c][slot] = index into pairs[c].handles / types[c]
+    log = []
+    pos = 0
+    for blk in range(10):
+        # ---- edits -------------------------------------------------------------------------------------------------------
+        for c in range(nch):
+            p = pairs[c]
+            r = rng.random()
+            if r < 0.25:                                              # a parameter gets a new value
+                slot = int(rng.integers(0, len(order[c])))
+                u = order[c][slot]
+                name = pkg.UNIT_NAMES[types[c][u]]
+                if name != "power_amp":
+                    newp = random_params(rng, types[c][u], allow_oversampling=any(pkg.UNIT_NAMES[t] == "power_amp" for t in types[c]) or name != "octaver")
+                    if name == "octaver" or not any(pkg.UNIT_NAMES[t] == "octaver" for t in types[c]):
+                        idx = int(rng.integers(0, len(newp)))
+                        ctx.unit_set_param(p.handles[u], idx, newp[idx])
+                        p.ref.unit(slot).set_param(idx, newp[idx])
+                        log.append((blk, c, "param", name, idx, newp[idx]))
+            elif r < 0.45:                                            # bypass toggled
+                slot = int(rng.integers(0, len(order[c])))
+                bypass[c][slot] = not bypass[c][slot]
+                ctx.chain_set(c, [p.handles[u] for u in order[c]], bypass[c])
+                p.ref.set_bypass(slot, bypass[c][slot])
+                log.append((blk, c, "bypass", slot, bypass[c][slot]))
+            elif r < 0.6 and len(order[c]) > 1:                       # a unit moves up (its state travels with it)
+                slot = int(rng.integers(1, len(order[c])))
+                order[c][slot - 1], order[c][slot] = order[c][slot], order[c][slot - 1]
+                bypass[c][slot - 1], bypass[c][slot] = bypass[c][slot], bypass[c][slot - 1]
+                ctx.chain_set(c, [p.handles[u] for u in order[c]], bypass[c])
+                p.ref.move_up(slot)
+                log.append((blk, c, "move_up", slot))
+        if rng.random() < 0.12:
+            sr = int(rng.choice(rates))
+            log.append((blk, "rate", sr))
+        frames = max_frames if rng.random() < 0.6 else int(rng.choice([max_frames // 2, max_frames // 4, 1000 if max_frames >= 1000 else 480]))
+        # frame sizes that are not a power of two with a long filter: the reference panics (filter.go:443-453) -- keep to the others there
+        if frames & (frames - 1) and any(pkg.UNIT_NAMES[t] == "power_amp" for ts in types for t in ts):
+            frames = max_frames // 2
+        # ---- one block --------------------------------------------------------------------------------------------------------
+        x = np.stack([synth_signal(3 + 5 * c, pos + frames, sr)[pos:] * 0.6 for c in range(nch)])
+        pos += frames
+        got = ctx.process(np.ascontiguousarray(x), sr)
+        for c in range(nch):
+            want = pairs[c].ref.process(x[c], sr)
+            err = rms(got[c] - want)
+            assert err <= TOL_RMS, "seed %d block %d channel %d (%d frames at %d Hz): RMS %.3e; units %s; edits %s" % (
+                seed, blk, c, frames, sr, err, [pkg.UNIT_NAMES[types[c][u]] for u in order[c]], log)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_chains_in_windows_give_the_bits_of_per_frame_calls(seed):
+    """Batch mode: the same random chains walked W frames per call (time-blocked convolution, one segment launch per window, the window size
+    changing from call to call like at the tail of a file) and one frame per call: identical samples, whatever the units."""
+    pkg = package()
+    rng = np.random.default_rng(9000 + seed)
+    sr = int(rng.choice([44100, 96000, 192000]))
+    frames, nch, blocks = 8192, 3, 14
+    chains = []
+    for c in range(nch):
+        units = []
+        for _ in range(int(rng.integers(1, 7))):
+            t = int(rng.integers(0, 21))
+            name = pkg.UNIT_NAMES[t]
+            if name == "power_amp":
+                units.append((name, synth_ir(int(rng.choice([100, 8192, 20000, 40000])), seed=int(rng.integers(1, 10 ** 6))) * 0.8, bool(rng.random() < 0.1)))
+            else:
+                units.append((name, random_params(rng, t, allow_oversampling=True), bool(rng.random() < 0.1)))
+        chains.append(units)
+    x = np.stack([synth_signal(int(rng.integers(0, 48)), frames * blocks, sr) * 0.7 for _ in range(nch)])
+    W = int(rng.choice([2, 4, 8, 16]))
+    plan, left = [], blocks                                     # windows of W, then the tail in windows of W/2 ... 1
+    w = W
+    while left > 0:
+        while w > left:
+            w //= 2
+        plan.append(w)
+        left -= w
+    outs = {}
+    for mode in ("windows", "frames"):
+        ctx = pkg.Context(nch, frames)
+        for c in range(nch):
+            for name, arg, bypass in chains[c]:
+                if name == "power_amp":
+                    ctx.append_unit(c, name, fir=arg, bypass=bypass)
+                else:
+                    ctx.append_unit(c, name, params=arg, bypass=bypass)
+        d_in, d_out = ctx.alloc(nch, blocks * frames), ctx.alloc(nch, blocks * frames)
+        d_in.upload(x)
+        if mode == "windows":
+            ctx.set_window(W)
+        b = 0
+        for w in (plan if mode == "windows" else [1] * blocks):
+            ctx.process_window_device(d_in.ptr + 8 * b * frames, d_out.ptr + 8 * b * frames, blocks * frames, w, sr)
+            b += w
+        outs[mode] = d_out.download()
+        ctx.close()
+    assert np.isfinite(outs["frames"]).all()
+    assert np.array_equal(outs["windows"], outs["frames"]), (seed, W, plan, [[(n, b) for n, _, b in ch] for ch in chains],
+                                                             float(np.max(np.abs(outs["windows"] - outs["frames"]))))
