@@ -305,3 +305,97 @@ def test_random_chains_in_windows_give_the_bits_of_per_frame_calls(seed):
     assert np.isfinite(outs["frames"]).all()
     assert np.array_equal(outs["windows"], outs["frames"]), (seed, W, plan, [[(n, b) for n, _, b in ch] for ch in chains],
                                                              float(np.max(np.abs(outs["windows"] - outs["frames"]))))
+
+
+FORMATS = ["lpcm8", "lpcm16", "lpcm24", "lpcm32", "ieee32", "ieee64"]
+BLOCK = 8192
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
+    """gdg_batch_run on random jobs: 2-5 inputs in random sample formats, lengths (odd ones included), rates (some need resample.Time),
+    interleaved files of which one channel is taken, empty inputs; random chains; a random window size; the metronome in or out of the
+    master mix; a random output format.  Against the oracle's pipeline (decode -> resample.Time -> pad -> per block: chains, metronome,
+    spatializer + aux -> encode): integer containers byte for byte, float containers within 1e-9 RMS."""
+    pkg = package()
+    rng = np.random.default_rng(7000 + seed)
+    rate = int(rng.choice([44100, 48000, 96000]))
+    nch = int(rng.integers(2, 6))
+    W = int(rng.choice([1, 2, 4, 8]))
+    out_fmt = str(rng.choice(FORMATS))
+    to_master = bool(rng.random() < 0.5)
+    # ---- the files ------------------------------------------------------------------------------------------------------------
+    inputs, decoded = [None] * nch, {}
+    for c in range(nch):
+        if rng.random() < 0.15:
+            continue                                             # "leaving channel empty"
+        fmt = str(rng.choice(FORMATS))
+        r = int(rng.choice([rate, rate, 44100, 22050]))
+        n = int(rng.choice([1, 7, 5000, BLOCK, BLOCK + 1, 3 * BLOCK - 5, 20000]))
+        chans = int(rng.choice([1, 1, 2, 3]))
+        take = int(rng.integers(0, chans))
+        w = pkg.lib().gdg_wave_bytes_per_sample(pkg.WAVE_FORMATS[fmt])
+        per_chan = [oracle.wave_encode(fmt, 0.8 * synth_signal(7 * c + k, n, r)).reshape(n, w) for k in range(chans)]
+        data = np.ascontiguousarray(np.stack(per_chan, axis=1)).reshape(-1)
+        inputs[c] = (data, fmt, r, chans, take)
+        xd = oracle.wave_decode(fmt, per_chan[take].reshape(-1))
+        decoded[c] = xd if r == rate else oracle.resample_time(xd, r, rate)
+    longest = max([len(v) for v in decoded.values()] + [0])
+    length = BLOCK * ((longest + BLOCK - 1) // BLOCK)
+    # ---- chains, spatializer, metronome on both sides ----------------------------------------------------------------------------
+    ctx = pkg.Context(nch, BLOCK)
+    ctx.set_window(W)
+    refs = []
+    for c in range(nch):
+        p = ChainPair(ctx, c, oracle)
+        fft = bool(rng.random() < 0.5)
+        for _ in range(int(rng.integers(0, 5))):
+            while True:
+                t = int(rng.integers(0, 21))
+                name = pkg.UNIT_NAMES[t]
+                if (name == "power_amp" and not fft) or (name == "octaver" and fft):
+                    continue
+                break
+            if name == "power_amp":
+                p.append(name, fir=synth_ir(int(rng.choice([50, 3000, 12000])), seed=int(rng.integers(1, 10 ** 6))) * 0.7)
+            else:
+                p.append(name, params=random_params(rng, t, allow_oversampling=fft))
+        refs.append(p.ref)
+    ref_sp = oracle.Spatializer(nch)
+    ctx.spatializer_set_sample_rate(rate)
+    ref_sp.set_sample_rate(rate)
+    for c in range(nch):
+        a, d, l = float(rng.uniform(-180, 180)), float(rng.uniform(0.1, 10)), float(rng.uniform(0, 1))
+        ctx.spatializer_set_position(c, a, d, l)
+        ref_sp.set_azimuth(c, a); ref_sp.set_distance(c, d); ref_sp.set_level(c, l)
+    tick, tock = rng.uniform(-0.5, 0.5, 700), rng.uniform(-0.5, 0.5, 300)
+    beats, bpm = int(rng.integers(1, 8)), int(rng.integers(40, 360))
+    ctx.metronome_set_sounds(tick, tock)
+    ctx.metronome_configure(beats, bpm, rate)
+    ref_met = oracle.Metronome()
+    ref_met.tick, ref_met.tock = tick, tock
+    ref_met.s.beats_per_period, ref_met.s.bpm_speed, ref_met.s.sample_rate = beats, bpm, rate
+    # ---- oracle pipeline ---------------------------------------------------------------------------------------------------------
+    xin = np.zeros((nch, length))
+    for c, v in decoded.items():
+        xin[c, :len(v)] = v
+    ref_out = np.zeros((nch + 3, length))
+    for b in range(length // BLOCK):
+        sl = slice(b * BLOCK, (b + 1) * BLOCK)
+        for c in range(nch):
+            ref_out[c, sl] = refs[c].process(xin[c, sl], rate)
+        ref_out[nch + 2, sl] = ref_met.process(BLOCK)
+        ref_out[nch, sl], ref_out[nch + 1, sl] = ref_sp.process(ref_out[:nch, sl], aux=(ref_out[nch + 2, sl] if to_master else None))
+    # ---- device: one call -----------------------------------------------------------------------------------------------------------
+    outs = ctx.batch_run(inputs, rate, out_fmt, metronome_to_master=to_master)
+    ctx.close()
+    wo = pkg.lib().gdg_wave_bytes_per_sample(pkg.WAVE_FORMATS[out_fmt])
+    assert len(outs) == nch + 3 and all(o.size == length * wo for o in outs), (seed, [o.size for o in outs], length)
+    for r in range(nch + 3):
+        want = oracle.wave_encode(out_fmt, ref_out[r]) if length else np.zeros(0, dtype=np.uint8)
+        if out_fmt in ("ieee32", "ieee64"):
+            err = rms(oracle.wave_decode(out_fmt, outs[r]) - oracle.wave_decode(out_fmt, want)) if length else 0.0
+            assert err <= TOL_RMS, (seed, r, out_fmt, err)
+        else:
+            bad = int(np.count_nonzero(outs[r] != want))
+            assert bad == 0, "seed %d output %d (%s, W = %d): %d bytes differ" % (seed, r, out_fmt, W, bad)
