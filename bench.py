@@ -26,6 +26,7 @@ HIP events over the timed region, the PCIe-inclusive host-buffer rates ("end_to_
 BASELINE configs' rates ("configs") and a CPU baseline (the oracle "port") timed on the host cores.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -506,7 +507,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (barrier + max of one scalar): gloo, so that NO RCCL / xGMI traffic exists anywhere in this job
-        dist.init_process_group("gloo")
+        # a rank that dies inside an extra leg must not hang the others for gloo's default 30 minutes: collectives give up after 5
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=int(os.environ.get("GDG_BENCH_DIST_TIMEOUT", "300"))))
     if os.environ.get("GDG_BENCH_ONE_DEVICE"):            # harness self-test on a one-GPU box: every rank shares device 0
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -626,101 +628,107 @@ def main():
             parity["ok"] = bool(float(t[0]) <= PARITY_TOL_RMS)
 
     extras = {}
-    if not args.no_extras and not strong:
-        if world == 1:
-            extras["end_to_end"] = end_to_end(pkg, ctx, nch, frames, sr)
-            if frames == 8192:
-                extras["end_to_end"]["batch_run"] = batch_run(pkg, ctx, nch, sr)
-                extras["time_blocked"] = time_blocked(pkg, ctx, nch, frames, sr)
-    ctx.close()
-    del x, y
-    if not args.no_extras and not strong:
-        if world > 1:
-            # the strong split of the same 512-channel job over these N GPUs (BASELINE config 4: 64 channels per GPU at N = 8)
-            T = args.channels
-            c0, n_loc = shard.channel_shard(T, world, rank)
-            sctx = make_context(pkg, n_loc, frames, local_rank, taps, channel0=c0)
-            sx = torch.from_numpy(synth_block(n_loc, frames, sr, channel0=c0)).to(dev)
-            sy = torch.empty_like(sx)
-
-            def sstep():
-                sctx.process_device(sx.data_ptr(), sy.data_ptr(), frames, sr)
-
-            def ssync():
-                sctx.synchronize()
-                torch.cuda.synchronize()
-
-            for _ in range(max(args.warmup, 1)):
-                sstep()
-            s_elapsed = shard.timed_steps(sstep, args.steps, ssync, dist, None)
-            extras["strong_split"] = {
-                "scaling": "strong", "total_channels": T, "channels_per_gpu": n_loc, "n_gpus": world,
-                "value": T * frames * args.steps / s_elapsed / 1e6, "unit": "Msamples/s",
-                "ms_per_step": s_elapsed / args.steps * 1e3, "realtime_factor": frames * args.steps / s_elapsed / sr,
-            }
-            if frames == 8192:
-                # the same split in batch mode: 16 consecutive frames per call, time blocked (every rank walks 2 windows of its shard)
-                W, windows = 16, 2
-                sctx.set_window(W)
-                wx = sx.repeat(1, W * windows).contiguous()
-                wy = torch.empty_like(wx)
-
-                def wstep():
-                    for b in range(0, W * windows, W):
-                        sctx.process_window_device(wx.data_ptr() + 8 * b * frames, wy.data_ptr() + 8 * b * frames, W * windows * frames, W, sr)
-                wstep()
-                w_elapsed = shard.timed_steps(wstep, 1, ssync, dist, None) / (W * windows)
-                extras["strong_split"]["batch_mode_window_16"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
-                                                                 "realtime_factor": frames / sr / w_elapsed}
-                del wx, wy
-                # ... and as the batch run proper: file bytes in, file bytes out, every rank its shard (gdg_batch_run_shard), the float64
-                # partial master mixes gathered on rank 0's HOST over gloo ("the host adds the partials") and finished there
-                blocks = 32
-                n = blocks * frames
-                for c in range(n_loc):
-                    sctx.spatializer_set_position(c, -90.0 + 180.0 * (c0 + c) / max(T - 1, 1), 1.0 + 0.01 * (c0 + c), 0.5)
-                files = batch_files(n_loc, sr, blocks, channel0=c0)
-                held = {"r": sctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0))}
-
-                def bstep():
-                    held["r"] = sctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0), outs=held["r"][0])
-                b_elapsed = shard.timed_steps(bstep, 1, ssync, dist, None)
-                dist.barrier()
-                t0 = time.perf_counter()
-                lefts, rights = shard.gather_master_partials(held["r"][1], held["r"][2], dist, dst=0)
-                master_ok = None
-                if rank == 0:
-                    ml, mr = sctx.batch_finish_master("lpcm24", lefts, rights, aux=None)
-                    master_ok = bool(ml.any() and mr.any())
-                t_finish = time.perf_counter() - t0
-                extras["strong_split"]["batch_run_sharded"] = {
-                    "blocks": blocks, "window": W, "files_in": "lpcm16", "files_out": "lpcm24", "shard_ms_max_over_ranks": b_elapsed * 1e3,
-                    "gather_and_finish_master_ms": t_finish * 1e3, "value": T * n / (b_elapsed + t_finish) / 1e6, "unit": "Msamples/s",
-                    "realtime_factor": n / sr / (b_elapsed + t_finish), "master_nonzero": master_ok,
-                    "what": "gdg_batch_run_shard on every rank (file bytes to file bytes, PCIe inside), partial master mixes gathered on "
-                            "rank 0's host over gloo, gdg_batch_finish_master there"}
-            sctx.close()
-        elif rank == 0:
-            legs = {}
-            for n_loc in (64, 128, 256):
-                st = leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank, 30)
-                dt = st["median"]
-                legs[str(n_loc)] = {"n_gpus_of_the_split": args.channels // n_loc, "us_per_step": dt * 1e6, "timing": us_stats(st),
-                                    "value_this_gpu": n_loc * frames / dt / 1e6,
-                                    "predicted_job_value": args.channels * frames / dt / 1e6, "unit": "Msamples/s",
-                                    "predicted_realtime_factor": frames / sr / dt}
+    # the extra legs may not take the headline with them: whatever goes wrong in one is reported in the line, not instead of it
+    try:
+        if not args.no_extras and not strong:
+            if world == 1:
+                extras["end_to_end"] = end_to_end(pkg, ctx, nch, frames, sr)
                 if frames == 8192:
-                    stw = window_leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank)
-                    dtw = stw["median"]
-                    legs[str(n_loc)]["batch_mode_window_16"] = {"us_per_frame": dtw * 1e6, "timing": us_stats(stw),
-                                                               "predicted_job_value": args.channels * frames / dtw / 1e6,
-                                                               "predicted_realtime_factor": frames / sr / dtw}
-            extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
-                                                   "(channels are independent: the job's step time is the slowest shard's step time)",
-                                           "legs": legs}
-            if frames == 8192:
-                extras["sharded_batch"] = sharded_batch_one_gpu(pkg, local_rank, args.channels, 2, sr, taps)
-            extras["configs"] = other_configs(pkg, local_rank)
+                    extras["end_to_end"]["batch_run"] = batch_run(pkg, ctx, nch, sr)
+                    extras["time_blocked"] = time_blocked(pkg, ctx, nch, frames, sr)
+        ctx.close()
+        del x, y
+        if not args.no_extras and not strong:
+            if world > 1:
+                # the strong split of the same 512-channel job over these N GPUs (BASELINE config 4: 64 channels per GPU at N = 8)
+                T = args.channels
+                c0, n_loc = shard.channel_shard(T, world, rank)
+                sctx = make_context(pkg, n_loc, frames, local_rank, taps, channel0=c0)
+                sx = torch.from_numpy(synth_block(n_loc, frames, sr, channel0=c0)).to(dev)
+                sy = torch.empty_like(sx)
+
+                def sstep():
+                    sctx.process_device(sx.data_ptr(), sy.data_ptr(), frames, sr)
+
+                def ssync():
+                    sctx.synchronize()
+                    torch.cuda.synchronize()
+
+                for _ in range(max(args.warmup, 1)):
+                    sstep()
+                s_elapsed = shard.timed_steps(sstep, args.steps, ssync, dist, None)
+                extras["strong_split"] = {
+                    "scaling": "strong", "total_channels": T, "channels_per_gpu": n_loc, "n_gpus": world,
+                    "value": T * frames * args.steps / s_elapsed / 1e6, "unit": "Msamples/s",
+                    "ms_per_step": s_elapsed / args.steps * 1e3, "realtime_factor": frames * args.steps / s_elapsed / sr,
+                }
+                if frames == 8192:
+                    # the same split in batch mode: 16 consecutive frames per call, time blocked (every rank walks 2 windows of its shard)
+                    W, windows = 16, 2
+                    sctx.set_window(W)
+                    wx = sx.repeat(1, W * windows).contiguous()
+                    wy = torch.empty_like(wx)
+
+                    def wstep():
+                        for b in range(0, W * windows, W):
+                            sctx.process_window_device(wx.data_ptr() + 8 * b * frames, wy.data_ptr() + 8 * b * frames, W * windows * frames, W, sr)
+                    wstep()
+                    w_elapsed = shard.timed_steps(wstep, 1, ssync, dist, None) / (W * windows)
+                    extras["strong_split"]["batch_mode_window_16"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
+                                                                     "realtime_factor": frames / sr / w_elapsed}
+                    del wx, wy
+                    # ... and as the batch run proper: file bytes in, file bytes out, every rank its shard (gdg_batch_run_shard), the float64
+                    # partial master mixes gathered on rank 0's HOST over gloo ("the host adds the partials") and finished there
+                    blocks = 32
+                    n = blocks * frames
+                    for c in range(n_loc):
+                        sctx.spatializer_set_position(c, -90.0 + 180.0 * (c0 + c) / max(T - 1, 1), 1.0 + 0.01 * (c0 + c), 0.5)
+                    files = batch_files(n_loc, sr, blocks, channel0=c0)
+                    held = {"r": sctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0))}
+
+                    def bstep():
+                        held["r"] = sctx.batch_run_shard(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0), outs=held["r"][0])
+                    b_elapsed = shard.timed_steps(bstep, 1, ssync, dist, None)
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    lefts, rights = shard.gather_master_partials(held["r"][1], held["r"][2], dist, dst=0)
+                    master_ok = None
+                    if rank == 0:
+                        ml, mr = sctx.batch_finish_master("lpcm24", lefts, rights, aux=None)
+                        master_ok = bool(ml.any() and mr.any())
+                    t_finish = time.perf_counter() - t0
+                    extras["strong_split"]["batch_run_sharded"] = {
+                        "blocks": blocks, "window": W, "files_in": "lpcm16", "files_out": "lpcm24", "shard_ms_max_over_ranks": b_elapsed * 1e3,
+                        "gather_and_finish_master_ms": t_finish * 1e3, "value": T * n / (b_elapsed + t_finish) / 1e6, "unit": "Msamples/s",
+                        "realtime_factor": n / sr / (b_elapsed + t_finish), "master_nonzero": master_ok,
+                        "what": "gdg_batch_run_shard on every rank (file bytes to file bytes, PCIe inside), partial master mixes gathered on "
+                                "rank 0's host over gloo, gdg_batch_finish_master there"}
+                sctx.close()
+            elif rank == 0:
+                legs = {}
+                for n_loc in (64, 128, 256):
+                    st = leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank, 30)
+                    dt = st["median"]
+                    legs[str(n_loc)] = {"n_gpus_of_the_split": args.channels // n_loc, "us_per_step": dt * 1e6, "timing": us_stats(st),
+                                        "value_this_gpu": n_loc * frames / dt / 1e6,
+                                        "predicted_job_value": args.channels * frames / dt / 1e6, "unit": "Msamples/s",
+                                        "predicted_realtime_factor": frames / sr / dt}
+                    if frames == 8192:
+                        stw = window_leg_on_one_gpu(pkg, n_loc, frames, sr, taps, local_rank)
+                        dtw = stw["median"]
+                        legs[str(n_loc)]["batch_mode_window_16"] = {"us_per_frame": dtw * 1e6, "timing": us_stats(stw),
+                                                                   "predicted_job_value": args.channels * frames / dtw / 1e6,
+                                                                   "predicted_realtime_factor": frames / sr / dtw}
+                extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
+                                                       "(channels are independent: the job's step time is the slowest shard's step time)",
+                                               "legs": legs}
+                if frames == 8192:
+                    extras["sharded_batch"] = sharded_batch_one_gpu(pkg, local_rank, args.channels, 2, sr, taps)
+                extras["configs"] = other_configs(pkg, local_rank)
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        extras["error"] = {"rank": rank, "exception": repr(e), "traceback": traceback.format_exc().splitlines()[-6:]}
+        print("bench.py: an extra leg failed on rank %d: %r" % (rank, e), file=sys.stderr, flush=True)
 
     if rank == 0:
         K = (taps + frames - 1) // frames
