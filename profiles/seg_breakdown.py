@@ -41,7 +41,8 @@ CASES = [
 def main():
     pkg = entry.load_package()
     nch, frames, sr, steps = 512, 8192, 192000, 10
-    args = [a for a in sys.argv[1:] if a != "--cold"]
+    args = [a for a in sys.argv[1:] if a != "--cold" and not a.startswith("--window=")]
+    W = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--window=")] + [0])      # > 0: gdg_process_window_device, W frames per launch
     cold = "--cold" in sys.argv[1:]          # evict L2 / MALL between launches (as after the 1 GB MAC stream in the bench)
     only = set(args)
     x = np.stack([synth_signal(c, frames, sr) for c in range(nch)])
@@ -55,6 +56,23 @@ def main():
         for c in range(nch):
             for unit, params in chain:
                 ctx.append_unit(c, unit, params=params)
+        if W:
+            ctx.set_window(W)
+            ctx.set_overlap(1)
+            d_in, d_out = ctx.alloc(nch, W * frames), ctx.alloc(nch, W * frames)
+            d_in.upload(np.tile(x, (1, W)))
+            for _ in range(2):
+                ctx.process_window_device(d_in.ptr, d_out.ptr, W * frames, W, sr)
+            ctx.synchronize()
+            ctx.profile_enable(True)
+            for _ in range(3):
+                ctx.process_window_device(d_in.ptr, d_out.ptr, W * frames, W, sr)
+            ctx.synchronize()
+            ms, n = ctx.profile_read(pkg.K_SEGMENT)
+            us = ms / n * 1e3 / W
+            print("%-16s %10.1f %12.0f %12.0f   per frame of a window of %d" % (name, us, nch * frames / us, nch * frames * 16 / us / 1e3, W), flush=True)
+            ctx.close()
+            continue
         d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
         d_in.upload(x)
         for _ in range(2):
