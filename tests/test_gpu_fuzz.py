@@ -399,3 +399,136 @@ def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
         else:
             bad = int(np.count_nonzero(outs[r] != want))
             assert bad == 0, "seed %d output %d (%s, W = %d): %d bytes differ" % (seed, r, out_fmt, W, bad)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_spatializer_jobs_follow_the_oracle(oracle, seed):
+    """spatializer.Process on random shards: channel counts either side of the kernel's limits (one lane group of 32, the 512 descriptors kept in
+    LDS), any rate, frame sizes that change from call to call, positions that move between calls (history carried over, spatializer.go:313-331)."""
+    pkg = package()
+    rng = np.random.default_rng(9000 + seed)
+    nch = int(rng.choice([1, 2, 3, 17, 32, 33, 64, 130, 513]))
+    max_frames = int(rng.choice([64, 1000, 8192]))
+    sr = int(rng.choice([22050, 44100, 48000, 96000, 192000]))
+    ctx = pkg.Context(nch, max_frames)
+    ref = oracle.Spatializer(nch)
+    ctx.spatializer_set_sample_rate(sr)
+    ref.set_sample_rate(sr)
+
+    def place(c):
+        a = float(rng.choice([-180.0, -90.0, 0.0, 90.0, 180.0, rng.uniform(-180, 180)]))
+        d = float(rng.choice([0.0, 0.05, 10.0, rng.uniform(0, 10)]))
+        l = float(rng.choice([0.0, 1.0, rng.uniform(0, 1)]))
+        ctx.spatializer_set_position(c, a, d, l)
+        assert ref.set_azimuth(c, a) == 0 and ref.set_distance(c, d) == 0 and ref.set_level(c, l) == 0
+
+    for c in range(nch):
+        if rng.random() < 0.8:
+            place(c)                                             # the others keep the defaults
+    for call in range(int(rng.integers(3, 7))):
+        frames = int(rng.choice([1, 2, max_frames, int(rng.integers(1, max_frames + 1))]))
+        x = rng.uniform(-1.0, 1.0, (nch, frames))
+        if rng.random() < 0.3:
+            x[int(rng.integers(0, nch))] = 0.0
+        gl, gr = ctx.spatialize(x)
+        wl, wr = ref.process(x)
+        assert rms(gl - wl) <= TOL_RMS and rms(gr - wr) <= TOL_RMS, (seed, call, nch, frames, sr, rms(gl - wl), rms(gr - wr))
+        for _ in range(int(rng.integers(0, 3))):
+            place(int(rng.integers(0, nch)))
+        if rng.random() < 0.2:
+            sr = int(rng.choice([44100, 96000, 192000]))
+            ctx.spatializer_set_sample_rate(sr)
+            ref.set_sample_rate(sr)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_tuner_signals_follow_the_oracle(oracle, seed):
+    """tuner.Process / Analyze on random harmonic tones (fundamental anywhere in the tuner's range, random partials and phases, noise 20 dB or more
+    below the tone), silence and short fills of the ring, at random rates and frame sizes: note, cents, and the frequency to 1e-9."""
+    pkg = package()
+    rng = np.random.default_rng(9500 + seed)
+    nch = int(rng.integers(1, 9))
+    sr = int(rng.choice([22050, 44100, 48000, 96000, 192000]))
+    frames = int(rng.choice([64, 1000, 4096, 8192]))
+    total = int(rng.choice([3 * frames, 96000 + 2 * frames, 50000]))
+    total = max(frames, (total // frames) * frames)
+    t = np.arange(total) / float(sr)
+    x = np.zeros((nch, total))
+    for c in range(nch):
+        kind = rng.random()
+        if kind < 0.15:
+            continue                                             # silence
+        f0 = float(np.exp(rng.uniform(np.log(62.0), np.log(1900.0))))
+        amps = [1.0] + [float(rng.uniform(0.0, 0.6)) / h for h in range(2, 6)]
+        tone = sum(a * np.sin(2 * np.pi * f0 * (h + 1) * t + rng.uniform(0, 2 * np.pi)) for h, a in enumerate(amps) if f0 * (h + 1) < 0.45 * sr)
+        tone = 0.5 * tone / max(np.max(np.abs(tone)), 1e-9)
+        x[c] = tone + float(rng.uniform(0.0, 0.03)) * rng.standard_normal(total)
+    ctx = pkg.Context(nch, frames)
+    refs = [oracle.Tuner() for _ in range(nch)]
+    for b in range(0, total, frames):
+        ctx.tuner_enqueue(x[:, b:b + frames], sr)
+        for c in range(nch):
+            refs[c].process(x[c, b:b + frames], sr)
+    got = ctx.tuner_analyze()
+    ctx.close()
+    for c in range(nch):
+        want = refs[c].analyze()
+        assert got[c]["note_index"] == want["note_index"] and got[c]["cents"] == want["cents"], (seed, c, got[c], want)
+        if np.isnan(want["frequency"]):                          # silence: 0 / 0 in the reference's interpolation (tuner.go:452-470)
+            assert np.isnan(got[c]["frequency"]), (seed, c, got[c], want)
+        elif want["frequency"] > 0.0:
+            assert abs(got[c]["frequency"] - want["frequency"]) / want["frequency"] <= 1e-9, (seed, c, got[c], want)
+        else:
+            assert got[c]["frequency"] == want["frequency"], (seed, c, got[c], want)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_host_calls_follow_the_oracle(oracle, seed):
+    """The host-buffer entry points on random jobs: gdg_process (all channels), gdg_process_subset and gdg_process_staged (random channel
+    subsets in random order -- the channels left out keep their state untouched), frame sizes changing from call to call, one context."""
+    pkg = package()
+    rng = np.random.default_rng(9900 + seed)
+    nch = int(rng.integers(2, 10))
+    max_frames = int(rng.choice([512, 2048, 8192]))
+    sr = int(rng.choice([44100, 48000, 96000, 192000]))
+    ctx = pkg.Context(nch, max_frames)
+    pairs = []
+    for c in range(nch):
+        p = ChainPair(ctx, c, oracle)
+        fft = bool(rng.random() < 0.4)
+        for _ in range(int(rng.integers(0, 4))):
+            while True:
+                t = int(rng.integers(0, 21))
+                name = pkg.UNIT_NAMES[t]
+                if (name == "power_amp" and not fft) or (name == "octaver" and fft):
+                    continue
+                break
+            if name == "power_amp":
+                taps = int(rng.choice([64, 900, 5000]))
+                p.append(name, fir=synth_ir(taps, seed=int(rng.integers(1, 10 ** 6))) * 0.7)
+            else:
+                p.append(name, params=random_params(rng, t, allow_oversampling=fft))
+        pairs.append(p)
+    pos = 0
+    for call in range(int(rng.integers(4, 9))):
+        frames = int(rng.choice([max_frames, max_frames // 2, max_frames // 8]))           # powers of two: no reference-panic pairs
+        how = rng.random()
+        if how < 0.4:
+            chans = list(range(nch))
+        else:
+            k = int(rng.integers(1, nch + 1))
+            chans = [int(c) for c in rng.permutation(nch)[:k]]
+        x = np.stack([0.7 * synth_signal(31 * c + 1, pos + frames, sr)[pos:] for c in chans])
+        if how < 0.4:
+            y = ctx.process(x, sr)
+        elif how < 0.7:
+            y = ctx.process_subset(chans, x, sr)
+        else:
+            y = ctx.process_staged(chans, x, sr)
+        for i, c in enumerate(chans):
+            want = pairs[c].ref.process(x[i], sr)
+            err = rms(y[i] - want)
+            assert err <= TOL_RMS, (seed, call, c, frames, err)
+        pos += frames
+    ctx.close()
