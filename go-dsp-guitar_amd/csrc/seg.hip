@@ -1003,17 +1003,37 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
                 s0 = sn; c0 = cn;
             }
         }
+        /* an integral delay (both weights 1, the sample counted twice) is rare -- depth 0 or a lucky phase -- and costs six selects per
+         * tap: the wave asks once per sample pair whether any of its lanes has one and otherwise takes the plain interpolation (the same
+         * operations in the same order: the same bits) */
+        bool any_whole = false;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (g < G) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) any_whole |= frs[g][j] == 0.0;
+            }
+        }
+        const bool plain = __builtin_amdgcn_ballot_w64(any_whole) == 0;
 #pragma unroll
         for (int g = 0; g < 2; g++) {
             if (g < G) {
                 double effected = 0.0;
+                if (plain) {
 #pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const double fr = frs[g][j];
-                    const bool whole = fr == 0.0;
-                    const double se = v[g][j].y, sl = whole ? v[g][j].y : v[g][j].x;
-                    const double we = whole ? 1.0 : 1.0 - fr, wl = whole ? 1.0 : fr;
-                    effected += 0.2 * ((we * se) + (wl * sl));
+                    for (int j = 0; j < 5; j++) {
+                        const double fr = frs[g][j];
+                        effected += 0.2 * (((1.0 - fr) * v[g][j].y) + (fr * v[g][j].x));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        const double fr = frs[g][j];
+                        const bool whole = fr == 0.0;
+                        const double se = v[g][j].y, sl = whole ? v[g][j].y : v[g][j].x;
+                        const double we = whole ? 1.0 : 1.0 - fr, wl = whole ? 1.0 : fr;
+                        effected += 0.2 * ((we * se) + (wl * sl));
+                    }
                 }
                 out[LX(idx[g])] = (0.5 * in[LX(idx[g])]) + (0.5 * effected);
             }
