@@ -1179,6 +1179,19 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     double t_fir = 0.0, t_unit = 0.0;
     const double t_plan0 = pnow();
     join_groups(ctx);                 /* a new plan replaces descriptors (and possibly unit state) the group streams may still be reading */
+    /* Scan tables live as long as some plan's descriptors point at them -- there is one plan, this one.  A caller that sweeps a parameter
+     * through thousands of values would let the cache grow without bound (12 KB per tone-stack setting): past the limit everything is
+     * dropped once the work in flight has drained, and this plan re-makes the few tables it needs. */
+    {
+        const char *e = getenv("GDG_SCAN_TABLES_MAX");           /* read per plan: a test lowers it */
+        long limit = e ? atol(e) : 1024;
+        if (limit < 1) limit = 1;
+        if ((long)ctx->scan_tabs.size() > limit) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (auto &kv : ctx->scan_tabs) ctx->arena.release(kv.second);
+            ctx->scan_tabs.clear();
+        }
+    }
     /* channel groups: contiguous runs of `active`, group g = [bounds[g], bounds[g + 1]) (equal shares unless the caller weights them) */
     std::vector<int> group_of((size_t)nch, 0);
     for (int g = 0; g < G; g++)

@@ -254,3 +254,32 @@ def test_adjacent_power_amps_chain_their_transforms(pkg, oracle, nch, fused, sha
                 ref.set_bypass(3, False)
             want.append(ref.process(x[c, b * frames:(b + 1) * frames], sr))
         assert rms(outs["1"][c] - np.concatenate(want)) <= TOL_RMS, c
+
+
+def test_scan_table_cache_is_trimmed_and_rebuilt(oracle, monkeypatch):
+    """A parameter sweep makes a new set of scan tables per setting (the band pass: one per pair of corner frequencies).  Past
+    GDG_SCAN_TABLES_MAX entries the cache is dropped at the next plan and the plan re-makes what it needs: the stream goes on unharmed."""
+    pkg = package()
+    monkeypatch.setenv("GDG_SCAN_TABLES_MAX", "3")
+    sr, frames, nch = 96000, 8192, 3
+    ctx = pkg.Context(nch, frames)
+    pairs = []
+    for c in range(nch):
+        p = ChainPair(ctx, c, oracle)
+        p.append("bandpass", params=[1, 200 + 10 * c, 3000])
+        p.append("compressor")
+        p.append("cabinet")
+        pairs.append(p)
+    x = np.stack([synth_signal(c, 14 * frames, sr) for c in range(nch)])
+    for b in range(14):
+        blk = x[:, b * frames:(b + 1) * frames]
+        got = ctx.process(blk, sr)
+        for c in range(nch):
+            want = pairs[c].ref.process(blk[c], sr)
+            assert rms(got[c] - want) <= TOL_RMS, (b, c)
+        # other corner frequencies on every channel (different ones per channel): new tables each time
+        for c in range(nch):
+            for idx, v in ((1, 100 + 37 * b + c), (2, 2000 + 101 * b + 7 * c)):
+                ctx.unit_set_param(pairs[c].handles[0], idx, v)
+                pairs[c].ref.unit(0).set_param(idx, v)
+    ctx.close()
