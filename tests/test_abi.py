@@ -59,3 +59,42 @@ def test_product_sources_do_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".go")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "gdg_oracle" not in text and "import oracle" not in text and "gdgo_" not in text, f
+
+
+C_PROBE = r"""
+#include <stdio.h>
+#include <string.h>
+#include "gdg.h"
+/* what cgo does with the header: compile it as C, link the symbols by their plain names */
+int main(void) {
+    gdg_ctx *ctx = NULL;
+    const char *v = gdg_version();
+    int n = gdg_device_count();
+    int rc = gdg_ctx_create(1, 256, 0, &ctx);
+    printf("%s|%d|%d|%d\n", v, n, rc, ctx != NULL);
+    if (ctx) gdg_ctx_destroy(ctx);
+    return strncmp(v, "gdg ", 4) != 0;
+}
+"""
+
+
+def test_header_is_plain_c_and_the_library_links_from_c(pkg, tmp_path):
+    """cgo compiles include/gdg.h as C: -std=c99 -pedantic must take it without a warning, and a C program must link against libgdg.so by
+    the plain symbol names.  Without a GPU gdg_ctx_create answers GDG_ERR_NO_DEVICE and leaves the handle NULL; with one it succeeds."""
+    import subprocess
+    src = tmp_path / "probe.c"
+    src.write_text(C_PROBE)
+    exe = tmp_path / "probe"
+    lib_dir = os.path.dirname(pkg.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", lib_dir, "-lgdg", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    version, n_dev, rc, has_ctx = r.stdout.strip().split("|")
+    assert version.startswith("gdg ")
+    if int(n_dev) == 0:
+        assert int(rc) == pkg.GDG_ERR_NO_DEVICE and has_ctx == "0"
+    else:
+        assert int(rc) == 0 and has_ctx == "1"
