@@ -697,6 +697,15 @@ func (this *Context) BatchRunShard(inputs []BatchInput, opt BatchOptions, jobSam
 	return res, nil
 }
 
+// BatchRelease returns the device buffers of the last batch run to the context's arena (gdg_batch_release); the next run re-makes them.
+func (this *Context) BatchRelease() error { return this.err(C.gdg_batch_release(this.ctx)) }
+
+// Synchronize waits for everything the context has launched (gdg_ctx_synchronize); the host-buffer calls above already do.
+func (this *Context) Synchronize() error { return this.err(C.gdg_ctx_synchronize(this.ctx)) }
+
+// Version of the library behind the binding (gdg_version).
+func Version() string { return C.GoString(C.gdg_version()) }
+
 // FinishMaster: master = ((p_0 + p_1) + ... + p_{G-1}) + aux per side, summed and encoded on this context's device
 // (gdg_batch_finish_master; spatializer/spatializer.go:300-310, controller/controller.go:3123-3219).  aux == nil: no aux input.
 func (this *Context) FinishMaster(outFormat int, shards []*ShardResult, aux []float64, sampleRate uint32, runMeters bool) (left []byte, right []byte, err error) {

@@ -61,3 +61,53 @@ def test_overlay_generator_writes_absolute_keys(tmp_path):
         assert os.path.isabs(key) and key.startswith(str(ref)), key
         assert os.path.isabs(val) and os.path.exists(val), val
     assert any(k.endswith("/gdg/gdg.go") for k in rep)
+
+
+def _split_top_level(args):
+    out, depth, cur = [], 0, ""
+    for ch in args:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _call_args(src, start):
+    """text between the parenthesis at src[start] and its partner"""
+    depth = 0
+    for i in range(start, len(src)):
+        if src[i] == "(":
+            depth += 1
+        elif src[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return src[start + 1:i]
+    raise AssertionError("unbalanced call")
+
+
+def test_every_c_call_of_the_binding_has_the_prototype_s_argument_count():
+    """What the cgo type checker would refuse first: a call with the wrong number of arguments.  Prototypes from include/gdg.h, calls from gdg.go
+    (comments and strings removed)."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gdg.h")).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(gdg_[a-z0-9_]+)\s*\(", header):
+        args = _call_args(header, m.end() - 1).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(_split_top_level(args))
+    src = _strip(open(os.path.join(GO, "gdg", "gdg.go")).read())
+    calls = 0
+    for m in re.finditer(r"\bC\.(gdg_[a-z0-9_]+)\s*\(", src):
+        name = m.group(1)
+        if name not in protos:
+            continue                                   # a type conversion such as C.gdg_batch_input(...) is not a call of a function
+        n = len(_split_top_level(_call_args(src, m.end() - 1)))
+        assert n == protos[name], "%s called with %d arguments, the header declares %d" % (name, n, protos[name])
+        calls += 1
+    assert calls >= 40, calls
