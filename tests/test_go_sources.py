@@ -111,3 +111,47 @@ def test_every_c_call_of_the_binding_has_the_prototype_s_argument_count():
         assert n == protos[name], "%s called with %d arguments, the header declares %d" % (name, n, protos[name])
         calls += 1
     assert calls >= 40, calls
+
+
+def test_no_go_file_imports_a_package_it_does_not_use():
+    """`imported and not used` is a compile error in Go: every import's name (alias or last path element) must qualify something."""
+    for rel in FILES:
+        code = _strip(open(os.path.join(GO, rel)).read())
+        m = re.search(r"import \(\s*(.*?)\)", code, flags=re.S)
+        assert m, rel
+        body = code[m.end():]
+        raw_block = re.search(r"import \(\s*(.*?)\)", open(os.path.join(GO, rel)).read(), flags=re.S).group(1)
+        for line in raw_block.strip().split("\n"):
+            mm = re.match(r'\s*(?:(\w+)\s+)?"([^"]+)"', line)
+            if not mm:
+                continue
+            alias = mm.group(1) or mm.group(2).split("/")[-1]
+            assert re.search(r"\b%s\." % re.escape(alias), body), "%s imports %s and never uses it" % (rel, mm.group(2))
+
+
+def test_no_go_function_declares_a_variable_it_never_reads():
+    """`declared and not used` is the other compile error a never-compiled Go file tends to carry: every name introduced with := or var inside a
+    function must occur at least once more in that function (a lexical check; shadowing could fool it, it has not yet)."""
+    for rel in FILES:
+        code = _strip(open(os.path.join(GO, rel)).read())
+        for m in re.finditer(r"^func [^\n]*\{\s*$", code, flags=re.M):
+            start = code.rfind("{", m.start(), m.end())
+            depth, j = 0, start
+            while True:
+                if code[j] == "{":
+                    depth += 1
+                elif code[j] == "}":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                j += 1
+            body = code[start:j + 1]
+            names = []
+            for d in re.finditer(r"(?:^|[\s;{(])((?:\w+\s*,\s*)*\w+)\s*:=", body):
+                names += [n.strip() for n in d.group(1).split(",")]
+            for d in re.finditer(r"\bvar\s+((?:\w+\s*,\s*)*\w+)\s", body):
+                names += [n.strip() for n in d.group(1).split(",")]
+            for name in names:
+                if name == "_":
+                    continue
+                assert len(re.findall(r"\b%s\b" % re.escape(name), body)) >= 2, (rel, code[m.start():start].strip()[:80], name)
