@@ -155,3 +155,18 @@ def test_no_go_function_declares_a_variable_it_never_reads():
                 if name == "_":
                     continue
                 assert len(re.findall(r"\b%s\b" % re.escape(name), body)) >= 2, (rel, code[m.start():start].strip()[:80], name)
+
+
+def test_everything_the_overlays_take_from_the_binding_is_defined_there():
+    """gdg.X in an overlay must be an exported function, type, constant or variable of go/gdg/gdg.go, and a method called on a binding object an
+    exported method of one of its types (the overlays' other methods belong to the reference's packages and the standard library)."""
+    g = _strip(open(os.path.join(GO, "gdg", "gdg.go")).read())
+    defined = set(re.findall(r"^func ([A-Z]\w*)\(", g, flags=re.M)) | set(re.findall(r"^type ([A-Z]\w*)\b", g, flags=re.M))
+    defined |= set(re.findall(r"^\s*([A-Z]\w*)\s*(?:=|[A-Za-z\[\]*.]+\s*=)", g, flags=re.M))
+    assert {"CreateContext", "Context"} <= defined
+    for rel in FILES[1:]:
+        s = _strip(open(os.path.join(GO, rel)).read())
+        used = set(re.findall(r"\bgdg\.([A-Z]\w*)", s))
+        assert used, rel
+        missing = sorted(u for u in used if u not in defined)
+        assert not missing, (rel, missing)
