@@ -170,3 +170,45 @@ def test_everything_the_overlays_take_from_the_binding_is_defined_there():
         assert used, rel
         missing = sorted(u for u in used if u not in defined)
         assert not missing, (rel, missing)
+
+
+def _binding_signatures():
+    """exported functions and methods of gdg.go: name -> [(parameter count, variadic, result count)]"""
+    g = _strip(open(os.path.join(GO, "gdg", "gdg.go")).read())
+    sigs = {}
+    for m in re.finditer(r"^func (?:\(\w+ \*?\w+\) )?([A-Za-z]\w*)\(", g, flags=re.M):
+        args = _call_args(g, m.end() - 1)
+        parts = [p for p in _split_top_level(args) if p.strip()]
+        rest = g[m.end() + len(args) + 1:]
+        rest = rest[:rest.index("{")].strip()
+        if rest == "":
+            n_res = 0
+        elif rest.startswith("("):
+            n_res = len(_split_top_level(rest[1:rest.rindex(")")]))
+        else:
+            n_res = 1
+        sigs.setdefault(m.group(1), []).append((len(parts), any("..." in p for p in parts), n_res))
+    return sigs
+
+
+def test_calls_of_the_binding_match_its_signatures():
+    """Argument counts of every call of a binding function or method in the overlays (and inside the binding), and the number of values on the
+    left of an assignment whose right side is such a call, against the definitions in gdg.go -- `not enough arguments in call` and
+    `assignment mismatch` are what the compiler would say."""
+    sigs = _binding_signatures()
+    assert len(sigs) >= 40
+    for rel in FILES:
+        s = _strip(open(os.path.join(GO, rel)).read())
+        if rel != FILES[0]:
+            for m in re.finditer(r"\.([A-Z]\w*)\(", s):
+                name = m.group(1)
+                if name not in sigs:
+                    continue
+                n = len([p for p in _split_top_level(_call_args(s, m.end() - 1)) if p.strip()])
+                assert any(n == c or (var and n >= c - 1) for c, var, _ in sigs[name]), (rel, s.count("\n", 0, m.start()) + 1, name, n, sigs[name])
+        for ln, line in enumerate(s.split("\n"), 1):
+            m = re.match(r"\s*(?:if\s+)?((?:[\w.\[\]*]+\s*,\s*)*[\w.\[\]*]+)\s*(?::=|=)\s*(?:[\w.\[\]()]+\.)?([A-Za-z]\w*)\((.*)\)\s*(?:;.*\{)?\s*$", line)
+            if not m or m.group(2) not in sigs:
+                continue
+            lhs = len(_split_top_level(m.group(1)))
+            assert lhs in {r for _, _, r in sigs[m.group(2)]}, (rel, ln, line.strip())
