@@ -542,7 +542,8 @@ def main():
     for _ in range(max(args.warmup, 1)):      # the first step also builds the plan and the IR spectra
         step()
     ctx.synchronize()
-    # timed region: HIP events around the DOMINANT kernel only (the roofline's kernel; ~0.5 us per event record).
+    # timed region: HIP events on the DOMINANT kernel only (the roofline's kernel).  The library hands the two events to the launch itself
+    # (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps, the duration rocprofv3 reports; GDG_PROFILE_ATTACH=0: recorded around it).
     # Bracketing all eight launches of a step costs ~7% of the step, so the other kernels are timed in an untimed pass below.
     # Every PROFILE_EVERY-th step's launches of that kernel are bracketed (gdg_profile_sample): an event pair also keeps the bracketed kernel
     # from overlapping its neighbours' ramp-up and tail -- with every step bracketed the timed region is 5 % slower than unobserved.

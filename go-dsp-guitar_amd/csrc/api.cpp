@@ -216,6 +216,7 @@ struct gdg_ctx {
     int prof_every = 1;                      /* gdg_profile_sample: bracket every n-th process call only */
     unsigned long long prof_calls = 0;
     bool prof_now = true;
+    bool prof_attach = true;                 /* the fused convolution kernel takes its events itself (kernel timestamps); GDG_PROFILE_ATTACH=0: recorded around it */
     std::vector<ProfEvent> prof;
     std::vector<hipEvent_t> event_pool;
     /* tuner / spatializer */
@@ -347,6 +348,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     { const char *e = getenv("GDG_FIR_FUSED"); if (e) ctx->fir_fused = atoi(e) != 0 ? 1 : 0; }
     { const char *e = getenv("GDG_FIR_SPLIT_MAX"); if (e) ctx->fir_split_max = atoi(e); }
     { const char *e = getenv("GDG_FIR_CHAIN"); if (e) ctx->fir_chain = atoi(e) != 0; }
+    { const char *e = getenv("GDG_PROFILE_ATTACH"); if (e) ctx->prof_attach = atoi(e) != 0; }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -1364,14 +1366,16 @@ static hipEvent_t take_event(gdg_ctx *ctx) {
     return e;
 }
 
+/* attached = true: the launch inside the scope takes the two events itself (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps);
+ * otherwise the events are recorded on the stream before and after whatever the scope launches */
 struct ProfScope {
-    gdg_ctx *ctx; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on = false;
-    ProfScope(gdg_ctx *c, int k, hipStream_t s = nullptr) : ctx(c), kind(k), st(s ? s : c->stream) {
+    gdg_ctx *ctx; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on = false, attached = false;
+    ProfScope(gdg_ctx *c, int k, hipStream_t s = nullptr, bool attach = false) : ctx(c), kind(k), st(s ? s : c->stream), attached(attach) {
         on = ctx->prof_now && ((ctx->profiling & 1u) || (ctx->profiling & (1u << (k + 1))));
-        if (on) { a = take_event(ctx); b = take_event(ctx); hipEventRecord(a, st); }
+        if (on) { a = take_event(ctx); b = take_event(ctx); if (!attached) hipEventRecord(a, st); }
     }
     ~ProfScope() {
-        if (on) { hipEventRecord(b, st); ctx->prof.push_back(ProfEvent{ kind, a, b }); }
+        if (on) { if (!attached) hipEventRecord(b, st); ctx->prof.push_back(ProfEvent{ kind, a, b }); }
     }
 };
 
@@ -1547,8 +1551,8 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                 if (fused) {
                     /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel; its chained
                      * variant, which also makes the next amp's forward transform, under a kind of its own) */
-                    ProfScope ps(ctx, d_next ? GDG_K_FIR_MAC_CHAIN : GDG_K_FIR_MAC, s);
-                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, shift, s, d_next));
+                    ProfScope ps(ctx, d_next ? GDG_K_FIR_MAC_CHAIN : GDG_K_FIR_MAC, s, ctx->prof_attach);
+                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, shift, s, d_next, ps.attached ? ps.a : nullptr, ps.attached ? ps.b : nullptr));
                 } else {
                     { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(P2, d, n, st.shared_spectra ? 1 : 0, s)); }
                     { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, shift, s, d_next)); }

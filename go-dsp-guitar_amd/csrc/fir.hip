@@ -22,6 +22,7 @@
  * complex128 per slot: bin 0 carries (Re X[0], Re X[P]) since both are real.
  */
 #include "gdg_internal.h"
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
@@ -1249,20 +1250,30 @@ template <int LG> static void launch_ir(const gdg_fir_irjob *d_jobs, int n, doub
 template <int LG> static void launch_raw_inv(const gdg_fir_rawjob *d_jobs, int n, double scale, const cplx *tw, const cplx *tw2, hipStream_t s) {
     fir_raw_inv_kernel<LG><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_jobs, scale, tw, tw2);
 }
+/* e0 / e1: HIP events that take the KERNEL's own begin and end timestamps (hipExtLaunchKernelGGL) -- what rocprofv3 reports as its duration.
+ * A pair of hipEventRecord calls around the launch measures 4-5 us more (two marker packets, the dispatch latency between them) and keeps the
+ * kernel from overlapping its neighbours' ramp-up and tail. */
+#define GDG_LAUNCH_INV(KERNEL, ...)                                                                                                   \
+    do {                                                                                                                              \
+        if (e0) hipExtLaunchKernelGGL((KERNEL), dim3(n), dim3(FftCfg<LG>::T), 0, s, e0, e1, 0, __VA_ARGS__);                           \
+        else hipLaunchKernelGGL((KERNEL), dim3(n), dim3(FftCfg<LG>::T), 0, s, __VA_ARGS__);                                           \
+    } while (0)
 template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, const cplx *tw, const cplx *tw2, int fused, gdg_shift shift, hipStream_t s,
-                                         const gdg_fir_chan *d_next) {
+                                         const gdg_fir_chan *d_next, hipEvent_t e0, hipEvent_t e1) {
+    const gdg_fir_chan *none = nullptr;
     if constexpr (LG == 13) {
         if (d_next) {       /* the next unit of every channel is a power amp: its forward transform rides along */
-            if (fused == 0) fir_inv_kernel<13, 0, true><<<dim3(n), dim3(FftCfg<13>::T), 0, s>>>(d_chans, 1, shift, tw, tw2, d_next);
-            else if (fused == 1) fir_inv_kernel<13, 1, true><<<dim3(n), dim3(FftCfg<13>::T), 0, s>>>(d_chans, 1, shift, tw, tw2, d_next);
-            else fir_inv_kernel<13, 2, true><<<dim3(n), dim3(FftCfg<13>::T), 0, s>>>(d_chans, 1, shift, tw, tw2, d_next);
+            if (fused == 0) GDG_LAUNCH_INV((fir_inv_kernel<13, 0, true>), d_chans, 1, shift, tw, tw2, d_next);
+            else if (fused == 1) GDG_LAUNCH_INV((fir_inv_kernel<13, 1, true>), d_chans, 1, shift, tw, tw2, d_next);
+            else GDG_LAUNCH_INV((fir_inv_kernel<13, 2, true>), d_chans, 1, shift, tw, tw2, d_next);
             return;
         }
     }
-    if (fused == 0) fir_inv_kernel<LG, 0><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
-    else if (fused == 1) fir_inv_kernel<LG, 1><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
-    else fir_inv_kernel<LG, 2><<<dim3(n), dim3(FftCfg<LG>::T), 0, s>>>(d_chans, 1, shift, tw, tw2);
+    if (fused == 0) GDG_LAUNCH_INV((fir_inv_kernel<LG, 0>), d_chans, 1, shift, tw, tw2, none);
+    else if (fused == 1) GDG_LAUNCH_INV((fir_inv_kernel<LG, 1>), d_chans, 1, shift, tw, tw2, none);
+    else GDG_LAUNCH_INV((fir_inv_kernel<LG, 2>), d_chans, 1, shift, tw, tw2, none);
 }
+#undef GDG_LAUNCH_INV
 
 static int cu_count() {
     static int n = 0;
@@ -1392,11 +1403,11 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, i
 
 /* fused: 0 = inverse only (Y from gdg_launch_fir_mac), 1 = MAC + inverse, 2 = MAC + inverse with shared (cacheable) IR spectra */
 hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, int fused, gdg_shift shift, hipStream_t s,
-                              const gdg_fir_chan *d_next_chans) {
+                              const gdg_fir_chan *d_next_chans, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (n_chans <= 0) return hipSuccess;
     int L = ilog2_exact(P);
     if (d_next_chans && L != 13) return hipErrorInvalidValue;
-    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, shift, s, d_next_chans));
+    GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, shift, s, d_next_chans, ev_begin, ev_end));
     return hipGetLastError();
 }
 

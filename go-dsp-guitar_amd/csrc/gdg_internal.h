@@ -78,7 +78,7 @@ int gdg_fir_window_chain_ok(int n_chans);
 hipError_t gdg_launch_fir_window_chain(int W, const gdg_fir_chan *d_chans, const gdg_fir_chan *d_next_chans, int n_chans, const double2 *d_tw,
                                        const double2 *d_tw2, gdg_shift shift, hipStream_t s);
 hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, gdg_shift shift, hipStream_t s,
-                              const gdg_fir_chan *d_next_chans = nullptr);
+                              const gdg_fir_chan *d_next_chans = nullptr, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 hipError_t gdg_launch_fir_ir(int P, const gdg_fir_irjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_jobs, double scale, const double2 *d_tw, const double2 *d_tw2, hipStream_t s);
 

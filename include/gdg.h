@@ -224,7 +224,9 @@ enum gdg_kernel_kind {
     GDG_K_COUNT
 };
 /* enable == 1: bracket every kernel launch with a HIP event pair from now on (costs a few microseconds per launch);
- * enable == 1 << (kind + 1) (or-able): only the launches of those kernel kinds; 0: off. */
+ * enable == 1 << (kind + 1) (or-able): only the launches of those kernel kinds; 0: off.
+ * The fused convolution launch (GDG_K_FIR_MAC / GDG_K_FIR_MAC_CHAIN) carries its two events itself: they hold the kernel's own begin and
+ * end timestamps, and nothing is inserted into the stream around it. */
 int gdg_profile_enable(gdg_ctx *ctx, int enable);
 /* Bracket only every `every`-th process call (gdg_process_device / _window_device / host-buffer calls) while profiling is on: an event
  * pair costs a few microseconds AND keeps the bracketed kernel from overlapping its neighbours' ramp-up and tail, which is 5 % of a
