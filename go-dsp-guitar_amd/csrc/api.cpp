@@ -2938,11 +2938,8 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
             HIP_TRY(ctx, hipEventRecord(ctx->batch_up_ready[h], ctx->batch_up_stream));
             return GDG_OK;
         };
-        if (trace) fprintf(stderr, "[batch] set-up %.2f ms\n", now_ms() - t_begin);
-        if ((r = stage(0)) != GDG_OK) return r;
-        if (trace) fprintf(stderr, "[batch] stage(0) done at %.2f ms\n", now_ms() - t_begin);
-        for (size_t i = 0; i < steps.size(); i++) {
-            const double t_it = now_ms();
+        /* step i on the compute stream: the block loop's work for its w blocks, then the encoder into the step's half of `enc` */
+        auto enqueue_compute = [&](size_t i) -> int {
             const size_t off = steps[i].off;
             const int w = steps[i].w, h = (int)(i & 1), wb = w * B;               /* this step fills the first wb samples of the window's rows */
             if (n_streamed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_up_ready[h], 0));
@@ -2981,27 +2978,43 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
                 }
             }
             HIP_TRY(ctx, hipEventRecord(ctx->batch_ready[h], ctx->stream));
+            return GDG_OK;
+        };
+        /* ... and its way down on the download stream, into the step's pinned half (which step i - 2 must have left: scatter(i - 2) is done) */
+        auto enqueue_down = [&](size_t i) -> int {
+            const int h = (int)(i & 1), wb = steps[i].w * B;
+            unsigned char *enc = d_enc + h * enc_bytes;
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_stream, ctx->batch_ready[h], 0));
             const size_t down = (((size_t)enc_rows * wb * out_width + 15) & ~(size_t)15) + (size_t)f64_rows * wb * sizeof(double);
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, sharded ? down : (size_t)NO * wb * out_width, hipMemcpyDeviceToHost, ctx->batch_stream));
             HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
-            const double t_enq = now_ms();
-            if ((r = stage(i + 1)) != GDG_OK) return r;                          /* while step i runs: the next step's inputs go up ... */
-            const double t_st = now_ms();
-            double t_wait = t_st;
-            if (i >= 1) {                                                        /* ... and step i - 1 goes into the files */
-                HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[h ^ 1]));
-                t_wait = now_ms();
-                scatter(i - 1);
-            }
-            if (trace) fprintf(stderr, "[batch] step %zu: enqueue %.2f | stage next %.2f | wait for step-1 download %.2f | scatter %.2f  (at %.2f ms)\n", i,
-                               t_enq - t_it, t_st - t_enq, t_wait - t_st, now_ms() - t_wait, now_ms() - t_begin);
+            return GDG_OK;
+        };
+        /* The compute stream is kept TWO steps ahead of the files.  Round 2 enqueued step i + 1 only after step i - 1 had been scattered into
+         * the caller's buffers, which closed a loop of compute -> download -> scatter over two steps: (5.7 + 4.0 + 3.1) / 2 = 6.4 ms per step
+         * of 16 blocks where the device needs 5.7 (GDG_BATCH_TRACE).  Now step i + 2 is enqueued as soon as step i's download has finished (before
+         * its bytes are scattered), while step i + 1 is already queued behind step i on the device. */
+        if (trace) fprintf(stderr, "[batch] set-up %.2f ms\n", now_ms() - t_begin);
+        for (size_t i = 0; i < 2 && i < steps.size(); i++) {
+            if ((r = stage(i)) != GDG_OK) return r;
+            if ((r = enqueue_compute(i)) != GDG_OK || (r = enqueue_down(i)) != GDG_OK) return r;
         }
-        const double t_l0 = now_ms();
-        HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[(steps.size() - 1) & 1]));
-        const double t_l1 = now_ms();
-        scatter(steps.size() - 1);
-        if (trace) fprintf(stderr, "[batch] last: wait %.2f | scatter %.2f (at %.2f ms)\n", t_l1 - t_l0, now_ms() - t_l1, now_ms() - t_begin);
+        if (trace) fprintf(stderr, "[batch] steps 0 and 1 staged and enqueued at %.2f ms\n", now_ms() - t_begin);
+        for (size_t i = 0; i < steps.size(); i++) {
+            const double t_it = now_ms();
+            if ((r = stage(i + 2)) != GDG_OK) return r;                          /* while steps i, i + 1 run: the inputs of step i + 2 go up ... */
+            const double t_st = now_ms();
+            HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[i & 1]));          /* ... step i comes down ... */
+            const double t_wait = now_ms();
+            /* step i + 2 needs step i's half of `enc` (free now) but not its pinned half: it goes onto the compute stream BEFORE the scatter, so
+             * the loop compute -> download -> compute spans 5.7 + 4.0 ms per two steps and the device, not the host, sets the pace */
+            if (i + 2 < steps.size() && (r = enqueue_compute(i + 2)) != GDG_OK) return r;
+            const double t_enq = now_ms();
+            scatter(i);                                                          /* ... and goes into the files */
+            if (i + 2 < steps.size() && (r = enqueue_down(i + 2)) != GDG_OK) return r;     /* its pinned half is free again */
+            if (trace) fprintf(stderr, "[batch] step %zu: stage %zu %.2f | wait for the download %.2f | enqueue %zu %.2f | scatter %.2f  (at %.2f ms)\n", i, i + 2,
+                               t_st - t_it, t_wait - t_st, i + 2, t_enq - t_wait, now_ms() - t_enq, now_ms() - t_begin);
+        }
         return check_device_error(ctx);
     };
     rc = body();
