@@ -9,6 +9,7 @@ pkg = entry.load_package()
 nch, sr, blocks = 512, 192000, 128
 ctx = bench.make_context(pkg, nch, 8192, 0, 65536)
 ctx.set_window(16)
+if os.environ.get("NGROUPS"): ctx.set_overlap(int(os.environ["NGROUPS"]))
 files = bench.batch_files(nch, sr, blocks)
 outs = ctx.batch_run(files, sr, "lpcm24")
 for rep in range(2):
