@@ -127,43 +127,71 @@ resample_time_kernel(const double *__restrict__ s, int n, double dx, double *__r
 #define METER_T 1024
 #define METER_CHK (GDG_METER_SEG / METER_T)
 
-__device__ __forceinline__ double block_max_d(double v, double *scr) {
-    int tid = threadIdx.x;
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+/* Two values reduced over the workgroup in one go: the maximum of `v` and the maximum of the pair (key, idx) in the order "larger key, then
+ * larger idx".  Wave level by shuffles, the 16 wave results through LDS, and EVERY wave finishes the reduction from those 16 cells with four
+ * more shuffle steps (no serial walk over the partials: that walk alone was ~1 000 cycles, and the kernel had four such reductions). */
+struct MeterRed { double v; double key; int idx; };
+__device__ __forceinline__ MeterRed meter_reduce(MeterRed x, double *scr_v, double *scr_k, int *scr_i) {
+    const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(x.v, o), ok = __shfl_down(x.key, o);
+        const int oi = __shfl_down(x.idx, o);
+        x.v = fmax(x.v, ov);
+        if (ok > x.key || (ok == x.key && oi > x.idx)) { x.key = ok; x.idx = oi; }
+    }
+    __syncthreads();                                    /* the cells of the reduction before are no longer read */
+    if (lane == 0) { scr_v[tid >> 6] = x.v; scr_k[tid >> 6] = x.key; scr_i[tid >> 6] = x.idx; }
     __syncthreads();
-    if ((tid & 63) == 0) scr[tid >> 6] = v;
-    __syncthreads();
-    double r = scr[0];
-    for (int w = 1; w < METER_T / 64; w++) r = fmax(r, scr[w]);
+    MeterRed r = { scr_v[lane & 15], scr_k[lane & 15], scr_i[lane & 15] };
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(r.v, o), ok = __shfl_xor(r.key, o);
+        const int oi = __shfl_xor(r.idx, o);
+        r.v = fmax(r.v, ov);
+        if (ok > r.key || (ok == r.key && oi > r.idx)) { r.key = ok; r.idx = oi; }
+    }
     return r;
 }
-__device__ __forceinline__ int block_max_i(int v, int *scr) {
-    int tid = threadIdx.x;
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o));
-    __syncthreads();
-    if ((tid & 63) == 0) scr[tid >> 6] = v;
-    __syncthreads();
-    int r = scr[0];
-    for (int w = 1; w < METER_T / 64; w++) r = max(r, scr[w]);
-    return r;
-}
+static_assert(METER_T / 64 == 16, "meter_reduce finishes from 16 wave results");
 
 __global__ void __launch_bounds__(METER_T)
 meter_kernel(const double *__restrict__ rows, size_t stride, int n, gdg_meter_rec *__restrict__ st,
              double decay, unsigned long long hold) {
-    __shared__ double scr_d[METER_T / 64];
+    __shared__ double scr_v[METER_T / 64], scr_k[METER_T / 64];
     __shared__ int scr_i[METER_T / 64];
+    /* a thread works on METER_CHK CONSECUTIVE samples (the follower is sequential inside a chunk), but the port is read the way memory
+     * likes it -- lane after lane, all loads of the thread in flight -- and turned through LDS (one pad cell per 32, as in the segment
+     * kernel).  Reading x[base + k] directly gave every lane its own 64-byte piece of a 4 KiB span per instruction: eight times the
+     * port's bytes between L2 and L1. */
+    __shared__ double turn[GDG_METER_SEG + GDG_METER_SEG / 32];
+    /* decay^m for the exponents the closed forms need (0 <= m <= n <= 8192): three small tables made by 73 threads with pow(), every
+     * other power is a product of three entries (pow() in every thread, three calls of ~300 FP64 instructions each, kept all SIMDs busy
+     * for ~11 us per round of 256 workgroups). */
+    __shared__ double pw_lo[32], pw_hi[33], pw_one[8];      /* (d^8)^j, (d^256)^i, d^j */
     const int tid = threadIdx.x;
     gdg_meter_rec *m = st + blockIdx.x;
-    if (!m->enabled) return;
     const double *x = rows + (size_t)blockIdx.x * stride;
+    double t[METER_CHK];
+#pragma unroll
+    for (int k = 0; k < METER_CHK; k++) { const int i = tid + METER_T * k; t[k] = (i < n) ? x[i] : 0.0; }     /* in flight while the tables are made */
+    if (!m->enabled) return;
     const double c0 = m->current, p0 = m->peak;
     const unsigned long long cnt0 = m->counter;
     const int base = tid * METER_CHK;
-
+    if (tid < 32) pw_lo[tid] = pow(decay, (double)(8 * tid));
+    else if (tid < 65) pw_hi[tid - 32] = pow(decay, (double)(256 * (tid - 32)));
+    else if (tid < 73) pw_one[tid - 65] = pow(decay, (double)(tid - 65));
+#pragma unroll
+    for (int k = 0; k < METER_CHK; k++) { const int i = tid + METER_T * k; turn[i + (i >> 5)] = t[k]; }
+    __syncthreads();
+    auto dpow = [&](long long e) -> double {                /* 0 <= e <= 8192 + 7 */
+        const int a8 = (int)(e >> 3);
+        return (pw_hi[a8 >> 5] * pw_lo[a8 & 31]) * pw_one[(int)(e & 7)];
+    };
     double a[METER_CHK];
 #pragma unroll
-    for (int k = 0; k < METER_CHK; k++) a[k] = (base + k < n) ? fabs(x[base + k]) : -1.0;
+    for (int k = 0; k < METER_CHK; k++) { const int i = base + k; a[k] = (i < n) ? fabs(turn[i + (i >> 5)]) : -1.0; }
 
     /* current value: zero-state follower over the chunk, then its decay to the end of the segment */
     double b = 0.0;
@@ -171,13 +199,12 @@ meter_kernel(const double *__restrict__ rows, size_t stride, int n, gdg_meter_re
 #pragma unroll
     for (int k = 0; k < METER_CHK; k++)
         if (base + k < n) { b *= decay; if (a[k] > b) b = a[k]; len++; }
-    double contrib = (len > 0) ? b * pow(decay, (double)(n - base - len)) : 0.0;
-    double cur = fmax(block_max_d(contrib, scr_d), c0 * pow(decay, (double)n));
+    const double contrib = (len > 0) ? b * dpow(n - base - len) : 0.0;
 
     /* first record: smallest i with |x_i| >= p_i;  p_i = p0 for i < e, p0 d^(i-e+1) from e on */
     const long long e = (cnt0 > hold) ? 0 : (long long)(hold - cnt0) + 1;
     double p = p0;
-    if ((long long)base >= e) p = p0 * pow(decay, (double)((long long)base - e));      /* value before sample `base` decays */
+    if ((long long)base >= e) p = p0 * dpow((long long)base - e);      /* value before sample `base` decays */
     int first = n;
 #pragma unroll
     for (int k = 0; k < METER_CHK; k++) {
@@ -187,28 +214,29 @@ meter_kernel(const double *__restrict__ rows, size_t stride, int n, gdg_meter_re
             if (first == n && a[k] >= p) first = i;
         }
     }
-    const int r = n - block_max_i(n - first, scr_i);        /* min over the block */
+    /* one reduction for both: the largest contribution, and the smallest `first` (as the largest n - first) */
+    const MeterRed r1 = meter_reduce(MeterRed{ contrib, 0.0, n - first }, scr_v, scr_k, scr_i);
+    const double cur = fmax(r1.v, c0 * dpow(n));
+    const int r = n - r1.idx;
 
     double peak;
     unsigned long long counter;
     if (r >= n) {       /* no record in this segment */
         long long dec = (long long)n - e;
-        peak = (dec > 0) ? p0 * pow(decay, (double)dec) : p0;
+        peak = (dec > 0) ? p0 * dpow(dec) : p0;
         counter = (cnt0 > hold) ? cnt0 : ((cnt0 + (unsigned long long)n < hold + 1) ? cnt0 + (unsigned long long)n : hold + 1);
     } else {
+        /* from the record on the peak is the running maximum, the counter the distance to the LAST sample attaining it: the pair
+         * (value, index) reduced in the order "larger value, then larger index" */
         double mx = -1.0;
-#pragma unroll
-        for (int k = 0; k < METER_CHK; k++)
-            if (base + k >= r && a[k] > mx) mx = a[k];
-        peak = block_max_d(mx, scr_d);
         int last = -1;
 #pragma unroll
         for (int k = 0; k < METER_CHK; k++)
-            if (base + k >= r && base + k < n && a[k] == peak) last = base + k;
-        last = block_max_i(last, scr_i);
-        counter = (unsigned long long)(n - 1 - last);
+            if (base + k >= r && base + k < n && a[k] >= mx) { mx = a[k]; last = base + k; }
+        const MeterRed r2 = meter_reduce(MeterRed{ 0.0, mx, last }, scr_v, scr_k, scr_i);
+        peak = r2.key;
+        counter = (unsigned long long)(n - 1 - r2.idx);
     }
-    __syncthreads();
     if (tid == 0) { m->current = cur; m->peak = peak; m->counter = counter; }
 }
 
