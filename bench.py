@@ -392,7 +392,7 @@ def other_configs(pkg, device):
     ctx.spatialize_device(d_x, d_lr, frames)
     ctx.tuner_analyze()
     st_sp = robust_time(lambda: [ctx.spatialize_device(d_x, d_lr, frames) for _ in range(20)], ctx.synchronize, units=20)
-    st_an = robust_time(lambda: [ctx.tuner_analyze() for _ in range(5)], ctx.synchronize, units=5)
+    st_an = robust_time(lambda: [ctx.tuner_analyze(raw=True) for _ in range(5)], ctx.synchronize, units=5)
     t_sp, t_an = st_sp["median"], st_an["median"]
     d_x.free()
     d_lr.free()
@@ -405,7 +405,7 @@ def other_configs(pkg, device):
     for _ in range(13):
         ctx32.tuner_enqueue_device(d32, frames, sr)
     ctx32.tuner_analyze()
-    st32 = robust_time(lambda: [ctx32.tuner_analyze() for _ in range(5)], ctx32.synchronize, units=5)
+    st32 = robust_time(lambda: [ctx32.tuner_analyze(raw=True) for _ in range(5)], ctx32.synchronize, units=5)
     d32.free()
     ctx32.close()
     out["config5_32_tuners_per_gpu"] = {"value": 32 / st32["median"], "unit": "analyses/s", "us_per_32_analyses": st32["median"] * 1e6,

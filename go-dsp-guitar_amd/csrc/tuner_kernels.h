@@ -213,19 +213,39 @@ __device__ __forceinline__ void tuner_pick(Corr corr, double sample_rate, const 
         double shift = half_diff / denominator;
         if (shift < -0.5) shift = -0.5; else if (shift > 0.5) shift = 0.5;
         idx_float += shift;
-        double freq = sample_rate / idx_float;
-        int note = -1;
-        double cents = INFINITY, cents_abs = INFINITY;
-        for (int k = 0; k < n_notes; k++) {
-            double ratio = freq / note_freqs[k];
-            double dc = 1200.0 * log2(ratio);
-            double da = fabs(dc);
-            if (da < cents_abs) { note = k; cents = dc; cents_abs = da; }
+        s_val[0] = sample_rate / idx_float;
+    }
+    __syncthreads();
+    /* the nearest note (tuner.go:470-497): one note per thread instead of one thread walking all of them through log2 (~10 us of a 190 us
+     * analysis); ties go to the first note, as in the reference's strict "<" walk */
+    const double freq = s_val[0];
+    __syncthreads();
+    double da = INFINITY, dc = INFINITY;
+    int note = -1;
+    for (int k = tid; k < n_notes; k += 256) {
+        double ratio = freq / note_freqs[k];
+        double c = 1200.0 * log2(ratio);
+        double ca = fabs(c);
+        if (ca < da) { note = k; dc = c; da = ca; }
+    }
+    __shared__ double s_cents[256];
+    s_val[tid] = da; s_idx[tid] = note; s_cents[tid] = dc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double a2 = s_val[tid + s], a1 = s_val[tid];
+            const int k2 = s_idx[tid + s], k1 = s_idx[tid];
+            const bool take = (k2 >= 0) && (k1 < 0 || a2 < a1 || (a2 == a1 && k2 < k1));
+            if (take) { s_val[tid] = a2; s_idx[tid] = k2; s_cents[tid] = s_cents[tid + s]; }
         }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cents = s_cents[0];
         int cents_int = 0;
         if (!(isinf(cents) || isnan(cents))) cents_int = (int)(signed char)(int)cents;
         out_ch->frequency = freq;
-        out_ch->note_index = note;
+        out_ch->note_index = s_idx[0];
         out_ch->cents = cents_int;
     }
 }

@@ -41,7 +41,7 @@ ctx.synchronize()
 t_enq = (time.perf_counter() - t0) / n
 t0 = time.perf_counter()
 for _ in range(5):
-    ctx.tuner_analyze()
+    ctx.tuner_analyze(raw=True)
 t_an = (time.perf_counter() - t0) / 5
 ms_sp, n_sp = ctx.profile_read(pkg.K_SPATIALIZER)
 ms_tu, n_tu = ctx.profile_read(pkg.K_TUNER)
