@@ -2,7 +2,7 @@
  * spat.hip -- spatializer.Process (spatializer/spatializer.go:140-335): the partial N -> 2 stereo
  * mixdown of one shard of channels.  Memory bound (8 B per channel-sample in, 16 B per sample out).
  *
- * Two levels so that the launch fills the chip: groups of 32 channels are summed in channel order, the
+ * Two levels so that the launch fills the chip: groups of 16 channels are summed in channel order, the
  * group partials in group order.  (The reference adds all channels in index order; the different
  * association changes the result by ~1e-16 * N, far inside the 1e-9 RMS bar.  Across shards the host adds
  * the partial pairs and the aux buffer, spatializer.go:300-310.)
@@ -11,20 +11,21 @@
  */
 #include "gdg_internal.h"
 
-#define SPAT_GROUP 32                    /* channels summed in index order by one lane */
+#define SPAT_GROUP 16                    /* channels summed in index order by one lane */
 #define SPAT_TILE 32                     /* samples per workgroup */
-#define SPAT_SUB 8                       /* channel groups a workgroup works on at the same time (256 threads = 32 samples x 8) */
+#define SPAT_SUB 16                      /* channel groups a workgroup works on at the same time (512 threads = 32 samples x 16) */
+#define SPAT_T (SPAT_TILE * SPAT_SUB)
 #define SPAT_UNROLL 16                   /* channels whose loads are in flight together */
-#define SPAT_MAX_GROUPS 64               /* 2048 channels per shard (32 KiB of group partials in LDS) */
+#define SPAT_MAX_GROUPS 128              /* 2048 channels per shard (32 KiB of group partials in LDS) */
 #define SPAT_LDS_DESC_MAX 512             /* up to this many channels the descriptors are staged in LDS (24 KiB), beyond it read from HBM */
 
 /* ONE launch per block (round 2: partial sums, reduce and history update were three launches, 23 us per 8192-frame block of 256
- * channels, all latency).  Workgroup t < tiles mixes samples [32 t, 32 t + 32): lane (s, q) sums channel groups q, q + 8, ... of 32
+ * channels, all latency).  Workgroup t < tiles mixes samples [32 t, 32 t + 32): lane (s, q) sums channel groups q, q + 16, ... of 16
  * channels each in channel order, the group partials meet in LDS and are added in group order -- the same association as before, so
  * the same bits.  The history (last H inputs of every channel, spatializer.go:313-331) is double buffered: this block reads
  * `hist_read` and the workgroups t >= tiles write `hist_write`, so nobody waits for anybody inside the launch. */
 template <bool LDS_DESC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SPAT_TILE * SPAT_SUB)
 spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__restrict__ in, int in_stride,
             const double *__restrict__ hist_read, double *__restrict__ hist_write, int H, double *__restrict__ out_lr, int out_stride,
             int frames, int tiles) {
@@ -33,7 +34,7 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
     if ((int)blockIdx.x >= tiles) {
         /* history: entry k of channel c = element k + frames - H of [old history | frame] shifted by H */
         const int total = nch * H;
-        for (int e = ((int)blockIdx.x - tiles) * 256 + tid; e < total; e += ((int)gridDim.x - tiles) * 256) {
+        for (int e = ((int)blockIdx.x - tiles) * SPAT_T + tid; e < total; e += ((int)gridDim.x - tiles) * SPAT_T) {
             const int c = e / H, k = e - c * H, src = k + frames - H;
             hist_write[e] = (src >= 0) ? in[(size_t)c * in_stride + src] : hist_read[(size_t)c * H + k + frames];
         }
@@ -45,7 +46,7 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
     /* the channel descriptors, once per workgroup, into LDS (behind the partials); very wide shards read them from HBM instead */
     gdg_spat_chan *l_ch = reinterpret_cast<gdg_spat_chan *>(part + (size_t)groups * 2 * SPAT_TILE);
     if constexpr (LDS_DESC) {
-        for (int c = tid; c < nch; c += 256) l_ch[c] = chans[c];
+        for (int c = tid; c < nch; c += SPAT_T) l_ch[c] = chans[c];
         __syncthreads();
     }
 #define s_ch (LDS_DESC ? (const gdg_spat_chan *)l_ch : chans)
@@ -109,8 +110,8 @@ hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const d
     const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
     const size_t part_bytes = (size_t)groups * 2 * SPAT_TILE * sizeof(double);
     if (nch <= SPAT_LDS_DESC_MAX)
-        spat_kernel<true><<<dim3(tiles + hist_blocks), dim3(256), part_bytes + (size_t)nch * sizeof(gdg_spat_chan), s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
+        spat_kernel<true><<<dim3(tiles + hist_blocks), dim3(SPAT_T), part_bytes + (size_t)nch * sizeof(gdg_spat_chan), s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
     else
-        spat_kernel<false><<<dim3(tiles + hist_blocks), dim3(256), part_bytes, s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
+        spat_kernel<false><<<dim3(tiles + hist_blocks), dim3(SPAT_T), part_bytes, s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
     return hipGetLastError();
 }
