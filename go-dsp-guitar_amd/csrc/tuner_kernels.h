@@ -289,25 +289,37 @@ __device__ __forceinline__ void tuner_accumulate_blocks(const double *ring, int 
     cplx pk[ITER], pn[ITER];
 #pragma unroll
     for (int i = 0; i < ITER; i++) { pk[i] = pn[i] = make_double2(0.0, 0.0); }
-    for (int blk = lead ? blk_begin - 1 : blk_begin; blk < blk_end; blk++) {
-        const bool count = blk >= blk_begin;
-        /* pass 0 straight from the ring: packed element e = (a[2e], a[2e+1]), a = block `blk` then 4096 zeros */
-        cplx v[16];
+    /* the samples of a block: packed element e = (a[2e], a[2e+1]) for e < 2048 (the other half of the transform's input is zeros); a thread's
+     * eight non-zero elements are the t < R0 / 2 of its butterflies.  They are requested ONE BLOCK AHEAD: a block's loads used to be waited
+     * for at the top of its transform, 24 exposed HBM latencies per analysis (~2 us each of the ~6 us a block took). */
+    constexpr int NZ = 16 / 2;
+    static_assert(B0 * (R0 / 2) == NZ && (N / R0) * (R0 / 2) == TUNER_BLK / 2, "the first half of every butterfly's inputs is the block, the second half zeros");
+    cplx nx[NZ];
+    auto request = [&](int blk) {
 #pragma unroll
         for (int b = 0; b < B0; b++) {
             const int j = tid + T * b;
 #pragma unroll
-            for (int t = 0; t < R0; t++) {
+            for (int t = 0; t < R0 / 2; t++) {
                 const int e = j + t * (N / R0);
                 cplx val = make_double2(0.0, 0.0);
-                if (e < TUNER_BLK / 2) {
-                    const int i0 = blk * TUNER_BLK + 2 * e;                                     /* oldest-first sample index */
-                    if (i0 < GDG_TUNER_RING) { int p = wp + i0; if (p >= GDG_TUNER_RING) p -= GDG_TUNER_RING; val.x = gload1(ring + p); }
-                    if (i0 + 1 < GDG_TUNER_RING) { int p = wp + i0 + 1; if (p >= GDG_TUNER_RING) p -= GDG_TUNER_RING; val.y = gload1(ring + p); }
-                }
-                v[b * R0 + t] = val;
+                const int i0 = blk * TUNER_BLK + 2 * e;                                         /* oldest-first sample index */
+                if (i0 < GDG_TUNER_RING) { int p = wp + i0; if (p >= GDG_TUNER_RING) p -= GDG_TUNER_RING; val.x = gload1(ring + p); }
+                if (i0 + 1 < GDG_TUNER_RING) { int p = wp + i0 + 1; if (p >= GDG_TUNER_RING) p -= GDG_TUNER_RING; val.y = gload1(ring + p); }
+                nx[b * (R0 / 2) + t] = val;
             }
         }
+    };
+    const int blk_first = lead ? blk_begin - 1 : blk_begin;
+    if (blk_first < blk_end) request(blk_first);
+    for (int blk = blk_first; blk < blk_end; blk++) {
+        const bool count = blk >= blk_begin;
+        cplx v[16];
+#pragma unroll
+        for (int b = 0; b < B0; b++)
+#pragma unroll
+            for (int t = 0; t < R0; t++) v[b * R0 + t] = (t < R0 / 2) ? nx[b * (R0 / 2) + t] : make_double2(0.0, 0.0);
+        if (blk + 1 < blk_end) request(blk + 1);                                                /* in flight during this block's transform */
         pass_compute<LOGN, LR0, 0, false>(v, tw, tid);
         pass_store<LOGN, LR0, 0>(v, sre, sim, tid);
         __syncthreads();
