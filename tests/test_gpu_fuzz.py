@@ -532,3 +532,52 @@ def test_random_host_calls_follow_the_oracle(oracle, seed):
             assert err <= TOL_RMS, (seed, call, c, frames, err)
         pos += frames
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_meter_streams_follow_the_oracle(oracle, seed):
+    """level.channelMeter on random streams cut into calls of random lengths (1 .. 8192, so segments that are not multiples of the kernel's chunk,
+    shorter than a wave, a single sample), with quantised samples (many equal maxima: the LAST one restarts the hold), bursts, silences, and rates
+    low enough for the two-second hold to run out inside the stream: the state triple (current value, peak, counter) and the integer dB readings
+    after every few calls."""
+    pkg = package()
+    rng = np.random.default_rng(12000 + seed)
+    sr = int(rng.choice([4000, 8000, 22050, 48000, 192000]))
+    ports = int(rng.integers(1, 6))
+    total = int(rng.choice([3 * sr, 30000, 70000]))
+    x = np.zeros((ports, total))
+    for p in range(ports):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            x[p] = np.round(rng.normal(0, 0.3, total) * 8) / 8                  # few distinct levels: ties everywhere
+        elif kind == 1:
+            a, b = sorted(rng.integers(0, total, 2))
+            x[p, a:b] = rng.uniform(-1, 1, b - a)                               # one burst, silence around it
+        elif kind == 2:
+            x[p] = 0.5 * np.sin(2 * np.pi * rng.uniform(20, 2000) * np.arange(total) / sr) * np.exp(-np.arange(total) / (0.3 * total))
+        # kind 3: silence
+    ctx = pkg.Context(1, 8192)
+    ctx.meter_configure(ports)
+    ctx.meter_set_enabled(True)
+    refs = [oracle.ChannelMeter() for _ in range(ports)]
+    for r in refs:
+        r.set_enabled(True)
+    pos, call = 0, 0
+    while pos < total:
+        n = int(rng.choice([1, 2, 63, 64, 1000, 8192, int(rng.integers(1, 8193))]))
+        n = min(n, total - pos)
+        ctx.meter_process(x[:, pos:pos + n], sr)
+        for p, r in enumerate(refs):
+            r.process(x[p, pos:pos + n], sr)
+        pos += n
+        call += 1
+        if call % 4 == 0 or pos >= total:
+            lv, pk = ctx.meter_analyze()
+            for p, r in enumerate(refs):
+                cur, peak, cnt = ctx.meter_state(p)
+                rc, rp, rn = r.state
+                assert cnt == rn, (seed, p, pos, n, cnt, rn)
+                assert abs(cur - rc) <= 1e-12 * max(rc, 1e-300), (seed, p, pos, cur, rc)
+                assert abs(peak - rp) <= 1e-12 * max(rp, 1e-300), (seed, p, pos, peak, rp)
+                assert (lv[p], pk[p]) == r.analyze(), (seed, p, pos)
+    ctx.close()
