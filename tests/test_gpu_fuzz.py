@@ -581,3 +581,38 @@ def test_random_meter_streams_follow_the_oracle(oracle, seed):
                 assert abs(peak - rp) <= 1e-12 * max(rp, 1e-300), (seed, p, pos, peak, rp)
                 assert (lv[p], pk[p]) == r.analyze(), (seed, p, pos)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_metronome_settings_follow_the_oracle(oracle, seed):
+    """metronome.Process with random tick / tock sounds (long, short, empty, none), beats per period (0 included: the reference counts it as 1),
+    speeds, rates and a random frame size per call, reconfigured in mid-stream: every block bit for bit."""
+    pkg = package()
+    rng = np.random.default_rng(13000 + seed)
+    ctx = pkg.Context(1, 8192)
+    ref = oracle.Metronome()
+
+    def sound():
+        k = rng.integers(0, 5)
+        if k == 0:
+            return None
+        if k == 1:
+            return np.zeros(0)
+        return rng.uniform(-1, 1, int(rng.choice([1, 50, 3000, 30000])))
+
+    def configure():
+        tick, tock = sound(), sound()
+        beats, bpm, sr = int(rng.integers(0, 9)), int(rng.choice([1, 40, 120, 360, 1000])), int(rng.choice([8000, 44100, 192000]))
+        ctx.metronome_set_sounds(tick, tock)
+        ctx.metronome_configure(beats, bpm, sr)
+        ref.tick, ref.tock = tick, tock
+        ref.s.beats_per_period, ref.s.bpm_speed, ref.s.sample_rate = beats, bpm, sr
+
+    configure()
+    for call in range(40):
+        n = int(rng.choice([1, 17, 1024, 8192, int(rng.integers(1, 8193))]))
+        got, want = ctx.metronome_process(n), ref.process(n)
+        assert np.array_equal(got, want), (seed, call, n, int(np.count_nonzero(got != want)))
+        if rng.random() < 0.15:
+            configure()
+    ctx.close()
