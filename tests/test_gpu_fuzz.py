@@ -616,3 +616,40 @@ def test_random_metronome_settings_follow_the_oracle(oracle, seed):
         if rng.random() < 0.15:
             configure()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_codec_and_resampler_jobs_follow_the_oracle(oracle, seed):
+    """The data formats either side of the path on random jobs: every sample format, random lengths (0 and 1 included), interleaved files of
+    1-4 channels, values beyond full scale (the encoders clip), then resample.Time between random rate pairs: encoders and the integer decoders
+    byte / bit exact, the resampler to 1e-9."""
+    pkg = package()
+    rng = np.random.default_rng(14000 + seed)
+    ctx = pkg.Context(1, 64)
+    for _ in range(6):
+        fmt = str(rng.choice(FORMATS))
+        n = int(rng.choice([0, 1, 3, 4, 5, 1023, 4096, int(rng.integers(1, 20000))]))
+        chans = int(rng.integers(1, 5))
+        x = rng.uniform(-1.3, 1.3, (chans, n))
+        if n:
+            x[0, 0] = float(rng.choice([-1.0, 1.0, 0.0, -2.0, 2.0]))
+        # encode every channel (planar), interleave on the host, decode the interleaved file on the device
+        enc = [ctx.wave_encode(fmt, x[c]) for c in range(chans)]
+        want = [oracle.wave_encode(fmt, x[c]) for c in range(chans)]
+        for c in range(chans):
+            assert np.array_equal(enc[c], want[c]), (seed, fmt, n, c)
+        w = pkg.lib().gdg_wave_bytes_per_sample(pkg.WAVE_FORMATS[fmt])
+        inter = np.ascontiguousarray(np.stack([e.reshape(n, w) for e in enc], axis=1)).reshape(-1) if n else np.zeros(0, dtype=np.uint8)
+        dec = np.asarray(ctx.wave_decode(fmt, inter, channels=chans)).reshape(chans, n)
+        for c in range(chans):
+            ref = oracle.wave_decode(fmt, want[c])
+            assert dec.shape == (chans, n) and np.array_equal(dec[c], ref), (seed, fmt, n, c)
+    for _ in range(4):
+        src, dst = int(rng.choice([8000, 22050, 44100, 48000, 96000])), int(rng.choice([44100, 48000, 96000, 192000]))
+        n = int(rng.choice([1, 2, 7, 500, int(rng.integers(1, 6000))]))
+        x = rng.uniform(-1, 1, n)
+        got, want = ctx.resample_time(x, src, dst), oracle.resample_time(x, src, dst)
+        assert got.shape == want.shape, (seed, src, dst, n, got.shape, want.shape)
+        if want.size:
+            assert rms(got - want) <= TOL_RMS, (seed, src, dst, n, rms(got - want))
+    ctx.close()
