@@ -653,3 +653,35 @@ def test_random_codec_and_resampler_jobs_follow_the_oracle(oracle, seed):
         if want.size:
             assert rms(got - want) <= TOL_RMS, (seed, src, dst, n, rms(got - want))
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_power_amp_compiles_follow_the_oracle(oracle, seed):
+    """effects/poweramp.go:25-127 on random slot lists: up to 8 slots -- absent, empty, 1 tap to tens of thousands --, random gain compensations and
+    levels, target orders below, between and above the slots' lengths (0 = keep): the composite tap by tap."""
+    from test_gpu_compile import oracle_compile
+    pkg = package()
+    rng = np.random.default_rng(15000 + seed)
+    ctx = pkg.Context(1, 256)
+    h = ctx.append_unit(0, "power_amp")
+    for _ in range(3):
+        filters = []
+        for _s in range(int(rng.integers(1, 9))):
+            k = rng.integers(0, 6)
+            if k == 0:
+                filters.append((None, 1.0, 0))
+            elif k == 1:
+                filters.append((np.zeros(0), 1.0, 0))
+            else:
+                n = int(rng.choice([1, 2, 100, 777, 4096, 5000, 20000, int(rng.integers(1, 40000))]))
+                filters.append((synth_ir(n, seed=int(rng.integers(1, 10 ** 6))) * float(rng.uniform(0.1, 2.0)),
+                                10.0 ** (0.05 * float(rng.uniform(-30, 0))), int(rng.integers(-30, 7))))
+        order = int(rng.choice([0, 1, 2, 3, 64, 1000, 1024, 4096, 30000, 65536]))
+        ctx.unit_compile_fir(h, filters, order)
+        got = ctx.unit_get_fir(h)
+        want = oracle_compile(oracle, filters, order)
+        assert len(got) == len(want), (seed, order, len(got), len(want))
+        if len(want):
+            assert rms(got - want) <= TOL_RMS * max(rms(want), 1e-300), (seed, order, rms(got - want), rms(want))
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * max(1.0, float(np.max(np.abs(want)))))
+    ctx.close()
