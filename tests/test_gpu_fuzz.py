@@ -316,7 +316,8 @@ def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
     """gdg_batch_run on random jobs: 2-5 inputs in random sample formats, lengths (odd ones included), rates (some need resample.Time),
     interleaved files of which one channel is taken, empty inputs; random chains; a random window size; the metronome in or out of the
     master mix; a random output format.  Against the oracle's pipeline (decode -> resample.Time -> pad -> per block: chains, metronome,
-    spatializer + aux -> encode): integer containers byte for byte, float containers within 1e-9 RMS."""
+    spatializer + aux -> encode): 8-, 16- and 24-bit containers byte for byte, 32-bit codes equal up to a handful that are off by one (see
+    below), float containers within 1e-9 RMS."""
     pkg = package()
     rng = np.random.default_rng(7000 + seed)
     rate = int(rng.choice([44100, 48000, 96000]))
@@ -396,6 +397,14 @@ def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
         if out_fmt in ("ieee32", "ieee64"):
             err = rms(oracle.wave_decode(out_fmt, outs[r]) - oracle.wave_decode(out_fmt, want)) if length else 0.0
             assert err <= TOL_RMS, (seed, r, out_fmt, err)
+        elif out_fmt == "lpcm32":
+            # a 32-bit code is 4.7e-10 wide: the chains' legitimate 1e-16 .. 1e-15 differences (device exp / sin / log10 against glibc's, scan
+            # association) move a sample across a truncation boundary about once in 10^6 samples (seed 2056 of profiles/probes/fuzz_soak.py).
+            # The encoder itself is bit exact on equal input (test_random_codec_and_resampler_jobs...): here a handful of codes may be off by one.
+            got_i = outs[r].view("<i4").astype(np.int64) if length else np.zeros(0, dtype=np.int64)
+            want_i = want.view("<i4").astype(np.int64) if length else np.zeros(0, dtype=np.int64)
+            d = np.abs(got_i - want_i)
+            assert d.max(initial=0) <= 1 and int(np.count_nonzero(d)) <= max(2, length // 100000), (seed, r, int(d.max(initial=0)), int(np.count_nonzero(d)))
         else:
             bad = int(np.count_nonzero(outs[r] != want))
             assert bad == 0, "seed %d output %d (%s, W = %d): %d bytes differ" % (seed, r, out_fmt, W, bad)
@@ -452,6 +461,10 @@ def test_random_tuner_signals_follow_the_oracle(oracle, seed):
     sr = int(rng.choice([22050, 44100, 48000, 96000, 192000]))
     frames = int(rng.choice([64, 1000, 4096, 8192]))
     total = int(rng.choice([3 * frames, 96000 + 2 * frames, 50000]))
+    # at least four times the longest lag the analysis looks at: with fewer samples than the lag the autocorrelation is identically zero there
+    # and the arg-max picks among rounding noise (1e-16) -- the reference's own result is then an accident of its FFT's rounding (seeds 1061
+    # and 1147 of profiles/probes/fuzz_soak.py: 192 samples at 192 kHz, a tone whose autocorrelation is negative at every lag that overlaps)
+    total = max(total, 4 * int(sr / 61.7 + 1.5))
     total = max(frames, (total // frames) * frames)
     t = np.arange(total) / float(sr)
     x = np.zeros((nch, total))
