@@ -43,33 +43,23 @@ def reference_panics(frames, taps):
     return (blocks - 1) * block > frames
 
 
-def _fft_computed(name, params):
-    """units whose output the reference computes through an FFT convolution (filter.Process): the power amp, and every oversampled unit
-    (its decimator, oversampling.go:126-184)"""
-    if name == "power_amp":
-        return True
-    if name in ("overdrive", "distortion", "excess"):
-        return params[-1] > 0
-    if name == "fuzz":
-        return params[6] > 0
-    return False
-
-
 def _split_points(units):
-    """Indices of octavers that sit downstream of an FFT-computed stage.  The octaver's polarity logic looks at the SIGN of its input
-    (octaver.go:86-100); where that input is digital silence -- e.g. the first samples behind a decimator's group delay -- the reference's
-    FFT leaves rounding noise of arbitrary sign (1e-18) and the octave registers it starts the stream with are decided by that noise.  No
-    implementation with another summation order reproduces those bits, so behind such a stage the octaver (and what follows) is compared
-    on the ORACLE's intermediate signal: same input, same output."""
-    cut, fft_seen = [], False
+    """Indices of octavers that have another (non-bypassed) unit in front of them.  The octaver's polarity logic looks at the SIGN of its
+    input and compares its magnitude with the follower's (octaver.go:86-100): a discontinuous function of the input.  Where that input is
+    digital silence or sits on the hysteresis threshold, the 1e-18 by which two correct implementations of the stages in front differ
+    decides the octave registers, and with them the sub-octaves' polarity for the rest of the stream.  First seen behind the stages the
+    reference computes by FFT (decimators, power amps: rounding noise of arbitrary sign where the signal is silent); the soak of round 3
+    (profiles/probes/fuzz_soak.py, seed 5419; taken apart by profiles/probes/chain_case.py) met it behind distortion -> band pass -> ring
+    modulator -> noise gate as well: stages agreeing to 3e-18, octaver outputs apart by 2.5e-7, the octaver alone on the oracle's signal
+    exact to 2e-17.  So every such octaver (and what follows it) is compared on the ORACLE's intermediate signal -- same input, same
+    output -- and the stages in front of it against the oracle as usual."""
+    cut, seen = [], False
     for i, (name, params, bypass) in enumerate(units):
         if bypass:
             continue
-        if name == "octaver" and fft_seen:
+        if name == "octaver" and seen:
             cut.append(i)
-            fft_seen = False
-        if _fft_computed(name, params):
-            fft_seen = True
+        seen = True
     return cut
 
 
@@ -193,7 +183,7 @@ def test_random_edits_in_mid_stream_follow_the_oracle(oracle, seed):
                 name = pkg.UNIT_NAMES[t]
                 if name == "power_amp" and not with_fft:
                     continue
-                if name == "octaver" and with_fft:          # ill-conditioned behind an FFT-computed stage (see above): not this test's subject
+                if name == "octaver":                       # discontinuous in its input (see _split_points): not this test's subject
                     continue
                 break
             if name == "power_amp":
@@ -354,7 +344,7 @@ def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
             while True:
                 t = int(rng.integers(0, 21))
                 name = pkg.UNIT_NAMES[t]
-                if (name == "power_amp" and not fft) or (name == "octaver" and fft):
+                if (name == "power_amp" and not fft) or (name == "octaver" and (fft or p.handles)):      # an octaver only at the head (see _split_points)
                     continue
                 break
             if name == "power_amp":
@@ -400,11 +390,13 @@ def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
         elif out_fmt == "lpcm32":
             # a 32-bit code is 4.7e-10 wide: the chains' legitimate 1e-16 .. 1e-15 differences (device exp / sin / log10 against glibc's, scan
             # association) move a sample across a truncation boundary about once in 10^6 samples (seed 2056 of profiles/probes/fuzz_soak.py).
-            # The encoder itself is bit exact on equal input (test_random_codec_and_resampler_jobs...): here a handful of codes may be off by one.
+            # The encoder itself is bit exact on equal input (test_random_codec_and_resampler_jobs...): here a few codes may be off by one.
             got_i = outs[r].view("<i4").astype(np.int64) if length else np.zeros(0, dtype=np.int64)
             want_i = want.view("<i4").astype(np.int64) if length else np.zeros(0, dtype=np.int64)
             d = np.abs(got_i - want_i)
-            assert d.max(initial=0) <= 1 and int(np.count_nonzero(d)) <= max(2, length // 100000), (seed, r, int(d.max(initial=0)), int(np.count_nonzero(d)))
+            # behind stages the reference computes by FFT (oversampled units, power amps) the float difference reaches 1e-13 and one sample in a
+            # few thousand moves (seed 5421 of the soak: 10 of 24576); the bound is the float tolerance expressed in codes
+            assert d.size == 0 or (d.max() <= 2 and float(np.sqrt(np.mean((d / 2147483648.0) ** 2))) <= TOL_RMS), (seed, r, int(d.max(initial=0)), int(np.count_nonzero(d)))
         else:
             bad = int(np.count_nonzero(outs[r] != want))
             assert bad == 0, "seed %d output %d (%s, W = %d): %d bytes differ" % (seed, r, out_fmt, W, bad)
@@ -514,7 +506,7 @@ def test_random_host_calls_follow_the_oracle(oracle, seed):
             while True:
                 t = int(rng.integers(0, 21))
                 name = pkg.UNIT_NAMES[t]
-                if (name == "power_amp" and not fft) or (name == "octaver" and fft):
+                if (name == "power_amp" and not fft) or (name == "octaver" and (fft or p.handles)):      # an octaver only at the head (see _split_points)
                     continue
                 break
             if name == "power_amp":
