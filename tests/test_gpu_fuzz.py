@@ -306,8 +306,8 @@ def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
     """gdg_batch_run on random jobs: 2-5 inputs in random sample formats, lengths (odd ones included), rates (some need resample.Time),
     interleaved files of which one channel is taken, empty inputs; random chains; a random window size; the metronome in or out of the
     master mix; a random output format.  Against the oracle's pipeline (decode -> resample.Time -> pad -> per block: chains, metronome,
-    spatializer + aux -> encode): 8-, 16- and 24-bit containers byte for byte, 32-bit codes equal up to a handful that are off by one (see
-    below), float containers within 1e-9 RMS."""
+    spatializer + aux -> encode): 8-, 16- and 24-bit containers byte for byte except samples that sit on a code boundary (see below), 32-bit
+    codes within the float tolerance, float containers within 1e-9 RMS."""
     pkg = package()
     rng = np.random.default_rng(7000 + seed)
     rate = int(rng.choice([44100, 48000, 96000]))
@@ -398,8 +398,16 @@ def test_random_batch_runs_follow_the_oracle_pipeline(oracle, seed):
             # few thousand moves (seed 5421 of the soak: 10 of 24576); the bound is the float tolerance expressed in codes
             assert d.size == 0 or (d.max() <= 2 and float(np.sqrt(np.mean((d / 2147483648.0) ** 2))) <= TOL_RMS), (seed, r, int(d.max(initial=0)), int(np.count_nonzero(d)))
         else:
-            bad = int(np.count_nonzero(outs[r] != want))
-            assert bad == 0, "seed %d output %d (%s, W = %d): %d bytes differ" % (seed, r, out_fmt, W, bad)
+            if not np.array_equal(outs[r], want):
+                # a sample that sits ON a code boundary may take either code: the compressor with a peak follower and a 0 dB target (or the
+                # auto-yoy at full level) puts its peaks at +-1 (1 +- one ulp) -- exactly the encoder's top boundary, where 254 or 255 is a matter
+                # of the last bit (soak seeds 20198, 20445).  Every differing sample must be the code of the oracle's value moved by <= 1e-9.
+                g = outs[r].reshape(length, wo)
+                ok = np.all(g == want.reshape(length, wo), axis=1)
+                for delta in (-1e-9, 1e-9):
+                    ok |= np.all(g == oracle.wave_encode(out_fmt, ref_out[r] + delta).reshape(length, wo), axis=1)
+                bad = int(np.count_nonzero(~ok))
+                assert bad == 0, "seed %d output %d (%s, W = %d): %d samples differ by more than a boundary case" % (seed, r, out_fmt, W, bad)
 
 
 @pytest.mark.parametrize("seed", range(24))
