@@ -98,3 +98,10 @@ def test_header_is_plain_c_and_the_library_links_from_c(pkg, tmp_path):
         assert int(rc) == pkg.GDG_ERR_NO_DEVICE and has_ctx == "0"
     else:
         assert int(rc) == 0 and has_ctx == "1"
+
+
+def test_makefiles_create_the_directory_they_link_into():
+    """go-dsp-guitar_amd/lib/ holds only built (git-ignored) libraries, so a fresh clone has no such directory: the link rules make it."""
+    for rel in ("go-dsp-guitar_amd/csrc/Makefile", "go-dsp-guitar_amd/host/Makefile"):
+        text = open(os.path.join(ROOT, rel)).read()
+        assert "../lib/" in text and "mkdir -p $(dir $(OUT))" in text, rel
