@@ -555,6 +555,28 @@ class Context:
             self._check(fn(h, arr, n, ref, ptrs))
         return call, outs
 
+    def batch_shard_prepared(self, inputs, target_rate, out_format, job_samples=0, metronome=False, run_meters=False, tuner_enqueue=False):
+        """gdg_batch_run_shard with its arguments marshalled and its result buffers allocated ONCE: returns (call, result) where call() is the C
+        call alone and result = (outs, left, right, metronome_bytes, metronome_f64) as batch_run_shard returns them."""
+        n = len(inputs)
+        arr, keep = self._batch_inputs(inputs)
+        fo = WAVE_FORMATS[out_format] if isinstance(out_format, str) else out_format
+        opt = BatchOptions(target_rate, fo, 0, int(bool(run_meters)), int(bool(tuner_enqueue)))
+        length = job_samples or self.batch_length(inputs, target_rate)
+        wo = lib().gdg_wave_bytes_per_sample(fo)
+        outs = [np.zeros(length * wo, dtype=np.uint8) for _ in range(n)]
+        left, right = np.zeros(max(length, 1)), np.zeros(max(length, 1))
+        mb = np.zeros(length * wo, dtype=np.uint8) if metronome else None
+        mf = np.zeros(length) if metronome else None
+        ptrs = (C.c_void_p * n)(*[(o.ctypes.data if o.size else None) for o in outs])
+        so = BatchShardOut(left.ctypes.data, right.ctypes.data, mb.ctypes.data if (metronome and length) else None,
+                           mf.ctypes.data if (metronome and length) else None, job_samples)
+        fn, h, ropt, rso = lib().gdg_batch_run_shard, self._h, C.byref(opt), C.byref(so)
+
+        def call(_keep=(keep, arr, opt, ptrs, so, outs, left, right, mb, mf)):
+            self._check(fn(h, arr, n, ropt, ptrs, rso))
+        return call, (outs, left[:length], right[:length], mb, mf)
+
     def batch_run_shard(self, inputs, target_rate, out_format, job_samples=0, metronome=False, run_meters=False, tuner_enqueue=False, outs=None):
         """One shard of a batch split over several contexts (gdg_batch_run_shard): returns (outs, left, right, metronome_bytes,
         metronome_f64): the shard's n encoded chain outputs, its float64 partial master mix, and -- on the shard that runs the
