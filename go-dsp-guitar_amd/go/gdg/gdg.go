@@ -1,8 +1,11 @@
 // Package gdg is the thin cgo binding of libgdg.so (include/gdg.h): the MI355X-native batch
 // implementation of go-dsp-guitar's per-channel effects pipeline.
 //
-// NOT compiled in the authoring container (no Go toolchain there); it is the stub a maintainer adds
-// next to the reference tree, see INTEGRATION.md.  It contains no DSP: every function is one C call.
+// NOT compiled in the authoring container (no Go toolchain there); it is the directory a maintainer copies into the reference
+// checkout as <ref>/gdg (package github.com/andrepxx/go-dsp-guitar/gdg, INTEGRATION.md section 3 -- cgo needs the package
+// directory on disk, an overlay-only directory will not do).  Written for the language level of the reference's go.mod (go 1.16):
+// no unsafe.Slice / unsafe.Add, no generics, no `any`, no typed atomics (tests/test_go_sources.py holds the deny-list).
+// It contains no DSP: every function is one C call.
 //
 //	CGO_CFLAGS="-I<repo>/include" CGO_LDFLAGS="-L<repo>/go-dsp-guitar_amd/lib -lgdg -Wl,-rpath,<repo>/go-dsp-guitar_amd/lib"
 package gdg
@@ -153,9 +156,11 @@ func (this *Context) Row(channel int, frames int) (in []float64, out []float64, 
 	if frames < 0 || frames > this.stride {
 		return nil, nil, fmt.Errorf("gdg: %d frames do not fit a staging row of %d", frames, this.stride)
 	}
-	off := uintptr(channel * this.stride * 8)
-	in = unsafe.Slice((*float64)(unsafe.Pointer(uintptr(this.in)+off)), frames)
-	out = unsafe.Slice((*float64)(unsafe.Pointer(uintptr(this.out)+off)), frames)
+	// slices over C memory the Go 1.16 way (the reference's go.mod:3 says `go 1.16`; unsafe.Slice is 1.17): a pointer to a
+	// huge array type, sliced down to the row with its capacity capped
+	off := uintptr(channel) * uintptr(this.stride) * 8
+	in = (*[1 << 37]float64)(unsafe.Pointer(uintptr(this.in) + off))[:frames:frames]
+	out = (*[1 << 37]float64)(unsafe.Pointer(uintptr(this.out) + off))[:frames:frames]
 	return in, out, nil
 }
 
@@ -495,8 +500,7 @@ func cbool(b bool) C.int {
 }
 
 // BatchRun: controller.processFiles between "the files are read" and "the files are written" (controller/controller.go:2884-3219)
-// in one call.  The C structs hold pointers, so the file bytes live in C memory for the duration of the call (C.CBytes: one
-// copy; with Go >= 1.21 a runtime.Pinner on the []byte would avoid it), and so do the N + 3 output data sections.
+// in one call.  The C structs hold pointers, so the file bytes live in C memory for the duration of the call (C.CBytes: one copy), and so do the N + 3 output data sections.
 func (this *Context) BatchRun(inputs []BatchInput, opt BatchOptions) ([][]byte, error) {
 	n := len(inputs)
 	if n == 0 {

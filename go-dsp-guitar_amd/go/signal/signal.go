@@ -29,7 +29,7 @@ import (
 	"github.com/andrepxx/go-dsp-guitar/effects"
 	"github.com/andrepxx/go-dsp-guitar/filter"
 
-	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding, added to the reference module by the overlay (go/overlay.json)
+	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding: a directory added to the reference checkout (INTEGRATION.md section 3)
 )
 
 const blockSize = 8192 // controller/controller.go:36 BLOCK_SIZE

@@ -22,7 +22,7 @@ import (
 	"os"
 	"sync"
 
-	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding, added to the reference module by the overlay (go/overlay.json)
+	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding: a directory added to the reference checkout (INTEGRATION.md section 3)
 )
 
 const (

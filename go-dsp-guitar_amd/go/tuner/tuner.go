@@ -1,11 +1,18 @@
 // Package tuner is the drop-in replacement for the reference's tuner/tuner.go (overlay, like ../signal): same exported
-// Tuner / Result interfaces (tuner/tuner.go:27-65) and Create (:592-610).  Process copies the samples into the pinned row of a
-// private one-channel context and enqueues them into the 96000-sample ring on the device; Analyze runs the 262144-point
-// autocorrelation, the arg-max over the note range, the parabolic refinement and the note search on the device
-// (tuner.go:379-577) and returns frequency, note name and truncated cents.
+// Tuner / Result interfaces (tuner/tuner.go:27-65) and Create (:592-610), and the reference's TWO locks (tuner.go:48-57):
+//
+//	mutexBuffer   guards the ring of the last NUM_SAMPLES samples and the rate.  Process -- the audio path, called from
+//	              controller.process() for every block (controller.go:2668-2672) -- takes it for one Enqueue and nothing else:
+//	              it never waits for the GPU.
+//	mutexAnalyze  serialises Analyze (the HTTP poll, tuner.go:380) and owns the device context.  Analyze holds mutexBuffer
+//	              (shared) only while it copies the ring out (tuner.go:408-412), then uploads the copy into the device ring and
+//	              runs the autocorrelation, the arg-max over the note range, the parabolic refinement and the note search there
+//	              (tuner.go:414-577) with the audio path free to enqueue.
+//
+// The ring itself is the reference's own circular.Buffer: its contents and order are what the device analyses.
 //
 // NOT compiled in the authoring container (no Go toolchain); the C++ twin gdg::tuner::Tuner (../../host/gdg_host.cpp) has the
-// same two methods over the same two C calls and is tested on the GPU against the oracle (tests/test_host_mirror.py).
+// same two methods, the same two locks and the same C calls and is tested on the GPU against the oracle (tests/test_host_mirror.py).
 package tuner
 
 import (
@@ -14,12 +21,13 @@ import (
 	"strconv"
 	"sync"
 
-	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding, added to the reference module by the overlay (go/overlay.json)
+	"github.com/andrepxx/go-dsp-guitar/circular"
+	"github.com/andrepxx/go-dsp-guitar/gdg" // the cgo binding: a directory added to the reference checkout (INTEGRATION.md section 3)
 )
 
 const (
 	NUM_SAMPLES = 96000 // tuner/tuner.go:16
-	blockSize   = 8192  // controller/controller.go:36 BLOCK_SIZE: the most the controller enqueues per call
+	blockSize   = 8192  // controller/controller.go:36 BLOCK_SIZE: the most a context takes per call
 )
 
 type resultStruct struct {
@@ -46,10 +54,15 @@ type Tuner interface {
 }
 
 type tunerStruct struct {
-	mutex sync.Mutex
-	ctx   *gdg.Context
+	mutexBuffer  sync.RWMutex
+	buffer       circular.Buffer
+	sampleRate   uint32
+	mutexAnalyze sync.Mutex
+	ctx          *gdg.Context // owned by Analyze (mutexAnalyze held)
+	snapshot     []float64    // the reference's bufCorrelation[0:n]: the ring, oldest sample first
 }
 
+// context (mutexAnalyze held): the private one-channel context, made at the first analysis.
 func (this *tunerStruct) context() (*gdg.Context, error) {
 	if this.ctx == nil {
 		dev, _ := strconv.Atoi(os.Getenv("GDG_TUNER_DEVICE")) // default: device 0
@@ -62,37 +75,47 @@ func (this *tunerStruct) context() (*gdg.Context, error) {
 	return this.ctx, nil
 }
 
-// Process: tuner/tuner.go:582-587 (circular.Enqueue of any number of samples; the rate is remembered for Analyze).
+// Process: tuner/tuner.go:582-587, statement for statement.
 func (this *tunerStruct) Process(samples []float64, sampleRate uint32) {
-	this.mutex.Lock()
-	defer this.mutex.Unlock()
-	ctx, err := this.context()
-	if err != nil {
-		return
-	}
-	for at := 0; at < len(samples); at += blockSize {
-		n := len(samples) - at
-		if n > blockSize {
-			n = blockSize
-		}
-		row, _, err := ctx.Row(0, n)
-		if err != nil {
-			return
-		}
-		copy(row, samples[at:at+n]) // Go memory -> pinned C slab
-		if ctx.TunerEnqueueStaged(n, sampleRate) != nil {
-			return
-		}
-	}
+	this.mutexBuffer.Lock()
+	this.buffer.Enqueue(samples...)
+	this.sampleRate = sampleRate
+	this.mutexBuffer.Unlock()
 }
 
 // Analyze: tuner/tuner.go:379-577.
 func (this *tunerStruct) Analyze() (Result, error) {
-	this.mutex.Lock()
-	defer this.mutex.Unlock()
+	this.mutexAnalyze.Lock()
+	defer this.mutexAnalyze.Unlock()
 	ctx, err := this.context()
 	if err != nil {
 		return nil, err
+	}
+	n := this.buffer.Length()
+	if len(this.snapshot) != n {
+		this.snapshot = make([]float64, n)
+	}
+	this.mutexBuffer.RLock()
+	sampleRate := this.sampleRate
+	err = this.buffer.Retrieve(this.snapshot)
+	this.mutexBuffer.RUnlock()
+	if err != nil {
+		return nil, fmt.Errorf("Failed to retrieve contents of circular buffer: %s", err.Error())
+	}
+	// the whole ring, oldest first, into the device ring (NUM_SAMPLES enqueued samples replace all of it)
+	for at := 0; at < n; at += blockSize {
+		m := n - at
+		if m > blockSize {
+			m = blockSize
+		}
+		row, _, err := ctx.Row(0, m)
+		if err != nil {
+			return nil, fmt.Errorf("Failed to analyze: %s", err.Error())
+		}
+		copy(row, this.snapshot[at:at+m]) // Go memory -> pinned C slab
+		if err := ctx.TunerEnqueueStaged(m, sampleRate); err != nil {
+			return nil, fmt.Errorf("Failed to analyze: %s", err.Error())
+		}
 	}
 	res, err := ctx.TunerAnalyze()
 	if err != nil {
@@ -104,5 +127,6 @@ func (this *tunerStruct) Analyze() (Result, error) {
 
 // Create: tuner/tuner.go:592-610.
 func Create() Tuner {
-	return &tunerStruct{}
+	t := tunerStruct{buffer: circular.CreateBuffer(NUM_SAMPLES)}
+	return &t
 }

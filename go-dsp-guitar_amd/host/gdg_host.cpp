@@ -1002,24 +1002,48 @@ std::shared_ptr<Spatializer> Create(Engine *engine, uint32_t inputChannels) { re
 /* ================================ tuner =================================================== */
 namespace tuner {
 
-Tuner::Tuner(int device) : device_(device) {}
+static const size_t NUM_SAMPLES = 96000;                                           /* tuner.go:16 */
+
+Tuner::Tuner(int device) : ring_(NUM_SAMPLES, 0.0), device_(device) {}
 Tuner::~Tuner() { if (ctx_) gdg_ctx_destroy(ctx_); }
 
-void Tuner::Process(const double *samples, size_t n, uint32_t sampleRate) {      /* tuner.go:582-587 */
-    std::lock_guard<std::mutex> lk(mutex_);
-    if (!ctx_ && gdg_ctx_create(1, GDG_HOST_MAX_FRAMES, device_, &ctx_) != GDG_OK) { ctx_ = nullptr; return; }
-    /* circular.Enqueue takes any number of samples; the context takes at most max_frames per call */
-    for (size_t at = 0; at < n; at += GDG_HOST_MAX_FRAMES) {
-        size_t m = std::min<size_t>(GDG_HOST_MAX_FRAMES, n - at);
-        const double *rows[1] = { samples + at };
-        gdg_tuner_enqueue(ctx_, rows, (int)m, sampleRate);
+/* tuner.go:582-587: one enqueue into the host ring under mutexBuffer -- the audio path never waits for the GPU.
+ * The enqueue is circular.Enqueue (circular.go:33-71): more samples than the ring holds keep the tail and reset the pointer. */
+void Tuner::Process(const double *samples, size_t n, uint32_t sampleRate) {
+    std::unique_lock<std::shared_mutex> lk(mutexBuffer_);
+    const size_t N = ring_.size();
+    if (n >= N) {
+        memcpy(ring_.data(), samples + (n - N), N * sizeof(double));
+        pointer_ = 0;
+    } else {
+        size_t first = std::min(n, N - pointer_);
+        memcpy(ring_.data() + pointer_, samples, first * sizeof(double));
+        memcpy(ring_.data(), samples + first, (n - first) * sizeof(double));
+        pointer_ = (pointer_ + n) % N;
     }
+    sampleRate_ = sampleRate;
 }
 
-std::pair<Result, Error> Tuner::Analyze() {                                        /* tuner.go:379-577 */
-    std::lock_guard<std::mutex> lk(mutex_);
+/* tuner.go:379-577: mutexAnalyze for the whole analysis, mutexBuffer (shared) for the copy of the ring only; the copy then replaces the
+ * device ring (NUM_SAMPLES enqueued samples) and the analysis runs there. */
+std::pair<Result, Error> Tuner::Analyze() {
+    std::lock_guard<std::mutex> lk(mutexAnalyze_);
     Result r{ 0, 0.0, "Unknown" };
     if (!ctx_ && gdg_ctx_create(1, GDG_HOST_MAX_FRAMES, device_, &ctx_) != GDG_OK) { ctx_ = nullptr; return { r, "no usable HIP device; there is no CPU fallback" }; }
+    const size_t N = ring_.size();
+    snapshot_.resize(N);
+    uint32_t sampleRate;
+    {
+        std::shared_lock<std::shared_mutex> rd(mutexBuffer_);
+        sampleRate = sampleRate_;
+        memcpy(snapshot_.data(), ring_.data() + pointer_, (N - pointer_) * sizeof(double));      /* circular.Retrieve: oldest first */
+        memcpy(snapshot_.data() + (N - pointer_), ring_.data(), pointer_ * sizeof(double));
+    }
+    for (size_t at = 0; at < N; at += GDG_HOST_MAX_FRAMES) {
+        size_t m = std::min<size_t>(GDG_HOST_MAX_FRAMES, N - at);
+        const double *rows[1] = { snapshot_.data() + at };
+        if (gdg_tuner_enqueue(ctx_, rows, (int)m, sampleRate) != GDG_OK) return { r, std::string("Failed to analyze: ") + gdg_last_error(ctx_) };
+    }
     gdg_tuner_result res;
     if (gdg_tuner_analyze(ctx_, &res) != GDG_OK) return { r, std::string("Failed to analyze: ") + gdg_last_error(ctx_) };
     r.cents = res.cents;

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -278,7 +279,14 @@ public:
     std::pair<Result, Error> Analyze();
     void Process(const double *samples, size_t n, uint32_t sampleRate);
 private:
-    std::mutex mutex_;
+    /* the reference's two locks (tuner.go:48-57): Process -- the audio path -- only ever takes mutexBuffer_ for one enqueue into the host ring;
+     * Analyze owns the device context under mutexAnalyze_ and holds mutexBuffer_ (shared) just while it copies the ring out (tuner.go:408-412) */
+    std::shared_mutex mutexBuffer_;
+    std::vector<double> ring_;             /* circular.Buffer of NUM_SAMPLES (circular.go:33-105) */
+    size_t pointer_ = 0;
+    uint32_t sampleRate_ = 0;
+    std::mutex mutexAnalyze_;
+    std::vector<double> snapshot_;         /* the ring, oldest sample first */
     gdg_ctx *ctx_ = nullptr;
     int device_;
 };
