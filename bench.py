@@ -71,6 +71,28 @@ def synth_block(n_channels, frames, sample_rate, channel0=0):
     return _synth().synth_block(n_channels, frames, sample_rate, channel0=channel0)
 
 
+INPUT_BLOCKS = 4              # the headline walks through this many DISTINCT consecutive blocks of the synthetic stream, round robin
+
+
+def synth_blocks(n_channels, frames, sample_rate, channel0=0, blocks=INPUT_BLOCKS):
+    """[blocks][channels][frames]: consecutive blocks of SURVEY 8(d)'s stream (block b = samples b * frames ..)"""
+    rows = _synth().synth_rows(n_channels, blocks * frames, sample_rate, channel0=channel0)
+    return np.ascontiguousarray(rows.reshape(n_channels, blocks, frames).transpose(1, 0, 2))
+
+
+def device_identity(index):
+    """PCI bus id of HIP device `index` (hipDeviceGetPCIBusId), so the line says WHICH devices the ranks ran on."""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    return None
+
+
 def ir_for(kind, index, taps):
     return synth_ir(taps, _synth().ir_seed(kind, index))
 
@@ -396,10 +418,26 @@ def other_configs(pkg, device):
     st_sp = robust_time(lambda: [ctx.spatialize_device(d_x, d_lr, frames) for _ in range(20)], ctx.synchronize, units=20)
     st_an = robust_time(lambda: [ctx.tuner_analyze(raw=True) for _ in range(5)], ctx.synchronize, units=5)
     t_sp, t_an = st_sp["median"], st_an["median"]
+    # the two kernels' own durations (HIP events on the launches) against SURVEY 8(d)'s algorithmic bytes: 768 kB per analysis (the ring,
+    # read once), 8 B per channel-sample for the mix
+    ctx.profile_enable(kinds=[pkg.K_TUNER, pkg.K_SPATIALIZER])
+    for _ in range(10):
+        ctx.spatialize_device(d_x, d_lr, frames)
+        ctx.tuner_analyze(raw=True)
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    roof = {}
+    for kind, name, nbytes in ((pkg.K_TUNER, "tuner", nch * 96000 * 8.0), (pkg.K_SPATIALIZER, "spatializer", nch * frames * 8.0 + 2 * frames * 8.0)):
+        ms, n = ctx.profile_read(kind)
+        avg = (ms / n) if n else None
+        gbs = (nbytes / (avg * 1e-3) / 1e9) if avg else None
+        roof[name] = {"bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg, "launches": n, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None}
     d_x.free()
     d_lr.free()
     ctx.close()
-    out["config5_256_tuners"] = {"value": nch / t_an, "unit": "analyses/s", "ms_per_256_analyses": t_an * 1e3, "timing": us_stats(st_an)}
+    out["config5_256_tuners"] = {"value": nch / t_an, "unit": "analyses/s", "ms_per_256_analyses": t_an * 1e3, "timing": us_stats(st_an),
+                                 "roofline": roof["tuner"]}
     # config 5's per-GPU shape on 8 GPUs: 32 tuners (a channel's blocks then go over 8 workgroups: gdg_tuner_short_parts)
     ctx32 = pkg.Context(32, frames, device)
     d32 = ctx32.alloc(32, frames)
@@ -413,7 +451,7 @@ def other_configs(pkg, device):
     out["config5_32_tuners_per_gpu"] = {"value": 32 / st32["median"], "unit": "analyses/s", "us_per_32_analyses": st32["median"] * 1e6,
                                         "predicted_256_tuners_on_8_gpus": 256 / st32["median"], "timing": us_stats(st32)}
     out["config5_spatializer_256_to_2"] = {"value": nch * frames / t_sp / 1e6, "unit": "Msamples/s", "us_per_block": t_sp * 1e6,
-                                           "timing": us_stats(st_sp)}
+                                           "timing": us_stats(st_sp), "roofline": roof["spatializer"]}
     return out
 
 
@@ -422,11 +460,11 @@ def other_configs(pkg, device):
 PARITY_TOL_RMS = 1e-9          # north_star: output matches the float64 reference within 1e-9 RMS
 
 
-def parity_gate(ctx_step, read_output, x_block, n_calls, nch, channel0, frames, sr, taps, n_distinct=0, extra_blocks=2):
+def parity_gate(ctx_step, read_output, x_blocks, n_calls, nch, channel0, frames, sr, taps, n_distinct=0, extra_blocks=2):
     """The oracle (CHECKER only, never timed, never on the product path) follows the first, the middle and the last channel of the
-    SAME context that was just timed: every call so far processed the block `x_block`, so the oracle replays `n_calls` blocks per
-    channel, compares the last one with what the device holds, then follows `extra_blocks` more steps.  Returns the worst per-channel
-    RMS and the max-abs difference over the compared blocks."""
+    SAME context that was just timed: call k so far processed the block `x_blocks[k % len(x_blocks)]`, so the oracle replays those
+    `n_calls` blocks per channel, compares the last one with what the device holds, then follows `extra_blocks` more steps.  Returns
+    the worst per-channel RMS and the max-abs difference over the compared blocks."""
     import __graft_entry__ as entry
     orc = entry.load_oracle()
     orc.build()
@@ -442,10 +480,12 @@ def parity_gate(ctx_step, read_output, x_block, n_calls, nch, channel0, frames, 
                 ch.append_unit(name, params=p)
         chains[c] = ch
     want = {c: None for c in channels}
+    fed = {c: 0 for c in channels}
 
     def replay(c, blocks):
         for _ in range(blocks):
-            want[c] = chains[c].process(x_block[c], sr)
+            want[c] = chains[c].process(x_blocks[fed[c] % len(x_blocks)][c], sr)
+            fed[c] += 1
 
     def all_channels(blocks):
         ths = [threading.Thread(target=replay, args=(c, blocks)) for c in channels]
@@ -495,15 +535,35 @@ def main():
                     help="number of distinct IR tap sets (0 = one per channel = the metric's d = 1; fewer lets power amps share spectra)")
     args = ap.parse_args()
 
-    import torch  # first: libgdg.so then binds to the same HIP runtime (same SONAME)
     import __graft_entry__ as entry
     pkg = entry.load_package()
     from go_dsp_guitar_amd import shard
 
+    # --gpus N means N ranks, whoever starts this file: a plain `python bench.py --gpus 8` re-executes itself under torch.distributed.run
+    # (one rank per device), a launcher whose WORLD_SIZE is not N is an error -- never a line that says "n_gpus": 1 for a job asked with N = 8
+    try:
+        plan = shard.launch_plan(args.gpus, os.environ)
+    except shard.LaunchError as e:
+        sys.stderr.write("bench.py: %s\n" % e.msg)
+        raise
+    if plan == "spawn":
+        cmd = shard.spawn_command(sys.executable, os.path.abspath(__file__), sys.argv[1:], args.gpus, shard.free_port())
+        sys.stderr.write("bench.py: --gpus %d without a launcher: %s\n" % (args.gpus, " ".join(cmd)))
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+
+    import torch  # before the library is loaded: libgdg.so then binds to the same HIP runtime (same SONAME)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus
     distributed = world > 1
+    try:
+        shard.check_devices(args.gpus, torch.cuda.device_count(), bool(os.environ.get("GDG_BENCH_ONE_DEVICE")))
+    except shard.LaunchError as e:
+        sys.stderr.write("bench.py: %s\n" % e.msg)
+        raise
     dist = None
     if distributed:
         import torch.distributed as dist
@@ -515,6 +575,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    devices = [{"rank": rank, "local_device": local_rank, "pci_bus_id": device_identity(local_rank), "name": torch.cuda.get_device_name(local_rank)}]
+    if distributed:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
 
     frames, sr, taps = args.frames, args.sample_rate, args.taps
     strong = args.total_channels > 0
@@ -532,13 +598,17 @@ def main():
     # same box, profiles/probes/bisect_g1.py), as a batch caller that only touches the results through the library would
     headline_groups = args.channel_groups if args.channel_groups > 0 else (2 if nch >= 384 else 1)
     ctx.set_overlap(headline_groups)
-    x = torch.from_numpy(synth_block(nch, frames, sr, channel0=channel0)).to(dev)
-    y = torch.empty_like(x)
+    # the steps walk round robin through INPUT_BLOCKS distinct consecutive blocks of the stream (delay lines of identical spectra would be
+    # a special case; the traffic is the same either way)
+    x_host = synth_blocks(nch, frames, sr, channel0=channel0)
+    x = torch.from_numpy(x_host).to(dev)
+    y = torch.empty_like(x[0])
+    x_ptrs = [x[b].data_ptr() for b in range(INPUT_BLOCKS)]
 
     calls = [0]
 
     def step():
-        ctx.process_device(x.data_ptr(), y.data_ptr(), frames, sr)
+        ctx.process_device(x_ptrs[calls[0] % INPUT_BLOCKS], y.data_ptr(), frames, sr)
         calls[0] += 1
 
     for _ in range(max(args.warmup, 1)):      # the first step also builds the plan and the IR spectra
@@ -623,7 +693,7 @@ def main():
         def read_output():
             synchronize()
             return y.cpu().numpy()
-        parity = parity_gate(step, read_output, x.cpu().numpy(), calls[0], nch, channel0, frames, sr, taps, n_distinct=n_distinct)
+        parity = parity_gate(step, read_output, x_host, calls[0], nch, channel0, frames, sr, taps, n_distinct=n_distinct)
         if distributed:
             t = torch.tensor([parity["rms_max"], parity["max_abs"]], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -776,6 +846,8 @@ def main():
             "value": value,
             "unit": "Msamples/s",
             "n_gpus": world,
+            "n_gpus_requested": args.gpus,
+            "devices": devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -829,6 +901,19 @@ def main():
         if parity is not None:
             out["parity"] = parity
         out.update(extras)
+        ss = extras.get("strong_split")
+        if ss:
+            # the strong split of the fixed 512-channel job (BASELINE config 4's shape at N = 8) in TOP-LEVEL keys, next to the weak headline
+            out["strong_value"], out["strong_unit"], out["strong_ms_per_step"] = ss["value"], ss["unit"], ss["ms_per_step"]
+            out["strong_total_channels"], out["strong_channels_per_gpu"] = ss["total_channels"], ss["channels_per_gpu"]
+            out["strong_realtime_factor"] = ss["realtime_factor"]
+            if "batch_mode_window_16" in ss:
+                out["strong_batch_mode_value"] = ss["batch_mode_window_16"]["value"]
+                out["strong_batch_mode_realtime_factor"] = ss["batch_mode_window_16"]["realtime_factor"]
+        cfg = extras.get("configs") or {}
+        for key, name in (("config5_256_tuners", "tuner"), ("config5_spatializer_256_to_2", "spatializer")):
+            if key in cfg and "roofline" in cfg[key]:
+                out["roofline"][name + "_kernel"] = cfg[key]["roofline"]
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: it is a property of the host, not of the GPU count
             out["cpu_baseline"] = cpu_baseline(sr, frames, taps)
         print(json.dumps(out))

@@ -68,3 +68,61 @@ def gather_master_partials(left, right, dist, dst=0):
     if rank != dst:
         return None, None
     return [g.numpy() for g in gl], [g.numpy() for g in gr]
+
+
+# ---- how `bench.py --gpus N` becomes N ranks, however it is started -------------------------------------------------------------
+
+class LaunchError(SystemExit):
+    """--gpus and the launcher disagree: the run must not print a line for a job it did not run (exit code 2)."""
+
+    def __init__(self, msg):
+        super().__init__(2)
+        self.msg = msg
+
+
+def launch_plan(gpus, environ):
+    """What a process started as `bench.py --gpus N` has to do:
+      "run"    -- it IS the job: N = 1 without a launcher, or one of the N ranks of a launcher (WORLD_SIZE == N);
+      "spawn"  -- N > 1 and no launcher (a plain `python bench.py --gpus N`): re-exec under torch.distributed.run with N ranks,
+                  one device per rank -- silently running ONE rank and printing "n_gpus": 1 is the failure this guards against;
+    LaunchError when a launcher is there and its WORLD_SIZE is not N (the line would carry another N than was asked for)."""
+    if gpus < 1:
+        raise LaunchError("--gpus %d: at least one" % gpus)
+    world = environ.get("WORLD_SIZE")
+    if world is None or world == "":
+        return "run" if gpus == 1 else "spawn"
+    try:
+        world = int(world)
+    except ValueError:
+        raise LaunchError("WORLD_SIZE=%r is not a number" % world)
+    if world != gpus:
+        raise LaunchError("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
+    for key in ("RANK", "LOCAL_RANK"):
+        if environ.get(key) in (None, ""):
+            raise LaunchError("WORLD_SIZE=%d is set but %s is not: not a torch.distributed.run environment" % (world, key))
+    return "run"
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_command(python, script, argv, gpus, port):
+    """The command line of the driver's own N > 1 launch (one node, one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script] + list(argv)
+
+
+def check_devices(gpus, visible, one_device):
+    """Every rank needs a device of its own unless the harness self-test (GDG_BENCH_ONE_DEVICE) puts all ranks on device 0."""
+    if one_device:
+        if visible < 1:
+            raise LaunchError("no HIP device visible")
+        return
+    if visible < gpus:
+        raise LaunchError("--gpus %d but only %d HIP device(s) are visible (GDG_BENCH_ONE_DEVICE=1 shares device 0 for a harness self-test)" % (gpus, visible))

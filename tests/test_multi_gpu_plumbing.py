@@ -100,3 +100,60 @@ def test_spatializer_partials_add_up_to_the_full_mix(oracle):
     got_l, got_r = shard.combine_spatializer_partials(partials, aux)
     np.testing.assert_allclose(got_l, want_l, rtol=0, atol=1e-13)
     np.testing.assert_allclose(got_r, want_r, rtol=0, atol=1e-13)
+
+
+# ---- `bench.py --gpus N` must become N ranks however it is started (round-3 review: a plain `python bench.py --gpus 8` ran one rank) ----
+
+def test_launch_plan_decides_run_spawn_or_error():
+    entry.load_package()
+    from go_dsp_guitar_amd import shard
+    assert shard.launch_plan(1, {}) == "run"
+    assert shard.launch_plan(8, {}) == "spawn"                                   # no launcher: re-exec under torch.distributed.run
+    assert shard.launch_plan(2, {"WORLD_SIZE": ""}) == "spawn"
+    assert shard.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3", "LOCAL_RANK": "3"}) == "run"
+    assert shard.launch_plan(1, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}) == "run"
+    for gpus, env in ((8, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}), (1, {"WORLD_SIZE": "8", "RANK": "0", "LOCAL_RANK": "0"}),
+                      (2, {"WORLD_SIZE": "two"}), (0, {}), (4, {"WORLD_SIZE": "4"})):
+        with pytest.raises(shard.LaunchError) as e:
+            shard.launch_plan(gpus, env)
+        assert e.value.code == 2 and e.value.msg
+    cmd = shard.spawn_command("/usr/bin/python3", "/x/bench.py", ["--gpus", "4", "--steps", "7"], 4, 29511)
+    assert cmd[:3] == ["/usr/bin/python3", "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "7"]
+    shard.check_devices(8, 8, False)
+    shard.check_devices(2, 1, True)                                               # harness self-test: every rank on device 0
+    with pytest.raises(shard.LaunchError):
+        shard.check_devices(8, 1, False)
+    with pytest.raises(shard.LaunchError):
+        shard.check_devices(2, 0, True)
+
+
+def _bench(args, env_extra, timeout=180):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_refuses_a_launcher_whose_world_size_is_not_gpus():
+    r = _bench(["--gpus", "8"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
+    r = _bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and r.stdout.strip() == ""
+
+
+def test_plain_python_bench_gpus_2_spawns_two_ranks():
+    """No launcher, --gpus 2: the process re-executes itself under torch.distributed.run; here (no GPU) both ranks then stop at the device
+    check -- with a non-zero exit and WITHOUT a JSON line (on a GPU box the same command prints "n_gpus": 2)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU variant of this test is tests/test_gpu_bench_launch.py")
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-parity"], {})
+    assert r.returncode != 0
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+    assert r.stderr.count("only 0 HIP device(s) are visible") >= 2, r.stderr[-2000:]       # BOTH ranks got that far
+    assert '"n_gpus"' not in r.stdout
