@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "gdg_version", "gdg_device_count", "gdg_ctx_create", "gdg_ctx_destroy", "gdg_last_error", "gdg_ctx_channels",
     "gdg_ctx_stream", "gdg_ctx_synchronize", "gdg_ctx_share_ir_spectra", "gdg_unit_create", "gdg_unit_destroy", "gdg_unit_set_param",
     "gdg_unit_get_param", "gdg_unit_set_fir", "gdg_unit_compile_fir", "gdg_unit_get_fir", "gdg_unit_reset", "gdg_chain_set", "gdg_process", "gdg_process_subset", "gdg_process_device",
-    "gdg_staging_buffers", "gdg_process_staged", "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_copy_rows_device", "gdg_fft_real", "gdg_fft_real_inverse", "gdg_profile_enable",
+    "gdg_staging_buffers", "gdg_process_staged", "gdg_device_alloc", "gdg_device_free", "gdg_copy_to_device", "gdg_copy_to_host", "gdg_copy_rows_device", "gdg_fft_real", "gdg_fft_real_inverse", "gdg_debug_oversample_decimate", "gdg_profile_enable",
     "gdg_profile_read", "gdg_tuner_enqueue", "gdg_tuner_enqueue_device", "gdg_tuner_enqueue_staged", "gdg_tuner_analyze", "gdg_tuner_note_name",
     "gdg_spatializer_set_position", "gdg_spatializer_set_sample_rate", "gdg_spatialize", "gdg_spatialize_device", "gdg_spatialize_staged",
     "gdg_wave_bytes_per_sample", "gdg_wave_decode", "gdg_wave_decode_device", "gdg_wave_encode", "gdg_wave_encode_device",
@@ -122,6 +122,7 @@ def lib():
             "gdg_copy_rows_device": (i32, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]),
             "gdg_fft_real": (i32, [vp, vp, i32, vp]),
             "gdg_fft_real_inverse": (i32, [vp, vp, i32, vp]),
+            "gdg_debug_oversample_decimate": (i32, [vp, i32, vp, i32, vp, vp, vp]),
             "gdg_profile_enable": (i32, [vp, i32]),
             "gdg_profile_read": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(i32)]),
             "gdg_tuner_enqueue": (i32, [vp, vp, i32, u32]),
@@ -370,6 +371,15 @@ class Context:
         out = np.empty(2 * (x.size // 2 + 1), dtype=np.float64)
         self._check(lib().gdg_fft_real(self._h, x.ctypes.data, x.size, out.ctypes.data))
         return out.view(np.complex128)
+
+    def debug_oversample_decimate(self, factor, x, state):
+        """OversamplerDecimator.Oversample then Decimate on the HIP tiles (debug entry); `state` (8 + taps - 1 doubles, zeros = fresh) is updated in place.
+        Returns (oversampled, decimated)."""
+        x = _f64(x)
+        assert state.dtype == np.float64 and state.flags.c_contiguous
+        up, down = np.empty(factor * x.size), np.empty(x.size)
+        self._check(lib().gdg_debug_oversample_decimate(self._h, factor, x.ctypes.data, x.size, state.ctypes.data, up.ctypes.data, down.ctypes.data))
+        return up, down
 
     def fft_real_inverse(self, spectrum, n):
         s = np.ascontiguousarray(spectrum, dtype=np.complex128)

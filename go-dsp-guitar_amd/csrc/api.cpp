@@ -18,7 +18,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -42,26 +45,37 @@ static const int32_t g_param_default[GDG_UNIT_COUNT][GDG_MAX_PARAMS] = {
 
 /* Device memory of the per-unit state.  A 512-channel context owns ~17 000 blocks (per unit: small state, history ring, and per
  * power amp the overlap-save history, delay line, product spectra, frame counter, IR spectra); as one hipMalloc / hipFree each they
- * cost ~1 s to release and scatter the state over the address space.  They come out of a few large chunks instead (geometric growth
- * up to 1 GiB, 288 GB of HBM to draw on), sub-allocated on the host: first fit over an address-ordered free list that coalesces on
- * free.  No implicit synchronisation: whoever frees a block has already waited for the work that used it (every call site does).
- * Blocks are NOT zeroed (neither is hipMalloc'ed memory by contract): every site that needs zeros sets them. */
+ * cost ~1 s to release and scatter the state over the address space.  They come out of a few chunks instead (the first 4 MiB, every
+ * further one as large as everything before it, up to 1 GiB -- a one-channel context holds 4 MiB, a 512-channel one a dozen chunks),
+ * sub-allocated on the host: first fit over an address-ordered free list that coalesces on free.  No implicit synchronisation: whoever
+ * frees a block has already waited for the work that used it (every call site does; GDG_ARENA_SYNC_RELEASE=1 synchronises the device in
+ * release() to catch a call site that forgets to).
+ * ZEROS.  Almost every block starts out as zeros (unit state, history rings, delay lines), and one hipMemsetAsync per block was 14 338
+ * fill dispatches -- a third of the GPU time of a 512-channel context's set-up trace.  A chunk is zeroed ONCE, when it is made, and
+ * remembers how far it has been handed out (`virgin`): alloc_zeroed() on space beyond that mark is free, only recycled space is filled. */
 struct DevArena {
-    struct Chunk { char *base; size_t size; std::map<size_t, size_t> holes; };       /* holes: offset -> bytes */
+    struct Chunk { char *base; size_t size; std::map<size_t, size_t> holes; size_t virgin; };   /* holes: offset -> bytes; [virgin, size) was never handed out: zeros */
     std::vector<Chunk> chunks;
     std::map<const void *, std::pair<size_t, size_t>> live;                           /* block -> (chunk index, bytes) */
     size_t total = 0;
+    hipStream_t stream = nullptr;                                                      /* the context's stream: chunk zeroing and fills are ordered on it */
+    size_t fills = 0, fills_saved = 0;                                                 /* alloc_zeroed: fill dispatches issued / avoided */
     /* Blocks of a page or more start on `big_align` (env GDG_ARENA_ALIGN, default 4 KiB like a hipMalloc of their own would): the
      * streaming kernels read delay lines and spectra front to back, and packing those at 256-byte offsets behind the small state
      * blocks cost the convolution 5-13 % (profiles/arena_ab_r03.txt).  GDG_ARENA=0: one hipMalloc per block (A/B measurements). */
     size_t big_align = 4096;
-    bool direct = false;
+    size_t first_chunk = (size_t)4 << 20;
+    bool direct = false, sync_release = false;
     DevArena() {
         if (const char *e = getenv("GDG_ARENA_ALIGN")) { size_t a = (size_t)atoll(e); if (a >= 256 && (a & (a - 1)) == 0) big_align = a; }
         if (const char *e = getenv("GDG_ARENA")) direct = atoi(e) == 0;
+        if (const char *e = getenv("GDG_ARENA_FIRST_CHUNK")) { size_t a = (size_t)atoll(e); if (a >= 4096) first_chunk = a; }
+        if (const char *e = getenv("GDG_ARENA_SYNC_RELEASE")) sync_release = atoi(e) != 0;
     }
     static size_t round_up(size_t b, size_t a) { return (b + a - 1) & ~(a - 1); }
-    hipError_t alloc(void **out, size_t bytes) {
+    /* *zeroed (optional): the block is known to hold zeros (never handed out since its chunk was made) */
+    hipError_t alloc(void **out, size_t bytes, bool *zeroed = nullptr) {
+        if (zeroed) *zeroed = false;
         if (direct) return hipMalloc(out, bytes ? bytes : 1);
         const size_t need = round_up(bytes ? bytes : 1, 256);
         const size_t align = need >= 4096 ? big_align : 256;
@@ -77,23 +91,40 @@ struct DevArena {
                 if (end > at + need) h.emplace(at + need, end - (at + need));
                 *out = chunks[c].base + at;
                 live.emplace(*out, std::make_pair(c, need));
+                if (at >= chunks[c].virgin) { if (zeroed) *zeroed = true; chunks[c].virgin = at + need; }
                 return hipSuccess;
             }
         }
-        size_t size = std::max(need, std::min((size_t)1 << 30, std::max((size_t)64 << 20, total)));
+        size_t size = std::max(need, std::min((size_t)1 << 30, std::max(first_chunk, total)));
         void *base = nullptr;
         hipError_t e = hipMalloc(&base, size);
         if (e != hipSuccess && size > need) { size = need; e = hipMalloc(&base, size); }
         if (e != hipSuccess) { *out = nullptr; return e; }
+        /* zeros, once: ONE fill for everything this chunk will ever hand out for the first time.  Waited for: not every later writer
+         * of the chunk is ordered on `stream` (synchronous hipMemcpy's of tables run on the null stream). */
+        e = hipMemsetAsync(base, 0, size, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { hipFree(base); *out = nullptr; return e; }
         total += size;
-        chunks.push_back(Chunk{ static_cast<char *>(base), size, {} });        /* hipMalloc'ed chunks of >= 64 MiB start on 2 MiB */
+        chunks.push_back(Chunk{ static_cast<char *>(base), size, {}, need });     /* hipMalloc'ed chunks of >= 2 MiB start on 2 MiB */
         if (size > need) chunks.back().holes.emplace(need, size - need);
         *out = base;
         live.emplace(*out, std::make_pair(chunks.size() - 1, need));
+        if (zeroed) *zeroed = true;
         return hipSuccess;
+    }
+    /* a block of zeros; a fill is enqueued on `st` only when the space has been used before */
+    hipError_t alloc_zeroed(void **out, size_t bytes, hipStream_t st) {
+        bool zeroed = false;
+        hipError_t e = alloc(out, bytes, &zeroed);
+        if (e != hipSuccess) return e;
+        if (zeroed) { fills_saved++; return hipSuccess; }
+        fills++;
+        return hipMemsetAsync(*out, 0, bytes ? bytes : 1, st);
     }
     void release(const void *p) {
         if (!p) return;
+        if (sync_release) hipDeviceSynchronize();
         if (direct) { hipFree(const_cast<void *>(p)); return; }
         auto it = live.find(p);
         if (it == live.end()) return;
@@ -164,6 +195,8 @@ struct StepDesc {
 };
 
 struct ProfEvent { int kind; hipEvent_t a, b; };
+class CopyPool;
+static void destroy_copy_pool(CopyPool *p);
 
 struct gdg_ctx {
     int nch = 0, max_frames = 0, device = 0;
@@ -262,6 +295,7 @@ struct gdg_ctx {
     std::vector<hipStream_t> gstreams;
     std::vector<hipEvent_t> gjoin;
     hipEvent_t gfork = nullptr;
+    CopyPool *copy_pool = nullptr;             /* host copy workers of the host-buffer paths, made on first use */
     /* metronome (metronome/metronome.go): sounds in HBM, the two counters on the host */
     double *d_tick = nullptr, *d_tock = nullptr;
     uint32_t n_tick = 0, n_tock = 0;
@@ -354,6 +388,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ctx->sp_level.assign((size_t)n_channels, 1.0);
     size_t row = (size_t)n_channels * (size_t)max_frames * sizeof(double);
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    ctx->arena.stream = ctx->stream;
     ok = ok && hipMalloc((void **)&ctx->d_w0, row) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_w1, row) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_scratch, row) == hipSuccess;
@@ -404,6 +439,9 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (auto &u : ctx->units) if (u.alive) free_unit(ctx, u);
     ctx->spectra.clear();
+    if (const char *e = getenv("GDG_ARENA_TRACE")) if (atoi(e))
+        fprintf(stderr, "[arena] %d channels: %zu chunks, %.1f MiB, %zu blocks live, zero fills issued %zu, avoided %zu\n", ctx->nch, ctx->arena.chunks.size(),
+                (double)ctx->arena.total / 1048576.0, ctx->arena.live.size(), ctx->arena.fills, ctx->arena.fills_saved);
     ctx->arena.destroy();
     for (void *p : ctx->user_allocs) hipFree(p);
     for (auto &kv : ctx->fir_tables) { hipFree(kv.second.first); hipFree(kv.second.second); }
@@ -434,6 +472,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     if (ctx->h_stage_in) hipHostFree(ctx->h_stage_in);
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+    destroy_copy_pool(ctx->copy_pool);
     delete ctx;
     return GDG_OK;
 }
@@ -473,10 +512,8 @@ int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle) {
     u.type = unit_type;
     u.channel = channel;
     memcpy(u.params, g_param_default[unit_type], sizeof(u.params));
-    hipError_t e = ctx->arena.alloc((void **)&u.d_ds, GDG_DS_LEN * sizeof(double));
-    if (e == hipSuccess) e = ctx->arena.alloc((void **)&u.d_is, GDG_IS_LEN * sizeof(int));
-    if (e == hipSuccess) e = hipMemsetAsync(u.d_ds, 0, GDG_DS_LEN * sizeof(double), ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(u.d_is, 0, GDG_IS_LEN * sizeof(int), ctx->stream);
+    hipError_t e = ctx->arena.alloc_zeroed((void **)&u.d_ds, GDG_DS_LEN * sizeof(double), ctx->stream);
+    if (e == hipSuccess) e = ctx->arena.alloc_zeroed((void **)&u.d_is, GDG_IS_LEN * sizeof(int), ctx->stream);
     if (e != hipSuccess) {
         hipStreamSynchronize(ctx->stream);
         free_unit(ctx, u);          /* the slot goes back to "not alive"; nothing leaks */
@@ -571,8 +608,7 @@ static int ensure_hist(gdg_ctx *ctx, Unit &u, size_t len, long long key) {
     u.hist_len = len;
     u.hist_key = key;
     if (len > 0) {
-        HIP_TRY(ctx, ctx->arena.alloc((void **)&u.d_hist, len * sizeof(double)));
-        HIP_TRY(ctx, hipMemsetAsync(u.d_hist, 0, len * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, ctx->arena.alloc_zeroed((void **)&u.d_hist, len * sizeof(double), ctx->stream));
     }
     return GDG_OK;
 }
@@ -1116,13 +1152,10 @@ static int prepare_fir(gdg_ctx *ctx, Unit &u, int hop, uint32_t sample_rate) {
             arena.release(d_jobs); d_jobs = nullptr;
         }
         size_t spec = (size_t)R * (size_t)P * sizeof(double2);
-        HIP_TRY(ctx, arena.alloc((void **)&u.d_prev, 2 * (size_t)P * sizeof(double)));
-        HIP_TRY(ctx, arena.alloc((void **)&u.d_fdl, spec));
+        HIP_TRY(ctx, arena.alloc_zeroed((void **)&u.d_prev, 2 * (size_t)P * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, arena.alloc_zeroed((void **)&u.d_fdl, spec, ctx->stream));
         HIP_TRY(ctx, arena.alloc((void **)&u.d_Y, (size_t)W * (size_t)P * sizeof(double2)));
-        HIP_TRY(ctx, arena.alloc((void **)&u.d_pos, sizeof(int)));
-        HIP_TRY(ctx, hipMemsetAsync(u.d_prev, 0, 2 * (size_t)P * sizeof(double), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(u.d_fdl, 0, spec, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(u.d_pos, 0, sizeof(int), ctx->stream));
+        HIP_TRY(ctx, arena.alloc_zeroed((void **)&u.d_pos, sizeof(int), ctx->stream));
         int r = fir_spectra(ctx, u, hop, P, K);
         if (r != GDG_OK) return r;
         if (carry) {
@@ -1357,6 +1390,34 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     return GDG_OK;
 }
 
+/* ---- debug: the oversampler / decimator tiles on their own ------------------------------------------------------------ */
+
+int gdg_debug_oversample_decimate(gdg_ctx *ctx, int factor, const double *in, int n, double *state, double *oversampled, double *decimated) {
+    if (!ctx || !in || !state || !decimated) return GDG_ERR_INVALID;
+    if (factor != 2 && factor != 4) return fail(ctx, GDG_ERR_INVALID, "oversampling factor %d: 2 or 4", factor);
+    if (n <= 0 || n > GDG_MAX_FRAMES) return fail(ctx, GDG_ERR_INVALID, "%d samples: 1 to %d", n, GDG_MAX_FRAMES);
+    enter(ctx);
+    const size_t n_state = 8 + (size_t)GDG_OS_TAPS(factor) - 1, n_up = (size_t)factor * (size_t)n;
+    double *d = nullptr;                                      /* [in | state | up | down] */
+    HIP_TRY(ctx, hipMalloc((void **)&d, ((size_t)n + n_state + n_up + (size_t)n) * sizeof(double)));
+    double *d_in = d, *d_state = d + n, *d_up = d_state + n_state, *d_down = d_up + n_up;
+    int rc = GDG_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(d_in, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_state, state, n_state * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, gdg_launch_os_debug(factor, d_in, n, d_state, d_up, d_down, ctx->os, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(state, d_state, n_state * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (oversampled) HIP_TRY(ctx, hipMemcpyAsync(oversampled, d_up, n_up * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(decimated, d_down, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return GDG_OK;
+    };
+    rc = body();
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    return rc;
+}
+
 /* ---- profiling -------------------------------------------------------------------------------------- */
 
 static hipEvent_t take_event(gdg_ctx *ctx) {
@@ -1427,17 +1488,32 @@ static std::vector<size_t> equal_group_bounds(size_t n, int G) {
     return b;
 }
 
-/* Groups of the host-buffer calls.  The first group's upload and the last group's download are the two transfers nothing overlaps,
- * so the outer groups are SMALL and the inner ones large: weights 1 : 2 : 1 ... (env GDG_PCIE_WEIGHTS, e.g. "1,3,3,1", also sets the
- * group count).  Measured: profiles/host_path_groups_r03.txt. */
-static std::vector<size_t> pcie_group_bounds(size_t n, int *G_io) {
-    static std::vector<int> forced = []() {
-        std::vector<int> w;
-        if (const char *e = getenv("GDG_PCIE_WEIGHTS")) {
-            for (const char *p = e; *p;) { int v = atoi(p); if (v > 0) w.push_back(v); while (*p && *p != ',') p++; if (*p == ',') p++; }
+/* Groups of the host-buffer calls: EQUAL shares by default (two of them from 128 channels on, pcie_groups).  The first group's upload
+ * and the last group's download are the two transfers nothing overlaps, so small outer and large inner groups looked attractive
+ * (1 : 2 : 1, 1 : 3 : 3 : 1) -- measured slower than two equal groups (profiles/host_path_weights_r03.txt) and kept only as an experiment
+ * knob: env GDG_PCIE_WEIGHTS="1,3,3,1" sets weights AND the group count.  A malformed list (an entry that is not a positive integer)
+ * is refused as a whole, with one line on stderr -- never half applied. */
+static std::vector<int> parse_pcie_weights(const char *e) {
+    std::vector<int> w;
+    if (!e || !*e) return w;
+    for (const char *p = e;;) {
+        char *end = nullptr;
+        long v = strtol(p, &end, 10);
+        while (end && (*end == ' ' || *end == '\t')) end++;
+        if (end == p || v <= 0 || v > 1000000 || (end && *end && *end != ',')) {
+            fprintf(stderr, "libgdg: GDG_PCIE_WEIGHTS=\"%s\" is not a comma-separated list of positive integers: ignored (equal groups)\n", e);
+            return std::vector<int>();
         }
-        return w;
-    }();
+        w.push_back((int)v);
+        if (!*end) break;
+        p = end + 1;
+        if (!*p) { fprintf(stderr, "libgdg: GDG_PCIE_WEIGHTS=\"%s\" ends in a comma: ignored (equal groups)\n", e); return std::vector<int>(); }
+    }
+    if (w.size() > 16) { fprintf(stderr, "libgdg: GDG_PCIE_WEIGHTS names %zu groups, at most 16: ignored (equal groups)\n", w.size()); w.clear(); }
+    return w;
+}
+static std::vector<size_t> pcie_group_bounds(size_t n, int *G_io) {
+    static std::vector<int> forced = parse_pcie_weights(getenv("GDG_PCIE_WEIGHTS"));
     int G = *G_io;
     std::vector<int> w = forced;
     if (!w.empty()) G = (int)w.size();
@@ -1674,16 +1750,27 @@ static int ensure_staging(gdg_ctx *ctx) {
 
 /* Host copy workers.  One core moves pageable memory at ~10 GB/s, which made the 2 x 32 MiB of a 512-channel block cost 3 ms -- more
  * than the whole chain -- so staging copies are spread over a few threads (env GDG_COPY_THREADS, default 8).  The workers are
- * PERSISTENT: a pool created on first use and parked on a condition variable between jobs (spawning and joining std::threads on
- * every call cost 60-100 us per call, twice per block).  One job at a time; a caller that finds the pool busy (another shard's
- * thread is copying) runs its slices itself -- the shards' copies are parallel with each other anyway.  The pool is never
- * destroyed: its threads are parked when the process exits. */
+ * PERSISTENT: created on a context's first host-buffer call and parked on a condition variable between jobs (spawning and joining
+ * std::threads on every call cost 60-100 us per call, twice per block).  One pool PER CONTEXT since round 4: with one process-wide
+ * pool only one of G shards copying at the same time got the workers and the others copied on their caller's thread alone
+ * (the reference's deployment is G shards in one process, controller.go:3262-3269).  Joined and freed with the context.
+ * fork(): a child inherits the pool object but none of its threads; it finds another pid in the pool and copies inline. */
 class CopyPool {
 public:
-    explicit CopyPool(int workers) {
+    explicit CopyPool(int workers) : pid_(getpid()) {
         for (int i = 0; i < workers; i++) threads_.emplace_back([this, i]() { loop((size_t)i + 1); });
     }
+    ~CopyPool() {
+        if (pid_ != getpid()) { for (auto &t : threads_) t.detach(); return; }      /* forked child: the threads do not exist here */
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true; gen_++;
+        }
+        cv_work_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
     size_t slots() const { return threads_.size() + 1; }
+    bool usable() const { return pid_ == getpid(); }
     /* slice t of T runs fn(t); the caller takes slice 0 and returns when all slices are done */
     void run(size_t T, const std::function<void(size_t)> &fn) {
         if (T <= 1) { fn(0); return; }
@@ -1707,6 +1794,7 @@ private:
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_work_.wait(lk, [&]() { return gen_ != seen; });
+                if (stop_) return;
                 seen = gen_;
                 if (slot < T_) fn = fn_;
             }
@@ -1722,27 +1810,31 @@ private:
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t T_ = 0, pending_ = 0;
     uint64_t gen_ = 0;
+    bool stop_ = false;
+    pid_t pid_;
 };
 
-static CopyPool &copy_pool() {
-    static CopyPool *pool = []() {
+static void destroy_copy_pool(CopyPool *p) { delete p; }
+
+static CopyPool &copy_pool(gdg_ctx *ctx) {
+    if (!ctx->copy_pool) {
         const char *e = getenv("GDG_COPY_THREADS");
         int threads = e ? atoi(e) : 8;
         unsigned hw = std::thread::hardware_concurrency();
         if (hw > 0 && threads > (int)hw) threads = (int)hw;
         if (threads < 1) threads = 1;
-        return new CopyPool(threads - 1);
-    }();
-    return *pool;
+        ctx->copy_pool = new CopyPool(threads - 1);
+    }
+    return *ctx->copy_pool;
 }
 
 /* rows [a, b) of a host-side staging copy, spread over the copy workers (at least ~1 MiB per thread) */
-static void copy_rows_parallel(size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes) {
+static void copy_rows_parallel(gdg_ctx *ctx, size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes) {
     size_t n = b > a ? b - a : 0;
     if (n == 0) return;
-    CopyPool &pool = copy_pool();
+    CopyPool &pool = copy_pool(ctx);
     size_t T = std::min(pool.slots(), n * row_bytes / (1u << 20) + 1);
-    if (T <= 1 || n < 2) { for (size_t i = a; i < b; i++) copy_row(i); return; }
+    if (T <= 1 || n < 2 || !pool.usable()) { for (size_t i = a; i < b; i++) copy_row(i); return; }
     pool.run(T, [&](size_t t) { for (size_t i = a + n * t / T; i < a + n * (t + 1) / T; i++) copy_row(i); });
 }
 
@@ -1768,7 +1860,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           /* the staging slabs may still be in use */
     GroupHook before = [&](int g, hipStream_t s) -> hipError_t {
         size_t a = lo(g), b = lo(g + 1);
-        copy_rows_parallel(a, b, [&](size_t i) { memcpy(ctx->h_stage_in + i * row, in[i], row * sizeof(double)); }, row * sizeof(double));
+        copy_rows_parallel(ctx, a, b, [&](size_t i) { memcpy(ctx->h_stage_in + i * row, in[i], row * sizeof(double)); }, row * sizeof(double));
         if (b == a) return hipSuccess;
         return hipMemcpyAsync(ctx->d_stage_in + a * row, ctx->h_stage_in + a * row, (b - a) * row * sizeof(double), hipMemcpyHostToDevice, s);
     };
@@ -1788,7 +1880,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     for (int g = 0; g < G; g++) {
         if (G > 1) HIP_TRY(ctx, hipStreamSynchronize(ctx->gstreams[(size_t)g]));
         else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        copy_rows_parallel(lo(g), lo(g + 1), [&](size_t i) { memcpy(out[i], ctx->h_stage_out + i * row, row * sizeof(double)); }, row * sizeof(double));
+        copy_rows_parallel(ctx, lo(g), lo(g + 1), [&](size_t i) { memcpy(out[i], ctx->h_stage_out + i * row, row * sizeof(double)); }, row * sizeof(double));
     }
     return check_device_error(ctx);
 }
@@ -2101,6 +2193,8 @@ const char *gdg_tuner_note_name(int note_index) { return (note_index >= 0 && not
 static int ensure_spatializer(gdg_ctx *ctx) {
     if (ctx->d_sp_hist) return GDG_OK;
     ctx->sp_hist_len = (int)ceil((double)ctx->sp_hist_sr * SPAT_GROUP_DELAY);
+    if (ctx->sp_hist_len > 1024)       /* the mix kernel's limit (spat.hip): rates beyond 1.6 MHz */
+        return fail(ctx, GDG_ERR_UNSUPPORTED, "spatializer history of %d samples (rate %u Hz): at most 1024 (rates up to 1 625 000 Hz)", ctx->sp_hist_len, ctx->sp_hist_sr);
     size_t hist_bytes = 2 * (size_t)ctx->nch * (size_t)ctx->sp_hist_len * sizeof(double);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sp_hist, hist_bytes));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_sp_hist, 0, hist_bytes, ctx->stream));
@@ -2718,10 +2812,10 @@ static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes, size_t up_half_byt
 
 /* host memcpy pieces (dst, src, bytes), spread over the copy threads */
 struct BatchPiece { unsigned char *dst; const unsigned char *src; size_t bytes; };
-static void move_pieces(const std::vector<BatchPiece> &pieces) {
+static void move_pieces(gdg_ctx *ctx, const std::vector<BatchPiece> &pieces) {
     size_t total = 0;
     for (auto &p : pieces) total += p.bytes;
-    copy_rows_parallel(0, pieces.size(), [&](size_t i) { memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); },
+    copy_rows_parallel(ctx, 0, pieces.size(), [&](size_t i) { memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); },
                        pieces.empty() ? 0 : total / pieces.size());
 }
 
@@ -2851,7 +2945,7 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
                 for (size_t q = s0; q < s1; q += (size_t)1 << 20)                 /* pieces of <= 1 MiB */
                     pieces.push_back({ ctx->h_batch[h] + (q - lo), static_cast<const unsigned char *>(in.bytes) + (q - a), std::min(s1 - q, (size_t)1 << 20) });
             }
-            move_pieces(pieces);
+            move_pieces(ctx, pieces);
             HIP_TRY(ctx, hipMemcpyAsync(d_arena + lo, ctx->h_batch[h], hi - lo, hipMemcpyHostToDevice, ctx->batch_stream));
             HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
             used[h] = 1;
@@ -2889,7 +2983,7 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
             const unsigned char *src = ctx->h_batch[i & 1];
             const size_t wb = (size_t)steps[i].w * B, row_bytes = wb * out_width, at = steps[i].off * out_width;
             const size_t f64_at = ((size_t)enc_rows * row_bytes + 15) & ~(size_t)15;
-            copy_rows_parallel(0, (size_t)enc_rows + (size_t)f64_rows, [&](size_t o) {
+            copy_rows_parallel(ctx, 0, (size_t)enc_rows + (size_t)f64_rows, [&](size_t o) {
                 if (o < (size_t)enc_rows) {
                     /* NULL: "skipping output" (:3143); a shard's row N is the metronome track */
                     void *dst = (sharded && o == (size_t)N) ? shard->metronome_bytes : out_bytes[o];
@@ -2931,7 +3025,7 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
             }
             up_used[h] = 1;
             if (n_rows) {
-                move_pieces(pieces);
+                move_pieces(ctx, pieces);
                 HIP_TRY(ctx, hipMemcpyAsync(db, hb, cur, hipMemcpyHostToDevice, ctx->batch_up_stream));
                 HIP_TRY(ctx, gdg_launch_wave_decode_rows(reinterpret_cast<const gdg_decode_row *>(db), n_rows, max_count, ctx->batch_up_stream));
             }
@@ -3032,6 +3126,11 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
 int gdg_batch_run_shard(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *opt, void *const *out_bytes,
                         const gdg_batch_shard_out *shard) {
     if (!shard) return GDG_ERR_INVALID;
+    /* a shard's master mix is a PARTIAL sum: the aux input joins the master once, in gdg_batch_finish_master (its `aux` = the float64
+     * metronome track of the shard that ran it).  A set flag here would be silently dropped -- refuse it instead. */
+    if (ctx && opt && opt->metronome_to_master)
+        return fail(ctx, GDG_ERR_INVALID, "gdg_batch_run_shard: metronome_to_master must be 0 -- a shard's master mix is a partial sum; pass the metronome's float64 "
+                    "track (gdg_batch_shard_out.metronome of the shard that runs it) as `aux` to gdg_batch_finish_master");
     return batch_run_impl(ctx, inputs, n_inputs, opt, out_bytes, shard);
 }
 

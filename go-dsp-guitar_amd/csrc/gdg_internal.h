@@ -155,6 +155,7 @@ struct gdg_os_tables {
 
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
                           gdg_os_tables os, int *d_error, hipStream_t s);
+hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_hist, double *d_up, double *d_down, gdg_os_tables os, hipStream_t s);
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);
 

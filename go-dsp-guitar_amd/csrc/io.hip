@@ -172,10 +172,12 @@ meter_kernel(const double *__restrict__ rows, size_t stride, int n, gdg_meter_re
     const int tid = threadIdx.x;
     gdg_meter_rec *m = st + blockIdx.x;
     const double *x = rows + (size_t)blockIdx.x * stride;
+    /* a disabled port's row is never touched: gdg_meter_process_device takes caller-supplied rows, and a caller may leave the rows of
+     * disabled ports unbacked (`enabled` is uniform over the workgroup: one scalar load in front of the row loads) */
+    if (!m->enabled) return;
     double t[METER_CHK];
 #pragma unroll
     for (int k = 0; k < METER_CHK; k++) { const int i = tid + METER_T * k; t[k] = (i < n) ? x[i] : 0.0; }     /* in flight while the tables are made */
-    if (!m->enabled) return;
     const double c0 = m->current, p0 = m->peak;
     const unsigned long long cnt0 = m->counter;
     const int base = tid * METER_CHK;

@@ -664,9 +664,11 @@ __device__ __forceinline__ void os_decimate(const double *stage, const GDG_CONST
     (void)BACK; (void)PADLO;
 }
 
-template <int F>
+/* DBG (gdg_debug_oversample_decimate only): no waveshaper between the two halves, and the oversampled stream -- sample F i + r of the
+ * call = phase r of input slot i -- also goes to `dbg_up`, so that oversampling_test.go's vectors meet these tiles directly */
+template <int F, bool DBG = false>
 __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, double *stage, double *scr, double *hist_generic,
-                                                   const double *taps_generic, const double *lw_generic, int N) {
+                                                   const double *taps_generic, const double *lw_generic, int N, double *dbg_up = nullptr) {
     constexpr int TAPS = OsCfg<F>::TAPS, BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, TILE = OsCfg<F>::S, PH = OsCfg<F>::PH;
     /* wave-uniform table pointers in SGPRs + constant address space: the taps arrive through scalar loads */
     const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);      /* phase-major, zero padded */
@@ -704,13 +706,15 @@ __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, 
                 double w6[6];
 #pragma unroll
                 for (int t = 0; t < 6; t++) w6[t] = s_at(i - 6 + t);
-                stage[idx] = shape(S, w6[2]);                 /* phase 0: s[i - 4], resample.go:160-164 */
+                stage[idx] = DBG ? w6[2] : shape(S, w6[2]);   /* phase 0: s[i - 4], resample.go:160-164 */
+                if (DBG && idx >= BACK) dbg_up[F * i] = w6[2];
 #pragma unroll
                 for (int r = 1; r < F; r++) {
                     double up = 0.0;
 #pragma unroll
                     for (int t = 0; t < 6; t++) up += w6[t] * lw[(r - 1) * 6 + t];
-                    stage[r * PH + idx] = shape(S, up);
+                    stage[r * PH + idx] = DBG ? up : shape(S, up);
+                    if (DBG && idx >= BACK) dbg_up[F * i + r] = up;
                 }
             }
         }
@@ -2103,6 +2107,28 @@ UNIT_FN unit_noisegate(UNIT_ARGS) {
         since++;
     }
     if (c1 == N && c0 < N) { U->is[0] = gate; U->is[1] = since; }
+}
+
+/* ---- debug: the oversampler / decimator tiles on their own (gdg_debug_oversample_decimate) ------------------------------------
+ * OversamplerDecimator.Oversample followed by Decimate on its output (oversampling/oversampling_test.go:84-128 does exactly that):
+ * `hist` = the object's state ([8 inputs | TAPS - 1 oversampled samples], zeros = a fresh object), `up` F N samples, `down` N. */
+template <int F>
+__global__ void __launch_bounds__(SEG_T)
+os_debug_kernel(const double *__restrict__ in, int N, double *hist, double *__restrict__ up, double *__restrict__ down, gdg_os_tables os) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = in[i];
+    __syncthreads();
+    Shaper S = {};
+    shaper_oversampled<F, true>(S, s_a, s_b, s_scr, hist, F == 2 ? os.tapsP2 : os.tapsP4, F == 2 ? os.lanczos2 : os.lanczos4, N, up);
+    __syncthreads();
+    for (int i = tid; i < N; i += SEG_T) down[i] = s_a[LX(i)];
+}
+
+hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_hist, double *d_up, double *d_down, gdg_os_tables os, hipStream_t s) {
+    if (factor == 2) hipLaunchKernelGGL(os_debug_kernel<2>, dim3(1), dim3(SEG_T), 0, s, d_in, n, d_hist, d_up, d_down, os);
+    else if (factor == 4) hipLaunchKernelGGL(os_debug_kernel<4>, dim3(1), dim3(SEG_T), 0, s, d_in, n, d_hist, d_up, d_down, os);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */

@@ -16,13 +16,16 @@
 #define SPAT_SUB 16                      /* channel groups a workgroup works on at the same time (512 threads = 32 samples x 16) */
 #define SPAT_T (SPAT_TILE * SPAT_SUB)
 #define SPAT_UNROLL 16                   /* channels whose loads are in flight together */
-#define SPAT_MAX_GROUPS 128              /* 2048 channels per shard (32 KiB of group partials in LDS) */
+#define SPAT_MAX_GROUPS 64               /* group partials held in LDS at a time: 64 x 2 x 32 doubles = 32 KiB = 1024 channels per round;
+                                          * wider shards take several rounds (any channel count runs) */
 #define SPAT_LDS_DESC_MAX 512             /* up to this many channels the descriptors are staged in LDS (24 KiB), beyond it read from HBM */
 
 /* ONE launch per block (round 2: partial sums, reduce and history update were three launches, 23 us per 8192-frame block of 256
  * channels, all latency).  Workgroup t < tiles mixes samples [32 t, 32 t + 32): lane (s, q) sums channel groups q, q + 16, ... of 16
- * channels each in channel order, the group partials meet in LDS and are added in group order -- the same association as before, so
- * the same bits.  The history (last H inputs of every channel, spatializer.go:313-331) is double buffered: this block reads
+ * channels each in channel order, the group partials meet in LDS and are added in group order (an association of its own: groups of
+ * 16 since late in round 3, of 32 before -- results differ from those versions in the last bits, ~1e-16 N, as they do from the reference's
+ * plain channel order).  Shards of more than SPAT_MAX_GROUPS groups go through the LDS partials in rounds; the running sums carry over,
+ * so the order of additions -- and the bits -- do not depend on the round size.  The history (last H inputs of every channel, spatializer.go:313-331) is double buffered: this block reads
  * `hist_read` and the workgroups t >= tiles write `hist_write`, so nobody waits for anybody inside the launch. */
 template <bool LDS_DESC>
 __global__ void __launch_bounds__(SPAT_TILE * SPAT_SUB)
@@ -50,7 +53,11 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
         __syncthreads();
     }
 #define s_ch (LDS_DESC ? (const gdg_spat_chan *)l_ch : chans)
-    for (int g = q; g < groups; g += SPAT_SUB) {
+    const int side = tid / SPAT_TILE, jj = blockIdx.x * SPAT_TILE + s;      /* the 2 x 32 finishing threads: (side, sample) */
+    double acc = 0.0;
+    for (int g0 = 0; g0 < groups; g0 += SPAT_MAX_GROUPS) {
+    const int g1 = min(groups, g0 + SPAT_MAX_GROUPS);
+    for (int g = g0 + q; g < g1; g += SPAT_SUB) {
         const int c_begin = g * SPAT_GROUP, c_end = min(nch, c_begin + SPAT_GROUP);
         double L = 0.0, R = 0.0;
         /* SPAT_UNROLL channels at a time: all their loads (current sample, the two neighbours of the delayed one -- from the block or from
@@ -85,30 +92,27 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
                 }
             }
         }
-        part[(g * 2 + 0) * SPAT_TILE + s] = L;
-        part[(g * 2 + 1) * SPAT_TILE + s] = R;
+        part[((g - g0) * 2 + 0) * SPAT_TILE + s] = L;
+        part[((g - g0) * 2 + 1) * SPAT_TILE + s] = R;
     }
     __syncthreads();
-    if (tid < 2 * SPAT_TILE) {
-        const int side = tid / SPAT_TILE, jj = blockIdx.x * SPAT_TILE + s;
-        if (jj < frames) {
-            double acc = 0.0;
-            for (int g = 0; g < groups; g++) acc += part[(g * 2 + side) * SPAT_TILE + s];
-            out_lr[(size_t)side * out_stride + jj] = acc;
-        }
+    if (tid < 2 * SPAT_TILE)
+        for (int g = g0; g < g1; g++) acc += part[((g - g0) * 2 + side) * SPAT_TILE + s];
+    if (g1 < groups) __syncthreads();                    /* the next round overwrites the partials */
     }
+    if (tid < 2 * SPAT_TILE && jj < frames) out_lr[(size_t)side * out_stride + jj] = acc;
 }
 
 #undef s_ch
 
 hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const double *d_in, int in_stride, const double *d_hist_read,
                                   double *d_hist_write, int H, double *d_out_lr, int out_stride, int frames, hipStream_t s) {
-    if (H > 1024 || nch > SPAT_MAX_GROUPS * SPAT_GROUP) return hipErrorInvalidValue;
+    if (H > 1024 || nch < 1) return hipErrorInvalidValue;
     const int tiles = (frames + SPAT_TILE - 1) / SPAT_TILE;
     int hist_blocks = (nch * H + 2047) / 2048;                    /* eight entries per thread */
     if (hist_blocks < 1) hist_blocks = 1;
     const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
-    const size_t part_bytes = (size_t)groups * 2 * SPAT_TILE * sizeof(double);
+    const size_t part_bytes = (size_t)(groups < SPAT_MAX_GROUPS ? groups : SPAT_MAX_GROUPS) * 2 * SPAT_TILE * sizeof(double);
     if (nch <= SPAT_LDS_DESC_MAX)
         spat_kernel<true><<<dim3(tiles + hist_blocks), dim3(SPAT_T), part_bytes + (size_t)nch * sizeof(gdg_spat_chan), s>>>(d_chans, nch, d_in, in_stride, d_hist_read, d_hist_write, H, d_out_lr, out_stride, frames, tiles);
     else

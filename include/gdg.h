@@ -207,6 +207,16 @@ int gdg_copy_rows_device(gdg_ctx *ctx, double *d_dst, size_t dst_stride, const d
 int gdg_fft_real(gdg_ctx *ctx, const double *samples, int n, double *spectrum);
 int gdg_fft_real_inverse(gdg_ctx *ctx, const double *spectrum, int n, double *samples);
 
+/*
+ * Debug entry: oversampling.OversamplerDecimator (oversampling/oversampling.go:27-30) as the 2x / 4x units' LDS tiles compute it --
+ * Oversample (:54-115: Lanczos-3 polyphase, 8 inputs of history) followed by Decimate of ITS output (:126-184: 77 / 155-tap
+ * anti-aliasing filter, clip, stride-f pick, x 0.944...), with no waveshaper in between: exactly the sequence
+ * oversampling/oversampling_test.go:84-128 checks, so the reference's own vectors run on the HIP tiles.
+ * factor 2 or 4; n <= 8192 samples in; `state` = the object's state across calls, 8 + (77 or 155) - 1 doubles, zeros = a fresh
+ * object (in / out); oversampled: factor * n samples out (may be NULL); decimated: n samples out.  Host buffers, blocking.
+ */
+int gdg_debug_oversample_decimate(gdg_ctx *ctx, int factor, const double *in, int n, double *state, double *oversampled, double *decimated);
+
 /* ---- per-kernel timing on the context's stream (HIP events), for bench.py's roofline ---------- */
 
 enum gdg_kernel_kind {
@@ -361,10 +371,14 @@ int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, con
  * gdg_batch_run_shard = gdg_batch_run except: out_bytes holds the shard's n_inputs chain outputs only; master_left / master_right
  * receive gdg_batch_length() float64 samples each (this shard's channels mixed, NO aux, not clipped); the metronome runs on the
  * shard that passes metronome_bytes (its encoded track, the N + 3rd file) and / or metronome (the float64 track = the master's aux
- * input when metrMasterOutput is set) -- exactly one shard should; with run_meters the context carries 2 n + 3 ports of which a
+ * input when metrMasterOutput is set) -- exactly one shard should; options->metronome_to_master must be 0 here (GDG_ERR_INVALID
+ * otherwise: the aux input joins the master once, as `aux` of gdg_batch_finish_master); with run_meters the context carries 2 n + 3 ports of which a
  * shard feeds its inputs, its outputs and, if it runs it, the metronome.
  * gdg_batch_finish_master: master = ((p_0 + p_1) + ... + p_{G-1}) + aux per side, summed and encoded on ctx's device (aux may be
- * NULL; left_bytes / right_bytes NULL = "skipping output"); run_meters != 0 feeds the two LAST ports of ctx's meters with the
+ * NULL; left_bytes / right_bytes NULL = "skipping output").  The shards' partial sums are associated differently from the single
+ * context's sum over all channels (groups of 16 channels per shard, then shard order), so the sharded master equals gdg_batch_run's
+ * to ~1e-16 relative, not bit for bit: a sample that sits on a 24- or 32-bit code boundary may come out one code apart.
+ * run_meters != 0 feeds the two LAST ports of ctx's meters with the
  * finished master, block by block.
  */
 typedef struct {

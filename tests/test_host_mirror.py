@@ -294,15 +294,38 @@ def test_spatializer_interface_and_error_strings(host):
     eng.close()
 
 
+def _every_visible_device(host):
+    """One shard per visible HIP device -- the reference's actual deployment: N chains over the GPUs of one node inside ONE process
+    (controller/controller.go:3262-3269, :3333-3341).  Skips on a one-GPU box, where the three-contexts-on-device-0 variants stand in."""
+    pkg = entry.load_package()
+    n = pkg.lib().gdg_device_count()
+    if n < 2:
+        pytest.skip("needs at least two HIP devices (%d visible)" % n)
+    return list(range(n))
+
+
 @pytest.mark.gpu
 def test_sharded_engine_matches_oracle(host, oracle):
     """Three shards (three independent contexts on device 0) behind ONE rendezvous: the Go shim's N/8 routing, on one GPU."""
-    sr, frames, nch, blocks = 48000, 1024, 7, 3
+    _sharded_engine_case(host, oracle, [0, 0, 0], 7)
+
+
+@pytest.mark.gpu
+def test_sharded_engine_on_every_visible_device_matches_oracle(host, oracle):
+    """The same with G = hipGetDeviceCount() shards on G REAL devices driven from one process (hipSetDevice per call, one copy pool per
+    context): 2 G + 1 channels, so that the blocks are uneven."""
+    devices = _every_visible_device(host)
+    _sharded_engine_case(host, oracle, devices, 2 * len(devices) + 1)
+
+
+def _sharded_engine_case(host, oracle, devices, nch):
+    sr, frames, blocks = 48000, 1024, 3
     taps = {"Cab": synth_ir(2000, seed=3), "Room": synth_ir(5000, seed=4)}
     irs = host.ImpulseResponses()
     irs.add("Cab", sr, -20, taps["Cab"])
     irs.add("Room", sr, -10, taps["Room"])
-    eng = host.Engine(nch, frames, devices=[0, 0, 0])
+    eng = host.Engine(nch, frames, devices=devices)
+    assert eng.shards() == min(len(devices), nch)
     chains, refs = [], []
     for c in range(nch):
         ch, ref = eng.create_chain(irs), oracle.Chain()
@@ -506,6 +529,17 @@ def test_control_plane_setters_race_with_processing(host, oracle):
 
 @pytest.mark.gpu
 def test_engine_batch_run_over_three_shards_matches_the_oracle_pipeline(host, oracle):
+    _engine_batch_case(host, oracle, [0, 0, 0])
+
+
+@pytest.mark.gpu
+def test_engine_batch_run_on_every_visible_device_matches_the_oracle_pipeline(host, oracle):
+    """Engine::BatchRun with one shard per REAL device (skipped below two devices): every shard's gdg_batch_run_shard runs on its own GPU at the
+    same time, the float64 partial master mixes meet on shard 0's device."""
+    _engine_batch_case(host, oracle, _every_visible_device(host)[:7])
+
+
+def _engine_batch_case(host, oracle, devices):
     """Engine::BatchRun (= what the Go shim's patched controller.processFiles calls): file bytes in, file bytes out, seven channels over
     THREE shards (three contexts on device 0), windows of 4 blocks, the master finished once from the shards' float64 partial mixes +
     the metronome as aux input (spatializer.go:300-310, controller.go:3123-3219).  Against the oracle's pipeline: decode ->
@@ -517,7 +551,7 @@ def test_engine_batch_run_over_three_shards_matches_the_oracle_pipeline(host, or
     irs = host.ImpulseResponses()
     irs.add("Cab", sr, -20, taps["Cab"])
     irs.add("Room", sr, -10, taps["Room"])
-    eng = host.Engine(nch, BLOCK, devices=[0, 0, 0])
+    eng = host.Engine(nch, BLOCK, devices=devices)
     chains, refs = [], []
     for c in range(nch):
         ch, ref = eng.create_chain(irs), oracle.Chain()

@@ -151,3 +151,43 @@ def test_hip_fft_small_sizes_against_numpy(n):
         assert np.max(np.abs(got - ref)) <= 1e-14 * max(1.0, np.max(np.abs(ref)))
         assert np.max(np.abs(ctx.fft_real_inverse(ref, n) - x)) <= 1e-14
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factor,name", [(2, "TestTwoTimesOversampling"), (4, "TestFourTimesOversampling")])
+def test_hip_oversampler_tiles_reproduce_the_reference_tests_own_vectors(golden, factor, name):
+    """oversampling/oversampling_test.go:48-131 / :136-219 on the HIP tiles (gdg_debug_oversample_decimate): four sequential frames through ONE
+    object -- Oversample, compare, Decimate the oversampled frame, compare -- at the reference's tolerance 1e-7 (:33).  Rows a19 / a20 met these
+    vectors only through the oracle before."""
+    pkg = package()
+    ctx = pkg.Context(1, 64)
+    t = golden("oversampling")["tests"][name]
+    state = np.zeros(8 + (77 if factor == 2 else 155) - 1)
+    for x, up_want, down_want in zip(t["in"]["value"], t["oversampledExpected"]["value"], t["decimatedExpected"]["value"]):
+        up, down = ctx.debug_oversample_decimate(factor, np.array(x), state)
+        np.testing.assert_allclose(up, up_want, atol=1e-7, rtol=0)
+        np.testing.assert_allclose(down, down_want, atol=1e-7, rtol=0)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("sizes", [[8192, 8192, 8192], [1000, 37, 4096, 5, 8192, 1], [64] * 12])
+def test_hip_oversampler_tiles_follow_the_oracle_object(oracle, factor, sizes):
+    """The same entry against the oracle's OversamplerDecimator over frames that exercise full tiles, partial tiles, frames shorter than the
+    8-sample history and the carried state (the oracle object is pinned by the vectors above: tests/test_oracle_golden.py)."""
+    pkg = package()
+    ctx = pkg.Context(1, 8192)
+    osd = oracle.OversamplerDecimator(factor)
+    state = np.zeros(8 + (77 if factor == 2 else 155) - 1)
+    rng = np.random.default_rng(factor)
+    for k, n in enumerate(sizes):
+        x = rng.uniform(-1.2, 1.2, n)                        # beyond full scale: the decimator's clip takes part
+        if k > 0 and n != sizes[k - 1]:
+            state[:8] = 0.0                                   # bufferPreUpsampling is re-made when the frame size changes (oversampling.go:86-89; api.cpp does the same)
+        up, down = ctx.debug_oversample_decimate(factor, x, state)
+        up_want = osd.oversample(x)
+        down_want = osd.decimate(up_want)
+        assert np.max(np.abs(up - up_want)) <= 1e-13, (k, n)
+        assert np.max(np.abs(down - down_want)) <= 1e-12, (k, n)
+    ctx.close()
