@@ -214,6 +214,9 @@ struct gdg_ctx {
     int plan_stride = 0, plan_stride_out = 0;
     bool plan_by_channel = false;
     std::vector<StepDesc> steps;
+    std::vector<int> plan_unit_slot;           /* unit handle -> index of its descriptor in the plan's array of gdg_seg_unit, -1: not in the plan */
+    std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
+    bool plan_patch = true;                    /* GDG_PLAN_PATCH=0: every parameter change rebuilds the whole plan (A/B measurements) */
     std::vector<unsigned char> blob;
     unsigned char *d_blob = nullptr;
     size_t d_blob_cap = 0;
@@ -383,6 +386,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     { const char *e = getenv("GDG_FIR_SPLIT_MAX"); if (e) ctx->fir_split_max = atoi(e); }
     { const char *e = getenv("GDG_FIR_CHAIN"); if (e) ctx->fir_chain = atoi(e) != 0; }
     { const char *e = getenv("GDG_PROFILE_ATTACH"); if (e) ctx->prof_attach = atoi(e) != 0; }
+    { const char *e = getenv("GDG_PLAN_PATCH"); if (e) ctx->plan_patch = atoi(e) != 0; }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -541,7 +545,15 @@ int gdg_unit_set_param(gdg_ctx *ctx, int handle, int param_index, int32_t value)
     if (param_index < 0 || param_index >= g_param_count[u->type]) return fail(ctx, GDG_ERR_INVALID, "bad parameter index %d", param_index);
     if (u->params[param_index] != value) {
         u->params[param_index] = value;
-        ctx->dirty = true;
+        /* The reference's setter is a mutex and one store (effects/effects.go:283-345).  Here a parameter reaches the device as ONE
+         * gdg_seg_unit of the plan's descriptor blob: the next process call re-derives that unit's constants and patches them in place
+         * (apply_patches) -- chain shape, launches and every other descriptor stay.  A power amp's parameters only matter through its
+         * taps (gdg_unit_set_fir), and a unit that is not in the plan (bypassed, or in no chain) has nothing on the device to update.
+         * Layout changes (gdg_chain_set), frame size, rate and new filters still rebuild the plan. */
+        if (ctx->dirty || !ctx->plan_patch) ctx->dirty = true;
+        else if (u->type != GDG_UNIT_POWERAMP && (size_t)handle < ctx->plan_unit_slot.size() && ctx->plan_unit_slot[(size_t)handle] >= 0) {
+            if (std::find(ctx->patch_units.begin(), ctx->patch_units.end(), handle) == ctx->patch_units.end()) ctx->patch_units.push_back(handle);
+        }
     }
     return GDG_OK;
 }
@@ -1268,6 +1280,8 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     std::vector<const double *> cur((size_t)nch);
     for (int c : active) cur[(size_t)c] = d_in + (size_t)row_of[(size_t)c] * stride;
     ctx->steps.clear();
+    ctx->plan_unit_slot.assign(ctx->units.size(), -1);
+    ctx->patch_units.clear();                  /* this plan reads every unit's current parameters */
     for (auto &kv : by_slot) {
         bool is_fir = (kv.first & 1) != 0;
         std::vector<gdg_seg_chan> sd;
@@ -1306,6 +1320,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                     int rc = prepare_unit(ctx, ctx->units[(size_t)h], frames, sample_rate, du);
                     t_unit += pnow() - tq;
                     if (rc != GDG_OK) return rc;
+                    ctx->plan_unit_slot[(size_t)h] = (int)seg_units.size();
                     seg_units.push_back(du);
                 }
                 sd.push_back(s);
@@ -1475,6 +1490,32 @@ int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
 
 /* ---- processing --------------------------------------------------------------------------------------- */
 
+/* Parameter changes since the plan was built (gdg_unit_set_param): re-derive the constants of exactly those units -- with every side
+ * effect the reference ties to the new value: histories re-made for a new delay, capacitors zeroed for a new band-pass order ... --
+ * and overwrite their descriptors in the device blob, one small copy each, ordered on the context's stream behind the launches
+ * that still read the old ones. */
+static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
+    join_groups(ctx);                          /* free-running channel groups may still read the descriptors */
+    {
+        const char *e = getenv("GDG_SCAN_TABLES_MAX");
+        long limit = e ? atol(e) : 1024;
+        if ((long)ctx->scan_tabs.size() > (limit < 1 ? 1 : limit)) { ctx->dirty = true; return GDG_OK; }       /* the rebuild trims the cache */
+    }
+    for (int h : ctx->patch_units) {
+        Unit *u = get_unit(ctx, h);
+        const int slot = (size_t)h < ctx->plan_unit_slot.size() ? ctx->plan_unit_slot[(size_t)h] : -1;
+        if (!u || slot < 0) { ctx->dirty = true; return GDG_OK; }
+        gdg_seg_unit du;
+        int rc = prepare_unit(ctx, *u, frames, sample_rate, du);
+        if (rc != GDG_OK) { ctx->dirty = true; return rc; }
+        const size_t off = ctx->units_offset + (size_t)slot * sizeof(gdg_seg_unit);
+        memcpy(ctx->blob.data() + off, &du, sizeof(du));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob + off, ctx->blob.data() + off, sizeof(du), hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->patch_units.clear();
+    return GDG_OK;
+}
+
 static int ensure_staging(gdg_ctx *ctx);
 static int check_device_error(gdg_ctx *ctx);
 
@@ -1556,6 +1597,12 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     if (group_bounds_in && (int)group_bounds_in->size() == G + 1) bounds = *group_bounds_in;
     else bounds = equal_group_bounds(active.size(), G);
     /* the plan holds pointers into the buffers it was built on; other buffers of the same shape are reached by a shift */
+    const bool plan_fits = !ctx->dirty && ctx->plan_frames == frames && ctx->plan_sr == sample_rate && ctx->plan_active == active && ctx->plan_stride == stride &&
+                           ctx->plan_stride_out == stride_out && ctx->plan_by_channel == rows_by_channel && ctx->plan_groups == G && ctx->plan_bounds == bounds;
+    if (plan_fits && !ctx->patch_units.empty()) {
+        int rc = apply_patches(ctx, frames, sample_rate);            /* knob moves: the affected descriptors only (may fall back to dirty) */
+        if (rc != GDG_OK) return rc;
+    }
     if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate ||
         ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_stride_out != stride_out || ctx->plan_by_channel != rows_by_channel ||
         ctx->plan_groups != G || ctx->plan_bounds != bounds) {

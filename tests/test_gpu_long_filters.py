@@ -25,7 +25,7 @@ def test_long_filters_per_frame_and_in_windows(oracle, taps, blocks):
     partitions (windows) -- same bits from both, oracle and direct convolution within 1e-9 RMS."""
     pkg = package()
     sr, nch = 96000, 2
-    h = [synth_ir(taps, seed=300 + c) * (1.0 if c == 0 else 3.0) for c in range(nch)]          # channel 1 clips
+    h = [synth_ir(taps, seed=300 + c) * (1.0 if c == 0 else 12.0) for c in range(nch)]         # channel 1 is driven into the output clip
     W = 16 if blocks >= 16 else 4
     n = blocks * B
     x = np.stack([0.7 * synth_signal(c, n, sr) for c in range(nch)])
@@ -44,7 +44,7 @@ def test_long_filters_per_frame_and_in_windows(oracle, taps, blocks):
         want = np.concatenate([refs[c].process(x[c, b * B:(b + 1) * B], sr) for b in range(blocks)])
         assert rms(got[c] - want) <= TOL_RMS, ("oracle", c, rms(got[c] - want))
         assert rms(got[c] - direct(x[c], h[c])) <= TOL_RMS, ("direct", c)
-    assert np.max(np.abs(got[1])) == 1.0                      # the clipping channel clips
+    assert np.max(np.abs(got[1])) == min(1.0, float(np.max(np.abs(fftconvolve(x[1], h[1])[:n]))))       # clips exactly where the convolution exceeds full scale
     # the same stream in windows: one full window of W frames, then the tail frame by frame -- bit-identical to the per-frame calls
     ctx = pkg.Context(nch, B)
     for c in range(nch):
