@@ -674,10 +674,14 @@ static void lin2_tab_host(double aH, double aL, double *tab) {
         }
     }
 }
-/* `tab` built for `key` (a tag + the coefficients): the device copy, made on first use */
-static int scan_tables(gdg_ctx *ctx, const std::vector<double> &key, const std::vector<double> &tab, const double **out) {
+/* the tables of `key` (a tag + the coefficients): the device copy, BUILT and uploaded on first use only -- 512 channels with the same
+ * tone-stack setting asked for the same 12 KB table 512 times, and building it (4 bands x ~200 triangular matrix powers) before the
+ * look-up cost 13 us each: 6.6 of the 6.2-6.8 ms a plan of 512 channels took to rebuild */
+static int scan_tables(gdg_ctx *ctx, const std::vector<double> &key, size_t n_doubles, const std::function<void(double *)> &build, const double **out) {
     auto it = ctx->scan_tabs.find(key);
     if (it == ctx->scan_tabs.end()) {
+        std::vector<double> tab(n_doubles, 0.0);
+        build(tab.data());
         double *d = nullptr;
         HIP_TRY(ctx, ctx->arena.alloc((void **)&d, tab.size() * sizeof(double)));
         HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -689,11 +693,11 @@ static int scan_tables(gdg_ctx *ctx, const std::vector<double> &key, const std::
 /* [follower | coupling capacitor] of fuzz / octaver, or the follower alone (compressor): follow 0 = peak (max-affine), 1 = level */
 static int follower_tables(gdg_ctx *ctx, int follow, double d_inv, double d, bool with_cap, const double **out) {
     std::vector<double> key = { 1.0, (double)follow, d_inv, d, with_cap ? 1.0 : 0.0 };
-    std::vector<double> tab((with_cap ? 2 : 1) * LT_SIZE, 0.0);
-    if (follow == 0) lin_tab_host(true, 0.0, d_inv, tab.data());
-    else lin_tab_host(false, d, d_inv, tab.data());
-    if (with_cap) lin_tab_host(false, d, 1.0 - d, tab.data() + LT_SIZE);
-    return scan_tables(ctx, key, tab, out);
+    return scan_tables(ctx, key, (size_t)(with_cap ? 2 : 1) * LT_SIZE, [&](double *tab) {
+        if (follow == 0) lin_tab_host(true, 0.0, d_inv, tab);
+        else lin_tab_host(false, d, d_inv, tab);
+        if (with_cap) lin_tab_host(false, d, 1.0 - d, tab + LT_SIZE);
+    }, out);
 }
 
 /* Fill the device-side description of one non-FIR unit; (re)build its history for this rate / frame size. */
@@ -759,18 +763,18 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
             d.dp[4 + j] = 1.0 - exp(m2pi_sr * freqs[j]);
             d.dp[8 + j] = 1.0 - exp(m2pi_sr * freqs[j + 1]);
         }
-        std::vector<double> key = { 2.0 }, tab(4 * L2_SIZE, 0.0);
-        for (int j = 0; j < 4; j++) { key.push_back(d.dp[4 + j]); key.push_back(d.dp[8 + j]); lin2_tab_host(d.dp[4 + j], d.dp[8 + j], tab.data() + j * L2_SIZE); }
-        rc = scan_tables(ctx, key, tab, &d.tab);
+        std::vector<double> key = { 2.0 };
+        for (int j = 0; j < 4; j++) { key.push_back(d.dp[4 + j]); key.push_back(d.dp[8 + j]); }
+        rc = scan_tables(ctx, key, 4 * L2_SIZE, [&](double *tab) { for (int j = 0; j < 4; j++) lin2_tab_host(d.dp[4 + j], d.dp[8 + j], tab + j * L2_SIZE); }, &d.tab);
         break;
     }
     case GDG_UNIT_CABINET: {
         static const double f[7] = { 300.0, 120.0, 80.0, 3000.0, 4000.0, 5000.0, 6000.0 };
         double m2pi_sr = -GO_MATH_TWO_PI / sr;
         for (int j = 0; j < 7; j++) d.dp[j] = 1.0 - exp(m2pi_sr * f[j]);
-        std::vector<double> key = { 3.0 }, tab(7 * LT_SIZE, 0.0);
-        for (int j = 0; j < 7; j++) { key.push_back(d.dp[j]); lin_tab_host(false, d.dp[j], 1.0 - d.dp[j], tab.data() + j * LT_SIZE); }
-        rc = scan_tables(ctx, key, tab, &d.tab);
+        std::vector<double> key = { 3.0 };
+        for (int j = 0; j < 7; j++) key.push_back(d.dp[j]);
+        rc = scan_tables(ctx, key, 7 * LT_SIZE, [&](double *tab) { for (int j = 0; j < 7; j++) lin_tab_host(false, d.dp[j], 1.0 - d.dp[j], tab + j * LT_SIZE); }, &d.tab);
         break;
     }
     case GDG_UNIT_CHORUS: {
@@ -940,9 +944,8 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         d.dp[0] = 1.0 - exp(m2pi_sr * (double)fa);
         d.dp[1] = 1.0 - exp(m2pi_sr * (double)fb);
         {
-            std::vector<double> key = { 4.0, d.dp[0], d.dp[1] }, tab(L2_SIZE, 0.0);
-            lin2_tab_host(d.dp[0], d.dp[1], tab.data());
-            rc = scan_tables(ctx, key, tab, &d.tab);
+            std::vector<double> key = { 4.0, d.dp[0], d.dp[1] };
+            rc = scan_tables(ctx, key, L2_SIZE, [&](double *tab) { lin2_tab_host(d.dp[0], d.dp[1], tab); }, &d.tab);
             if (rc != GDG_OK) return rc;
         }
         d.jp[0] = half;
@@ -1220,8 +1223,8 @@ struct Op { bool is_fir; std::vector<int> handles; };
 static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
                       int stride, int stride_out, bool rows_by_channel, int G, const std::vector<size_t> &bounds) {
     const int nch = ctx->nch;
-    static int ptrace = -1;
-    if (ptrace < 0) { const char *e = getenv("GDG_PLAN_TRACE"); ptrace = e ? atoi(e) : 0; }
+    int ptrace = 0;
+    { const char *e = getenv("GDG_PLAN_TRACE"); ptrace = e ? atoi(e) : 0; }        /* read per plan: a test switches it on */
     auto pnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_fir = 0.0, t_unit = 0.0;
     const double t_plan0 = pnow();
@@ -1501,6 +1504,7 @@ static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
         long limit = e ? atol(e) : 1024;
         if ((long)ctx->scan_tabs.size() > (limit < 1 ? 1 : limit)) { ctx->dirty = true; return GDG_OK; }       /* the rebuild trims the cache */
     }
+    size_t lo = (size_t)-1, hi = 0;
     for (int h : ctx->patch_units) {
         Unit *u = get_unit(ctx, h);
         const int slot = (size_t)h < ctx->plan_unit_slot.size() ? ctx->plan_unit_slot[(size_t)h] : -1;
@@ -1510,7 +1514,17 @@ static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }
         const size_t off = ctx->units_offset + (size_t)slot * sizeof(gdg_seg_unit);
         memcpy(ctx->blob.data() + off, &du, sizeof(du));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob + off, ctx->blob.data() + off, sizeof(du), hipMemcpyHostToDevice, ctx->stream));
+        lo = std::min(lo, off); hi = std::max(hi, off + sizeof(du));
+    }
+    /* a few knobs: one small copy each; a preset change over many channels: ONE copy of the span they cover (descriptors in between are
+     * rewritten with the bytes they already hold) */
+    if (ctx->patch_units.size() > 4) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob + lo, ctx->blob.data() + lo, hi - lo, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (int h : ctx->patch_units) {
+            const size_t off = ctx->units_offset + (size_t)ctx->plan_unit_slot[(size_t)h] * sizeof(gdg_seg_unit);
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob + off, ctx->blob.data() + off, sizeof(gdg_seg_unit), hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     ctx->patch_units.clear();
     return GDG_OK;

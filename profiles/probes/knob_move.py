@@ -38,6 +38,8 @@ def step():
     return (time.perf_counter() - t0) * 1e6
 
 
+first = step()                                            # builds the plan, the IR spectra, every unit's state
+print("# first call on the fresh 512-channel context (plan + %d IR transforms + state): %.1f ms" % (2 * nch, first / 1e3))
 for _ in range(5):
     step()
 steady = sorted(step() for _ in range(20))[10]

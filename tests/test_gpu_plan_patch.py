@@ -38,17 +38,21 @@ def run(pkg, oracle, monkeypatch, patch, name, sr, frames, blocks, edits, groups
     monkeypatch.setenv("GDG_PLAN_PATCH", "1" if patch else "0")
     ctx = pkg.Context(3, frames)
     fir = synth_ir(700, seed=5)
-    layout = [[name], ["compressor", name, "power_amp", "cabinet"] if name != "octaver" else [name, "power_amp", "cabinet"], [name, "tone_stack"]]
+    lead = "compressor" if name != "compressor" else "distortion"           # neighbours of another type than the unit under test
+    tail = "cabinet" if name != "cabinet" else "tone_stack"
+    other = "tone_stack" if name != "tone_stack" else "cabinet"
+    layout = [[name], [lead, name, "power_amp", tail] if name != "octaver" else [name, "power_amp", tail], [name, other]]
     refs, target = [], []
     for c, units in enumerate(layout):
         ref = oracle.Chain() if oracle is not None else None
-        for u in units:
+        for k, u in enumerate(units):
             h = ctx.append_unit(c, u, fir=fir if u == "power_amp" else None)
             if ref is not None:
                 ref.append_unit(u, fir=fir if u == "power_amp" else None)
             if u == name:
-                target.append((h, units.index(u)))
+                target.append((h, k))
         refs.append(ref)
+    assert len(target) == 3
     ctx.set_overlap(groups)
     x = np.stack([0.6 * synth_signal(3 + c, frames * blocks, sr) for c in range(3)])
     d_in, d_out = ctx.alloc(3, frames), ctx.alloc(3, frames)
