@@ -191,6 +191,7 @@ struct StepDesc {
     bool shared_spectra = false;      /* FIR step: some channels read the same IR spectra */
     bool chain_next = false;          /* FIR step whose every channel feeds another power amp next (the following step): that amp's forward
                                        * transform rides on this step's inverse (fir_inv_kernel CHAIN) in per-frame calls */
+    bool fast = false;                /* segment step: every unit of every channel works in place on 8192-sample frames -> the two-per-CU kernel (segf) */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
 
@@ -215,6 +216,8 @@ struct gdg_ctx {
     bool plan_by_channel = false;
     std::vector<StepDesc> steps;
     std::vector<int> plan_unit_slot;           /* unit handle -> index of its descriptor in the plan's array of gdg_seg_unit, -1: not in the plan */
+    std::vector<char> plan_unit_fast;          /* ... and whether its segment runs on the two-per-CU kernel (scan tables for 16-sample chunks) */
+    bool seg_fast = true;                      /* GDG_SEG_FAST=0: every segment on the general kernel (A/B measurements, bit-identity tests) */
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
     bool plan_patch = true;                    /* GDG_PLAN_PATCH=0: every parameter change rebuilds the whole plan (A/B measurements) */
     std::vector<unsigned char> blob;
@@ -387,6 +390,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     { const char *e = getenv("GDG_FIR_CHAIN"); if (e) ctx->fir_chain = atoi(e) != 0; }
     { const char *e = getenv("GDG_PROFILE_ATTACH"); if (e) ctx->prof_attach = atoi(e) != 0; }
     { const char *e = getenv("GDG_PLAN_PATCH"); if (e) ctx->plan_patch = atoi(e) != 0; }
+    { const char *e = getenv("GDG_SEG_FAST"); if (e) ctx->seg_fast = atoi(e) != 0; }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -640,14 +644,15 @@ static double pow_u(double A, int e) {
     for (int k = 0; k < 10; k++) { if (e & (1 << k)) r *= b; b *= b; }
     return r;
 }
-static void lin_tab_host(bool maxop, double a, double keep, double *tab) {
-    const double k2 = keep * keep, k4 = k2 * k2, A = k4 * k4;
+/* chk = samples per thread of the kernel that will read the table: 8 (seg_kernel) or 16 (the two-per-CU kernel, GDG_CHK_FAST) */
+static void lin_tab_host(bool maxop, double a, double keep, double *tab, int chk) {
+    const double k2 = keep * keep, k4 = k2 * k2, A8 = k4 * k4, A = chk == 16 ? A8 * A8 : A8;
     for (int lane = 0; lane < 64; lane++) {
-        tab[LT_PC + lane] = pow_u(A, lane);
-        if (lane < 16) tab[LT_PA + lane] = pow_u(A, lane + 1);
-        if (lane >= 32) tab[LT_PB + lane - 32] = pow_u(A, lane - 31);
-        if (lane < 10) tab[LT_ST + lane] = pow_u(A, 1 << lane);
-        if (lane < GDG_CHK) tab[LT_W + lane] = (maxop ? 1.0 : a) * pow_u(keep, GDG_CHK - 1 - lane);
+        tab[LT_PC_(chk) + lane] = pow_u(A, lane);
+        if (lane < 16) tab[LT_PA_(chk) + lane] = pow_u(A, lane + 1);
+        if (lane >= 32) tab[LT_PB_(chk) + lane - 32] = pow_u(A, lane - 31);
+        if (lane < 10) tab[LT_ST_(chk) + lane] = pow_u(A, 1 << lane);
+        if (lane < chk) tab[LT_W_(chk) + lane] = (maxop ? 1.0 : a) * pow_u(keep, chk - 1 - lane);
     }
 }
 struct Tri { double a, b, c; };                                /* [[a, 0], [b, c]] */
@@ -659,18 +664,18 @@ static Tri tri_pow(Tri M, int e) {
 }
 static void tri_store(double *p, const Tri &t) { p[0] = t.a; p[1] = t.b; p[2] = t.c; }
 /* per sample (h, l) <- M (h, l) + (aH, aL) x, M = [[1-aH, 0], [-aL, 1-aL]] */
-static void lin2_tab_host(double aH, double aL, double *tab) {
+static void lin2_tab_host(double aH, double aL, double *tab, int chk) {
     const Tri M = { 1.0 - aH, -aL, 1.0 - aL };
-    const Tri P = tri_pow(M, GDG_CHK);
+    const Tri P = tri_pow(M, chk);
     for (int lane = 0; lane < 64; lane++) {
-        tri_store(tab + L2_PC + 3 * lane, tri_pow(P, lane));
-        if (lane < 16) tri_store(tab + L2_PA + 3 * lane, tri_pow(P, lane + 1));
-        if (lane >= 32) tri_store(tab + L2_PB + 3 * (lane - 32), tri_pow(P, lane - 31));
-        if (lane < 10) tri_store(tab + L2_ST + 3 * lane, tri_pow(P, 1 << lane));
-        if (lane < GDG_CHK) {
-            Tri G = tri_pow(M, GDG_CHK - 1 - lane);
-            tab[L2_W + 2 * lane] = G.a * aH;
-            tab[L2_W + 2 * lane + 1] = (G.b * aH) + (G.c * aL);
+        tri_store(tab + L2_PC_(chk) + 3 * lane, tri_pow(P, lane));
+        if (lane < 16) tri_store(tab + L2_PA_(chk) + 3 * lane, tri_pow(P, lane + 1));
+        if (lane >= 32) tri_store(tab + L2_PB_(chk) + 3 * (lane - 32), tri_pow(P, lane - 31));
+        if (lane < 10) tri_store(tab + L2_ST_(chk) + 3 * lane, tri_pow(P, 1 << lane));
+        if (lane < chk) {
+            Tri G = tri_pow(M, chk - 1 - lane);
+            tab[L2_W_(chk) + 2 * lane] = G.a * aH;
+            tab[L2_W_(chk) + 2 * lane + 1] = (G.b * aH) + (G.c * aL);
         }
     }
 }
@@ -691,17 +696,36 @@ static int scan_tables(gdg_ctx *ctx, const std::vector<double> &key, size_t n_do
     return GDG_OK;
 }
 /* [follower | coupling capacitor] of fuzz / octaver, or the follower alone (compressor): follow 0 = peak (max-affine), 1 = level */
-static int follower_tables(gdg_ctx *ctx, int follow, double d_inv, double d, bool with_cap, const double **out) {
-    std::vector<double> key = { 1.0, (double)follow, d_inv, d, with_cap ? 1.0 : 0.0 };
-    return scan_tables(ctx, key, (size_t)(with_cap ? 2 : 1) * LT_SIZE, [&](double *tab) {
-        if (follow == 0) lin_tab_host(true, 0.0, d_inv, tab);
-        else lin_tab_host(false, d, d_inv, tab);
-        if (with_cap) lin_tab_host(false, d, 1.0 - d, tab + LT_SIZE);
+static int follower_tables(gdg_ctx *ctx, int follow, double d_inv, double d, bool with_cap, const double **out, int chk) {
+    std::vector<double> key = { 1.0 + 0.001 * chk, (double)follow, d_inv, d, with_cap ? 1.0 : 0.0 };
+    return scan_tables(ctx, key, (size_t)(with_cap ? 2 : 1) * LT_SIZE_(chk), [&](double *tab) {
+        if (follow == 0) lin_tab_host(true, 0.0, d_inv, tab, chk);
+        else lin_tab_host(false, d, d_inv, tab, chk);
+        if (with_cap) lin_tab_host(false, d, 1.0 - d, tab + LT_SIZE_(chk), chk);
     }, out);
 }
 
+/* May this unit run on the two-per-CU segment kernel (seg.hip compiled with SEG_FAST: 8192-sample frames, one LDS frame buffer, every
+ * unit in place)?  By type (gdg_segf_supported), then by what the in-place variants assume: no oversampling (the oversampled shapers
+ * stage a whole output frame in a second buffer); the reverb with every tap at least a frame back (rates from 42.7 kHz) and all-pass
+ * rings of at most 3072 / 1024 values for the two short ones (rates up to 226 kHz). */
+static bool segf_unit_ok(const Unit &u, int frames, uint32_t sample_rate) {
+    if (frames != GDG_MAX_FRAMES || !gdg_segf_supported(u.type)) return false;
+    const int32_t *p = u.params;
+    const double sr = (double)sample_rate;
+    switch (u.type) {
+    case GDG_UNIT_OVERDRIVE: return p[5] == 0;
+    case GDG_UNIT_DISTORTION: return p[3] == 0;
+    case GDG_UNIT_EXCESS: return p[2] == 0;
+    case GDG_UNIT_REVERB:
+        return (uint32_t)round(0.19196 * sr) >= (uint32_t)frames && (int)round(0.01348 * sr) - 1 <= 3072 && (int)round(0.00452 * sr) - 1 <= 1024 &&
+               (int)round(0.00452 * sr) - 1 >= 1;
+    default: return true;
+    }
+}
+
 /* Fill the device-side description of one non-FIR unit; (re)build its history for this rate / frame size. */
-static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate, gdg_seg_unit &d) {
+static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate, gdg_seg_unit &d, int chk = GDG_CHK) {
     memset(&d, 0, sizeof(d));
     d.type = u.type;
     for (int i = 0; i < GDG_MAX_PARAMS; i++) d.ip[i] = u.params[i];
@@ -714,7 +738,7 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         d.dp[1] = decibels_to_factor(p[2]);
         d.dp[2] = exp(-20.0 / sr);
         d.dp[3] = 1.0 - d.dp[2];
-        rc = follower_tables(ctx, p[0], d.dp[2], d.dp[3], false, &d.tab);
+        rc = follower_tables(ctx, p[0], d.dp[2], d.dp[3], false, &d.tab, chk);
         break;
     }
     case GDG_UNIT_OVERDRIVE:
@@ -763,18 +787,18 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
             d.dp[4 + j] = 1.0 - exp(m2pi_sr * freqs[j]);
             d.dp[8 + j] = 1.0 - exp(m2pi_sr * freqs[j + 1]);
         }
-        std::vector<double> key = { 2.0 };
+        std::vector<double> key = { 2.0 + 0.001 * chk };
         for (int j = 0; j < 4; j++) { key.push_back(d.dp[4 + j]); key.push_back(d.dp[8 + j]); }
-        rc = scan_tables(ctx, key, 4 * L2_SIZE, [&](double *tab) { for (int j = 0; j < 4; j++) lin2_tab_host(d.dp[4 + j], d.dp[8 + j], tab + j * L2_SIZE); }, &d.tab);
+        rc = scan_tables(ctx, key, 4 * L2_SIZE_(chk), [&](double *tab) { for (int j = 0; j < 4; j++) lin2_tab_host(d.dp[4 + j], d.dp[8 + j], tab + j * L2_SIZE_(chk), chk); }, &d.tab);
         break;
     }
     case GDG_UNIT_CABINET: {
         static const double f[7] = { 300.0, 120.0, 80.0, 3000.0, 4000.0, 5000.0, 6000.0 };
         double m2pi_sr = -GO_MATH_TWO_PI / sr;
         for (int j = 0; j < 7; j++) d.dp[j] = 1.0 - exp(m2pi_sr * f[j]);
-        std::vector<double> key = { 3.0 };
+        std::vector<double> key = { 3.0 + 0.001 * chk };
         for (int j = 0; j < 7; j++) key.push_back(d.dp[j]);
-        rc = scan_tables(ctx, key, 7 * LT_SIZE, [&](double *tab) { for (int j = 0; j < 7; j++) lin_tab_host(false, d.dp[j], 1.0 - d.dp[j], tab + j * LT_SIZE); }, &d.tab);
+        rc = scan_tables(ctx, key, 7 * LT_SIZE_(chk), [&](double *tab) { for (int j = 0; j < 7; j++) lin_tab_host(false, d.dp[j], 1.0 - d.dp[j], tab + j * LT_SIZE_(chk), chk); }, &d.tab);
         break;
     }
     case GDG_UNIT_CHORUS: {
@@ -890,7 +914,7 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         double inner_rate = (double)((uint32_t)f * sample_rate);
         d.dp[5] = exp(-20.0 / inner_rate);
         d.dp[6] = 1.0 - d.dp[5];
-        rc = follower_tables(ctx, p[0], d.dp[5], d.dp[6], true, &d.tab);
+        rc = follower_tables(ctx, p[0], d.dp[5], d.dp[6], true, &d.tab, GDG_CHK);
         if (rc != GDG_OK) return rc;
         if (f > 1) {
             const size_t len2 = 8 + 76, len4 = 8 + 154;
@@ -945,7 +969,7 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         d.dp[1] = 1.0 - exp(m2pi_sr * (double)fb);
         {
             std::vector<double> key = { 4.0, d.dp[0], d.dp[1] };
-            rc = scan_tables(ctx, key, L2_SIZE, [&](double *tab) { lin2_tab_host(d.dp[0], d.dp[1], tab); }, &d.tab);
+            rc = scan_tables(ctx, key, L2_SIZE, [&](double *tab) { lin2_tab_host(d.dp[0], d.dp[1], tab, GDG_CHK); }, &d.tab);
             if (rc != GDG_OK) return rc;
         }
         d.jp[0] = half;
@@ -960,7 +984,7 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
         for (int i = 0; i < 6; i++) d.dp[i] = decibels_to_factor(p[1 + i]);
         d.dp[6] = exp(-20.0 / sr);
         d.dp[7] = 1.0 - d.dp[6];
-        rc = follower_tables(ctx, p[0], d.dp[6], d.dp[7], true, &d.tab);
+        rc = follower_tables(ctx, p[0], d.dp[6], d.dp[7], true, &d.tab, GDG_CHK);
         break;
     }
     case GDG_UNIT_NOISEGATE: {
@@ -1285,10 +1309,16 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     ctx->steps.clear();
     ctx->plan_unit_slot.assign(ctx->units.size(), -1);
     ctx->patch_units.clear();                  /* this plan reads every unit's current parameters */
+    ctx->plan_unit_fast.assign(ctx->units.size(), 0);
     for (auto &kv : by_slot) {
         bool is_fir = (kv.first & 1) != 0;
         std::vector<gdg_seg_chan> sd;
         std::vector<gdg_fir_chan> fd;
+        /* a segment step goes to the two-per-CU kernel when EVERY unit of EVERY channel in it can (one launch per step) */
+        bool step_fast = !is_fir && ctx->seg_fast && frames == GDG_MAX_FRAMES;
+        if (step_fast)
+            for (auto &entry : kv.second)
+                for (int h : entry.second.handles) if (!segf_unit_ok(ctx->units[(size_t)h], frames, sample_rate)) { step_fast = false; break; }
         for (auto &entry : kv.second) {
             int c = entry.first;
             Op &op = entry.second;
@@ -1320,10 +1350,11 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 for (int h : op.handles) {
                     gdg_seg_unit du;
                     const double tq = pnow();
-                    int rc = prepare_unit(ctx, ctx->units[(size_t)h], frames, sample_rate, du);
+                    int rc = prepare_unit(ctx, ctx->units[(size_t)h], frames, sample_rate, du, step_fast ? GDG_CHK_FAST : GDG_CHK);
                     t_unit += pnow() - tq;
                     if (rc != GDG_OK) return rc;
                     ctx->plan_unit_slot[(size_t)h] = (int)seg_units.size();
+                    ctx->plan_unit_fast[(size_t)h] = step_fast ? 1 : 0;
                     seg_units.push_back(du);
                 }
                 sd.push_back(s);
@@ -1333,6 +1364,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         }
         StepDesc st;
         st.is_fir = is_fir;
+        st.fast = step_fast;
         st.n = is_fir ? (int)fd.size() : (int)sd.size();
         st.offset = 0;
         /* descriptors are in `active` order, so every channel group owns one contiguous run of them */
@@ -1509,8 +1541,10 @@ static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
         Unit *u = get_unit(ctx, h);
         const int slot = (size_t)h < ctx->plan_unit_slot.size() ? ctx->plan_unit_slot[(size_t)h] : -1;
         if (!u || slot < 0) { ctx->dirty = true; return GDG_OK; }
+        const bool fast = ctx->plan_unit_fast[(size_t)h] != 0;
+        if (fast && !segf_unit_ok(*u, frames, sample_rate)) { ctx->dirty = true; return GDG_OK; }      /* e.g. oversampling switched on: the segment changes kernels */
         gdg_seg_unit du;
-        int rc = prepare_unit(ctx, *u, frames, sample_rate, du);
+        int rc = prepare_unit(ctx, *u, frames, sample_rate, du, fast ? GDG_CHK_FAST : GDG_CHK);
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }
         const size_t off = ctx->units_offset + (size_t)slot * sizeof(gdg_seg_unit);
         memcpy(ctx->blob.data() + off, &du, sizeof(du));
@@ -1698,7 +1732,8 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);
                 /* one launch per window: a channel's workgroup walks its frames in order, the units' state runs through them */
-                HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s));
+                if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s));
+                else HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s));
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));

@@ -110,20 +110,37 @@ struct gdg_seg_unit {
                                * host at plan time -- they depend on the coefficients only -- and shared by all units with the same ones */
 };
 
-/* scan tables (seg.hip: lin_scan / lin2_scan); layouts shared with the host builder in api.cpp */
+/* scan tables (seg.hip: lin_scan / lin2_scan); layouts shared with the host builder in api.cpp.  A thread's chunk has GDG_CHK samples:
+ * 8 in the general segment kernel (1024 threads per frame), 16 in the two-per-CU kernel for the batch block size (512 threads,
+ * seg.hip compiled with -DSEG_FAST); the layouts below take the chunk size as a parameter because the host builds both. */
+#ifndef GDG_CHK
 #define GDG_CHK 8                 /* samples per thread at the batch block size (8192 / 1024) */
-#define LT_W 0                    /* [8]  dot weights */
-#define LT_ST 8                   /* [10] A^(2^k), k = 0..9 */
-#define LT_PA 18                  /* [16] A^(q + 1), q = lane & 15 */
-#define LT_PB 34                  /* [32] A^(lane - 31), lane = 32..63, at index lane - 32 */
-#define LT_PC 66                  /* [64] A^lane */
-#define LT_SIZE 130
-#define L2_W 0                    /* [8][2]  dot weights (gH_i, gL_i) */
-#define L2_ST 16                  /* [10][3] P^(2^k) */
-#define L2_PA 46                  /* [16][3] */
-#define L2_PB 94                  /* [32][3] */
-#define L2_PC 190                 /* [64][3] */
-#define L2_SIZE 382
+#endif
+#define GDG_CHK_FAST 16           /* ... of the 512-thread kernel */
+#define LT_W_(c) 0                /* [c]  dot weights */
+#define LT_ST_(c) (c)             /* [10] A^(2^k), k = 0..9 */
+#define LT_PA_(c) ((c) + 10)      /* [16] A^(q + 1), q = lane & 15 */
+#define LT_PB_(c) ((c) + 26)      /* [32] A^(lane - 31), lane = 32..63, at index lane - 32 */
+#define LT_PC_(c) ((c) + 58)      /* [64] A^lane */
+#define LT_SIZE_(c) ((c) + 122)
+#define L2_W_(c) 0                /* [c][2]  dot weights (gH_i, gL_i) */
+#define L2_ST_(c) (2 * (c))       /* [10][3] P^(2^k) */
+#define L2_PA_(c) (2 * (c) + 30)  /* [16][3] */
+#define L2_PB_(c) (2 * (c) + 78)  /* [32][3] */
+#define L2_PC_(c) (2 * (c) + 174) /* [64][3] */
+#define L2_SIZE_(c) (2 * (c) + 366)
+#define LT_W LT_W_(GDG_CHK)
+#define LT_ST LT_ST_(GDG_CHK)
+#define LT_PA LT_PA_(GDG_CHK)
+#define LT_PB LT_PB_(GDG_CHK)
+#define LT_PC LT_PC_(GDG_CHK)
+#define LT_SIZE LT_SIZE_(GDG_CHK)
+#define L2_W L2_W_(GDG_CHK)
+#define L2_ST L2_ST_(GDG_CHK)
+#define L2_PA L2_PA_(GDG_CHK)
+#define L2_PB L2_PB_(GDG_CHK)
+#define L2_PC L2_PC_(GDG_CHK)
+#define L2_SIZE L2_SIZE_(GDG_CHK)
 
 struct gdg_seg_chan {
     const double *src;
@@ -155,6 +172,10 @@ struct gdg_os_tables {
 
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
                           gdg_os_tables os, int *d_error, hipStream_t s);
+/* the same for segments that only hold units the two-per-CU kernel runs (gdg_segf_supported) on frames of 8192 samples */
+hipError_t gdg_launch_segf(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
+                           gdg_os_tables os, int *d_error, hipStream_t s);
+int gdg_segf_supported(int unit_type);
 hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_hist, double *d_up, double *d_down, gdg_os_tables os, hipStream_t s);
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);

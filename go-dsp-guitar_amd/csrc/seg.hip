@@ -26,25 +26,65 @@
  *
  * Compiled with -ffp-contract=off: Go never fuses multiply-add.
  */
+/*
+ * This file is compiled TWICE (csrc/Makefile):
+ *   seg.o                 the general kernel: 1024 threads per channel (8-sample chunks), two LDS frame buffers + a 26 KiB tile = 159 KiB,
+ *                         ONE workgroup per CU; every unit type, every frame size;
+ *   segf.o  (-DSEG_FAST)  the kernel of the batch block size (8192 frames) for segments made of units that work IN PLACE:
+ *                         512 threads per channel (16-sample chunks), ONE LDS frame buffer + a 13 KiB tile = 80 KiB, TWO workgroups per CU.
+ *                         A workgroup's life is a chain of dependent phases (descriptor -> state -> data, scan -> replay, barriers; ~25 us
+ *                         per segment whatever the frame size) plus its VALU work (~18 us per channel); with one workgroup per CU a
+ *                         512-channel launch pays the chain twice (two rounds), with two per CU once (profiles/experiments/README.md, r04).
+ * Same source, same arithmetic, same state layout in HBM (a stream may move between the two from call to call); the association of the
+ * workgroup scans differs (512 chunks of 16 instead of 1024 of 8), i.e. results differ by the scans' rounding (~1e-16).
+ */
+#ifdef SEG_FAST
+#define GDG_CHK 16                        /* before gdg_internal.h: the scan-table layouts follow the chunk size */
+#endif
 #include "gdg_internal.h"
 #include "go_consts.h"
 #include "../../include/gdg.h"
 #include <math.h>
 
+#ifdef SEG_FAST
+#define SEG_T 512                         /* 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD (128 VGPRs each) */
+#define SEG_MIN_WAVES_PER_EU 4
+#define SEG_SCR 1600                      /* the tone stack's four tables (4 x L2_SIZE = 1592 doubles) are the largest tenant */
+#define seg_kernel segf_kernel
+#define gdg_launch_seg gdg_launch_segf
+#define gdg_seg_supported gdg_segf_supported
+#else
 #define SEG_T 1024                        /* 16 waves = 4 per SIMD: hides the FP64 / LDS / HBM latencies of one workgroup per CU */
+#define SEG_MIN_WAVES_PER_EU 4
+#define SEG_SCR 3328
+#endif
 #define SEG_WAVES (SEG_T / 64)
 #define SEG_LBUF (8192 + 256 + 8)
-#define SEG_SCR 3328
 #define LX(e) ((e) + ((e) >> 5))
 #define CHK (GDG_MAX_FRAMES / SEG_T)     /* samples per thread at the batch block size */
 static_assert(CHK * SEG_T == GDG_MAX_FRAMES, "chunk size");
+static_assert(CHK == GDG_CHK, "chunk size of the scan tables");
 
 /* the workgroup's LDS, at file scope so that the (non-inlined) unit functions address it as LDS, not through flat pointers */
 __shared__ double s_a[SEG_LBUF];                     /* frame ping */
+#ifdef SEG_FAST
+#define s_b s_a                                      /* ONE frame buffer: every unit of this configuration works in place */
+#else
 __shared__ double s_b[SEG_LBUF];                     /* frame pong */
+#endif
 __shared__ double s_scr[SEG_SCR];                    /* oversampling / run-list tile */
-__shared__ double s_tmp[2 * 4 * (SEG_T / 64) + 32 + 8];  /* scan scratch: (A, B) x up to 4 recurrences x waves; + 32 state cells + 16 unit types */
-#define SEG_STASH (2 * 4 * (SEG_T / 64))          /* first state cell inside s_tmp */
+#ifdef SEG_FAST
+__shared__ double *s_scratch_row;                    /* this channel's frame of global scratch (gdg_seg_chan.scratch) */
+#define scratch_row s_scratch_row
+#endif
+#define SEG_STASH 128                             /* first state cell inside s_tmp: behind the scan scratch (block_scan: 2 x 4 recurrences x 16 waves;
+                                                   * lin_scan / lin2_scan: two alternating pairs of 17-cell exchange slots = 68) */
+__shared__ double s_tmp[SEG_STASH + 32 + 8];        /* scan scratch + 32 state cells + 16 unit types */
+static_assert(2 * 4 * (SEG_T / 64) <= SEG_STASH, "block_scan scratch");
+#ifdef SEG_FAST
+static_assert(sizeof(double) * (SEG_LBUF + SEG_SCR + SEG_STASH + 32 + 8 + 1) <= 81920, "two workgroups per CU: 80 KiB of LDS each");
+static_assert(4 * L2_SIZE <= SEG_SCR && 7 * LT_SIZE <= SEG_SCR, "scan tables fit the tile");
+#endif
 
 /* every unit is its own function (own register allocation); `flip` says which LDS frame is the input */
 #define UNIT_FN __device__ __attribute__((noinline)) void
@@ -186,7 +226,6 @@ __device__ __forceinline__ double apply_map(double A, double B, double s) {
  * lower-triangular matrix [[1-aH, 0], [-aL, 1-aL]] per sample, so ONE scan of vectors replaces two scans and one of the
  * three passes. */
 /* table layout (LT_*, L2_*): gdg_internal.h -- the tables are built on the host at plan time (api.cpp scan_tables) */
-static_assert(GDG_CHK == CHK, "chunk size of the scan tables");
 #define LX_SLOT 17                /* exchange slot: [state before the frame | 16 wave totals] */
 
 template <int CTRL, int ROWMASK>
@@ -751,8 +790,10 @@ __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tab
         for (int i = threadIdx.x; i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
         return 0;
     }
+#ifndef SEG_FAST                                    /* the oversampled shapers stage a whole output frame in the second buffer */
     if (f == 2) shaper_oversampled<2>(S, in, out, scr, U->hist, os.tapsP2, os.lanczos2, N);
     else shaper_oversampled<4>(S, in, out, scr, U->hist, os.tapsP4, os.lanczos4, N);
+#endif
     return 1;
 }
 
@@ -1062,6 +1103,7 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
     }
 }
 
+#ifndef SEG_FAST
 /* ---- flanger / phaser: effects/flanger.go:19-119, effects/phaser.go:19-125 --------------------------------
  * dp0 depth (0..1), dp1 angular speed, dp2 sr, dp3 1/sr, dp4 dry factor, dp5 wet factor; jp0 ring capacity */
 UNIT_FN unit_flanger(UNIT_ARGS) {
@@ -1110,6 +1152,8 @@ UNIT_FN unit_delay(UNIT_ARGS) {
     __syncthreads();
     ring_append(U->hist, D, &U->is[0], in, N);
 }
+
+#endif
 
 /* ---- ring modulator: effects/ringmodulator.go:18-45.  dp0 phase increment per sample; ds0 phase ---------- */
 UNIT_FN unit_ringmod(UNIT_ARGS) {
@@ -1260,6 +1304,113 @@ __device__ __attribute__((noinline)) void allpass_generic(double *buf, double *r
     allpass_chains<REVERB_QMAX>(buf, ring, M, rp, N, pm0, rp_out);
 }
 
+#ifdef SEG_FAST
+/* The reverb IN PLACE (one frame buffer), for the shape the host checks (gdg_segf_supported + api.cpp segf_unit_ok): N = 8192, every tap
+ * at least a frame back (rates from 42.7 kHz), all-pass rings of at most 16 / 6 / 2 values per thread.  Same arithmetic as below; what moves
+ * is WHERE values wait: the tapped sums and dry * x stay in registers while the all-passes run in the buffer, the frame joins the delay
+ * line (from registers) as soon as every thread has consumed its taps, and the tap loads come in two batches (16 sixteen-byte loads in
+ * flight per lane instead of 32: the register file is shared by two workgroups). */
+UNIT_FN unit_reverb(UNIT_ARGS) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
+    const int tid = threadIdx.x;
+    const double dry = Uc->dp[0], half_wet = Uc->dp[1];
+    const double coeff[4] = { 0.1855, 0.18325, 0.17875, 0.17425 };
+    int taps[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) taps[j] = Uc->jp[j];
+    const int DL = Uc->jp[4];
+    double *dl_ring = Uc->hist;
+    int *is_state = Uc->is;
+    const int dl_wp = as_global(is_state)[0];
+    int M[3], rp[3];
+    double *ring[3];
+    {
+        double *r = dl_ring + DL;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { M[k] = Uc->jp[5 + k] - 1; rp[k] = as_global(is_state)[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
+    }
+    constexpr int QA = REVERB_QMAX, QB = 3 * 1024 / SEG_T, QC = 1024 / SEG_T, NP = REVERB_QMAX / 2;      /* NP sample pairs per thread */
+    GDG_GLOBAL double *g = as_global(dl_ring);
+    GDG_GLOBAL double *tapped = as_global(scratch_row);                    /* this channel's row of global scratch: the tapped sums wait there */
+    const double g0 = g[0];
+    /* 1. per sample pair (2p, 2p + 1), p = tid + q SEG_T, everything in the thread's OWN cells: the tapped delay line (reverb.go:65-116),
+     * then the frame's pair into the delay line -- the cell it replaces holds sample i - DL, which only tap 3 of sample i itself reads
+     * (DL = the longest tap), so no thread waits for another --, the tapped sums into the buffer (the all-passes' input) and into the
+     * scratch row (the final mix wants them again; 32 registers held across the all-passes spilled).  A real loop of NB batches:
+     * unrolled, the compiler hoists all 32 loads to the top and parks them in scratch memory. */
+    constexpr int NB = 4, PB = NP / NB;
+#pragma unroll 1
+    for (int b = 0; b < NB; b++) {
+        seg_v2d tv[PB][4];
+        int wrapm = 0;
+#pragma unroll
+        for (int qq = 0; qq < PB; qq++) {
+            const int i0 = 2 * (tid + (b * PB + qq) * SEG_T);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int p = dl_wp + (i0 - taps[j]);
+                if (p < 0) p += DL;
+                const bool wraps = p + 1 >= DL;
+                wrapm |= wraps ? (1 << (qq * 4 + j)) : 0;
+                tv[qq][j] = *(const GDG_GLOBAL seg_v2d *)(g + (wraps ? DL - 2 : p));
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < PB; qq++) {
+            const int i0 = 2 * (tid + (b * PB + qq) * SEG_T);
+            double pre0 = 0.0, pre1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool wraps = (wrapm >> (qq * 4 + j)) & 1;
+                const double c0 = wraps ? tv[qq][j].y : tv[qq][j].x, c1 = wraps ? g0 : tv[qq][j].y;
+                pre0 += coeff[j] * c0;
+                pre1 += coeff[j] * c1;
+            }
+            const double x0 = in[LX(i0)], x1 = in[LX(i0 + 1)];
+            const int p = (dl_wp + i0) % DL;
+            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
+            else { g[p] = x0; g[0] = x1; }
+            seg_v2d t2 = { pre0, pre1 };
+            *(GDG_GLOBAL seg_v2d *)(tapped + i0) = t2;
+            out[LX(i0)] = pre0;
+            out[LX(i0 + 1)] = pre1;
+        }
+    }
+    if (tid == 0) as_global(is_state)[0] = (dl_wp + N) % DL;
+    /* 2. ring heads of the three all-passes; every old value must have arrived before any thread overwrites the rings below: vmcnt(0),
+     * then the barrier (which also completes the buffer) */
+    double pm_a[QA], pm_b[QB], pm_c[QC];
+    allpass_fetch<QA>(ring[0], M[0], rp[0], N, pm_a);
+    allpass_fetch<QB>(ring[1], M[1], rp[1], N, pm_b);
+    allpass_fetch<QC>(ring[2], M[2], rp[2], N, pm_c);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    allpass_chains<QA>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1]);
+    allpass_chains<QB>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2]);
+    allpass_chains<QC>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3]);
+    /* 3. the mix; the dry samples come back from the delay line and the tapped sums from the scratch row (this thread's own stores of step 1) */
+#pragma unroll 1
+    for (int b = 0; b < 2; b++) {
+        seg_v2d xr[NP / 2], tr[NP / 2];
+#pragma unroll
+        for (int qq = 0; qq < NP / 2; qq++) {
+            const int i0 = 2 * (tid + (b * (NP / 2) + qq) * SEG_T);
+            const int p = (dl_wp + i0) % DL;
+            if (p + 1 < DL) xr[qq] = *(const GDG_GLOBAL seg_v2d *)(g + p);
+            else { xr[qq].x = g[p]; xr[qq].y = g[0]; }
+            tr[qq] = *(const GDG_GLOBAL seg_v2d *)(tapped + i0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < NP / 2; qq++) {
+            const int i0 = 2 * (tid + (b * (NP / 2) + qq) * SEG_T);
+            const double s0 = tr[qq].x + out[LX(i0)], s1 = tr[qq].y + out[LX(i0 + 1)];
+            out[LX(i0)] = clip1((dry * xr[qq].x) + (half_wet * s0));
+            out[LX(i0 + 1)] = clip1((dry * xr[qq].y) + (half_wet * s1));
+        }
+    }
+}
+#else
 UNIT_FN unit_reverb(UNIT_ARGS) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
@@ -1372,6 +1523,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     __syncthreads();
     ring_append(dl_ring, DL, &is_state[0], in, N);
 }
+#endif
 
 /* ---- generic one-pole section on an in-place sequence ----------------------------------------------------------------
  * state recurrence (every reference unit writes it the same way):  diff = v - s;  s += diff * a
@@ -1480,6 +1632,7 @@ __device__ __forceinline__ IMap block_scan_imap(IMap mine, IMap identity, Compos
     return e;
 }
 
+#ifndef SEG_FAST          /* from here to the segment kernel: units of the general kernel only */
 /* ---- fuzz without oversampling: effects/fuzz.go:24-108 ------------------------------------------------------------------------
  * ip0 follow; dp0 bias, dp1 gain, dp2 fuzz, dp3 1 - fuzz, dp4 level, dp5 exp(-20/sr), dp6 1 - dp5; ds0 envelope, ds1 coupling cap */
 UNIT_FN unit_fuzz(UNIT_ARGS) {
@@ -2130,18 +2283,22 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+#endif
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
 /* MULTI = false: one frame per launch (the loop below disappears: this is the kernel of the per-frame calls, and a loop around its
  * body costs it 8 us in scalar register spills).  MULTI = true: a window of n_frames frames per launch. */
 template <bool MULTI>
-__global__ void __launch_bounds__(SEG_T)
+__global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU)
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
            gdg_os_tables os, int *d_error) {
     gdg_seg_chan ch = chans[blockIdx.x];
     if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
     const int tid = threadIdx.x;
+#ifdef SEG_FAST
+    if (tid == 0) s_scratch_row = ch.scratch;
+#endif
     /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
     int *s_types = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32);       /* 16 ints behind the stash cells */
     int my_type = 0;
@@ -2182,13 +2339,14 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N); break;
         case GDG_UNIT_CABINET: unit_cabinet(U, flip, N); break;
         case GDG_UNIT_CHORUS: unit_chorus(U, flip, N); break;
-        case GDG_UNIT_FLANGER:
-        case GDG_UNIT_PHASER: unit_flanger(U, flip, N); break;
-        case GDG_UNIT_DELAY: unit_delay(U, flip, N); break;
         case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N); break;
         case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N); break;
         case GDG_UNIT_REVERB: unit_reverb(U, flip, N); break;
+#ifndef SEG_FAST                                    /* units that read other threads' cells of their input after writing output, or stage a frame: two buffers */
+        case GDG_UNIT_FLANGER:
+        case GDG_UNIT_PHASER: unit_flanger(U, flip, N); break;
+        case GDG_UNIT_DELAY: unit_delay(U, flip, N); break;
         case GDG_UNIT_FUZZ:
             if (U->jp[0] > 1) inplace = unit_fuzz_os(U, flip, N, os);
             else unit_fuzz(U, flip, N);
@@ -2198,6 +2356,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         case GDG_UNIT_BANDPASS: unit_bandpass(U, flip, N); break;
         case GDG_UNIT_OCTAVER: unit_octaver(U, flip, N); break;
         case GDG_UNIT_NOISEGATE: unit_noisegate(U, flip, N); break;
+#endif
         default:
             if (tid == 0) atomicExch(d_error, 1 + type);
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
@@ -2218,6 +2377,17 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
 }
 
 int gdg_seg_supported(int unit_type) {
+#ifdef SEG_FAST
+    /* by type; the host adds the per-unit conditions (no oversampling, the reverb's shape: api.cpp segf_unit_ok) */
+    switch (unit_type) {
+    case GDG_UNIT_COMPRESSOR: case GDG_UNIT_OVERDRIVE: case GDG_UNIT_DISTORTION: case GDG_UNIT_EXCESS: case GDG_UNIT_TONESTACK:
+    case GDG_UNIT_CABINET: case GDG_UNIT_CHORUS: case GDG_UNIT_RINGMODULATOR: case GDG_UNIT_TREMOLO: case GDG_UNIT_SIGNALGENERATOR:
+    case GDG_UNIT_REVERB:
+        return 1;
+    default:
+        return 0;
+    }
+#endif
     switch (unit_type) {
     case GDG_UNIT_COMPRESSOR: case GDG_UNIT_OVERDRIVE: case GDG_UNIT_DISTORTION: case GDG_UNIT_EXCESS:
     case GDG_UNIT_TONESTACK: case GDG_UNIT_CABINET: case GDG_UNIT_CHORUS: case GDG_UNIT_FLANGER:
