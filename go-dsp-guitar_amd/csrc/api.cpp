@@ -217,6 +217,7 @@ struct gdg_ctx {
     std::vector<StepDesc> steps;
     std::vector<int> plan_unit_slot;           /* unit handle -> index of its descriptor in the plan's array of gdg_seg_unit, -1: not in the plan */
     std::vector<char> plan_unit_fast;          /* ... and whether its segment runs on the two-per-CU kernel (scan tables for 16-sample chunks) */
+    std::vector<char> plan_unit_fast_ok;       /* ... and whether the unit itself could (segf_unit_ok at plan time): a change of that rebuilds the plan */
     bool seg_fast = true;                      /* GDG_SEG_FAST=0: every segment on the general kernel (A/B measurements, bit-identity tests) */
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
     bool plan_patch = true;                    /* GDG_PLAN_PATCH=0: every parameter change rebuilds the whole plan (A/B measurements) */
@@ -889,8 +890,10 @@ static int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate,
             d.jp[i] = (int)t;
             if (t > max_index) max_index = t;
         }
-        d.jp[4] = (int)max_index;
-        size_t len = max_index;
+        /* the delay line holds the longest tap PLUS one frame of the batch block size: the in-place reverb of the two-per-CU kernel appends
+         * the frame before it reads the taps (seg.hip); the general kernel only sees a longer ring */
+        d.jp[4] = (int)max_index + GDG_MAX_FRAMES;
+        size_t len = (size_t)max_index + GDG_MAX_FRAMES;
         for (int i = 0; i < 3; i++) {
             int D = (int)round(ap_delays[i] * sr);
             d.jp[5 + i] = D;
@@ -1310,6 +1313,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     ctx->plan_unit_slot.assign(ctx->units.size(), -1);
     ctx->patch_units.clear();                  /* this plan reads every unit's current parameters */
     ctx->plan_unit_fast.assign(ctx->units.size(), 0);
+    ctx->plan_unit_fast_ok.assign(ctx->units.size(), 0);
     for (auto &kv : by_slot) {
         bool is_fir = (kv.first & 1) != 0;
         std::vector<gdg_seg_chan> sd;
@@ -1355,6 +1359,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                     if (rc != GDG_OK) return rc;
                     ctx->plan_unit_slot[(size_t)h] = (int)seg_units.size();
                     ctx->plan_unit_fast[(size_t)h] = step_fast ? 1 : 0;
+                    ctx->plan_unit_fast_ok[(size_t)h] = segf_unit_ok(ctx->units[(size_t)h], frames, sample_rate) ? 1 : 0;
                     seg_units.push_back(du);
                 }
                 sd.push_back(s);
@@ -1542,7 +1547,8 @@ static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
         const int slot = (size_t)h < ctx->plan_unit_slot.size() ? ctx->plan_unit_slot[(size_t)h] : -1;
         if (!u || slot < 0) { ctx->dirty = true; return GDG_OK; }
         const bool fast = ctx->plan_unit_fast[(size_t)h] != 0;
-        if (fast && !segf_unit_ok(*u, frames, sample_rate)) { ctx->dirty = true; return GDG_OK; }      /* e.g. oversampling switched on: the segment changes kernels */
+        /* e.g. oversampling switched on or off: the segment may change kernels -- the rebuild decides (and patched == rebuilt stays true bit for bit) */
+        if ((segf_unit_ok(*u, frames, sample_rate) ? 1 : 0) != ctx->plan_unit_fast_ok[(size_t)h]) { ctx->dirty = true; return GDG_OK; }
         gdg_seg_unit du;
         int rc = prepare_unit(ctx, *u, frames, sample_rate, du, fast ? GDG_CHK_FAST : GDG_CHK);
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }

@@ -73,16 +73,13 @@ __shared__ double s_a[SEG_LBUF];                     /* frame ping */
 __shared__ double s_b[SEG_LBUF];                     /* frame pong */
 #endif
 __shared__ double s_scr[SEG_SCR];                    /* oversampling / run-list tile */
-#ifdef SEG_FAST
-__shared__ double *s_scratch_row;                    /* this channel's frame of global scratch (gdg_seg_chan.scratch) */
-#define scratch_row s_scratch_row
-#endif
+
 #define SEG_STASH 128                             /* first state cell inside s_tmp: behind the scan scratch (block_scan: 2 x 4 recurrences x 16 waves;
                                                    * lin_scan / lin2_scan: two alternating pairs of 17-cell exchange slots = 68) */
 __shared__ double s_tmp[SEG_STASH + 32 + 8];        /* scan scratch + 32 state cells + 16 unit types */
 static_assert(2 * 4 * (SEG_T / 64) <= SEG_STASH, "block_scan scratch");
 #ifdef SEG_FAST
-static_assert(sizeof(double) * (SEG_LBUF + SEG_SCR + SEG_STASH + 32 + 8 + 1) <= 81920, "two workgroups per CU: 80 KiB of LDS each");
+static_assert(sizeof(double) * (SEG_LBUF + SEG_SCR + SEG_STASH + 32 + 8) <= 81920, "two workgroups per CU: 80 KiB of LDS each");
 static_assert(4 * L2_SIZE <= SEG_SCR && 7 * LT_SIZE <= SEG_SCR, "scan tables fit the tile");
 #endif
 
@@ -1251,7 +1248,8 @@ UNIT_FN unit_siggen(UNIT_ARGS) {
 }
 
 /* ---- reverb: effects/reverb.go:41-116, :179-338 ------------------------------------------------------------------
- * dp0 dry, dp1 0.5 * wet; jp0..3 tap offsets, jp4 delay-line ring capacity, jp5..7 all-pass ring sizes D_k.
+ * dp0 dry, dp1 0.5 * wet; jp0..3 tap offsets, jp4 delay-line ring capacity (the longest tap + one frame of 8192: the in-place variant
+ * appends the frame BEFORE it reads the taps), jp5..7 all-pass ring sizes D_k.
  * hist: [delay-line ring | all-pass 1 ring | all-pass 2 ring | all-pass 3 ring]; is0 delay-line wp, is1..3 all-pass ring pos.
  * An all-pass ring of size D delays by M = D - 1 samples (write at ptr, read at ptr + 1, reverb.go:51-58).
  * Here each ring keeps the last M values of p[n] = in[n] - g p[n - M]; o[n] = g p[n] + p[n - M].
@@ -1332,13 +1330,12 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     }
     constexpr int QA = REVERB_QMAX, QB = 3 * 1024 / SEG_T, QC = 1024 / SEG_T, NP = REVERB_QMAX / 2;      /* NP sample pairs per thread */
     GDG_GLOBAL double *g = as_global(dl_ring);
-    GDG_GLOBAL double *tapped = as_global(scratch_row);                    /* this channel's row of global scratch: the tapped sums wait there */
     const double g0 = g[0];
-    /* 1. per sample pair (2p, 2p + 1), p = tid + q SEG_T, everything in the thread's OWN cells: the tapped delay line (reverb.go:65-116),
-     * then the frame's pair into the delay line -- the cell it replaces holds sample i - DL, which only tap 3 of sample i itself reads
-     * (DL = the longest tap), so no thread waits for another --, the tapped sums into the buffer (the all-passes' input) and into the
-     * scratch row (the final mix wants them again; 32 registers held across the all-passes spilled).  A real loop of NB batches:
-     * unrolled, the compiler hoists all 32 loads to the top and parks them in scratch memory. */
+    /* 1. per sample pair (2p, 2p + 1), p = tid + q SEG_T, everything in the thread's OWN cells: the frame's pair joins the delay line, the
+     * tapped sums (reverb.go:65-116) take its place in the buffer (the all-passes' input).  The ring holds one frame more than the longest
+     * tap (jp4 = taps[3] + 8192), so the cells the frame overwrites are older than anything a tap of this frame reads and the taps -- all
+     * at least a frame back -- never meet the new cells: appending and tapping commute, nobody waits for anybody.  A real loop of NB
+     * batches of eight loads: unrolled, the compiler hoists all 32 loads to the top and parks them in scratch memory. */
     constexpr int NB = 4, PB = NP / NB;
 #pragma unroll 1
     for (int b = 0; b < NB; b++) {
@@ -1359,6 +1356,10 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
 #pragma unroll
         for (int qq = 0; qq < PB; qq++) {
             const int i0 = 2 * (tid + (b * PB + qq) * SEG_T);
+            const double x0 = in[LX(i0)], x1 = in[LX(i0 + 1)];
+            const int p = (dl_wp + i0) % DL;
+            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
+            else { g[p] = x0; g[0] = x1; }
             double pre0 = 0.0, pre1 = 0.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1367,47 +1368,41 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
                 pre0 += coeff[j] * c0;
                 pre1 += coeff[j] * c1;
             }
-            const double x0 = in[LX(i0)], x1 = in[LX(i0 + 1)];
-            const int p = (dl_wp + i0) % DL;
-            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
-            else { g[p] = x0; g[0] = x1; }
-            seg_v2d t2 = { pre0, pre1 };
-            *(GDG_GLOBAL seg_v2d *)(tapped + i0) = t2;
             out[LX(i0)] = pre0;
             out[LX(i0 + 1)] = pre1;
         }
     }
     if (tid == 0) as_global(is_state)[0] = (dl_wp + N) % DL;
-    /* 2. ring heads of the three all-passes; every old value must have arrived before any thread overwrites the rings below: vmcnt(0),
-     * then the barrier (which also completes the buffer) */
+    /* 2. ring heads of the three all-passes, and the tapped sums back into registers (own cells, written above: the mix wants them after
+     * the all-passes have replaced them in the buffer) */
     double pm_a[QA], pm_b[QB], pm_c[QC];
     allpass_fetch<QA>(ring[0], M[0], rp[0], N, pm_a);
     allpass_fetch<QB>(ring[1], M[1], rp[1], N, pm_b);
     allpass_fetch<QC>(ring[2], M[2], rp[2], N, pm_c);
+    double dlr[REVERB_QMAX];
+#pragma unroll
+    for (int q = 0; q < REVERB_QMAX; q++) dlr[q] = out[LX(2 * (tid + (q >> 1) * SEG_T) + (q & 1))];
+    /* every old all-pass value must have arrived before any thread overwrites the rings below: vmcnt(0), then the barrier (which also
+     * completes the buffer) */
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     allpass_chains<QA>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1]);
     allpass_chains<QB>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2]);
+    /* the dry samples come back from the delay line (this thread's own stores of step 1) while the last all-pass runs */
+    seg_v2d xr[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const int p = (dl_wp + 2 * (tid + q * SEG_T)) % DL;
+        if (p + 1 < DL) xr[q] = *(const GDG_GLOBAL seg_v2d *)(g + p);
+        else { xr[q].x = g[p]; xr[q].y = g[0]; }
+    }
     allpass_chains<QC>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3]);
-    /* 3. the mix; the dry samples come back from the delay line and the tapped sums from the scratch row (this thread's own stores of step 1) */
-#pragma unroll 1
-    for (int b = 0; b < 2; b++) {
-        seg_v2d xr[NP / 2], tr[NP / 2];
 #pragma unroll
-        for (int qq = 0; qq < NP / 2; qq++) {
-            const int i0 = 2 * (tid + (b * (NP / 2) + qq) * SEG_T);
-            const int p = (dl_wp + i0) % DL;
-            if (p + 1 < DL) xr[qq] = *(const GDG_GLOBAL seg_v2d *)(g + p);
-            else { xr[qq].x = g[p]; xr[qq].y = g[0]; }
-            tr[qq] = *(const GDG_GLOBAL seg_v2d *)(tapped + i0);
-        }
-#pragma unroll
-        for (int qq = 0; qq < NP / 2; qq++) {
-            const int i0 = 2 * (tid + (b * (NP / 2) + qq) * SEG_T);
-            const double s0 = tr[qq].x + out[LX(i0)], s1 = tr[qq].y + out[LX(i0 + 1)];
-            out[LX(i0)] = clip1((dry * xr[qq].x) + (half_wet * s0));
-            out[LX(i0 + 1)] = clip1((dry * xr[qq].y) + (half_wet * s1));
-        }
+    for (int q = 0; q < REVERB_QMAX; q++) {
+        const int i = 2 * (tid + (q >> 1) * SEG_T) + (q & 1);
+        const double x = (q & 1) ? xr[q >> 1].y : xr[q >> 1].x;
+        const double sum = dlr[q] + out[LX(i)];
+        out[LX(i)] = clip1((dry * x) + (half_wet * sum));
     }
 }
 #else
@@ -2296,26 +2291,26 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
     if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
     const int tid = threadIdx.x;
-#ifdef SEG_FAST
-    if (tid == 0) s_scratch_row = ch.scratch;
-#endif
     /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
     int *s_types = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32);       /* 16 ints behind the stash cells */
     int my_type = 0;
     if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
     /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
      * through global memory from one frame to the next exactly as from one launch to the next (same CU, same L1; a barrier between) */
+  seg_v2d nxt[CHK / 2];                 /* MULTI: the next frame, requested while this frame's results are stored */
+  bool have_next = false;
   for (int wf = 0; wf < (MULTI ? n_frames : 1); wf++, ch.src += N, ch.dst += N) {
     const bool aligned = ((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0;
     if (aligned && N == CHK * SEG_T) {
         /* the batch block size: every load of the thread is in flight before the first one is consumed (a loop waits for
          * each load in turn: four exposed HBM latencies per workgroup) */
         const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)ch.src;
-        seg_v2d v[CHK / 2];
+        if (!(MULTI && have_next)) {
 #pragma unroll
-        for (int q = 0; q < CHK / 2; q++) v[q] = s2[tid + q * SEG_T];
+            for (int q = 0; q < CHK / 2; q++) nxt[q] = s2[tid + q * SEG_T];
+        }
 #pragma unroll
-        for (int q = 0; q < CHK / 2; q++) { const int i = tid + q * SEG_T; s_a[LX(2 * i)] = v[q].x; s_a[LX(2 * i + 1)] = v[q].y; }
+        for (int q = 0; q < CHK / 2; q++) { const int i = tid + q * SEG_T; s_a[LX(2 * i)] = nxt[q].x; s_a[LX(2 * i + 1)] = nxt[q].y; }
     } else if (aligned) {
         /* 16 bytes per lane: half the load instructions, 1 KiB per wave access */
         const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)ch.src;
@@ -2366,6 +2361,14 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         if (!__builtin_amdgcn_readfirstlane(inplace)) flip ^= 1;
     }
     const double *fin = flip ? s_b : s_a;
+    have_next = false;
+    if (MULTI && wf + 1 < n_frames && aligned && N == CHK * SEG_T) {
+        /* the window's next frame (same alignment: consecutive frames of one row), in flight behind this frame's stores, the fence and the barrier */
+        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)(ch.src + N);
+#pragma unroll
+        for (int q = 0; q < CHK / 2; q++) nxt[q] = s2[tid + q * SEG_T];
+        have_next = true;
+    }
     if (aligned) {
         GDG_GLOBAL seg_v2d *d2 = (GDG_GLOBAL seg_v2d *)ch.dst;
         for (int i = tid; i < N / 2; i += SEG_T) { seg_v2d v = { fin[LX(2 * i)], fin[LX(2 * i + 1)] }; d2[i] = v; }
