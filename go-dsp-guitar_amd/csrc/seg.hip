@@ -45,6 +45,7 @@
 #include "go_consts.h"
 #include "../../include/gdg.h"
 #include <math.h>
+#include <stdlib.h>
 
 #ifdef SEG_FAST
 #define SEG_T 512                         /* 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD (128 VGPRs each) */
@@ -1269,6 +1270,9 @@ __device__ __forceinline__ void allpass_fetch(const double *ring, int M, int rp,
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         int r = (int)threadIdx.x + q * SEG_T;
+        /* (the modulo costs ~40 instructions, but the conditional-subtraction form makes the in-place reverb of the two-per-CU build allocate 128
+         * registers and 236 bytes of scratch instead of 120 / 132 -- and the KERNEL's register count is the largest of its units': every
+         * segment, also those without a reverb, then ran 12 us slower, profiles/experiments/README.md r04) */
         pm0[q] = as_global(ring)[(r < cnt) ? (rp + r) % M : 0];
     }
 }
@@ -1288,7 +1292,7 @@ __device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M,
                 n += M;
             } while (n < N);
             if (N >= M) as_global(ring)[n - N] = p;         /* the last M values of p, oldest first (n - M is this chain's last index) */
-            else as_global(ring)[(rp + r) % M] = p;
+            else { int at = rp + r; if (at >= M) at -= M; as_global(ring)[at] = p; }
         }
     }
     if (threadIdx.x == 0) *rp_out = (N >= M) ? 0 : (rp + N) % M;
@@ -1357,7 +1361,8 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         for (int qq = 0; qq < PB; qq++) {
             const int i0 = 2 * (tid + (b * PB + qq) * SEG_T);
             const double x0 = in[LX(i0)], x1 = in[LX(i0 + 1)];
-            const int p = (dl_wp + i0) % DL;
+            int p = dl_wp + i0;                             /* dl_wp < DL, i0 < N <= DL */
+            if (p >= DL) p -= DL;
             if (p + 1 < DL) { seg_v2d v = { x0, x1 }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
             else { g[p] = x0; g[0] = x1; }
             double pre0 = 0.0, pre1 = 0.0;
@@ -1392,7 +1397,8 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     seg_v2d xr[NP];
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-        const int p = (dl_wp + 2 * (tid + q * SEG_T)) % DL;
+        int p = dl_wp + 2 * (tid + q * SEG_T);
+        if (p >= DL) p -= DL;
         if (p + 1 < DL) xr[q] = *(const GDG_GLOBAL seg_v2d *)(g + p);
         else { xr[q].x = g[p]; xr[q].y = g[0]; }
     }
@@ -2281,56 +2287,50 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
 #endif
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
-/* MULTI = false: one frame per launch (the loop below disappears: this is the kernel of the per-frame calls, and a loop around its
- * body costs it 8 us in scalar register spills).  MULTI = true: a window of n_frames frames per launch. */
-template <bool MULTI>
-__global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU)
-seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
-           gdg_os_tables os, int *d_error) {
-    gdg_seg_chan ch = chans[blockIdx.x];
-    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
-    if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
-    const int tid = threadIdx.x;
-    /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
+/* one frame of one channel: HBM -> LDS, the segment's units, LDS -> HBM */
+__device__ __forceinline__ void seg_frame(const double *src, double *dst, const gdg_seg_unit *units, int unit_begin, int unit_count, int N,
+                                          const gdg_os_tables &os, int *d_error, int my_type) {
+    int tid = threadIdx.x;
+#ifdef SEG_FAST
+    /* opaque per call: in the window walk the compiler otherwise hoists every per-thread address of the frame's load and store loops out of
+     * the frame loop and keeps them in callee-saved vector registers across the unit calls (v120-v123: over the 120 the units need) */
+    asm volatile("" : "+v"(tid));
+#endif
     int *s_types = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32);       /* 16 ints behind the stash cells */
-    int my_type = 0;
-    if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
-    /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
-     * through global memory from one frame to the next exactly as from one launch to the next (same CU, same L1; a barrier between) */
-  seg_v2d nxt[CHK / 2];                 /* MULTI: the next frame, requested while this frame's results are stored */
-  bool have_next = false;
-  for (int wf = 0; wf < (MULTI ? n_frames : 1); wf++, ch.src += N, ch.dst += N) {
-    const bool aligned = ((N & 1) | (int)((size_t)ch.src & 15) | (int)((size_t)ch.dst & 15)) == 0;
+    const bool aligned = ((N & 1) | (int)((size_t)src & 15) | (int)((size_t)dst & 15)) == 0;
     if (aligned && N == CHK * SEG_T) {
         /* the batch block size: every load of the thread is in flight before the first one is consumed (a loop waits for
          * each load in turn: four exposed HBM latencies per workgroup) */
-        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)ch.src;
-        if (!(MULTI && have_next)) {
+        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)src;
+        seg_v2d v[CHK / 2];
 #pragma unroll
-            for (int q = 0; q < CHK / 2; q++) nxt[q] = s2[tid + q * SEG_T];
-        }
+        for (int q = 0; q < CHK / 2; q++) v[q] = s2[tid + q * SEG_T];
 #pragma unroll
-        for (int q = 0; q < CHK / 2; q++) { const int i = tid + q * SEG_T; s_a[LX(2 * i)] = nxt[q].x; s_a[LX(2 * i + 1)] = nxt[q].y; }
+        for (int q = 0; q < CHK / 2; q++) { const int i = tid + q * SEG_T; s_a[LX(2 * i)] = v[q].x; s_a[LX(2 * i + 1)] = v[q].y; }
     } else if (aligned) {
         /* 16 bytes per lane: half the load instructions, 1 KiB per wave access */
-        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)ch.src;
+        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)src;
         for (int i = tid; i < N / 2; i += SEG_T) { seg_v2d v = s2[i]; s_a[LX(2 * i)] = v.x; s_a[LX(2 * i + 1)] = v.y; }
     } else {
-        for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = as_global(ch.src)[i];
+        for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = as_global(src)[i];
     }
-    if (tid < ch.unit_count && tid < 16) s_types[tid] = my_type;
+    if (tid < unit_count && tid < 16) s_types[tid] = my_type;
     __syncthreads();
     int flip = 0;                                   /* 0: s_a holds the current frame, 1: s_b */
-    for (int u = 0; u < ch.unit_count; u++) {
+    for (int u = 0; u < unit_count; u++) {
         double *out = flip ? s_a : s_b;
-        const gdg_seg_unit *U = units + ch.unit_begin + u;
+        const gdg_seg_unit *U = units + unit_begin + u;
         const int type = (u < 16) ? __builtin_amdgcn_readfirstlane(s_types[u]) : U->type;
         int inplace = 0;
         switch (type) {
         case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N); break;
         case GDG_UNIT_OVERDRIVE:
         case GDG_UNIT_DISTORTION:
+#ifdef SEG_FAST                                     /* no oversampling here: the six table pointers need not live across the unit calls */
+        case GDG_UNIT_EXCESS: { gdg_os_tables none = {}; inplace = unit_shaper(U, flip, N, none); break; }
+#else
         case GDG_UNIT_EXCESS: inplace = unit_shaper(U, flip, N, os); break;
+#endif
         case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N); break;
         case GDG_UNIT_CABINET: unit_cabinet(U, flip, N); break;
         case GDG_UNIT_CHORUS: unit_chorus(U, flip, N); break;
@@ -2361,22 +2361,40 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
         if (!__builtin_amdgcn_readfirstlane(inplace)) flip ^= 1;
     }
     const double *fin = flip ? s_b : s_a;
-    have_next = false;
-    if (MULTI && wf + 1 < n_frames && aligned && N == CHK * SEG_T) {
-        /* the window's next frame (same alignment: consecutive frames of one row), in flight behind this frame's stores, the fence and the barrier */
-        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)(ch.src + N);
-#pragma unroll
-        for (int q = 0; q < CHK / 2; q++) nxt[q] = s2[tid + q * SEG_T];
-        have_next = true;
-    }
     if (aligned) {
-        GDG_GLOBAL seg_v2d *d2 = (GDG_GLOBAL seg_v2d *)ch.dst;
+        GDG_GLOBAL seg_v2d *d2 = (GDG_GLOBAL seg_v2d *)dst;
         for (int i = tid; i < N / 2; i += SEG_T) { seg_v2d v = { fin[LX(2 * i)], fin[LX(2 * i + 1)] }; d2[i] = v; }
     } else {
-        for (int i = tid; i < N; i += SEG_T) as_global(ch.dst)[i] = fin[LX(i)];
+        for (int i = tid; i < N; i += SEG_T) as_global(dst)[i] = fin[LX(i)];
     }
-    if (MULTI && wf + 1 < n_frames) { __threadfence_block(); __syncthreads(); }      /* state and LDS frames before the next frame touches them */
-  }
+}
+/* MULTI = false: one frame per launch (the loop below disappears: this is the kernel of the per-frame calls, and a loop around its
+ * body costs it 8 us in scalar register spills).  MULTI = true: a window of n_frames frames per launch. */
+#ifdef SEG_FAST
+/* A kernel's register count is the largest of its own body and of every unit it can call, and it applies to ALL its waves.  The units of
+ * this configuration stay at 120; a build in which one unit (or the window loop's scalars parked in vector lanes) took 124-128 ran EVERY
+ * segment 15 % slower -- also segments that never call that unit (profiles/experiments/README.md, r04).  Hence the explicit ceiling. */
+#define SEG_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(120)))
+#else
+#define SEG_KERNEL_ATTR
+#endif
+template <bool MULTI>
+__global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU) SEG_KERNEL_ATTR
+seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
+           gdg_os_tables os, int *d_error) {
+    gdg_seg_chan ch = chans[blockIdx.x];
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
+    if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
+    const int tid = threadIdx.x;
+    /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
+    int my_type = 0;
+    if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
+    /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
+     * through global memory from one frame to the next exactly as from one launch to the next (same CU, same L1; a barrier between) */
+    for (int wf = 0; wf < (MULTI ? n_frames : 1); wf++, ch.src += N, ch.dst += N) {
+        seg_frame(ch.src, ch.dst, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type);
+        if (MULTI && wf + 1 < n_frames) { __threadfence_block(); __syncthreads(); }      /* state and LDS frames before the next frame touches them */
+    }
 }
 
 int gdg_seg_supported(int unit_type) {
