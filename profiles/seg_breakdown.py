@@ -41,7 +41,8 @@ CASES = [
 def main():
     pkg = entry.load_package()
     nch, frames, sr, steps = 512, 8192, 192000, 10
-    args = [a for a in sys.argv[1:] if a != "--cold" and not a.startswith("--window=")]
+    args = [a for a in sys.argv[1:] if a != "--cold" and not a.startswith("--window=") and not a.startswith("--pad=")]
+    pad = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad=")] + [0])      # window mode: extra doubles per row (row stride = W * frames + pad)
     W = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--window=")] + [0])      # > 0: gdg_process_window_device, W frames per launch
     cold = "--cold" in sys.argv[1:]          # evict L2 / MALL between launches (as after the 1 GB MAC stream in the bench)
     only = set(args)
@@ -59,14 +60,15 @@ def main():
         if W:
             ctx.set_window(W)
             ctx.set_overlap(1)
-            d_in, d_out = ctx.alloc(nch, W * frames), ctx.alloc(nch, W * frames)
-            d_in.upload(np.tile(x, (1, W)))
+            stride = W * frames + pad
+            d_in, d_out = ctx.alloc(nch, stride), ctx.alloc(nch, stride)
+            d_in.upload(np.concatenate([np.tile(x, (1, W)), np.zeros((nch, pad))], axis=1))
             for _ in range(2):
-                ctx.process_window_device(d_in.ptr, d_out.ptr, W * frames, W, sr)
+                ctx.process_window_device(d_in.ptr, d_out.ptr, stride, W, sr)
             ctx.synchronize()
             ctx.profile_enable(True)
             for _ in range(3):
-                ctx.process_window_device(d_in.ptr, d_out.ptr, W * frames, W, sr)
+                ctx.process_window_device(d_in.ptr, d_out.ptr, stride, W, sr)
             ctx.synchronize()
             ms, n = ctx.profile_read(pkg.K_SEGMENT)
             us = ms / n * 1e3 / W
