@@ -15,5 +15,6 @@ for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ
   DB=$(find /tmp/pmc_$i -name '*.db' | head -1)
   echo "# set: $SET" >> "$OUT"
   python "$REPO/profiles/pmc_summary.py" "$DB" seg_kernel >> "$OUT" 2>&1
+  python "$REPO/profiles/pmc_summary.py" "$DB" segf_kernel >> "$OUT" 2>&1
   python "$REPO/profiles/pmc_summary.py" "$DB" fir_inv_kernel >> "$OUT" 2>&1
 done

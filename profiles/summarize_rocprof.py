@@ -47,5 +47,5 @@ if __name__ == "__main__":
         w = pmc(sys.argv[3], "WRITE_SIZE")
         print("\ncorrected HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (see module docstring)")
         for k in f:
-            if k in w and ("fir_" in k or "seg_" in k or "tuner" in k or "spat" in k):
+            if k in w and ("fir_" in k or "seg_" in k or "segf_" in k or "tuner" in k or "spat" in k):
                 print("%-62s read %10.1f MB  write %10.1f MB  total %10.1f MB" % (k, 2 * f[k] * 1024 / 1e6, w[k] * 1024 / 1e6, (2 * f[k] + w[k]) * 1024 / 1e6))
