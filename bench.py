@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path's headline metric on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: N ranks under torch.distributed.run -- started by a launcher, or by
+                                                             this file itself when it finds none; a launcher with another WORLD_SIZE is an error)
 
 One "step" = one pass of the full effects chain over one 8192-frame block of every channel
 (what controller.process() does per BLOCK_SIZE block, controller/controller.go:3076-3107), with
@@ -234,9 +235,9 @@ def us_stats(st):
             "warmup_calls": st["warmup_calls"]}
 
 
-def leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, channel0=0, chain=CHAIN, second_amp=True):
+def leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, channel0=0, chain=CHAIN, second_amp=True, n_distinct=0):
     """Per-frame calls of a fresh `nch`-channel context: `steps` steps per timed call (robust_time)."""
-    ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0, chain=chain, second_amp=second_amp)
+    ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0, chain=chain, second_amp=second_amp, n_distinct=n_distinct)
     d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
     d_in.upload(synth_block(nch, frames, sr, channel0=channel0))
 
@@ -402,6 +403,15 @@ def other_configs(pkg, device):
         dt = st["median"]
         out[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "us_per_block": dt * 1e6, "realtime_factor": frames / sr / dt,
                     "timing": us_stats(st)}
+    # the ends of the power amp's range (effects/poweramp.go:303-329): the DEFAULT filter order, 1 048 576 taps = 128 partitions at the batch block
+    # size, and a 9600-tap filter at the live path's 64-sample hops = 150 partitions; one power amp per chain, 64 channels, 4 distinct IRs
+    # (the spectra of 64 private 1M-tap IRs alone would be 2 GiB of synthetic data to make on the host)
+    for key, nch, frames, sr, taps, steps in (("long_filter_1048576_taps_64ch_192k", 64, 8192, 192000, 1048576, 10),
+                                              ("small_hop_64_frames_9600_taps_64ch_96k", 64, 64, 96000, 9600, 200)):
+        st = leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, chain=CHAIN, second_amp=False, n_distinct=4)
+        dt = st["median"]
+        out[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "us_per_block": dt * 1e6, "realtime_factor": frames / sr / dt,
+                    "partitions": -(-taps // frames), "timing": us_stats(st)}
     # config 5: 256 tuners (96000-sample windows, 262144-point autocorrelation each) + spatializer 256 -> 2 at 192 kHz
     nch, frames, sr = 256, 8192, 192000
     ctx = pkg.Context(nch, frames, device)

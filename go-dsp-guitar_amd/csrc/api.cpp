@@ -219,6 +219,10 @@ struct gdg_ctx {
     std::vector<char> plan_unit_fast;          /* ... and whether its segment runs on the two-per-CU kernel (scan tables for 16-sample chunks) */
     std::vector<char> plan_unit_fast_ok;       /* ... and whether the unit itself could (segf_unit_ok at plan time): a change of that rebuilds the plan */
     bool seg_fast = true;                      /* GDG_SEG_FAST=0: every segment on the general kernel (A/B measurements, bit-identity tests) */
+    int seg_fast_min = 257;                    /* GDG_SEG_FAST_MIN: fewest channels of a call that take the two-per-CU kernel.  Up to a chip's worth of
+                                                * channels (256 CUs) the general kernel's 1024 threads per channel run in ONE round and finish a frame
+                                                * 2-3 % sooner (64 channels: 159 vs 162 us per step, 128: 215 vs 222, 256: 307 vs 307); beyond that it needs
+                                                * a second round and the two-per-CU kernel wins (512: 90.8 -> 82.1 us per segment launch) */
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
     bool plan_patch = true;                    /* GDG_PLAN_PATCH=0: every parameter change rebuilds the whole plan (A/B measurements) */
     std::vector<unsigned char> blob;
@@ -392,6 +396,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     { const char *e = getenv("GDG_PROFILE_ATTACH"); if (e) ctx->prof_attach = atoi(e) != 0; }
     { const char *e = getenv("GDG_PLAN_PATCH"); if (e) ctx->plan_patch = atoi(e) != 0; }
     { const char *e = getenv("GDG_SEG_FAST"); if (e) ctx->seg_fast = atoi(e) != 0; }
+    { const char *e = getenv("GDG_SEG_FAST_MIN"); if (e) ctx->seg_fast_min = atoi(e); }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -1319,7 +1324,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         std::vector<gdg_seg_chan> sd;
         std::vector<gdg_fir_chan> fd;
         /* a segment step goes to the two-per-CU kernel when EVERY unit of EVERY channel in it can (one launch per step) */
-        bool step_fast = !is_fir && ctx->seg_fast && frames == GDG_MAX_FRAMES;
+        bool step_fast = !is_fir && ctx->seg_fast && frames == GDG_MAX_FRAMES && (int)active.size() >= ctx->seg_fast_min;
         if (step_fast)
             for (auto &entry : kv.second)
                 for (int h : entry.second.handles) if (!segf_unit_ok(ctx->units[(size_t)h], frames, sample_rate)) { step_fast = false; break; }
