@@ -1335,7 +1335,65 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     constexpr int QA = REVERB_QMAX, QB = 3 * 1024 / SEG_T, QC = 1024 / SEG_T, NP = REVERB_QMAX / 2;      /* NP sample pairs per thread */
     GDG_GLOBAL double *g = as_global(dl_ring);
     const double g0 = g[0];
-    /* 1. per sample pair (2p, 2p + 1), p = tid + q SEG_T, everything in the thread's OWN cells: the frame's pair joins the delay line, the
+    /* 1. The frame's pairs (2p, 2p + 1), p = tid + q SEG_T, join the delay line and the tapped sums (reverb.go:65-116) take their place in the
+     * buffer (the all-passes' input).  The ring holds one frame more than the longest tap (jp4 = taps[3] + 8192), so the cells the frame
+     * overwrites are older than anything a tap of this frame reads and the taps -- all at least a frame back -- never meet the new cells:
+     * appending and tapping commute. */
+    /* the union of the four tap windows fits REVERB_QMAX pairs per thread: rates up to 204 kHz (below ~43 kHz the unit is not here at all) */
+    const bool union_ok = taps[3] - taps[0] + N + 1 <= 2 * REVERB_QMAX * SEG_T;
+    if (union_ok) {
+        /* The four tap windows of a frame overlap: 4 x 64 KiB are read for a union
+         * of (taps[3] - taps[0] + 8192) samples = 124 KiB at 192 kHz, and with 64 workgroups per XCD the overlaps no longer meet in L2 -- the
+         * segment is HBM bound.  So every value of the union is loaded ONCE and handed to the (up to) four outputs it belongs to:
+         * value r (relative to the frame's start) adds coeff[j] v to sample n = r + taps[j], tap after tap with a barrier between: a cell
+         * receives its terms in the order j = 0, 1, 2, 3 -- tap 0 STORES (0.0 + c v: the reference's first addition), the others add: the
+         * same sums in the same order, bit for bit, as the four-stream form below and the general kernel. */
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const int i0 = 2 * (tid + q * SEG_T);
+            const double x0 = in[LX(i0)], x1 = in[LX(i0 + 1)];
+            int p = dl_wp + i0;                             /* dl_wp < DL, i0 < N <= DL */
+            if (p >= DL) p -= DL;
+            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
+            else { g[p] = x0; g[0] = x1; }
+        }
+        __syncthreads();                                    /* every thread has its pair out of the buffer: tap 0 may overwrite it */
+        const int rtop = N - 1 - taps[0];                   /* the newest value any tap of this frame reads (negative) */
+        const int npairs = (taps[3] - taps[0] + N + 1) / 2; /* pair k = values (rtop - 2 k - 1, rtop - 2 k) */
+        auto fetch = [&](int k) -> seg_v2d {
+            const int kk = min(k, npairs - 1);
+            int pl = dl_wp + (rtop - 2 * kk - 1);            /* ring cell of the pair's older value; >= -DL */
+            if (pl < 0) pl += DL;
+            seg_v2d v;
+            if (pl + 1 < DL) v = *(const GDG_GLOBAL seg_v2d *)(g + pl);
+            else { v.x = g[pl]; v.y = g0; }
+            return v;
+        };
+        /* all of the thread's pairs first (up to 16 sixteen-byte loads in flight: nothing else of the unit is live yet), then the steps */
+        seg_v2d pr[REVERB_QMAX];
+#pragma unroll
+        for (int it = 0; it < REVERB_QMAX; it++) pr[it] = fetch(it * SEG_T + tid);
+        /* tap by tap: within one tap every value goes to a cell of its own (n = r + taps[j] is one to one), so FOUR barriers order the
+         * four additions of every cell (walking the window in steps, tap order from step to step, took sixteen) */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int it = 0; it < REVERB_QMAX; it++) {
+                const int k = it * SEG_T + tid;
+                const int rh = rtop - 2 * k;                /* k >= npairs: r + taps[j] < 0 for every tap, nothing is written */
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int n = rh - h + taps[j];
+                    if (n >= 0 && n < N) {
+                        const double term = coeff[j] * (h ? pr[it].x : pr[it].y);
+                        out[LX(n)] = (j == 0 ? 0.0 : out[LX(n)]) + term;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+    /* per sample pair everything in the thread's OWN cells: the frame's pair joins the delay line, the
      * tapped sums (reverb.go:65-116) take its place in the buffer (the all-passes' input).  The ring holds one frame more than the longest
      * tap (jp4 = taps[3] + 8192), so the cells the frame overwrites are older than anything a tap of this frame reads and the taps -- all
      * at least a frame back -- never meet the new cells: appending and tapping commute, nobody waits for anybody.  A real loop of NB
@@ -1376,6 +1434,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
             out[LX(i0)] = pre0;
             out[LX(i0 + 1)] = pre1;
         }
+    }
     }
     if (tid == 0) as_global(is_state)[0] = (dl_wp + N) % DL;
     /* 2. ring heads of the three all-passes, and the tapped sums back into registers (own cells, written above: the mix wants them after
