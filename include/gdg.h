@@ -89,7 +89,10 @@ int gdg_ctx_synchronize(gdg_ctx *ctx);
 /* effects.CreateUnit(unitType) (effects/effects.go:443-516); parameters start at the reference's defaults. */
 int gdg_unit_create(gdg_ctx *ctx, int channel, int unit_type, int *handle);
 int gdg_unit_destroy(gdg_ctx *ctx, int handle);
-/* Resolved value of one parameter (the host side has already done effects.go:144-384's checks). */
+/* Resolved value of one parameter (the host side has already done effects.go:144-384's checks).  Effective from the next process call, like the
+ * reference's setter (effects/effects.go:283-345: a store under a mutex).  Cheap on a live context: the call itself stores the value; the next
+ * process call re-derives that unit's constants and patches its descriptor on the device in place -- the launch plan is only rebuilt by changes of
+ * a chain's layout (gdg_chain_set), of the frame size or rate, or by new filter taps. */
 int gdg_unit_set_param(gdg_ctx *ctx, int handle, int param_index, int32_t value);
 int gdg_unit_get_param(gdg_ctx *ctx, int handle, int param_index, int32_t *value);
 /*
