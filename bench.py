@@ -569,8 +569,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus
     distributed = world > 1
+    one_device = bool(os.environ.get("GDG_BENCH_ONE_DEVICE"))     # harness self-test on a one-GPU box: every rank shares device 0
     try:
-        shard.check_devices(args.gpus, torch.cuda.device_count(), bool(os.environ.get("GDG_BENCH_ONE_DEVICE")))
+        local_rank = shard.pick_device(args.gpus, local_rank, torch.cuda.device_count(), one_device)
     except shard.LaunchError as e:
         sys.stderr.write("bench.py: %s\n" % e.msg)
         raise
@@ -581,8 +582,6 @@ def main():
         # control plane only (barrier + max of one scalar): gloo, so that NO RCCL / xGMI traffic exists anywhere in this job
         # a rank that dies inside an extra leg must not hang the others for gloo's default 30 minutes: collectives give up after 5
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=int(os.environ.get("GDG_BENCH_DIST_TIMEOUT", "300"))))
-    if os.environ.get("GDG_BENCH_ONE_DEVICE"):            # harness self-test on a one-GPU box: every rank shares device 0
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -591,6 +590,13 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, devices[0])
         devices = gathered
+        try:
+            shard.check_distinct([d["pci_bus_id"] for d in devices], one_device)      # the same verdict on every rank
+        except shard.LaunchError as e:
+            if rank == 0:
+                sys.stderr.write("bench.py: %s\n" % e.msg)
+            dist.destroy_process_group()
+            raise
 
     frames, sr, taps = args.frames, args.sample_rate, args.taps
     strong = args.total_channels > 0

@@ -118,11 +118,28 @@ def spawn_command(python, script, argv, gpus, port):
             "--master-port", str(port), script] + list(argv)
 
 
-def check_devices(gpus, visible, one_device):
-    """Every rank needs a device of its own unless the harness self-test (GDG_BENCH_ONE_DEVICE) puts all ranks on device 0."""
+def pick_device(gpus, local_rank, visible, one_device):
+    """The HIP device index of this rank.  Normally local_rank (every rank sees all the node's devices).  A launcher may instead give
+    every rank ONE visible device of its own (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank): then it is device 0, and
+    check_distinct() makes sure afterwards that the ranks really sit on different devices.  GDG_BENCH_ONE_DEVICE (harness self-test on
+    a one-GPU box): every rank on device 0, on purpose."""
+    if visible < 1:
+        raise LaunchError("no HIP device visible")
     if one_device:
-        if visible < 1:
-            raise LaunchError("no HIP device visible")
+        return 0
+    if local_rank < visible:
+        return local_rank
+    if visible == 1:
+        return 0
+    raise LaunchError("--gpus %d, local rank %d, but %d HIP devices are visible" % (gpus, local_rank, visible))
+
+
+def check_distinct(pci_bus_ids, one_device):
+    """After the ranks have exchanged the PCI bus ids of their devices: N ranks on fewer than N devices is not an N-GPU measurement
+    (unless the harness self-test asked for exactly that)."""
+    if one_device:
         return
-    if visible < gpus:
-        raise LaunchError("--gpus %d but only %d HIP device(s) are visible (GDG_BENCH_ONE_DEVICE=1 shares device 0 for a harness self-test)" % (gpus, visible))
+    ids = [i for i in pci_bus_ids if i]
+    if len(ids) == len(pci_bus_ids) and len(set(ids)) != len(ids):
+        raise LaunchError("%d ranks share %d device(s) (%s): every rank needs a GPU of its own (GDG_BENCH_ONE_DEVICE=1 shares device 0 "
+                          "for a harness self-test)" % (len(ids), len(set(ids)), ", ".join(sorted(set(ids)))))

@@ -25,3 +25,20 @@ def test_plain_python_bench_gpus_2_prints_a_two_rank_line():
     assert line["config"]["total_channels"] == 128 and line["config"]["channels_per_gpu"] == 64
     assert line["parity"]["ok"] and line["parity"]["rms_max_all_ranks"] <= 1e-9
     assert line["value"] > 0 and line["roofline"]["frac"] is not None
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_are_refused_unless_asked_for():
+    """Without GDG_BENCH_ONE_DEVICE the same command on a one-GPU box must NOT print a line that says "n_gpus": 2: the ranks exchange the PCI bus ids
+    of their devices and stop when they are not distinct (on a box with two or more GPUs the ranks get a device each and the run succeeds)."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GDG_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--channels", "8", "--taps", "8192",
+                        "--no-extras", "--no-cpu-baseline", "--no-parity"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+        assert len({d["pci_bus_id"] for d in json.loads(lines[0])["devices"]}) == 2
+    else:
+        assert r.returncode != 0 and not lines, r.stdout[-500:]
+        assert "share 1 device" in r.stderr

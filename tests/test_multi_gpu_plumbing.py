@@ -122,12 +122,19 @@ def test_launch_plan_decides_run_spawn_or_error():
     assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
     assert cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "7"]
-    shard.check_devices(8, 8, False)
-    shard.check_devices(2, 1, True)                                               # harness self-test: every rank on device 0
+    assert shard.pick_device(8, 5, 8, False) == 5                                # every rank sees the node's eight devices
+    assert shard.pick_device(8, 5, 1, False) == 0                                # the launcher gave every rank ONE visible device
+    assert shard.pick_device(2, 1, 1, True) == 0                                 # harness self-test: every rank on device 0
     with pytest.raises(shard.LaunchError):
-        shard.check_devices(8, 1, False)
+        shard.pick_device(8, 5, 4, False)                                         # neither shape
     with pytest.raises(shard.LaunchError):
-        shard.check_devices(2, 0, True)
+        shard.pick_device(2, 0, 0, True)
+    shard.check_distinct(["0000:05:00.0", "0000:15:00.0"], False)
+    shard.check_distinct(["0000:05:00.0", "0000:05:00.0"], True)
+    shard.check_distinct([None, None], False)                                     # ids unknown: nothing to say
+    with pytest.raises(shard.LaunchError) as e:
+        shard.check_distinct(["0000:05:00.0", "0000:05:00.0"], False)             # two ranks, one GPU: not a 2-GPU measurement
+    assert "share 1 device" in e.value.msg
 
 
 def _bench(args, env_extra, timeout=180):
@@ -155,5 +162,5 @@ def test_plain_python_bench_gpus_2_spawns_two_ranks():
     r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-parity"], {})
     assert r.returncode != 0
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
-    assert r.stderr.count("only 0 HIP device(s) are visible") >= 2, r.stderr[-2000:]       # BOTH ranks got that far
+    assert r.stderr.count("no HIP device visible") >= 2, r.stderr[-2000:]                  # BOTH ranks got that far
     assert '"n_gpus"' not in r.stdout
