@@ -98,7 +98,7 @@ def launch_plan(gpus, environ):
     if world != gpus:
         raise LaunchError("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
     for key in ("RANK", "LOCAL_RANK"):
-        if environ.get(key) in (None, ""):
+        if world > 1 and environ.get(key) in (None, ""):       # a lone WORLD_SIZE=1 is simply a single process
             raise LaunchError("WORLD_SIZE=%d is set but %s is not: not a torch.distributed.run environment" % (world, key))
     return "run"
 

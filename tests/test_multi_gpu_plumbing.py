@@ -112,6 +112,7 @@ def test_launch_plan_decides_run_spawn_or_error():
     assert shard.launch_plan(2, {"WORLD_SIZE": ""}) == "spawn"
     assert shard.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3", "LOCAL_RANK": "3"}) == "run"
     assert shard.launch_plan(1, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}) == "run"
+    assert shard.launch_plan(1, {"WORLD_SIZE": "1"}) == "run"                     # a lone WORLD_SIZE=1: a single process
     for gpus, env in ((8, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}), (1, {"WORLD_SIZE": "8", "RANK": "0", "LOCAL_RANK": "0"}),
                       (2, {"WORLD_SIZE": "two"}), (0, {}), (4, {"WORLD_SIZE": "4"})):
         with pytest.raises(shard.LaunchError) as e:
