@@ -140,3 +140,52 @@ def test_small_contexts_stay_on_the_general_kernel_by_default(monkeypatch):
         outs.append(stream(ctx, [None, None], x, sr, [B, B])[0])
         ctx.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_in_place_chains_on_the_two_per_cu_kernel(oracle, monkeypatch, seed):
+    """Random chains of the units the two-per-CU kernel runs (power amps between them cut the chains into segments), parameters anywhere in the
+    reference's ranges (oversampling off), 8192-sample frames at a random rate: against the oracle, and run TWICE -- every unit of this kernel
+    shares one LDS buffer with its neighbours' threads, a race would show as a difference between the runs."""
+    import json
+    import os
+    import __graft_entry__ as entry
+    with open(os.path.join(entry.ROOT, "tests", "golden", "params.json")) as f:
+        PARAMS = json.load(f)
+    pkg = package()
+    monkeypatch.setenv("GDG_SEG_FAST_MIN", "0")
+    rng = np.random.default_rng(7000 + seed)
+    sr = int(rng.choice([44100, 48000, 96000, 192000]))
+    names = ["compressor", "overdrive", "distortion", "excess", "tone_stack", "cabinet", "chorus", "reverb", "ring_modulator", "tremolo", "signal_generator"]
+    chains = []
+    for c in range(3):
+        chain = []
+        for _ in range(int(rng.integers(1, 7))):
+            if rng.random() < 0.15:
+                chain.append(("power_amp", "ir"))
+                continue
+            name = names[int(rng.integers(0, len(names)))]
+            vals = []
+            for p in PARAMS[str(pkg.UNIT[name])]["params"]:
+                if p["Type"] == "PARAMETER_TYPE_DISCRETE":
+                    vals.append(0 if p["Name"] == "oversampling" else int(rng.integers(0, len(p["DiscreteValues"]))))
+                else:
+                    lo, hi = int(p["Minimum"]), int(p["Maximum"])
+                    vals.append(int(rng.choice([lo, hi, int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))])))
+            chain.append((name, vals))
+        chains.append(chain)
+    blocks = 3
+    x = np.stack([synth_signal(int(rng.integers(0, 48)), blocks * B, sr) * float(rng.choice([0.05, 0.5, 1.0])) for _ in range(3)])
+    runs = []
+    want = None
+    for k in range(2):
+        ctx, refs = build(pkg, oracle if k == 0 else None, chains)
+        got, w = stream(ctx, refs if k == 0 else [None] * 3, x, sr, [B] * blocks)
+        ctx.close()
+        runs.append(got)
+        if k == 0:
+            want = w
+    for c in range(3):
+        assert np.isfinite(runs[0][c]).all(), (seed, c, chains[c])
+        assert np.array_equal(runs[0][c], runs[1][c]), (seed, c, chains[c])
+        assert rms(runs[0][c] - want[c]) <= TOL_RMS, (seed, c, sr, chains[c], rms(runs[0][c] - want[c]))
