@@ -189,3 +189,42 @@ def test_random_in_place_chains_on_the_two_per_cu_kernel(oracle, monkeypatch, se
         assert np.isfinite(runs[0][c]).all(), (seed, c, chains[c])
         assert np.array_equal(runs[0][c], runs[1][c]), (seed, c, chains[c])
         assert rms(runs[0][c] - want[c]) <= TOL_RMS, (seed, c, sr, chains[c], rms(runs[0][c] - want[c]))
+
+
+def test_full_load_equals_light_load_bit_for_bit(monkeypatch):
+    """512 channels (two workgroups on every CU, all phases of all units colliding) against the SAME channels alone in a three-channel context on
+    the same kernel: channels are independent, so every bit must agree -- a race between co-resident workgroups or between the threads that
+    share the one LDS buffer would show here (and the big run is repeated: equal to itself as well)."""
+    pkg = package()
+    sr, nch, blocks = 192000, 512, 4
+    ir = synth_ir(4000, seed=9)
+    chain = [("compressor", [1, 30, -20]), ("overdrive", [0, 20, 100, 0, 1, 0]), ("tone_stack", None), ("chorus", None), ("power_amp", ir),
+             ("cabinet", None), ("reverb", [50]), ("tremolo", None)]
+    pick = [0, 255, 511]
+
+    def run(channels):
+        ctx = pkg.Context(len(channels), B)
+        for c in range(len(channels)):
+            for name, p in chain:
+                if name == "power_amp":
+                    ctx.append_unit(c, name, fir=p)
+                else:
+                    ctx.append_unit(c, name, params=p)
+        x = np.stack([0.6 * synth_signal(g % 48, blocks * B, sr) * (1.0 + 0.001 * g) for g in channels])
+        d_in, d_out = ctx.alloc(len(channels), B), ctx.alloc(len(channels), B)
+        out = np.zeros_like(x)
+        for b in range(blocks):
+            d_in.upload(np.ascontiguousarray(x[:, b * B:(b + 1) * B]))
+            ctx.process_device(d_in, d_out, B, sr)
+            out[:, b * B:(b + 1) * B] = d_out.download()
+        ctx.close()
+        return out
+
+    big1 = run(list(range(nch)))
+    big2 = run(list(range(nch)))
+    assert np.array_equal(big1, big2)
+    monkeypatch.setenv("GDG_SEG_FAST_MIN", "0")
+    small = run(pick)
+    for k, g in enumerate(pick):
+        assert np.array_equal(small[k], big1[g]), (g, float(np.max(np.abs(small[k] - big1[g]))))
+    assert np.isfinite(big1).all() and np.max(np.abs(big1)) > 0.01
