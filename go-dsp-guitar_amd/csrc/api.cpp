@@ -91,7 +91,10 @@ struct DevArena {
                 if (end > at + need) h.emplace(at + need, end - (at + need));
                 *out = chunks[c].base + at;
                 live.emplace(*out, std::make_pair(c, need));
-                if (at >= chunks[c].virgin) { if (zeroed) *zeroed = true; chunks[c].virgin = at + need; }
+                /* zeros only if the WHOLE block lies in never-used space; the mark always moves past what is handed out (a freed block that
+                 * coalesced with the untouched tail gives a hole that straddles the mark) */
+                if (at >= chunks[c].virgin && zeroed) *zeroed = true;
+                chunks[c].virgin = std::max(chunks[c].virgin, at + need);
                 return hipSuccess;
             }
         }
