@@ -32,6 +32,8 @@
 #include <thread>
 #include <vector>
 
+#include "arena.h"
+
 #define NUM_FILTERS 8
 
 /* ---- parameter tables (defaults), effects/<unit>.go create*() ------------------------------------ */
@@ -43,112 +45,18 @@ static const int32_t g_param_default[GDG_UNIT_COUNT][GDG_MAX_PARAMS] = {
     { 100, 30 }, { 100, 10 }, { 100, 10, 45 }, { 100, 50, -10 }, { 100 }, { 200, -5, -5 }, { 50 }, { 14 }, { 0 },
 };
 
-/* Device memory of the per-unit state.  A 512-channel context owns ~17 000 blocks (per unit: small state, history ring, and per
- * power amp the overlap-save history, delay line, product spectra, frame counter, IR spectra); as one hipMalloc / hipFree each they
- * cost ~1 s to release and scatter the state over the address space.  They come out of a few chunks instead (the first 4 MiB, every
- * further one as large as everything before it, up to 1 GiB -- a one-channel context holds 4 MiB, a 512-channel one a dozen chunks),
- * sub-allocated on the host: first fit over an address-ordered free list that coalesces on free.  No implicit synchronisation: whoever
- * frees a block has already waited for the work that used it (every call site does; GDG_ARENA_SYNC_RELEASE=1 synchronises the device in
- * release() to catch a call site that forgets to).
- * ZEROS.  Almost every block starts out as zeros (unit state, history rings, delay lines), and one hipMemsetAsync per block was 14 338
- * fill dispatches -- a third of the GPU time of a 512-channel context's set-up trace.  A chunk is zeroed ONCE, when it is made, and
- * remembers how far it has been handed out (`virgin`): alloc_zeroed() on space beyond that mark is free, only recycled space is filled. */
-struct DevArena {
-    struct Chunk { char *base; size_t size; std::map<size_t, size_t> holes; size_t virgin; };   /* holes: offset -> bytes; [virgin, size) was never handed out: zeros */
-    std::vector<Chunk> chunks;
-    std::map<const void *, std::pair<size_t, size_t>> live;                           /* block -> (chunk index, bytes) */
-    size_t total = 0;
-    hipStream_t stream = nullptr;                                                      /* the context's stream: chunk zeroing and fills are ordered on it */
-    size_t fills = 0, fills_saved = 0;                                                 /* alloc_zeroed: fill dispatches issued / avoided */
-    /* Blocks of a page or more start on `big_align` (env GDG_ARENA_ALIGN, default 4 KiB like a hipMalloc of their own would): the
-     * streaming kernels read delay lines and spectra front to back, and packing those at 256-byte offsets behind the small state
-     * blocks cost the convolution 5-13 % (profiles/arena_ab_r03.txt).  GDG_ARENA=0: one hipMalloc per block (A/B measurements). */
-    size_t big_align = 4096;
-    size_t first_chunk = (size_t)4 << 20;
-    bool direct = false, sync_release = false;
-    DevArena() {
-        if (const char *e = getenv("GDG_ARENA_ALIGN")) { size_t a = (size_t)atoll(e); if (a >= 256 && (a & (a - 1)) == 0) big_align = a; }
-        if (const char *e = getenv("GDG_ARENA")) direct = atoi(e) == 0;
-        if (const char *e = getenv("GDG_ARENA_FIRST_CHUNK")) { size_t a = (size_t)atoll(e); if (a >= 4096) first_chunk = a; }
-        if (const char *e = getenv("GDG_ARENA_SYNC_RELEASE")) sync_release = atoi(e) != 0;
-    }
-    static size_t round_up(size_t b, size_t a) { return (b + a - 1) & ~(a - 1); }
-    /* *zeroed (optional): the block is known to hold zeros (never handed out since its chunk was made) */
-    hipError_t alloc(void **out, size_t bytes, bool *zeroed = nullptr) {
-        if (zeroed) *zeroed = false;
-        if (direct) return hipMalloc(out, bytes ? bytes : 1);
-        const size_t need = round_up(bytes ? bytes : 1, 256);
-        const size_t align = need >= 4096 ? big_align : 256;
-        for (size_t c = 0; c < chunks.size(); c++) {
-            auto &h = chunks[c].holes;
-            const uintptr_t base = (uintptr_t)chunks[c].base;
-            for (auto it = h.begin(); it != h.end(); ++it) {
-                const size_t off = it->first, end = off + it->second;
-                const size_t at = (size_t)(round_up(base + off, align) - base);
-                if (at + need > end) continue;
-                h.erase(it);
-                if (at > off) h.emplace(off, at - off);
-                if (end > at + need) h.emplace(at + need, end - (at + need));
-                *out = chunks[c].base + at;
-                live.emplace(*out, std::make_pair(c, need));
-                /* zeros only if the WHOLE block lies in never-used space; the mark always moves past what is handed out (a freed block that
-                 * coalesced with the untouched tail gives a hole that straddles the mark) */
-                if (at >= chunks[c].virgin && zeroed) *zeroed = true;
-                chunks[c].virgin = std::max(chunks[c].virgin, at + need);
-                return hipSuccess;
-            }
-        }
-        size_t size = std::max(need, std::min((size_t)1 << 30, std::max(first_chunk, total)));
-        void *base = nullptr;
-        hipError_t e = hipMalloc(&base, size);
-        if (e != hipSuccess && size > need) { size = need; e = hipMalloc(&base, size); }
-        if (e != hipSuccess) { *out = nullptr; return e; }
-        /* zeros, once: ONE fill for everything this chunk will ever hand out for the first time.  Waited for: not every later writer
-         * of the chunk is ordered on `stream` (synchronous hipMemcpy's of tables run on the null stream). */
-        e = hipMemsetAsync(base, 0, size, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) { hipFree(base); *out = nullptr; return e; }
-        total += size;
-        chunks.push_back(Chunk{ static_cast<char *>(base), size, {}, need });     /* hipMalloc'ed chunks of >= 2 MiB start on 2 MiB */
-        if (size > need) chunks.back().holes.emplace(need, size - need);
-        *out = base;
-        live.emplace(*out, std::make_pair(chunks.size() - 1, need));
-        if (zeroed) *zeroed = true;
-        return hipSuccess;
-    }
-    /* a block of zeros; a fill is enqueued on `st` only when the space has been used before */
-    hipError_t alloc_zeroed(void **out, size_t bytes, hipStream_t st) {
-        bool zeroed = false;
-        hipError_t e = alloc(out, bytes, &zeroed);
-        if (e != hipSuccess) return e;
-        if (zeroed) { fills_saved++; return hipSuccess; }
-        fills++;
-        return hipMemsetAsync(*out, 0, bytes ? bytes : 1, st);
-    }
-    void release(const void *p) {
-        if (!p) return;
-        if (sync_release) hipDeviceSynchronize();
-        if (direct) { hipFree(const_cast<void *>(p)); return; }
-        auto it = live.find(p);
-        if (it == live.end()) return;
-        Chunk &ch = chunks[it->second.first];
-        size_t off = (size_t)(static_cast<const char *>(p) - ch.base), n = it->second.second;
-        live.erase(it);
-        auto next = ch.holes.lower_bound(off);
-        if (next != ch.holes.end() && off + n == next->first) { n += next->second; next = ch.holes.erase(next); }
-        if (next != ch.holes.begin()) {
-            auto prev = std::prev(next);
-            if (prev->first + prev->second == off) { prev->second += n; return; }
-        }
-        ch.holes.emplace(off, n);
-    }
-    void destroy() {
-        for (auto &c : chunks) hipFree(c.base);
-        chunks.clear();
-        live.clear();
-        total = 0;
-    }
+/* DevArena: arena.h over the HIP runtime */
+struct HipArenaBackend {
+    using err_t = hipError_t;
+    using stream_t = hipStream_t;
+    static err_t ok() { return hipSuccess; }
+    static err_t malloc(void **p, size_t n) { return hipMalloc(p, n); }
+    static void free(void *p) { (void)hipFree(p); }
+    static err_t fill_zero(void *p, size_t n, stream_t st) { return hipMemsetAsync(p, 0, n, st); }
+    static err_t wait(stream_t st) { return hipStreamSynchronize(st); }
+    static void wait_device() { (void)hipDeviceSynchronize(); }
 };
+using DevArena = ArenaT<HipArenaBackend>;
 
 /* IR spectra of one (taps, partition size) pair; power amps with identical composite filters share one copy in HBM
  * (the MAC then streams it from L2 / MALL for all but the first channel: SURVEY.md 8d, d < 1) */
@@ -457,8 +365,9 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     for (auto &u : ctx->units) if (u.alive) free_unit(ctx, u);
     ctx->spectra.clear();
     if (const char *e = getenv("GDG_ARENA_TRACE")) if (atoi(e))
-        fprintf(stderr, "[arena] %d channels: %zu chunks, %.1f MiB, %zu blocks live, zero fills issued %zu, avoided %zu\n", ctx->nch, ctx->arena.chunks.size(),
-                (double)ctx->arena.total / 1048576.0, ctx->arena.live.size(), ctx->arena.fills, ctx->arena.fills_saved);
+        fprintf(stderr, "[arena] %d channels: %zu chunks, %.1f MiB (peak %.1f MiB, %zu chunks given back), %zu blocks live, zero fills issued %zu, avoided %zu\n",
+                ctx->nch, ctx->arena.chunks_held(), (double)ctx->arena.total / 1048576.0, (double)ctx->arena.peak_total / 1048576.0, ctx->arena.trimmed,
+                ctx->arena.live.size(), ctx->arena.fills, ctx->arena.fills_saved);
     ctx->arena.destroy();
     for (void *p : ctx->user_allocs) hipFree(p);
     for (auto &kv : ctx->fir_tables) { hipFree(kv.second.first); hipFree(kv.second.second); }

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import TOL_RMS, package, rms, synth_signal
+from helpers import TOL_RMS, ChainPair, package, rms, run_pairs, synth_signal
 
 pytestmark = pytest.mark.gpu
 
@@ -110,7 +110,7 @@ def test_small_context_holds_a_small_arena(pkg, capfd, monkeypatch):
     ctx.close()
     err = capfd.readouterr().err
     line = [l for l in err.splitlines() if l.startswith("[arena]")][-1]
-    mib = float(line.split("chunks, ")[1].split(" MiB")[0])
+    mib = float(line.split("peak ")[1].split(" MiB")[0])
     issued = int(line.split("issued ")[1].split(",")[0])
     avoided = int(line.split("avoided ")[1])
     assert mib <= 8.0, line
@@ -138,3 +138,81 @@ def test_malformed_pcie_weights_are_refused_as_a_whole(pkg):
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.startswith("OK 0.0"), (env_value, r.stderr[-500:])
         assert ("GDG_PCIE_WEIGHTS" in r.stderr) == complains, (env_value, r.stderr[-500:])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_state_of_new_units_is_zero_after_arena_churn(pkg, oracle, seed):
+    """Unit state, delay lines and history rings come out of the arena without a fill when the space was never handed out.  Blocks that
+    straddle the never-used mark (a freed temporary that coalesced with the untouched tail) must move the mark: here units and filters of random
+    sizes come and go while noise runs through them, then fresh units with long memories are created and must behave like the oracle's fresh
+    ones."""
+    frames, sr = 512, 48000
+    rng = np.random.default_rng(seed)
+    ctx = pkg.Context(2, frames)
+    live = []                                                   # (handle, unit type, channel)
+    stateful = ["chorus", "reverb", "delay", "flanger", "phaser", "compressor", "auto_wah", "tone_stack"]
+
+    def clear():
+        for c in range(2):
+            ctx.chain_set(c, [], [])
+
+    for it in range(24):
+        kind = rng.integers(0, 3)
+        clear()
+        if kind == 0 or not live:
+            name, ch = str(rng.choice(stateful + ["power_amp"])), int(rng.integers(0, 2))
+            h = ctx.unit_create(ch, name)
+            if name == "power_amp":
+                ctx.unit_set_fir(h, rng.standard_normal(int(rng.integers(10, 6000))))
+            live.append((h, name, ch))
+        elif kind == 1:
+            ctx.unit_destroy(live.pop(int(rng.integers(0, len(live))))[0])
+        else:
+            fir = [u for u in live if u[1] == "power_amp"]
+            if fir:
+                ctx.unit_set_fir(fir[int(rng.integers(0, len(fir)))][0], rng.standard_normal(int(rng.integers(10, 20000))))
+        for c in range(2):
+            hs = [u[0] for u in live if u[2] == c]
+            ctx.chain_set(c, hs, [False] * len(hs))
+        ctx.process(rng.uniform(-0.9, 0.9, (2, frames)), sr)
+    for c in range(2):
+        ctx.chain_set(c, [], [])
+    for u in live:
+        ctx.unit_destroy(u[0])
+    pairs = [ChainPair(ctx, c, oracle) for c in range(2)]
+    for p in pairs:
+        for name in ("delay", "chorus", "reverb", "flanger", "compressor"):
+            p.append(name)
+        p.append("power_amp", fir=rng.standard_normal(3000) * 0.01)
+    x = np.zeros((2, 8 * frames))
+    x[:, 0] = 0.5                                               # an impulse: whatever sits in the delay lines comes out after it
+    got, want = run_pairs(ctx, pairs, x, frames, sr)
+    assert rms(got - want) <= TOL_RMS
+    ctx.close()
+
+
+def test_chunks_of_destroyed_long_filters_go_back_to_the_device(pkg, oracle, capfd, monkeypatch):
+    """Entirely free chunks (but the first and one spare) are returned: a run of 1M-tap filters does not pin its memory for the life of the
+    context.  The context keeps working afterwards, new units start from zeros."""
+    monkeypatch.setenv("GDG_ARENA_TRACE", "1")
+    frames, sr = 8192, 192000
+    ctx = pkg.Context(2, frames)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-0.5, 0.5, (2, frames))
+    hs = [ctx.append_unit(c, "power_amp", fir=rng.standard_normal(1 << 20) * 1e-3) for c in range(2)]
+    ctx.process(x, sr)
+    for c in range(2):
+        ctx.chain_set(c, [], [])
+    for h in hs:
+        ctx.unit_destroy(h)
+    pairs = [ChainPair(ctx, c, oracle) for c in range(2)]
+    pairs[0].append("reverb")
+    pairs[1].append("power_amp", fir=rng.standard_normal(500) * 0.05)
+    got, want = run_pairs(ctx, pairs, np.concatenate([x, x], axis=1), frames, sr)
+    assert rms(got - want) <= TOL_RMS
+    ctx.close()
+    line = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[arena]")][-1]
+    held = float(line.split("chunks, ")[1].split(" MiB")[0])
+    peak = float(line.split("peak ")[1].split(" MiB")[0])
+    back = int(line.split("MiB, ")[1].split(" chunks given back")[0])
+    assert peak >= 64.0 and back >= 1 and held <= peak / 2, line
