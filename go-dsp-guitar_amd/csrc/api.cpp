@@ -1474,7 +1474,8 @@ static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
         lo = std::min(lo, off); hi = std::max(hi, off + sizeof(du));
     }
     /* a few knobs: one small copy each; a preset change over many channels: ONE copy of the span they cover (descriptors in between are
-     * rewritten with the bytes they already hold) */
+     * rewritten with the bytes they already hold).  `blob` is pageable on purpose: the runtime has copied such a source into its staging
+     * buffer when the call returns, so the next patch may rewrite the same bytes at once (a pinned blob would need a fence per patch). */
     if (ctx->patch_units.size() > 4) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob + lo, ctx->blob.data() + lo, hi - lo, hipMemcpyHostToDevice, ctx->stream));
     } else {
