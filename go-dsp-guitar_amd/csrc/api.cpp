@@ -1624,7 +1624,7 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                     /* `window` frames per channel: every spectrum is read once for all of them (fir.hip, "Time blocking"); with adjacent
                      * power amps the inverse transforms of one make the forward transforms of the next (one launch, no frame round trip) */
                     const int sh = st.shared_spectra ? 1 : 0;
-                    const bool chain_ok = gdg_fir_window_chain_ok(n) != 0;
+                    const bool chain_ok = gdg_fir_window_chain_ok(n, window) != 0;
                     const bool chained_w = chain_ok && si > 0 && ctx->steps[si - 1].chain_next;
                     const bool chains_w = chain_ok && st.chain_next;
                     if (!chained_w) { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_window(window, d, n, sh, tw, tw2, 0, shift, s)); }

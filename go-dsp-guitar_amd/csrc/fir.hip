@@ -31,7 +31,13 @@ typedef double2 cplx;
 
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+/* Rounding is spelled out in this file: no contraction by the compiler (which product of a sum of two it fuses depends on the code around
+ * it -- two kernels inlining the same butterfly could differ in the last bit, and the window / chained / one-buffer variants of a
+ * transform must give the SAME bits as the per-frame kernels), fused multiply-adds written where they are wanted. */
+#pragma clang fp contract(off)
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
+}
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 /* Frames and spectra live in HBM, but their pointers come out of the channel descriptors in memory, so the compiler only knows
@@ -72,7 +78,7 @@ __device__ __forceinline__ cplx mul_w16(cplx a) {
         constexpr double wr = (m == 1) ? GDG_C1 : (m == 3) ? GDG_S1 : (m == 5) ? -GDG_S1 : -GDG_C1;
         constexpr double wi_f = (m == 1) ? -GDG_S1 : (m == 3) ? -GDG_C1 : (m == 5) ? -GDG_C1 : -GDG_S1;
         constexpr double wi = INV ? -wi_f : wi_f;
-        return make_double2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+        return make_double2(__builtin_fma(a.x, wr, -(a.y * wi)), __builtin_fma(a.x, wi, a.y * wr));
     }
 }
 
@@ -218,6 +224,51 @@ __device__ __forceinline__ void run_lds_passes(cplx (&v)[16], double *sre, doubl
         __syncthreads();
         run_lds_passes<LOGN, P + 1, LAST, INV>(v, sre, sim, tw, tid);
     }
+}
+
+/* ---- one component at a time through LDS ------------------------------------------------------------------------------------------
+ * The 8192-point transforms hold their data in registers (16 points per thread); LDS is only the exchange between passes.  With the real
+ * parts and the imaginary parts taking turns in ONE buffer the exchange needs 70 KiB instead of 140, and TWO workgroups fit a CU: one
+ * streams its frame in or its spectrum out while the other computes (a lone workgroup per CU adds its HBM, LDS and FP64 phases up:
+ * profiles/experiments/README.md).  Same passes, same arithmetic, same bits. */
+template <int C> __device__ __forceinline__ double &part(cplx &z) { if constexpr (C == 0) return z.x; else return z.y; }
+template <int C> __device__ __forceinline__ double part(const cplx &z) { if constexpr (C == 0) return z.x; else return z.y; }
+
+template <int LOGN, int LOGR, int C>
+__device__ __forceinline__ void pass_load1(cplx (&v)[16], const double *s, int tid) {
+    constexpr int N = 1 << LOGN, T = N / 16, R = 1 << LOGR, B = 16 / R;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int j = tid + T * b;
+#pragma unroll
+        for (int t = 0; t < R; t++) part<C>(v[b * R + t]) = s[GDG_PAD(j + t * (N / R))];
+    }
+}
+template <int LOGN, int LOGR, int LOGNS, int C>
+__device__ __forceinline__ void pass_store1(const cplx (&v)[16], double *s, int tid) {
+    constexpr int N = 1 << LOGN, T = N / 16, R = 1 << LOGR, B = 16 / R, NS = 1 << LOGNS;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int j = tid + T * b;
+        int base = ((j >> LOGNS) << (LOGNS + LOGR)) + (j & (NS - 1));
+#pragma unroll
+        for (int t = 0; t < R; t++) s[GDG_PAD(base + t * NS)] = part<C>(v[b * R + t]);
+    }
+}
+/* results of pass P -> operands of pass P + 1, across the workgroup (WAVE = false) or inside one wave's region (WAVE = true: a wave's
+ * LDS operations execute in order, nothing to wait for) */
+template <int LOGN, int P, bool WAVE>
+__device__ __forceinline__ void exchange1(cplx (&v)[16], double *s, int tid) {
+    constexpr int LR = sched_lr(LOGN, P), LNS = sched_lns(LOGN, P), LR1 = sched_lr(LOGN, P + 1);
+    auto meet = [&]() { if constexpr (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
+    meet();                                                   /* the buffer's previous contents have been read */
+    pass_store1<LOGN, LR, LNS, 0>(v, s, tid);
+    meet();
+    pass_load1<LOGN, LR1, 0>(v, s, tid);
+    meet();
+    pass_store1<LOGN, LR, LNS, 1>(v, s, tid);
+    meet();
+    pass_load1<LOGN, LR1, 1>(v, s, tid);
 }
 
 /*
@@ -440,6 +491,104 @@ fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift
     }
 }
 
+/* fir_fwd13w_kernel with one LDS buffer (see exchange1): two workgroups per CU, 128 VGPRs */
+template <int TB>
+__global__ void __launch_bounds__(512, 4)
+fir_fwd13wh_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int N = 8192, T = 512;
+    __shared__ double s[GDG_W_LDS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jw = TB ? (int)(blockIdx.x % (unsigned)W) : 0;
+    gdg_fir_chan ch = chans[TB ? blockIdx.x / (unsigned)W : blockIdx.x];
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
+    const int pos = *ch.pos;
+    const double *a = ch.prev + (size_t)((pos + 1) & 1) * N;
+    if (TB && jw > 0) a = ch.src + (size_t)jw * N - N;
+    double *prev_out = ch.prev + (size_t)(pos & 1) * N;
+    const double *bsrc = ch.src + (size_t)jw * N;
+    cplx *out = ch.fdl + (size_t)((pos + jw) % ch.R) * N;
+
+    cplx ua[2][8], wa[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int n1 = tid + T * b;
+        wa[b] = tw[n1];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; n2++) {
+            const int e = n1 + 1024 * n2;
+            ua[b][n2] = (n2 < 4) ? gload(reinterpret_cast<const cplx *>(a + 2 * e)) : gload(reinterpret_cast<const cplx *>(bsrc + 2 * (e - N / 2)));
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int n1 = tid + T * b;
+        if constexpr (!TB) {
+#pragma unroll
+            for (int n2 = 4; n2 < 8; n2++) gstore(reinterpret_cast<cplx *>(prev_out + 2 * (n1 + 1024 * n2 - N / 2)), ua[b][n2]);
+        }
+        Dft<8, false>::run(ua[b]);
+        twiddle_powers8(ua[b], wa[b]);
+        /* step A -> step B: thread (n1) holds y[n1][k2], wave k2 wants region k2; the real parts go first */
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) s[k2 * GDG_W_RL + GDG_PAD(n1)] = ua[b][k2].x;
+    }
+    double *rs = s + wave * GDG_W_RL;
+    cplx v[16];
+    __syncthreads();
+    pass_load1<10, 4, 0>(v, rs, lane);
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) s[k2 * GDG_W_RL + GDG_PAD(tid + T * b)] = ua[b][k2].y;
+    __syncthreads();
+    pass_load1<10, 4, 1>(v, rs, lane);
+    /* wave_fft1024 on the wave's own region */
+    pass_compute<10, 4, 0, false, 8>(v, tw, lane);
+    exchange1<10, 0, true>(v, rs, lane);
+    pass_compute<10, 3, 4, false, 8>(v, tw, lane);
+    exchange1<10, 1, true>(v, rs, lane);
+    pass_compute<10, 3, 7, false, 8>(v, tw, lane);
+    /* X[8 k1 + wave] back into the region in natural k1 order, then the un-packing in k order: real parts, then imaginary parts */
+    auto Zs = [&](int k) { return s[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)]; };
+    double zkx[8], znx[8];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) rs[GDG_PAD((lane + 64 * b) + 128 * t)] = v[b * 8 + t].x;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+        zkx[i] = Zs(k);
+        znx[i] = Zs(n);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) rs[GDG_PAD((lane + 64 * b) + 128 * t)] = v[b * 8 + t].y;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = tid + T * i;
+        if (k == 0) {
+            cplx z0 = make_double2(zkx[i], Zs(0)), zh = make_double2(znx[i], Zs(N / 2));
+            gstore(out, make_double2(z0.x + z0.y, z0.x - z0.y));
+            gstore(out + N / 2, make_double2(zh.x, -zh.y));
+        } else {
+            const int n = N - k;
+            cplx zk = make_double2(zkx[i], Zs(k)), zn = make_double2(znx[i], Zs(n));
+            cplx A = make_double2(zk.x + zn.x, zk.y - zn.y);
+            cplx Bv = make_double2(zk.x - zn.x, zk.y + zn.y);
+            cplx cw = cmul(tw2[k], Bv);
+            gstore(out + k, make_double2((A.x + cw.y) * 0.5, (A.y - cw.x) * 0.5));
+            gstore(out + n, make_double2((A.x - cw.y) * 0.5, (-A.y - cw.x) * 0.5));
+        }
+    }
+}
+
 /* The window's forward transforms, one workgroup per CHANNEL walking its W frames: the second half of a transform's input (the
  * current frame) is the first half of the next one's (the previous frame) and stays in the registers of the very threads that need it
  * -- element e = n1 + 1024 n2 of the packed sequence: n2 >= 4 now, n2 - 4 next time -- so every frame is read from HBM once instead of
@@ -606,25 +755,30 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
 /* Inverse: packed half spectrum Y -> second half of the 2N-point real sequence -> clip -> dst */
 /* first stage of the packed-real inverse: the spectrum pair (Y[k], Y[n]) -> Z[k], Z[n] in LDS (k = 0: n = N/2) */
 template <int LOGN>
-__device__ __forceinline__ void inv_head_store(int k, cplx yk, cplx yn, double *sre, double *sim, const cplx *__restrict__ tw2) {
-    constexpr int N = FftCfg<LOGN>::N;
+__device__ __forceinline__ void inv_head_values(int k, cplx yk, cplx yn, const cplx *__restrict__ tw2, cplx &zk, cplx &zn) {
     if (k == 0) {
-        sre[0] = yk.x + yk.y;
-        sim[0] = yk.x - yk.y;
-        sre[GDG_PAD(N / 2)] = 2.0 * yn.x;
-        sim[GDG_PAD(N / 2)] = -2.0 * yn.y;
+        zk = make_double2(yk.x + yk.y, yk.x - yk.y);
+        zn = make_double2(2.0 * yn.x, -2.0 * yn.y);
     } else {
-        int n = N - k;
         cplx A = make_double2(yk.x + yn.x, yk.y - yn.y);
         cplx Bv = make_double2(yk.x - yn.x, yk.y + yn.y);
         cplx w = tw2[k];
         w.y = -w.y;
         cplx O = cmul(Bv, w);
-        sre[GDG_PAD(k)] = A.x - O.y;
-        sim[GDG_PAD(k)] = A.y + O.x;
-        sre[GDG_PAD(n)] = A.x + O.y;
-        sim[GDG_PAD(n)] = -A.y + O.x;
+        zk = make_double2(A.x - O.y, A.y + O.x);
+        zn = make_double2(A.x + O.y, -A.y + O.x);
     }
+}
+template <int LOGN>
+__device__ __forceinline__ void inv_head_store(int k, cplx yk, cplx yn, double *sre, double *sim, const cplx *__restrict__ tw2) {
+    constexpr int N = FftCfg<LOGN>::N;
+    const int n = (k == 0) ? N / 2 : N - k;
+    cplx zk, zn;
+    inv_head_values<LOGN>(k, yk, yn, tw2, zk, zn);
+    sre[GDG_PAD(k)] = zk.x;
+    sim[GDG_PAD(k)] = zk.y;
+    sre[GDG_PAD(n)] = zn.x;
+    sim[GDG_PAD(n)] = zn.y;
 }
 
 /* The fused head: the workgroup walks ONE partition at a time through all its bins (partition-major), accumulating the
@@ -840,6 +994,70 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, c
         int pos = *ch.pos + 1;
         int wrap = 2 * ch.R;
         *ch.pos = (pos >= wrap) ? pos - wrap : pos;
+    }
+}
+
+/* fir_inv_kernel<13, 3> (frame j of a window, Y from the time-blocked multiply-accumulate) with one LDS buffer (see exchange1): two
+ * workgroups per CU, 128 VGPRs */
+__global__ void __launch_bounds__(512, 4)
+fir_inv13h_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+    constexpr int LOGN = 13, N = 8192, T = 512, ITER = (N / 2) / T;
+    __shared__ double s[FftCfg<LOGN>::LDS];
+    const int tid = threadIdx.x;
+    const int jw = (int)(blockIdx.x % (unsigned)W);
+    const gdg_fir_chan ch = chans[blockIdx.x / (unsigned)W];
+    const cplx *__restrict__ Y = ch.Y + (size_t)jw * N;
+    cplx zk[ITER], zn[ITER];
+    {
+        cplx yk[ITER], yn[ITER];
+#pragma unroll
+        for (int i = 0; i < ITER; i++) {
+            const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+            yk[i] = gload(Y + k);
+            yn[i] = gload(Y + n);
+        }
+#pragma unroll
+        for (int i = 0; i < ITER; i++) inv_head_values<LOGN>(tid + T * i, yk[i], yn[i], tw2, zk[i], zn[i]);
+    }
+    cplx v[16];
+#pragma unroll
+    for (int i = 0; i < ITER; i++) {
+        const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+        s[GDG_PAD(k)] = zk[i].x;
+        s[GDG_PAD(n)] = zn[i].x;
+    }
+    __syncthreads();
+    pass_load1<LOGN, 4, 0>(v, s, tid);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITER; i++) {
+        const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+        s[GDG_PAD(k)] = zk[i].y;
+        s[GDG_PAD(n)] = zn[i].y;
+    }
+    __syncthreads();
+    pass_load1<LOGN, 4, 1>(v, s, tid);
+    static_assert(sched_npass(LOGN) == 4 && sched_lr(LOGN, 0) == 4 && sched_lr(LOGN, 3) == 3, "8192 = 16 x 8 x 8 x 8");
+    pass_compute<LOGN, 4, 0, true>(v, tw, tid);
+    exchange1<LOGN, 0, false>(v, s, tid);
+    pass_compute<LOGN, 3, 4, true>(v, tw, tid);
+    exchange1<LOGN, 1, false>(v, s, tid);
+    pass_compute<LOGN, 3, 7, true>(v, tw, tid);
+    exchange1<LOGN, 2, false>(v, s, tid);
+    pass_compute<LOGN, 3, 10, true>(v, tw, tid);
+    /* outputs n = j + t N/8 in natural order; only n >= N/2 is kept (frames of 8192 samples: hop == N) */
+    double *__restrict__ dst = ch.dst + (size_t)jw * N + ((ch.flags & GDG_DST_IS_OUTPUT) ? shift.out : 0);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int j = tid + T * b;
+#pragma unroll
+        for (int t = 4; t < 8; t++) {
+            const int n = j + t * (N / 8);
+            cplx z = v[b * 8 + t];
+            z.x = fmin(1.0, fmax(-1.0, z.x));               /* filter/filter.go:487-493 */
+            z.y = fmin(1.0, fmax(-1.0, z.y));
+            gstore(reinterpret_cast<cplx *>(dst + 2 * (n - N / 2)), z);
+        }
     }
 }
 
@@ -1285,6 +1503,19 @@ static int cu_count() {
     return n;
 }
 
+/* Which 8192-point transforms exchange through ONE LDS buffer, two workgroups per CU (env GDG_FFT_HALF_LDS, bits: 1 the window's forward,
+ * 2 the window's inverse, 4 the per-frame forward, 8 no chained inverse -> forward kernel in windows of four frames or more).  Default 10, measured at W = 16 with
+ * 512 channels (profiles/fft_half_lds_r04.txt): the inverse 32 -> 23 us per frame (it reads 128 KiB and writes 64 per channel-frame: the
+ * second workgroup streams while the first computes); with that, two separate launches (inverse, then the per-channel forward walk) beat
+ * the chained kernel, which needs both LDS buffers AND the previous frame in registers: 46.7 against 54.5 us per frame.  The forward
+ * transforms stay as they are: per frame they read their previous frame a second time and spill (30 us against the walk's 24), and the
+ * per-frame forward of the real-time path already runs at its bytes (39 us for 201 MB). */
+static int fft_half_lds() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GDG_FFT_HALF_LDS"); v = e ? atoi(e) : 10; }
+    return v;
+}
+
 /* a window of W frames of 8192 samples per channel (W in {2, 4, 8, 16}); the four launches of one power-amp step */
 template <int W, int C> static void launch_mac_tb(const gdg_fir_chan *d_chans, int n, bool shared, hipStream_t s) {
     if (shared) fir_mac_tb_kernel<W, C, false><<<dim3(8192 / 256, n), dim3(256), 0, s>>>(d_chans, 8192);
@@ -1296,7 +1527,10 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
     if (W != 2 && W != 4 && W != 8 && W != 16) return hipErrorInvalidValue;
     static int per_channel = -1;
     if (per_channel < 0) { const char *e = getenv("GDG_FWD_PER_CHANNEL"); per_channel = e ? atoi(e) : 1; }
-    if (what == 0) {
+    const int half = fft_half_lds();
+    if (what == 0 && (half & 1)) {
+        fir_fwd13wh_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
+    } else if (what == 0) {
         /* one workgroup per channel needs a chip's worth of channels; below that the (channel, frame) grid fills the CUs better
          * (64 channels: 9.7 vs 18.8 us per frame) */
         if (per_channel && n_chans >= cu_count()) fir_fwd13w_chan_kernel<<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
@@ -1306,16 +1540,18 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
         else if (W == 4) launch_mac_tb<4, 4>(d_chans, n_chans, shared_spectra != 0, s);
         else if (W == 8) launch_mac_tb<8, 8>(d_chans, n_chans, shared_spectra != 0, s);
         else launch_mac_tb<16, 8>(d_chans, n_chans, shared_spectra != 0, s);
-    } else if (what == 2) fir_inv_kernel<13, 3><<<dim3(n_chans * W), dim3(FftCfg<13>::T), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
+    } else if (what == 2 && (half & 2)) fir_inv13h_kernel<<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
+    else if (what == 2) fir_inv_kernel<13, 3><<<dim3(n_chans * W), dim3(FftCfg<13>::T), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
     else fir_tb_finish_kernel<<<dim3(n_chans), dim3(256), 0, s>>>(d_chans, W, shift);
     return hipGetLastError();
 }
 
 /* 1 when a window's inverse transforms of one power amp can produce the forward transforms of the next (one workgroup per channel
  * walking the frames: needs a chip's worth of channels, like the per-channel forward kernel) */
-int gdg_fir_window_chain_ok(int n_chans) {
+int gdg_fir_window_chain_ok(int n_chans, int W) {
     static int per_channel = -1;
     if (per_channel < 0) { const char *e = getenv("GDG_FWD_PER_CHANNEL"); per_channel = e ? atoi(e) : 1; }
+    if ((fft_half_lds() & 8) && W >= 4) return 0;       /* two frames: the chained kernel still wins (513 against 518 us per frame) */
     return per_channel && n_chans >= cu_count();
 }
 
@@ -1332,6 +1568,10 @@ hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n
     if (n_chans <= 0) return hipSuccess;
     static int wave_fft = -1;
     if (wave_fft < 0) { const char *e = getenv("GDG_WAVE_FFT"); wave_fft = e ? atoi(e) : 1; }
+    if (P == 8192 && hop == P && (fft_half_lds() & 4)) {
+        fir_fwd13wh_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, shift, d_tw, d_tw2);
+        return hipGetLastError();
+    }
     if (P == 8192 && hop == P && (wave_fft & 1)) {
         fir_fwd13w_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, shift, d_tw, d_tw2);
         return hipGetLastError();
@@ -1411,4 +1651,5 @@ hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, c
     return hipGetLastError();
 }
 
+#pragma clang fp contract(fast)     /* the tuner has no second path to agree with bit for bit */
 #include "tuner_kernels.h"

@@ -74,7 +74,7 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
 /* d_next_chans != NULL (P == 8192, frames of 8192): descriptor i is the power amp that follows chans[i] in the same channel's chain; its
  * forward transform (history + delay-line slot) is produced by this launch and gdg_launch_fir_fwd is NOT called for it */
 /* time blocking with adjacent power amps: what = 2 of d_chans and what = 0 of d_next_chans in one launch (needs gdg_fir_window_chain_ok) */
-int gdg_fir_window_chain_ok(int n_chans);
+int gdg_fir_window_chain_ok(int n_chans, int W);
 hipError_t gdg_launch_fir_window_chain(int W, const gdg_fir_chan *d_chans, const gdg_fir_chan *d_next_chans, int n_chans, const double2 *d_tw,
                                        const double2 *d_tw2, gdg_shift shift, hipStream_t s);
 hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, int fused, gdg_shift shift, hipStream_t s,
