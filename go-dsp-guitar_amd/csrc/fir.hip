@@ -494,12 +494,19 @@ fir_fwd13w_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift
 /* fir_fwd13w_kernel with one LDS buffer (see exchange1): two workgroups per CU, 128 VGPRs */
 template <int TB>
 __global__ void __launch_bounds__(512, 4)
-fir_fwd13wh_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2) {
+fir_fwd13wh_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, const cplx *__restrict__ tw, const cplx *__restrict__ tw2, int by_xcd) {
     constexpr int N = 8192, T = 512;
     __shared__ double s[GDG_W_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int jw = TB ? (int)(blockIdx.x % (unsigned)W) : 0;
-    gdg_fir_chan ch = chans[TB ? blockIdx.x / (unsigned)W : blockIdx.x];
+    /* by_xcd (channel count a multiple of 8): workgroups go round the eight XCDs, so XCD x takes the channels = x (mod 8), their frames in
+     * order: frame j is read as "current" and, by the next workgroup of the same XCD, as "previous" -- the second read meets the first in L2 */
+    unsigned cw = TB ? blockIdx.x / (unsigned)W : blockIdx.x, jw = TB ? blockIdx.x % (unsigned)W : 0u;
+    if (TB && by_xcd) {
+        const unsigned x = blockIdx.x & 7u, q = blockIdx.x >> 3;
+        cw = x + 8u * (q / (unsigned)W);
+        jw = q % (unsigned)W;
+    }
+    gdg_fir_chan ch = chans[cw];
     if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     const int pos = *ch.pos;
     const double *a = ch.prev + (size_t)((pos + 1) & 1) * N;
@@ -553,14 +560,19 @@ fir_fwd13wh_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shif
     auto Zs = [&](int k) { return s[(k & 7) * GDG_W_RL + GDG_PAD(k >> 3)]; };
     double zkx[8], znx[8];
     __builtin_amdgcn_wave_barrier();
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                    /* likewise: these sixteen addresses are made here */
+    double *rn = rs + GDG_PAD(ln);                  /* PAD(ln + c) = PAD(ln) + c + c / 16 for multiples of 16 */
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
-        for (int t = 0; t < 8; t++) rs[GDG_PAD((lane + 64 * b) + 128 * t)] = v[b * 8 + t].x;
+        for (int t = 0; t < 8; t++) rn[GDG_PAD(64 * b + 128 * t)] = v[b * 8 + t].x;
     __syncthreads();
+    int tu = tid;
+    asm volatile("" : "+v"(tu));                    /* the un-packing's sixteen LDS addresses are made here, not hoisted to the top and spilled */
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+        const int k = tu + T * i, n = (k == 0) ? N / 2 : N - k;
         zkx[i] = Zs(k);
         znx[i] = Zs(n);
     }
@@ -568,11 +580,11 @@ fir_fwd13wh_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shif
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
-        for (int t = 0; t < 8; t++) rs[GDG_PAD((lane + 64 * b) + 128 * t)] = v[b * 8 + t].y;
+        for (int t = 0; t < 8; t++) rn[GDG_PAD(64 * b + 128 * t)] = v[b * 8 + t].y;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const int k = tid + T * i;
+        const int k = tu + T * i;
         if (k == 0) {
             cplx z0 = make_double2(zkx[i], Zs(0)), zh = make_double2(znx[i], Zs(N / 2));
             gstore(out, make_double2(z0.x + z0.y, z0.x - z0.y));
@@ -1504,15 +1516,17 @@ static int cu_count() {
 }
 
 /* Which 8192-point transforms exchange through ONE LDS buffer, two workgroups per CU (env GDG_FFT_HALF_LDS, bits: 1 the window's forward,
- * 2 the window's inverse, 4 the per-frame forward, 8 no chained inverse -> forward kernel in windows of four frames or more).  Default 10, measured at W = 16 with
- * 512 channels (profiles/fft_half_lds_r04.txt): the inverse 32 -> 23 us per frame (it reads 128 KiB and writes 64 per channel-frame: the
- * second workgroup streams while the first computes); with that, two separate launches (inverse, then the per-channel forward walk) beat
- * the chained kernel, which needs both LDS buffers AND the previous frame in registers: 46.7 against 54.5 us per frame.  The forward
- * transforms stay as they are: per frame they read their previous frame a second time and spill (30 us against the walk's 24), and the
- * per-frame forward of the real-time path already runs at its bytes (39 us for 201 MB). */
+ * 2 the window's inverse, 4 the per-frame forward, 8 no chained inverse -> forward kernel in windows of four frames or more, 32 the window's
+ * forward workgroups XCD by XCD).  Default 43, measured at W = 16 with 512 channels, us per frame (profiles/fft_half_lds_r04.txt):
+ *   inverse 32 -> 23: it reads 128 KiB and writes 64 per channel-frame, the second workgroup streams while the first computes;
+ *   chained inverse -> forward kernel 54.5 -> two launches 23 + 22: the chained kernel needs both LDS buffers and the previous frame in registers;
+ *   forward 24 (one workgroup per channel walking the frames, previous frame in registers) -> 22 (one per frame, two per CU; the previous
+ *   frame is read again, from the L2 of the XCD that has just read it as "current": 0.5 us of the 2).
+ * Not kept: the per-channel walk with one buffer (26 us: 512 workgroups, nothing to balance with), non-temporal spectrum stores and product
+ * loads (no difference).  The per-frame forward of the real-time path (bit 4) already runs at its bytes (39 us for 201 MB). */
 static int fft_half_lds() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("GDG_FFT_HALF_LDS"); v = e ? atoi(e) : 10; }
+    if (v < 0) { const char *e = getenv("GDG_FFT_HALF_LDS"); v = e ? atoi(e) : 43; }
     return v;
 }
 
@@ -1529,7 +1543,7 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
     if (per_channel < 0) { const char *e = getenv("GDG_FWD_PER_CHANNEL"); per_channel = e ? atoi(e) : 1; }
     const int half = fft_half_lds();
     if (what == 0 && (half & 1)) {
-        fir_fwd13wh_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2);
+        fir_fwd13wh_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2, ((half & 32) && n_chans % 8 == 0) ? 1 : 0);
     } else if (what == 0) {
         /* one workgroup per channel needs a chip's worth of channels; below that the (channel, frame) grid fills the CUs better
          * (64 channels: 9.7 vs 18.8 us per frame) */
@@ -1569,7 +1583,7 @@ hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n
     static int wave_fft = -1;
     if (wave_fft < 0) { const char *e = getenv("GDG_WAVE_FFT"); wave_fft = e ? atoi(e) : 1; }
     if (P == 8192 && hop == P && (fft_half_lds() & 4)) {
-        fir_fwd13wh_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, shift, d_tw, d_tw2);
+        fir_fwd13wh_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, shift, d_tw, d_tw2, 0);
         return hipGetLastError();
     }
     if (P == 8192 && hop == P && (wave_fft & 1)) {
