@@ -218,13 +218,15 @@ def test_every_unit_type_in_windows():
         assert np.array_equal(got[c], want[c]), "chain %d: max diff %.3e" % (c, np.max(np.abs(got[c] - want[c])))
 
 
-def test_window_chain_of_adjacent_power_amps_gives_the_same_bits():
-    """Time blocking with two power amps in a row, a chip's worth of channels: one workgroup per channel walks the window, the inverse
-    transform of amp 1 running into the forward transform of amp 2 (fir_inv_fwd_chain_chan_kernel).  GDG_FIR_CHAIN=0 keeps the launches
-    separate; per-frame calls are the third way.  All three: identical samples."""
+@pytest.mark.parametrize("W", [2, 4])
+def test_window_chain_of_adjacent_power_amps_gives_the_same_bits(W):
+    """Time blocking with two power amps in a row, a chip's worth of channels.  W = 2: one workgroup per channel walks the window, the
+    inverse transform of amp 1 running into the forward transform of amp 2 (fir_inv_fwd_chain_chan_kernel).  W = 4: two launches, both
+    transforms through one LDS buffer with two workgroups per CU (fir_inv13h_kernel, fir_fwd13wh_kernel).  GDG_FIR_CHAIN=0 drops the
+    chain hint from the plan; per-frame calls are the third way.  All three: identical samples."""
     import os
     pkg = package()
-    nch, frames, sr, taps, W, blocks = 256, 8192, 96000, 20000, 4, 8
+    nch, frames, sr, taps, blocks = 256, 8192, 96000, 20000, 8
     x = np.stack([synth_signal(c % 7, frames * blocks, sr) * (0.5 + 0.001 * c) for c in range(nch)])
     irs = [[synth_ir(taps, seed=70 + 2 * k + j) * 0.9 for j in range(2)] for k in range(3)]
     outs = {}
@@ -253,3 +255,17 @@ def test_window_chain_of_adjacent_power_amps_gives_the_same_bits():
     assert np.array_equal(outs["window_chain"], outs["window_separate"])
     assert np.array_equal(outs["window_chain"], outs["per_frame"])
     assert np.abs(outs["per_frame"]).max() > 0.01
+
+
+@pytest.mark.parametrize("bits", [0, 47])
+def test_transform_variants_give_the_same_bits(bits):
+    """GDG_FFT_HALF_LDS picks the kernels of the 8192-point transforms (read once per process: a child each).  0: two LDS buffers, one
+    workgroup per CU, chained inverse -> forward kernel in every window; 47: one buffer everywhere it exists, the real-time path's forward
+    transform included.  Each must pass the bit-for-bit tests of this file that the default (43) passes in the parent."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GDG_FFT_HALF_LDS=str(bits))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "equals_single_frames or chain_of_adjacent or shared_ir"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
