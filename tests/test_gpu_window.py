@@ -221,8 +221,8 @@ def test_every_unit_type_in_windows():
 @pytest.mark.parametrize("W", [2, 4])
 def test_window_chain_of_adjacent_power_amps_gives_the_same_bits(W):
     """Time blocking with two power amps in a row, a chip's worth of channels.  W = 2: one workgroup per channel walks the window, the
-    inverse transform of amp 1 running into the forward transform of amp 2 (fir_inv_fwd_chain_chan_kernel).  W = 4: two launches, both
-    transforms through one LDS buffer with two workgroups per CU (fir_inv13h_kernel, fir_fwd13wh_kernel).  GDG_FIR_CHAIN=0 drops the
+    inverse transform of amp 1 running into the forward transform of amp 2 (fir_inv_fwd_chain_chan_kernel).  W = 4: two launches, the inverse
+    through one LDS buffer with two workgroups per CU (fir_inv13h_kernel), then the forward walk.  GDG_FIR_CHAIN=0 drops the
     chain hint from the plan; per-frame calls are the third way.  All three: identical samples."""
     import os
     pkg = package()
@@ -261,7 +261,7 @@ def test_window_chain_of_adjacent_power_amps_gives_the_same_bits(W):
 def test_transform_variants_give_the_same_bits(bits):
     """GDG_FFT_HALF_LDS picks the kernels of the 8192-point transforms (read once per process: a child each).  0: two LDS buffers, one
     workgroup per CU, chained inverse -> forward kernel in every window; 47: one buffer everywhere it exists, the real-time path's forward
-    transform included.  Each must pass the bit-for-bit tests of this file that the default (43) passes in the parent."""
+    transform included.  Each must pass the bit-for-bit tests of this file that the default (10) passes in the parent."""
     import os
     import subprocess
     import sys
