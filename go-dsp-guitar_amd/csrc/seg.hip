@@ -84,8 +84,24 @@ static_assert(sizeof(double) * (SEG_LBUF + SEG_SCR + SEG_STASH + 32 + 8) <= 8192
 static_assert(4 * L2_SIZE <= SEG_SCR && 7 * LT_SIZE <= SEG_SCR, "scan tables fit the tile");
 #endif
 
-/* every unit is its own function (own register allocation); `flip` says which LDS frame is the input */
+/* General build: every unit is its own function (own register allocation); `flip` says which LDS frame is the input.
+ * Two-per-CU build (SEG_FAST): the units are INLINED into the kernel.  A call costs more than it looks: the callee saves and restores the
+ * callee-saved half of the vector registers it touches (v40-47, v56-63, ...: 20 to 36 dwords per lane and unit, straight to scratch memory) --
+ * 84 dwords per lane for the bench's first segment = 88 MB written and read back per launch, more than the frames themselves
+ * (rocprofv3 WRITE_SIZE: 146 MB where 67 are data).  Inlining alone does not work either: every unit's thread-index arithmetic is then
+ * hoisted to the top of the kernel and lives through all units (128 registers, 772 bytes of scratch).  seg_tid() hands every use its own opaque
+ * copy of the thread index, so addresses are made where they are used: 120 registers, a dozen spill stores per kernel. */
+#ifdef SEG_FAST
+#define UNIT_FN static __device__ __forceinline__ void
+__device__ __forceinline__ unsigned seg_tid() {
+    unsigned t = __builtin_amdgcn_workitem_id_x();
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#else
 #define UNIT_FN __device__ __attribute__((noinline)) void
+__device__ __forceinline__ unsigned seg_tid() { return __builtin_amdgcn_workitem_id_x(); }
+#endif
 #define UNIT_ARGS const gdg_seg_unit *U, int flip, int N
 #define UNIT_PROLOGUE                                                                     \
     double *in = flip ? s_b : s_a;                                                        \
@@ -146,7 +162,7 @@ __device__ __forceinline__ void scan_row_step(double (&a)[C], double (&b)[C], in
 
 template <int C, bool MAXOP>
 __device__ __forceinline__ void block_scan(const double (&A)[C], const double (&B)[C], double (&Ap)[C], double (&Bp)[C], double *tmp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
+    const int tid = seg_tid(), lane = tid & 63, wave = tid >> 6, row = lane >> 4;
     double a[C], b[C];
 #pragma unroll
     for (int c = 0; c < C; c++) { a[c] = A[c]; b[c] = B[c]; }
@@ -242,7 +258,7 @@ __device__ __forceinline__ double dpp0(double v) {       /* DPP move, lanes with
  * tone stack's 24 000 cycles) for values that only change with the sample rate or a parameter. */
 __device__ __forceinline__ void tab_fetch(double *dst, const double *src_generic, int n) {
     const double *src = src_generic;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = *(const __attribute__((address_space(1))) double *)(src + i);
+    for (int i = seg_tid(); i < n; i += blockDim.x) dst[i] = *(const __attribute__((address_space(1))) double *)(src + i);
 }
 
 template <bool MAXOP>
@@ -260,7 +276,7 @@ __device__ __forceinline__ double lin_chunk_map(const double (&x)[CHK], const do
 /* B = zero-state chunk result of this thread; *s0 (LDS) = state before the frame; returns the state at this thread's chunk start */
 template <bool MAXOP>
 __device__ __forceinline__ double lin_scan(double B, const double *tab, const double *s0, double *xch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = seg_tid() & 63, wave = seg_tid() >> 6;
     double I = B;
     I = lin_comb<MAXOP>(I, tab[LT_ST + 0], dpp0<DPP_ROW_SHR(1), 0xf>(I));
     I = lin_comb<MAXOP>(I, tab[LT_ST + 1], dpp0<DPP_ROW_SHR(2), 0xf>(I));
@@ -292,7 +308,7 @@ __device__ __forceinline__ void lin2_step(double &h, double &l, const double *m)
 }
 /* (ch, cl): zero-state chunk result; s0h / s0l (LDS): state before the frame; returns the chunk start state in (ch, cl) */
 __device__ __forceinline__ void lin2_scan(double &ch, double &cl, const double *tab, const double *s0h, const double *s0l, double *xch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = seg_tid() & 63, wave = seg_tid() >> 6;
     double h = ch, l = cl;
     lin2_step<DPP_ROW_SHR(1), 0xf>(h, l, tab + L2_ST + 0);
     lin2_step<DPP_ROW_SHR(2), 0xf>(h, l, tab + L2_ST + 3);
@@ -342,20 +358,20 @@ __device__ __forceinline__ void ring_append(double *ring, int C, int *wp_ptr, co
     if (((N - first) & 1) == 0) {
         /* sample pairs: one 16-byte store per pair (two stores where the ring wraps inside the pair) */
         GDG_GLOBAL double *g = as_global(ring);
-        for (int i = first + 2 * (int)threadIdx.x; i < N; i += 2 * SEG_T) {
+        for (int i = first + 2 * (int)seg_tid(); i < N; i += 2 * SEG_T) {
             int p = (wp + i) % C;
             const double a = in[LX(i)], b = in[LX(i + 1)];
             if (p + 1 < C) { seg_v2d v = { a, b }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
             else { g[p] = a; g[0] = b; }
         }
     } else {
-        for (int i = first + (int)threadIdx.x; i < N; i += SEG_T) {
+        for (int i = first + (int)seg_tid(); i < N; i += SEG_T) {
             int p = (wp + i) % C;
             as_global(ring)[p] = in[LX(i)];
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) *as_global(wp_ptr) = (wp + N) % C;
+    if (seg_tid() == 0) *as_global(wp_ptr) = (wp + N) % C;
 }
 /* the reference's fractional delay read (e.g. effects/flanger.go:63-90): both weights are 1 when the delay is integral */
 __device__ __forceinline__ double frac_delay(const double *in, const double *ring, int C, int wp, int i, double delay_samples) {
@@ -384,7 +400,7 @@ __device__ __forceinline__ double frac_delay(const double *in, const double *rin
  */
 __device__ __forceinline__ void envelope_to(const double *in, double *dst, int N, int follow, double d_inv, double d,
                                             double *state, double *tmp) {
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     const int m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     double s0 = *state;
@@ -436,16 +452,16 @@ typedef ChunkT<false> Chunk;
 __device__ __forceinline__ Chunk my_chunk(int N) {
     const int m = (N + SEG_T - 1) / SEG_T;
     Chunk c;
-    c.c0 = min(N, (int)threadIdx.x * m);
+    c.c0 = min(N, (int)seg_tid() * m);
     c.len = min(N, c.c0 + m) - c.c0;
     c.last = (c.len > 0) && (c.c0 + c.len == N);
     return c;
 }
 __device__ __forceinline__ ChunkT<true> full_chunk() {
     ChunkT<true> c;
-    c.c0 = (int)threadIdx.x * CHK;
+    c.c0 = (int)seg_tid() * CHK;
     c.len = CHK;
-    c.last = threadIdx.x == SEG_T - 1;
+    c.last = seg_tid() == SEG_T - 1;
     return c;
 }
 template <class C>
@@ -564,7 +580,7 @@ __device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     const int follow = U->ip[0];
     const double d_inv = U->dp[2], d = U->dp[3], limit = U->dp[0], target = U->dp[1];
     GDG_GLOBAL double *ds = as_global(U->ds);
@@ -711,7 +727,7 @@ __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, 
     const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);      /* phase-major, zero padded */
     const GDG_CONST double *lw = (const GDG_CONST double *)uniform_ptr(lw_generic);
     GDG_GLOBAL double *hist = as_global(hist_generic);
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     /* the previous call's state, before it is replaced: scr[0 .. TAPS-2] the oversampled tail, scr[TAPS-1 .. TAPS+6] the 8 inputs */
     for (int q = tid; q < TAPS - 1 + 8; q += SEG_T) scr[q] = (q < TAPS - 1) ? hist[8 + q] : hist[q - (TAPS - 1)];
     __syncthreads();
@@ -785,7 +801,7 @@ __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tab
     S.gain = U->dp[0]; S.drive = U->dp[1]; S.clean = U->dp[2]; S.level = U->dp[3];
     const int f = U->jp[0];
     if (f <= 1) {
-        for (int i = threadIdx.x; i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
+        for (int i = seg_tid(); i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
         return 0;
     }
 #ifndef SEG_FAST                                    /* the oversampled shapers stage a whole output frame in the second buffer */
@@ -801,7 +817,7 @@ template <class C>
 __device__ __forceinline__ void tonestack_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
     UNIT_PROLOGUE
     double *st = tmp + SEG_STASH;                    /* the eight capacitor voltages, stashed in LDS (not in live registers) */
-    if (threadIdx.x < 8) st[threadIdx.x] = U->ds[threadIdx.x];
+    if (seg_tid() < 8) st[seg_tid()] = U->ds[seg_tid()];
     double x[CHK];
     chunk_load(in, c, x);
     __syncthreads();
@@ -876,7 +892,7 @@ __device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip)
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;                    /* [0..7] the capacitor voltages, [16..27] factors and coefficients */
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     GDG_GLOBAL double *ds = as_global(U->ds);
     if (tid < 8) st[tid] = ds[tid];
     if (tid < 12) st[16 + tid] = U->dp[tid];
@@ -922,7 +938,7 @@ template <class C>
 __device__ __forceinline__ void cabinet_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
     UNIT_PROLOGUE
     double *st = tmp + SEG_STASH;                    /* the seven capacitor voltages, fetched once, kept in LDS */
-    if (threadIdx.x < 7) st[threadIdx.x] = U->ds[threadIdx.x];
+    if (seg_tid() < 7) st[seg_tid()] = U->ds[seg_tid()];
     double v[CHK];
     chunk_load(in, c, v);
     __syncthreads();
@@ -943,7 +959,7 @@ __device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;                    /* [0..6] the capacitor voltages, [16..22] the coefficients */
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     GDG_GLOBAL double *ds = as_global(U->ds);
     if (tid < 7) { st[tid] = ds[tid]; st[16 + tid] = U->dp[tid]; }
     tab_fetch(scr, U->tab, 7 * LT_SIZE);
@@ -993,14 +1009,14 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
     const double prev = ds[0];
     /* 1. append the frame (pairs where possible); cell 0 is mirrored into the guard cell mask + 1 */
     if ((N & 1) == 0 && (wp & 1) == 0) {
-        for (int i = 2 * (int)threadIdx.x; i < N; i += 2 * SEG_T) {
+        for (int i = 2 * (int)seg_tid(); i < N; i += 2 * SEG_T) {
             const int p = (wp + i) & mask;                          /* even, so p + 1 <= mask */
             seg_v2d v = { in[LX(i)], in[LX(i + 1)] };
             *(GDG_GLOBAL seg_v2d *)(ring + p) = v;
             if (p == 0) ring[mask + 1] = v.x;
         }
     } else {
-        for (int i = threadIdx.x; i < N; i += SEG_T) {
+        for (int i = seg_tid(); i < N; i += SEG_T) {
             const int p = (wp + i) & mask;
             const double v = in[LX(i)];
             ring[p] = v;
@@ -1016,7 +1032,7 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
      * next and (sin, cos) follow by rotation (error ~1e-16 per step, eight steps) */
     double s0, c0, sd, cd;
     {
-        double time = (double)threadIdx.x / sr;
+        double time = (double)seg_tid() / sr;
         double zero_phase = fmod_2pi(prev + (angular * time));
         sincos(zero_phase, &s0, &c0);
         sincos(angular * ((double)SEG_T / sr), &sd, &cd);
@@ -1085,16 +1101,16 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
     if (N == CHK * SEG_T) {
 #pragma unroll
         for (int q = 0; q < CHK; q += 2) {                         /* the batch block size: a fixed trip count */
-            const int idx[2] = { (int)threadIdx.x + q * SEG_T, (int)threadIdx.x + (q + 1) * SEG_T };
+            const int idx[2] = { (int)seg_tid() + q * SEG_T, (int)seg_tid() + (q + 1) * SEG_T };
             samples(idx, 2);
         }
     } else {
-        for (int i = threadIdx.x; i < N; i += 2 * SEG_T) {
+        for (int i = seg_tid(); i < N; i += 2 * SEG_T) {
             const int idx[2] = { i, i + SEG_T };
             samples(idx, (i + SEG_T < N) ? 2 : 1);
         }
     }
-    if (threadIdx.x == 0) {
+    if (seg_tid() == 0) {
         double buffer_time = (double)C / sr;          /* quirk: advances by the buffer length, not by N */
         ds[0] = fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI);
         is[0] = (wp + N) & mask;
@@ -1114,11 +1130,11 @@ UNIT_FN unit_flanger(UNIT_ARGS) {
     /* one sincos per thread, then rotation by the fixed phase step between a thread's samples (as in the chorus) */
     double s0, c0, sd, cd;
     {
-        double time = (double)threadIdx.x * sr_inv;
+        double time = (double)seg_tid() * sr_inv;
         sincos(fmod_2pi(prev + (angular * time)), &s0, &c0);
         sincos(angular * ((double)SEG_T * sr_inv), &sd, &cd);
     }
-    for (int i = threadIdx.x; i < N; i += SEG_T) {
+    for (int i = seg_tid(); i < N; i += SEG_T) {
         double offset = depth * s0;
         double delay_time = 0.001 * (depth + offset);
         double delay_samples = delay_time * sr;
@@ -1128,7 +1144,7 @@ UNIT_FN unit_flanger(UNIT_ARGS) {
         s0 = sn; c0 = cn;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (seg_tid() == 0) {
         double duration = (double)C * sr_inv;
         U->ds[0] = fmod(prev + (angular * duration), GO_MATH_TWO_PI);
     }
@@ -1142,7 +1158,7 @@ UNIT_FN unit_delay(UNIT_ARGS) {
     const double feedback = U->dp[0], level = U->dp[1];
     const int D = U->jp[0], wp = U->is[0];
     const double *ring = U->hist;
-    for (int i = threadIdx.x; i < N; i += SEG_T) {
+    for (int i = seg_tid(); i < N; i += SEG_T) {
         int idx = i - D;
         double delayed = (idx >= 0) ? in[LX(idx)] : ring_read(ring, D, wp, idx);
         out[LX(i)] = clip1(level * (in[LX(i)] + (feedback * delayed)));
@@ -1157,12 +1173,12 @@ UNIT_FN unit_delay(UNIT_ARGS) {
 UNIT_FN unit_ringmod(UNIT_ARGS) {
     UNIT_PROLOGUE
     const double fraction = U->dp[0], phase = U->ds[0];
-    for (int i = threadIdx.x; i < N; i += SEG_T) {
+    for (int i = seg_tid(); i < N; i += SEG_T) {
         double cur = fmod(phase + ((double)i * fraction), GO_MATH_TWO_PI);
         out[LX(i)] = sin(cur) * in[LX(i)];
     }
     __syncthreads();
-    if (threadIdx.x == 0) U->ds[0] = fmod(phase + ((double)N * fraction), GO_MATH_TWO_PI);
+    if (seg_tid() == 0) U->ds[0] = fmod(phase + ((double)N * fraction), GO_MATH_TWO_PI);
 }
 
 /* ---- tremolo: effects/tremolo.go:15-65 ----------------------------------------------------------------------
@@ -1172,7 +1188,7 @@ UNIT_FN unit_tremolo(UNIT_ARGS) {
     UNIT_PROLOGUE
     const double fac = U->dp[0];
     int *runs = reinterpret_cast<int *>(scr);          /* pairs (start, attenuated), terminated by start = N */
-    if (threadIdx.x == 0) {
+    if (seg_tid() == 0) {
         const unsigned on = (unsigned)U->jp[0], off = (unsigned)U->jp[1];
         int att = U->is[0];
         unsigned cnt = (unsigned)U->is[1];
@@ -1194,7 +1210,7 @@ UNIT_FN unit_tremolo(UNIT_ARGS) {
         U->is[1] = (int)cnt;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < N; i += SEG_T) {
+    for (int i = seg_tid(); i < N; i += SEG_T) {
         int r = 0;
         while (runs[2 * (r + 1)] <= i) r++;
         double v = in[LX(i)];
@@ -1215,7 +1231,7 @@ UNIT_FN unit_siggen(UNIT_ARGS) {
     if (type == 4) {                                    /* "noise": random/random.go LCG, seed 1337 */
         unsigned x0 = U->is[1] ? (unsigned)U->is[0] : (unsigned)((64979ull * 1337ull + 83ull) % 2147483647ull);
         __syncthreads();
-        const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+        const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
         const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
         /* jump ahead: x_{c0} = 16807^c0 * x0 mod (2^31 - 1) */
         unsigned p = 1u, base = 16807u;
@@ -1230,7 +1246,7 @@ UNIT_FN unit_siggen(UNIT_ARGS) {
         if (c1 == N && c0 < N) { U->is[0] = (int)x; U->is[1] = 1; }
         return;
     }
-    for (int i = threadIdx.x; i < N; i += SEG_T) {
+    for (int i = seg_tid(); i < N; i += SEG_T) {
         double cur = fmod(phase + ((double)i * inc), GO_MATH_TWO_PI);
         double signal = 0.0;
         switch (type) {
@@ -1242,7 +1258,7 @@ UNIT_FN unit_siggen(UNIT_ARGS) {
         out[LX(i)] = (fac_in * in[LX(i)]) + (fac_sig * signal);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (seg_tid() == 0) {
         double ph = phase + ((double)N * inc);
         U->ds[0] = fmod(ph, GO_MATH_TWO_PI);
     }
@@ -1269,7 +1285,7 @@ __device__ __forceinline__ void allpass_fetch(const double *ring, int M, int rp,
      * turned these twelve "prefetches" into twelve exposed latencies */
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        int r = (int)threadIdx.x + q * SEG_T;
+        int r = (int)seg_tid() + q * SEG_T;
         /* (the modulo costs ~40 instructions, but the conditional-subtraction form makes the in-place reverb of the two-per-CU build allocate 128
          * registers and 236 bytes of scratch instead of 120 / 132 -- and the KERNEL's register count is the largest of its units': every
          * segment, also those without a reverb, then ran 12 us slower, profiles/experiments/README.md r04) */
@@ -1281,7 +1297,7 @@ __device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M,
     const int cnt = min(M, N);
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        int r = (int)threadIdx.x + q * SEG_T;
+        int r = (int)seg_tid() + q * SEG_T;
         if (r < cnt) {
             double pm = pm0[q], p;
             int n = r;
@@ -1295,7 +1311,7 @@ __device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M,
             else { int at = rp + r; if (at >= M) at -= M; as_global(ring)[at] = p; }
         }
     }
-    if (threadIdx.x == 0) *rp_out = (N >= M) ? 0 : (rp + N) % M;
+    if (seg_tid() == 0) *rp_out = (N >= M) ? 0 : (rp + N) % M;
     __syncthreads();
 }
 /* any ring size: fetch at use (exposes the latency; only sample rates far above 192 kHz come here) */
@@ -1315,7 +1331,7 @@ __device__ __attribute__((noinline)) void allpass_generic(double *buf, double *r
 UNIT_FN unit_reverb(UNIT_ARGS) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     const double dry = Uc->dp[0], half_wet = Uc->dp[1];
     const double coeff[4] = { 0.1855, 0.18325, 0.17875, 0.17425 };
     int taps[4];
@@ -1474,7 +1490,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
 UNIT_FN unit_reverb(UNIT_ARGS) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     const double dry = Uc->dp[0], half_wet = Uc->dp[1];
     const double coeff[4] = { 0.1855, 0.18325, 0.17875, 0.17425 };
     int taps[4];
@@ -1592,7 +1608,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
  * VAR: the coefficient varies per sample and is read from abuf (auto-wah). */
 template <int MODE, bool VAR>
 __device__ __forceinline__ void onepole(double *buf, const double *abuf, double a_const, double *state, int N, double *tmp) {
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     const double s0 = *state;                       /* read before the scan's barriers, rewritten after them */
     double A[1] = { 1.0 }, B[1] = { 0.0 }, Ap[1], Bp[1];
@@ -1625,7 +1641,7 @@ struct IMap { int f[5]; };
 
 template <class Compose>
 __device__ __forceinline__ IMap block_scan_imap(IMap mine, IMap identity, Compose comp, int *itmp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
+    const int tid = seg_tid(), lane = tid & 63, wave = tid >> 6, row = lane >> 4;
     IMap a = mine;
     {
         IMap o;
@@ -1699,7 +1715,7 @@ UNIT_FN unit_fuzz(UNIT_ARGS) {
     UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
     const double bias = U->dp[0], gain = U->dp[1], fuzz = U->dp[2], fuzz_inv = U->dp[3], level = U->dp[4];
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     for (int i = c0; i < c1; i++) {
         double sample = in[LX(i)];
@@ -1719,7 +1735,7 @@ UNIT_FN unit_fuzz(UNIT_ARGS) {
  * dp5 / dp6 are exp(-20 / (f sr)) and its complement; hist as in unit_shaper. */
 __device__ __forceinline__ void lin_chunk(int cnt, int &c0, int &c1) {
     const int m = (cnt + SEG_T - 1) / SEG_T;
-    c0 = min(cnt, (int)threadIdx.x * m);
+    c0 = min(cnt, (int)seg_tid() * m);
     c1 = min(cnt, c0 + m);
 }
 
@@ -1755,7 +1771,7 @@ template <int F>
 __device__ __forceinline__ void fir_decimate_linear(const double *scr, const double *taps_generic, double *out, int o0, int S_out) {
     constexpr int TAPS = (F == 2) ? 77 : 155;
     const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);
-    for (int o = threadIdx.x; o < S_out; o += SEG_T) {
+    for (int o = seg_tid(); o < S_out; o += SEG_T) {
         const double *base = scr + F * o + (TAPS - 1);
         double acc = 0.0;
 #pragma unroll
@@ -1774,7 +1790,7 @@ __device__ __forceinline__ void fuzz_os_tiles(const gdg_seg_unit *Ug, double *in
     constexpr int TAPS = OsCfg<F>::TAPS, BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, TILE = OsCfg<F>::S, PH = OsCfg<F>::PH;
     static_assert(F * R == CHK, "a thread's share of a tile is one register chunk");
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
-    const int tid = threadIdx.x, follow = U->ip[0];
+    const int tid = seg_tid(), follow = U->ip[0];
     const double bias = U->dp[0], gain = U->dp[1], fuzz = U->dp[2], fuzz_inv = U->dp[3], level = U->dp[4];
     const double d_inv = U->dp[5], d = U->dp[6];
     const GDG_CONST double *tp = (const GDG_CONST double *)uniform_ptr(F == 2 ? os.tapsP2 : os.tapsP4);
@@ -1894,7 +1910,7 @@ __device__ __attribute__((noinline)) int unit_fuzz_os(UNIT_ARGS, const gdg_os_ta
     UNIT_PROLOGUE
     if (U->jp[0] == 4 && N % OsCfg<4>::S == 0) { fuzz_os_tiles<4>(U, in, out, scr, tmp, os, N); return 1; }
     if (U->jp[0] == 2 && N % OsCfg<2>::S == 0) { fuzz_os_tiles<2>(U, in, out, scr, tmp, os, N); return 1; }
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     const int f = U->jp[0];
     const int follow = U->ip[0];
     const double bias = U->dp[0], gain = U->dp[1], fuzz = U->dp[2], fuzz_inv = U->dp[3], level = U->dp[4];
@@ -1975,7 +1991,7 @@ UNIT_FN unit_autoyoy(UNIT_ARGS) {
     const double la = U->dp[0], lb = U->dp[1], da = U->dp[2], db = U->dp[3], slope = U->dp[4], sr = U->dp[7];
     const int C = U->jp[0], wp = U->is[0];
     const double *ring = U->hist;
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     for (int i = c0; i < c1; i++) {
         double level = 20.0 * log10(out[LX(i)]);
@@ -2002,7 +2018,7 @@ __device__ __forceinline__ void autowah_full(const gdg_seg_unit *Ug, int flip) {
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;                    /* [0] envelope, [1..8] hcv, [9..16] lcv */
     GDG_GLOBAL double *ds = as_global(U->ds);
-    if (threadIdx.x < 17) st[threadIdx.x] = ds[threadIdx.x];
+    if (seg_tid() < 17) st[seg_tid()] = ds[seg_tid()];
     const double la = U->dp[0], lb = U->dp[1], fa = U->dp[2], fb = U->dp[3], slope = U->dp[4], sr = U->dp[7];
     const ChunkT<true> c = full_chunk();
     double v[CHK], al[CHK];
@@ -2040,7 +2056,7 @@ UNIT_FN unit_autowah(UNIT_ARGS) {
     UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[5], U->dp[6], &U->ds[0], tmp);
     const double la = U->dp[0], lb = U->dp[1], fa = U->dp[2], fb = U->dp[3], slope = U->dp[4], sr = U->dp[7];
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     for (int i = c0; i < c1; i++) {
         double level = 20.0 * log10(out[LX(i)]);
@@ -2070,7 +2086,7 @@ __device__ __forceinline__ void bandpass_full(const gdg_seg_unit *Ug, int flip) 
     GDG_GLOBAL double *ds = as_global(U->ds);
     const double aH = U->dp[0], aL = U->dp[1];
     const int half = U->jp[0];
-    if (threadIdx.x < 8) st[threadIdx.x] = ds[threadIdx.x];
+    if (seg_tid() < 8) st[seg_tid()] = ds[seg_tid()];
     tab_fetch(scr, U->tab, L2_SIZE);
     const ChunkT<true> c = full_chunk();
     double v[CHK];
@@ -2099,7 +2115,7 @@ __device__ __forceinline__ void bandpass_full(const gdg_seg_unit *Ug, int flip) 
 UNIT_FN unit_bandpass(UNIT_ARGS) {
     if (N == CHK * SEG_T) { bandpass_full(U, flip); return; }
     UNIT_PROLOGUE
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     for (int i = c0; i < c1; i++) out[LX(i)] = in[LX(i)];
     const int half = U->jp[0];
@@ -2122,7 +2138,7 @@ __device__ __forceinline__ void octaver_full(const gdg_seg_unit *Ug, int flip) {
     double *st = tmp + SEG_STASH;                    /* [0] envelope, [1] coupling capacitor */
     GDG_GLOBAL double *ds = as_global(U->ds);
     GDG_GLOBAL int *is = as_global(U->is);
-    const int tid = threadIdx.x, follow = U->ip[0];
+    const int tid = seg_tid(), follow = U->ip[0];
     const double f_up = U->dp[0], f_clean = U->dp[1], f_dist = U->dp[2], f_d1 = U->dp[3], f_d2 = U->dp[4], f_hyst = U->dp[5];
     const double d_inv = U->dp[6], d = U->dp[7];
     double *tab_env = scr, *tab_cap = scr + LT_SIZE;
@@ -2202,7 +2218,7 @@ UNIT_FN unit_octaver(UNIT_ARGS) {
     UNIT_PROLOGUE
     envelope_to(in, out, N, U->ip[0], U->dp[6], U->dp[7], &U->ds[0], tmp);
     const double f_up = U->dp[0], f_clean = U->dp[1], f_dist = U->dp[2], f_d1 = U->dp[3], f_d2 = U->dp[4], f_hyst = U->dp[5];
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     const int pp0 = U->is[0], reg0 = U->is[1];
     IMap mine = { { 0, 0, 0, 0, 0 } }, ident = { { 0, 0, 0, 0, 0 } };
@@ -2258,7 +2274,7 @@ UNIT_FN unit_octaver(UNIT_ARGS) {
 #define GATE_INF 0x3fffffff
 UNIT_FN unit_noisegate(UNIT_ARGS) {
     UNIT_PROLOGUE
-    const int tid = threadIdx.x, m = (N + SEG_T - 1) / SEG_T;
+    const int tid = seg_tid(), m = (N + SEG_T - 1) / SEG_T;
     const int c0 = min(N, tid * m), c1 = min(N, c0 + m);
     if (U->jp[1]) {
         for (int i = c0; i < c1; i++) out[LX(i)] = in[LX(i)];
@@ -2328,7 +2344,7 @@ UNIT_FN unit_noisegate(UNIT_ARGS) {
 template <int F>
 __global__ void __launch_bounds__(SEG_T)
 os_debug_kernel(const double *__restrict__ in, int N, double *hist, double *__restrict__ up, double *__restrict__ down, gdg_os_tables os) {
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     for (int i = tid; i < N; i += SEG_T) s_a[LX(i)] = in[i];
     __syncthreads();
     Shaper S = {};
@@ -2349,7 +2365,7 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
 /* one frame of one channel: HBM -> LDS, the segment's units, LDS -> HBM */
 __device__ __forceinline__ void seg_frame(const double *src, double *dst, const gdg_seg_unit *units, int unit_begin, int unit_count, int N,
                                           const gdg_os_tables &os, int *d_error, int my_type) {
-    int tid = threadIdx.x;
+    int tid = seg_tid();
 #ifdef SEG_FAST
     /* opaque per call: in the window walk the compiler otherwise hoists every per-thread address of the frame's load and store loops out of
      * the frame loop and keeps them in callee-saved vector registers across the unit calls (v120-v123: over the 120 the units need) */
@@ -2433,7 +2449,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
 /* A kernel's register count is the largest of its own body and of every unit it can call, and it applies to ALL its waves.  The units of
  * this configuration stay at 120; a build in which one unit (or the window loop's scalars parked in vector lanes) took 124-128 ran EVERY
  * segment 15 % slower -- also segments that never call that unit (profiles/experiments/README.md, r04).  Hence the explicit ceiling. */
-#define SEG_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(120)))
+#define SEG_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(60)))      /* counted in pairs on the unified register file of gfx90a and later: 120 */
 #else
 #define SEG_KERNEL_ATTR
 #endif
@@ -2444,7 +2460,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
     gdg_seg_chan ch = chans[blockIdx.x];
     if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
-    const int tid = threadIdx.x;
+    const int tid = seg_tid();
     /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
     int my_type = 0;
     if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
