@@ -794,6 +794,7 @@ __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, 
 }
 
 /* returns 1 when the result is in the INPUT buffer (oversampled: in place), 0 when it is in the other one */
+/* (stays a call in the two-per-CU build too: inlined, its 34 constants are made at the top of the kernel and parked in scratch for every launch) */
 __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
     UNIT_PROLOGUE
     Shaper S;
