@@ -1,0 +1,47 @@
+"""Register and scratch budgets of the kernels whose speed depends on them, read from the compiler's own summary (no GPU needed: hipcc
+cross-compiles).  Two workgroups per CU need <= 128 vector registers per lane -- and the two-per-CU segment kernel ran 15 % slower at 128 than at
+120; a `noinline` unit in that build costs 20-36 callee-saved register saves per lane and call, a third of the kernel's HBM
+traffic (profiles/experiments/README.md, r04): its units are inlined, only the shapers stay a call."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "go-dsp-guitar_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-x", "hip"]
+
+
+def summary(tmp_path, source, extra):
+    out = str(tmp_path / (source + ".s"))
+    subprocess.run([HIPCC] + FLAGS + extra + [os.path.join(CSRC, source), "-o", out], check=True, timeout=900, cwd=CSRC,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_Z\w+):\s*; @.*?^; NumVgprs: (\d+).*?^; ScratchSize: (\d+)", text, re.S | re.M):
+        res[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_two_per_cu_segment_kernel_keeps_120_registers_and_has_no_unit_calls(tmp_path):
+    res = summary(tmp_path, "seg.hip", ["-ffp-contract=off", "-DSEG_FAST"])
+    kernels = {k: v for k, v in res.items() if "segf_kernel" in k}
+    assert len(kernels) == 2, sorted(res)
+    for name, (vgprs, scratch) in kernels.items():
+        assert vgprs <= 120, (name, vgprs)
+        assert scratch <= 256, (name, scratch)
+    callees = [k for k in res if "kernel" not in k]
+    assert len(callees) == 1 and "unit_shaper" in callees[0], callees
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_one_buffer_transforms_fit_two_workgroups_per_cu(tmp_path):
+    res = summary(tmp_path, "fir.hip", [])
+    for key in ("fir_inv13h_kernel", "fir_fwd13wh_kernel"):
+        found = {k: v for k, v in res.items() if key in k}
+        assert found, (key, sorted(res)[:5])
+        for name, (vgprs, scratch) in found.items():
+            assert vgprs <= 128 and scratch == 0, (name, vgprs, scratch)
