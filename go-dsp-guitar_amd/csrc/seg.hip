@@ -84,24 +84,19 @@ static_assert(sizeof(double) * (SEG_LBUF + SEG_SCR + SEG_STASH + 32 + 8) <= 8192
 static_assert(4 * L2_SIZE <= SEG_SCR && 7 * LT_SIZE <= SEG_SCR, "scan tables fit the tile");
 #endif
 
-/* General build: every unit is its own function (own register allocation); `flip` says which LDS frame is the input.
- * Two-per-CU build (SEG_FAST): the units are INLINED into the kernel.  A call costs more than it looks: the callee saves and restores the
- * callee-saved half of the vector registers it touches (v40-47, v56-63, ...: 20 to 36 dwords per lane and unit, straight to scratch memory) --
- * 84 dwords per lane for the bench's first segment = 88 MB written and read back per launch, more than the frames themselves
- * (rocprofv3 WRITE_SIZE: 146 MB where 67 are data).  Inlining alone does not work either: every unit's thread-index arithmetic is then
- * hoisted to the top of the kernel and lives through all units (128 registers, 772 bytes of scratch).  seg_tid() hands every use its own opaque
- * copy of the thread index, so addresses are made where they are used: 120 registers, a dozen spill stores per kernel. */
-#ifdef SEG_FAST
+/* The units are INLINED into the kernel (`flip` says which LDS frame is the input).  A call costs more than it looks: the callee saves and
+ * restores the callee-saved half of the vector registers it touches (v40-47, v56-63, ...: 20 to 36 dwords per lane and unit, straight to scratch
+ * memory) -- 84 dwords per lane for the bench's first segment = 88 MB written and read back per launch, more than the frames themselves
+ * (rocprofv3 WRITE_SIZE: 146 MB where 67 are data).  Inlining alone does not work: every unit's thread-index arithmetic and every constant of
+ * the transcendental functions is hoisted to the top of the kernel and lives through all units (128 registers, 772 bytes of scratch).  Two
+ * things keep values where they are used: seg_tid() hands every use of the thread index its own opaque copy, and this file is compiled with
+ * -mllvm -disable-machine-licm (Makefile): 115-120 registers, no spills in the two-per-CU build, three spill stores in the general one. */
 #define UNIT_FN static __device__ __forceinline__ void
 __device__ __forceinline__ unsigned seg_tid() {
     unsigned t = __builtin_amdgcn_workitem_id_x();
     asm volatile("" : "+v"(t));
     return t;
 }
-#else
-#define UNIT_FN __device__ __attribute__((noinline)) void
-__device__ __forceinline__ unsigned seg_tid() { return __builtin_amdgcn_workitem_id_x(); }
-#endif
 #define UNIT_ARGS const gdg_seg_unit *U, int flip, int N
 #define UNIT_PROLOGUE                                                                     \
     double *in = flip ? s_b : s_a;                                                        \
@@ -794,8 +789,12 @@ __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, 
 }
 
 /* returns 1 when the result is in the INPUT buffer (oversampled: in place), 0 when it is in the other one */
-/* (stays a call in the two-per-CU build too: inlined, its 34 constants are made at the top of the kernel and parked in scratch for every launch) */
+/* (the general build keeps the call: the oversampled variants are large) */
+#ifdef SEG_FAST
+static __device__ __forceinline__ int unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
+#else
 __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
+#endif
     UNIT_PROLOGUE
     Shaper S;
     S.type = U->type; S.valve = U->ip[4];

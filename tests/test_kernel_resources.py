@@ -1,7 +1,7 @@
 """Register and scratch budgets of the kernels whose speed depends on them, read from the compiler's own summary (no GPU needed: hipcc
 cross-compiles).  Two workgroups per CU need <= 128 vector registers per lane -- and the two-per-CU segment kernel ran 15 % slower at 128 than at
 120; a `noinline` unit in that build costs 20-36 callee-saved register saves per lane and call, a third of the kernel's HBM
-traffic (profiles/experiments/README.md, r04): its units are inlined, only the shapers stay a call."""
+traffic (profiles/experiments/README.md, r04): the units are inlined (both builds; the general one keeps calls for the oversampled shapers and the any-size all-pass)."""
 import os
 import re
 import subprocess
@@ -25,16 +25,36 @@ def summary(tmp_path, source, extra):
     return res
 
 
+SEG_FLAGS = ["-ffp-contract=off", "-mllvm", "-disable-machine-licm"]          # the Makefile's seg.o / segf.o rules
+
+
+def test_makefile_compiles_the_segment_kernels_with_these_flags():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "SEG_LICM := -mllvm -disable-machine-licm" in mk
+    assert mk.count("-ffp-contract=off $(SEG_LICM)") == 2
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_two_per_cu_segment_kernel_keeps_120_registers_and_has_no_unit_calls(tmp_path):
-    res = summary(tmp_path, "seg.hip", ["-ffp-contract=off", "-DSEG_FAST"])
+    res = summary(tmp_path, "seg.hip", SEG_FLAGS + ["-DSEG_FAST"])
     kernels = {k: v for k, v in res.items() if "segf_kernel" in k}
     assert len(kernels) == 2, sorted(res)
     for name, (vgprs, scratch) in kernels.items():
         assert vgprs <= 120, (name, vgprs)
-        assert scratch <= 256, (name, scratch)
-    callees = [k for k in res if "kernel" not in k]
-    assert len(callees) == 1 and "unit_shaper" in callees[0], callees
+        assert scratch <= 64, (name, scratch)
+    assert [k for k in res if "kernel" not in k] == []
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_general_segment_kernel_calls_only_the_oversampled_units(tmp_path):
+    res = summary(tmp_path, "seg.hip", SEG_FLAGS)
+    kernels = {k: v for k, v in res.items() if "seg_kernel" in k}
+    assert len(kernels) == 2, sorted(res)
+    for name, (vgprs, scratch) in kernels.items():
+        assert vgprs <= 128, (name, vgprs)                 # 1024 threads per workgroup
+        assert scratch <= 128, (name, scratch)
+    callees = sorted(k for k in res if "kernel" not in k)
+    assert len(callees) == 3 and all(any(n in k for n in ("unit_shaper", "unit_fuzz_os", "allpass_generic")) for k in callees), callees
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
