@@ -130,11 +130,11 @@ struct gdg_ctx {
     std::vector<char> plan_unit_fast;          /* ... and whether its segment runs on the two-per-CU kernel (scan tables for 16-sample chunks) */
     std::vector<char> plan_unit_fast_ok;       /* ... and whether the unit itself could (segf_unit_ok at plan time): a change of that rebuilds the plan */
     bool seg_fast = true;                      /* GDG_SEG_FAST=0: every segment on the general kernel (A/B measurements, bit-identity tests) */
-    int seg_fast_min = 256;                    /* GDG_SEG_FAST_MIN: fewest channels of a call that take the two-per-CU kernel.  Below a chip's worth of
-                                                * channels (256 CUs) the general kernel's 1024 threads per channel finish a frame sooner (64 channels:
-                                                * 159 vs 164 us per step, 128: 217 vs 222); from 256 on the two-per-CU kernel, its units inlined, wins
-                                                * (256: 309 -> 306 us per step, W = 16 157 -> 153 us per frame; 512: 90.8 -> 69.8 us per segment launch;
-                                                * profiles/fast_min_ab_r04.txt) */
+    int seg_fast_min = 257;                    /* GDG_SEG_FAST_MIN: fewest channels of a call that take the two-per-CU kernel.  Up to a chip's worth of
+                                                * channels (256 CUs) the general kernel's 1024 threads per channel run in ONE round and finish a frame
+                                                * sooner (64 channels: 158 vs 163 us per step, 128: 214 vs 217, 256: 301 vs 305; W = 16: 77 / 102 / 147 vs
+                                                * 83 / 108 / 152 us per frame); beyond that it needs a second round and the two-per-CU kernel wins
+                                                * (512: 75-81 vs 60-65 us per segment launch; profiles/fast_min_ab_r04.txt) */
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
     bool plan_patch = true;                    /* GDG_PLAN_PATCH=0: every parameter change rebuilds the whole plan (A/B measurements) */
     std::vector<unsigned char> blob;

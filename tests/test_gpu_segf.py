@@ -1,5 +1,5 @@
 """The two-per-CU segment kernel (seg.hip compiled with SEG_FAST: 512 threads per channel, ONE LDS frame buffer, every unit in place) takes over
-segments of 8192-sample frames from 256 channels on.  Here it is forced on for small contexts (GDG_SEG_FAST_MIN=0) and held against the oracle
+segments of 8192-sample frames from 257 channels on.  Here it is forced on for small contexts (GDG_SEG_FAST_MIN=0) and held against the oracle
 (1e-9 RMS), against the general kernel (same arithmetic, another association of the workgroup scans: ~1e-16) and against itself in windows
 (bit for bit); streams that move between the two kernels -- frame-size changes, a unit that loses its eligibility -- must stay continuous:
 both kernels share one state layout in HBM."""
