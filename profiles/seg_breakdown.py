@@ -40,7 +40,7 @@ CASES = [
 
 def main():
     pkg = entry.load_package()
-    nch, frames, sr, steps = 512, 8192, 192000, 10
+    nch, frames, sr, steps = int(os.environ.get("NCH", "512")), 8192, 192000, 10
     args = [a for a in sys.argv[1:] if a != "--cold" and not a.startswith("--window=") and not a.startswith("--pad=")]
     pad = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad=")] + [0])      # window mode: extra doubles per row (row stride = W * frames + pad)
     W = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--window=")] + [0])      # > 0: gdg_process_window_device, W frames per launch
