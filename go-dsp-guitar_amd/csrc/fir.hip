@@ -1517,18 +1517,20 @@ static int cu_count() {
 
 /* Which 8192-point transforms exchange through ONE LDS buffer, two workgroups per CU (env GDG_FFT_HALF_LDS, bits: 1 the window's forward,
  * 2 the window's inverse, 4 the per-frame forward, 8 no chained inverse -> forward kernel in windows of four frames or more, 32 the window's
- * forward workgroups XCD by XCD).  Default 10, measured at W = 16 with 512 channels, us per frame (profiles/fft_half_lds_r04.txt):
+ * forward workgroups XCD by XCD).  Default 14, measured at W = 16 with 512 channels, us per frame (profiles/fft_half_lds_r04.txt):
  *   inverse 32 -> 23: it reads 128 KiB and writes 64 per channel-frame, the second workgroup streams while the first computes;
  *   chained inverse -> forward kernel 54.5 -> two launches 23 + 24: the chained kernel needs both LDS buffers and the previous frame in registers;
  *   forward: the walk (one workgroup per channel, previous frame in registers) 24, one buffer and one workgroup per frame 22 (the previous
  *   frame is read again, from the L2 of the XCD that has just read it as "current") -- faster alone, but two such workgroups take a CU's
  *   whole register file, and with the two channel groups of the batch path the walk (one 140 KiB workgroup, half the registers) shares its
  *   CU with the other group's multiply-accumulate: 272-278 against 279-280 us per frame for the window as a whole.  The walk stays (bits 1, 32 off).
+ *   per-frame forward of the real-time path (bit 4, on): 38.4 us alone for its 165 MB; with one buffer the step is 7-10 us shorter with one
+ *   channel group (593 -> 583-586 us) and a wash to +0.4 % with two (profiles/fft_half_lds_groups_r04.txt).
  * Not kept: the per-channel walk with one buffer (26 us: 512 workgroups, nothing to balance with), non-temporal spectrum stores and product
- * loads (no difference).  The per-frame forward of the real-time path (bit 4) already runs at its bytes (39 us for 201 MB). */
+ * loads (no difference). */
 static int fft_half_lds() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("GDG_FFT_HALF_LDS"); v = e ? atoi(e) : 10; }
+    if (v < 0) { const char *e = getenv("GDG_FFT_HALF_LDS"); v = e ? atoi(e) : 14; }
     return v;
 }
 

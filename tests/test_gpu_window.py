@@ -261,7 +261,7 @@ def test_window_chain_of_adjacent_power_amps_gives_the_same_bits(W):
 def test_transform_variants_give_the_same_bits(bits):
     """GDG_FFT_HALF_LDS picks the kernels of the 8192-point transforms (read once per process: a child each).  0: two LDS buffers, one
     workgroup per CU, chained inverse -> forward kernel in every window; 47: one buffer everywhere it exists, the real-time path's forward
-    transform included.  Each must pass the bit-for-bit tests of this file that the default (10) passes in the parent."""
+    transform included.  Each must pass the bit-for-bit tests of this file that the default (14) passes in the parent."""
     import os
     import subprocess
     import sys
