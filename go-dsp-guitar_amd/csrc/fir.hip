@@ -52,6 +52,11 @@ __device__ __forceinline__ void gstore(cplx *p, cplx c) {
     v2d v = { c.x, c.y };
     *reinterpret_cast<GDG_GLOBAL v2d *>((GDG_GLOBAL void *)p) = v;
 }
+/* written once, read a gigabyte of traffic later (a window's spectra and products): past the caches */
+__device__ __forceinline__ void gstore_nt(cplx *p, cplx c) {
+    v2d v = { c.x, c.y };
+    __builtin_nontemporal_store(v, reinterpret_cast<GDG_GLOBAL v2d *>((GDG_GLOBAL void *)p));
+}
 __device__ __forceinline__ double gload1(const double *p) { return *(const GDG_GLOBAL double *)p; }
 __device__ __forceinline__ void gstore1(double *p, double x) { *(GDG_GLOBAL double *)p = x; }
 
@@ -1169,7 +1174,7 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     }
     if (b != 0) {
 #pragma unroll
-        for (int j = 0; j < W; j++) gstore(ch.Y + (size_t)j * P + b, make_double2(ar[j], ai[j]));
+        for (int j = 0; j < W; j++) gstore_nt(ch.Y + (size_t)j * P + b, make_double2(ar[j], ai[j]));
     }
     /* bin 0 = (DC, Nyquist) as two reals: component-wise products, the same ascending order.  Lane j of the channel's first workgroup
      * takes frame j: its operands were loaded a moment ago (cache), eight partitions' worth are issued before they are consumed */
