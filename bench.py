@@ -562,6 +562,10 @@ def main():
         sys.stderr.flush()
         os.execv(sys.executable, cmd)
 
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:         # one line per rank before anything can fail (a launcher kills the other ranks when one dies)
+        sys.stderr.write("bench.py: rank %s of %s started\n" % (os.environ.get("RANK", "?"), os.environ["WORLD_SIZE"]))
+        sys.stderr.flush()
+
     import torch  # before the library is loaded: libgdg.so then binds to the same HIP runtime (same SONAME)
 
     rank = int(os.environ.get("RANK", "0"))
