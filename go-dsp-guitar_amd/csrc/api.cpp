@@ -94,6 +94,8 @@ struct Unit {
 };
 
 struct Slot { int handle; bool bypass; };
+#define GDG_WAVE_STEPS 64             /* segment steps of a plan that can run as WAVE launches (a chain with more power amps than that walks) */
+#define GDG_WAVE_GROUPS 16            /* = the most channel groups of a call (every group's launch of a step draws its own tickets) */
 
 struct StepDesc {
     bool is_fir;
@@ -103,6 +105,7 @@ struct StepDesc {
     bool chain_next = false;          /* FIR step whose every channel feeds another power amp next (the following step): that amp's forward
                                        * transform rides on this step's inverse (fir_inv_kernel CHAIN) in per-frame calls */
     bool fast = false;                /* segment step: every unit of every channel works in place on 8192-sample frames -> the two-per-CU kernel (segf) */
+    int wave_tickets = -1;            /* segment step: first of its GDG_WAVE_GROUPS ticket counters in d_wave (seg.hip, WAVE), -1: none */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
 
@@ -135,6 +138,13 @@ struct gdg_ctx {
                                                 * sooner (64 channels: 158 vs 163 us per step, 128: 214 vs 217, 256: 301 vs 305; W = 16: 77 / 102 / 147 vs
                                                 * 83 / 108 / 152 us per frame); beyond that it needs a second round and the two-per-CU kernel wins
                                                 * (512: 75-81 vs 60-65 us per segment launch; profiles/fast_min_ab_r04.txt) */
+    /* Windows of few channels (seg.hip, WAVE): up to this many channels per launch a window's segment launch puts every FRAME of a channel on a
+     * workgroup of its own, the frames meeting unit by unit through counters in HBM -- a GPU's share of the 512-channel job on eight GPUs is 64
+     * channels, and one workgroup per channel walking the window leaves 3/4 of the CUs idle (64 channels, W = 16: 417 us per segment launch,
+     * 52 of the 77 us per frame).  0: never.  gdg_ctx_set_option("seg_wave_max_channels"), env GDG_SEG_WAVE_MAX. */
+    int seg_wave_max = 128;
+    int *d_wave = nullptr;                     /* [GDG_WAVE_STEPS x GDG_WAVE_GROUPS ticket counters | one counter per unit in a segment]: zero between launches */
+    size_t d_wave_cap = 0;
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
     bool plan_patch = true;                    /* GDG_PLAN_PATCH=0: every parameter change rebuilds the whole plan (A/B measurements) */
     std::vector<unsigned char> blob;
@@ -309,6 +319,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     { const char *e = getenv("GDG_PLAN_PATCH"); if (e) ctx->plan_patch = atoi(e) != 0; }
     { const char *e = getenv("GDG_SEG_FAST"); if (e) ctx->seg_fast = atoi(e) != 0; }
     { const char *e = getenv("GDG_SEG_FAST_MIN"); if (e) ctx->seg_fast_min = atoi(e); }
+    { const char *e = getenv("GDG_SEG_WAVE_MAX"); if (e) ctx->seg_wave_max = atoi(e); }
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -374,7 +385,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     for (auto &kv : ctx->fir_tables) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &p : ctx->prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error);
+    hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error); hipFree(ctx->d_wave);
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
     hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_part); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
@@ -1220,6 +1231,20 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         n_ops[(size_t)c] = count;
     }
     (void)any_fir;
+    /* counters of the WAVE launches: tickets per (segment step, channel group), then one frame counter per unit that sits in a segment */
+    {
+        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + ctx->units.size() + (size_t)nch + 64;
+        if (need > ctx->d_wave_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ctx->d_wave);
+            ctx->d_wave = nullptr;
+            ctx->d_wave_cap = need * 2;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_wave, ctx->d_wave_cap * sizeof(int)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_wave, 0, ctx->d_wave_cap * sizeof(int), ctx->stream));
+        }
+    }
+    size_t wave_next = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS;
+    int seg_steps = 0;
     /* blob layout: [step 0 descs][step 1 descs]...[seg units] */
     std::vector<gdg_seg_unit> seg_units;
     std::vector<std::vector<gdg_seg_chan>> seg_descs;
@@ -1269,6 +1294,22 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 s.scratch = ctx->d_scratch + (size_t)c * ctx->max_frames;
                 s.unit_begin = (int)seg_units.size();
                 s.unit_count = (int)op.handles.size();
+                s.wave = ctx->d_wave + wave_next;
+                wave_next += op.handles.size();
+                {   /* which units meet their predecessor frame in a WAVE launch, and whether their stores are write-through there (seg.hip, wt) */
+                    unsigned mask = 0;
+                    for (size_t ui = 0; ui < op.handles.size(); ui++) {
+                        const Unit &wu = ctx->units[(size_t)op.handles[ui]];
+                        const bool shaper = wu.type == GDG_UNIT_OVERDRIVE || wu.type == GDG_UNIT_DISTORTION || wu.type == GDG_UNIT_EXCESS;
+                        const int os_param = wu.type == GDG_UNIT_OVERDRIVE ? 5 : (wu.type == GDG_UNIT_DISTORTION ? 3 : 2);
+                        if (shaper && wu.params[os_param] == 0) continue;                       /* memoryless: no state, no meeting */
+                        if (ui < 31) mask |= 1u << ui;
+                        const bool write_through = wu.type == GDG_UNIT_COMPRESSOR || wu.type == GDG_UNIT_TONESTACK || wu.type == GDG_UNIT_CABINET ||
+                                                   wu.type == GDG_UNIT_CHORUS || (wu.type == GDG_UNIT_REVERB && !step_fast);
+                        if (!write_through) mask |= 1u << 31;
+                    }
+                    s.wave_mask = (int)mask;
+                }
                 for (int h : op.handles) {
                     gdg_seg_unit du;
                     const double tq = pnow();
@@ -1290,6 +1331,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         st.fast = step_fast;
         st.n = is_fir ? (int)fd.size() : (int)sd.size();
         st.offset = 0;
+        if (!is_fir && seg_steps < GDG_WAVE_STEPS && G <= GDG_WAVE_GROUPS) st.wave_tickets = GDG_WAVE_GROUPS * seg_steps++;
         /* descriptors are in `active` order, so every channel group owns one contiguous run of them */
         st.group_range.assign((size_t)G, std::make_pair(0, 0));
         {
@@ -1657,8 +1699,10 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);
                 /* one launch per window: a channel's workgroup walks its frames in order, the units' state runs through them */
-                if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s));
-                else HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s));
+                /* ... unless the channels are few: then a workgroup per frame, the frames of a channel meeting unit by unit (seg.hip, WAVE) */
+                int *tickets = (window > 1 && n <= ctx->seg_wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
+                if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets));
+                else HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets));
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));

@@ -77,10 +77,10 @@ __shared__ double s_scr[SEG_SCR];                    /* oversampling / run-list 
 
 #define SEG_STASH 128                             /* first state cell inside s_tmp: behind the scan scratch (block_scan: 2 x 4 recurrences x 16 waves;
                                                    * lin_scan / lin2_scan: two alternating pairs of 17-cell exchange slots = 68) */
-__shared__ double s_tmp[SEG_STASH + 32 + 8];        /* scan scratch + 32 state cells + 16 unit types */
+__shared__ double s_tmp[SEG_STASH + 32 + 8 + 2];    /* scan scratch + 32 state cells + 16 unit types + the workgroup's ticket (WAVE) */
 static_assert(2 * 4 * (SEG_T / 64) <= SEG_STASH, "block_scan scratch");
 #ifdef SEG_FAST
-static_assert(sizeof(double) * (SEG_LBUF + SEG_SCR + SEG_STASH + 32 + 8) <= 81920, "two workgroups per CU: 80 KiB of LDS each");
+static_assert(sizeof(double) * (SEG_LBUF + SEG_SCR + SEG_STASH + 32 + 8 + 2) <= 81920, "two workgroups per CU: 80 KiB of LDS each");
 static_assert(4 * L2_SIZE <= SEG_SCR && 7 * LT_SIZE <= SEG_SCR, "scan tables fit the tile");
 #endif
 
@@ -97,7 +97,10 @@ __device__ __forceinline__ unsigned seg_tid() {
     asm volatile("" : "+v"(t));
     return t;
 }
-#define UNIT_ARGS const gdg_seg_unit *U, int flip, int N
+/* wt ("write-through"): the launch runs a channel's frames on several workgroups (WAVE, at the segment kernel): what a unit leaves in HBM
+ * for its next frame -- state cells, ring cells -- is stored with sc1 (st_* below), so that the hand-off needs no write-back of the XCD's L2.
+ * A compile-time constant in every instantiation (the units are inlined). */
+#define UNIT_ARGS const gdg_seg_unit *U, int flip, int N, const bool wt
 #define UNIT_PROLOGUE                                                                     \
     double *in = flip ? s_b : s_a;                                                        \
     double *out = flip ? s_a : s_b;                                                       \
@@ -339,6 +342,22 @@ __device__ __forceinline__ const GDG_GLOBAL double *as_global(const double *p) {
 __device__ __forceinline__ GDG_GLOBAL double *as_global(double *p) { return (GDG_GLOBAL double *)p; }
 __device__ __forceinline__ GDG_GLOBAL int *as_global(int *p) { return (GDG_GLOBAL int *)p; }
 
+/* Stores of what the NEXT frame of the channel reads (unit state, rings).  Plain, unless that frame runs on another workgroup (wt): then
+ * write-through (sc1: relaxed agent-scope atomics for the cells, a 16-byte sc1 store for ring pairs), which leaves nothing in this XCD's
+ * L2 for a release fence to write back (MI355X_MICROARCH.md, visibility: "sc1 payload -> every storing wave drains -> flag"). */
+__device__ __forceinline__ void st_f64(GDG_GLOBAL double *p, double v, bool wt) {
+    if (wt) __hip_atomic_store((GDG_GLOBAL unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ void st_i32(GDG_GLOBAL int *p, int v, bool wt) {
+    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ void st_v2d(GDG_GLOBAL seg_v2d *p, seg_v2d v, bool wt) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+
 __device__ __forceinline__ double ring_read(const double *ring, int C, int wp, int idx) {
     int p = wp + idx;
     if (p < 0) p += C;
@@ -346,7 +365,7 @@ __device__ __forceinline__ double ring_read(const double *ring, int C, int wp, i
 }
 
 /* append the frame held in LDS buffer `in` to the ring (all threads), then thread 0 advances wp */
-__device__ __forceinline__ void ring_append(double *ring, int C, int *wp_ptr, const double *in, int N) {
+__device__ __forceinline__ void ring_append(double *ring, int C, int *wp_ptr, const double *in, int N, const bool wt = false) {
     if (C <= 0) return;
     const int wp = *wp_ptr;
     int first = N > C ? N - C : 0;
@@ -356,17 +375,18 @@ __device__ __forceinline__ void ring_append(double *ring, int C, int *wp_ptr, co
         for (int i = first + 2 * (int)seg_tid(); i < N; i += 2 * SEG_T) {
             int p = (wp + i) % C;
             const double a = in[LX(i)], b = in[LX(i + 1)];
-            if (p + 1 < C) { seg_v2d v = { a, b }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
-            else { g[p] = a; g[0] = b; }
+            if (p + 1 < C) { seg_v2d v = { a, b }; st_v2d((GDG_GLOBAL seg_v2d *)(g + p), v, wt); }
+            else { st_f64(g + p, a, wt); st_f64(g, b, wt); }
         }
     } else {
         for (int i = first + (int)seg_tid(); i < N; i += SEG_T) {
             int p = (wp + i) % C;
-            as_global(ring)[p] = in[LX(i)];
+            st_f64(as_global(ring) + p, in[LX(i)], wt);
         }
     }
+    if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the sc1 pair stores are inline assembly: the compiler does not wait for them */
     __syncthreads();
-    if (seg_tid() == 0) *as_global(wp_ptr) = (wp + N) % C;
+    if (seg_tid() == 0) st_i32(as_global(wp_ptr), (wp + N) % C, wt);
 }
 /* the reference's fractional delay read (e.g. effects/flanger.go:63-90): both weights are 1 when the delay is integral */
 __device__ __forceinline__ double frac_delay(const double *in, const double *ring, int C, int wp, int i, double delay_samples) {
@@ -553,7 +573,7 @@ __device__ __forceinline__ const GDG_CONST gdg_seg_unit *uniform_unit(const gdg_
 /* ---- compressor: effects/compressor.go:18-84 ---------------------------------------------------
  * ip0 follow; dp0 gain limit factor, dp1 target factor, dp2 exp(-20/sr), dp3 1 - dp2; ds0 envelope */
 template <class C>
-__device__ __forceinline__ void compressor_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
+__device__ __forceinline__ void compressor_body(const gdg_seg_unit *U, int flip, int N, const C &c, const bool wt) {
     UNIT_PROLOGUE
     double s = U->ds[0];
     double x[CHK], e[CHK];
@@ -568,10 +588,10 @@ __device__ __forceinline__ void compressor_body(const gdg_seg_unit *U, int flip,
         x[i] = clip1(gain * x[i]);
     }
     chunk_store(out, c, x);
-    if (c.last) U->ds[0] = s;
+    if (c.last) st_f64(as_global(U->ds), s, wt);
 }
 /* the batch block size: constant-coefficient scan (see lin_scan) */
-__device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip) {
+__device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip, const bool wt) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;
@@ -605,11 +625,11 @@ __device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip
         x[i] = clip1(gain * x[i]);
     }
     chunk_store(out, c, x);
-    if (c.last) ds[0] = s;
+    if (c.last) st_f64(ds, s, wt);
 }
 UNIT_FN unit_compressor(UNIT_ARGS) {
-    if (N == CHK * SEG_T) compressor_full(U, flip);
-    else compressor_body(U, flip, N, my_chunk(N));
+    if (N == CHK * SEG_T) compressor_full(U, flip, wt);
+    else compressor_body(U, flip, N, my_chunk(N), wt);
 }
 
 /* ---- memoryless waveshapers ---------------------------------------------------------------------- */
@@ -814,7 +834,7 @@ __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tab
 /* ---- tone stack: effects/tonestack.go:19-100 ------------------------------------------------------
  * dp0..3 band factors, dp4..7 (1 - exp(-2 pi fA/sr)), dp8..11 (1 - exp(-2 pi fB/sr)); ds0..3 hcv, ds4..7 lcv */
 template <class C>
-__device__ __forceinline__ void tonestack_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
+__device__ __forceinline__ void tonestack_body(const gdg_seg_unit *U, int flip, int N, const C &c, const bool wt) {
     UNIT_PROLOGUE
     double *st = tmp + SEG_STASH;                    /* the eight capacitor voltages, stashed in LDS (not in live registers) */
     if (seg_tid() < 8) st[seg_tid()] = U->ds[seg_tid()];
@@ -882,13 +902,13 @@ __device__ __forceinline__ void tonestack_body(const gdg_seg_unit *U, int flip, 
         }
         if (c.last) {
 #pragma unroll
-            for (int j = 0; j < 2; j++) { U->ds[2 * pair + j] = h[j]; U->ds[4 + 2 * pair + j] = l[j]; }
+            for (int j = 0; j < 2; j++) { st_f64(as_global(U->ds) + 2 * pair + j, h[j], wt); st_f64(as_global(U->ds) + 4 + 2 * pair + j, l[j], wt); }
         }
     }
 }
 /* the batch block size: per band ONE scan of the (high-pass, low-pass) state pair with the constant 2 x 2 chunk matrix, then the
  * reference's loop body from the scanned chunk-start state; the band sum stays in registers (j = 0..3 as in the reference) */
-__device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip) {
+__device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip, const bool wt) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;                    /* [0..7] the capacitor voltages, [16..27] factors and coefficients */
@@ -920,22 +940,22 @@ __device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip)
             l += diff * aL;
             sum[i] += fac * pre;
         }
-        if (c.last) { ds[j] = h; ds[4 + j] = l; }
+        if (c.last) { st_f64(ds + j, h, wt); st_f64(ds + 4 + j, l, wt); }
     }
 #pragma unroll
     for (int i = 0; i < CHK; i++) sum[i] = clip1(sum[i]);
     chunk_store(out, c, sum);
 }
 UNIT_FN unit_tonestack(UNIT_ARGS) {
-    if (N == CHK * SEG_T) tonestack_full(U, flip);
-    else tonestack_body(U, flip, N, my_chunk(N));
+    if (N == CHK * SEG_T) tonestack_full(U, flip, wt);
+    else tonestack_body(U, flip, N, my_chunk(N), wt);
 }
 
 /* ---- cabinet (IIR): effects/cabinet.go:27-162 -------------------------------------------------------
  * dp0..2 high-pass (1 - exp(-2 pi f/sr)) for 300/120/80 Hz, dp3..6 low-pass for 3/4/5/6 kHz; ds0..2 hcv, ds3..6 lcv.
  * Seven one-pole sections in series on a register chunk: per section a zero-state pass, a workgroup scan, an exact replay. */
 template <class C>
-__device__ __forceinline__ void cabinet_body(const gdg_seg_unit *U, int flip, int N, const C &c) {
+__device__ __forceinline__ void cabinet_body(const gdg_seg_unit *U, int flip, int N, const C &c, const bool wt) {
     UNIT_PROLOGUE
     double *st = tmp + SEG_STASH;                    /* the seven capacitor voltages, fetched once, kept in LDS */
     if (seg_tid() < 7) st[seg_tid()] = U->ds[seg_tid()];
@@ -948,14 +968,14 @@ __device__ __forceinline__ void cabinet_body(const gdg_seg_unit *U, int flip, in
         double s = st[p];
         if (p < 3) onepole_reg<OP_DIFF_OLD>(v, c, a, s, tmp);
         else onepole_reg<OP_OLD>(v, c, a, s, tmp);
-        if (c.last) U->ds[p] = s;
+        if (c.last) st_f64(as_global(U->ds) + p, s, wt);
     }
 #pragma unroll
     for (int i = 0; i < CHK; i++) v[i] = clip1(v[i]);
     chunk_store(out, c, v);
 }
 /* the batch block size: per section a dot product, a constant-coefficient scan (lin_scan) and the exact replay */
-__device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip) {
+__device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip, const bool wt) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;                    /* [0..6] the capacitor voltages, [16..22] the coefficients */
@@ -979,15 +999,15 @@ __device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip) {
 #pragma unroll
             for (int i = 0; i < CHK; i++) { double diff = v[i] - s; v[i] = s; s += diff * a; }             /* cabinet.go:135-139 */
         }
-        if (c.last) ds[p] = s;
+        if (c.last) st_f64(ds + p, s, wt);
     }
 #pragma unroll
     for (int i = 0; i < CHK; i++) v[i] = clip1(v[i]);
     chunk_store(out, c, v);
 }
 UNIT_FN unit_cabinet(UNIT_ARGS) {
-    if (N == CHK * SEG_T) cabinet_full(U, flip);
-    else cabinet_body(U, flip, N, my_chunk(N));
+    if (N == CHK * SEG_T) cabinet_full(U, flip, wt);
+    else cabinet_body(U, flip, N, my_chunk(N), wt);
 }
 
 /* ---- chorus: effects/chorus.go:19-131 ------------------------------------------------------------------
@@ -1012,17 +1032,18 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
         for (int i = 2 * (int)seg_tid(); i < N; i += 2 * SEG_T) {
             const int p = (wp + i) & mask;                          /* even, so p + 1 <= mask */
             seg_v2d v = { in[LX(i)], in[LX(i + 1)] };
-            *(GDG_GLOBAL seg_v2d *)(ring + p) = v;
-            if (p == 0) ring[mask + 1] = v.x;
+            st_v2d((GDG_GLOBAL seg_v2d *)(ring + p), v, wt);
+            if (p == 0) st_f64(ring + mask + 1, v.x, wt);
         }
     } else {
         for (int i = seg_tid(); i < N; i += SEG_T) {
             const int p = (wp + i) & mask;
             const double v = in[LX(i)];
-            ring[p] = v;
-            if (p == 0) ring[mask + 1] = v;
+            st_f64(ring + p, v, wt);
+            if (p == 0) st_f64(ring + mask + 1, v, wt);
         }
     }
+    if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the sc1 pair stores are inline assembly: the compiler does not wait for them */
     __syncthreads();                                                /* the frame is in the ring (visible to the whole workgroup) */
     /* sin(zero_phase + j 2pi/5) by the angle-addition formula from ONE sincos (the five LFOs are 72 degrees apart):
      * differs from the reference's sin(fmod(zero_phase + j 2pi/5, 2pi)) by ~1e-16, i.e. ~1e-13 samples of delay */
@@ -1112,8 +1133,8 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
     }
     if (seg_tid() == 0) {
         double buffer_time = (double)C / sr;          /* quirk: advances by the buffer length, not by N */
-        ds[0] = fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI);
-        is[0] = (wp + N) & mask;
+        st_f64(ds, fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI), wt);
+        st_i32(is, (wp + N) & mask, wt);
     }
 }
 
@@ -1293,7 +1314,7 @@ __device__ __forceinline__ void allpass_fetch(const double *ring, int M, int rp,
     }
 }
 template <int Q>
-__device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M, int rp, int N, const double (&pm0)[Q], int *rp_out) {
+__device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M, int rp, int N, const double (&pm0)[Q], int *rp_out, const bool wt = false) {
     const int cnt = min(M, N);
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -1307,19 +1328,20 @@ __device__ __forceinline__ void allpass_chains(double *buf, double *ring, int M,
                 pm = p;
                 n += M;
             } while (n < N);
-            if (N >= M) as_global(ring)[n - N] = p;         /* the last M values of p, oldest first (n - M is this chain's last index) */
-            else { int at = rp + r; if (at >= M) at -= M; as_global(ring)[at] = p; }
+            if (N >= M) st_f64(as_global(ring) + (n - N), p, wt);      /* the last M values of p, oldest first (n - M is this chain's last index) */
+            else { int at = rp + r; if (at >= M) at -= M; st_f64(as_global(ring) + at, p, wt); }
         }
     }
-    if (seg_tid() == 0) *rp_out = (N >= M) ? 0 : (rp + N) % M;
+    if (seg_tid() == 0) st_i32(as_global(rp_out), (N >= M) ? 0 : (rp + N) % M, wt);
     __syncthreads();
 }
 /* any ring size: fetch at use (exposes the latency; only sample rates far above 192 kHz come here) */
-__device__ __attribute__((noinline)) void allpass_generic(double *buf, double *ring, int M, int rp, int N, int *rp_out) {
+__device__ __attribute__((noinline)) void allpass_generic(double *buf, double *ring, int M, int rp, int N, int *rp_out, bool wt) {
     double pm0[REVERB_QMAX];
     allpass_fetch<REVERB_QMAX>(ring, M, rp, N, pm0);
     __syncthreads();                                        /* every old ring value is in a register before anyone overwrites the ring */
-    allpass_chains<REVERB_QMAX>(buf, ring, M, rp, N, pm0, rp_out);
+    if (wt) allpass_chains<REVERB_QMAX>(buf, ring, M, rp, N, pm0, rp_out, true);
+    else allpass_chains<REVERB_QMAX>(buf, ring, M, rp, N, pm0, rp_out, false);
 }
 
 #ifdef SEG_FAST
@@ -1580,13 +1602,13 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
      * needed here anyway), then the barrier */
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (M[0] >= 1) allpass_chains<REVERB_QMAX>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1]);
+    if (M[0] >= 1) allpass_chains<REVERB_QMAX>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1], wt);
     if (fast) {
-        if (M[1] >= 1) allpass_chains<3>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2]);
-        if (M[2] >= 1) allpass_chains<1>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3]);
+        if (M[1] >= 1) allpass_chains<3>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2], wt);
+        if (M[2] >= 1) allpass_chains<1>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3], wt);
     } else {
-        if (M[1] >= 1) allpass_generic(out, ring[1], M[1], rp[1], N, &is_state[2]);
-        if (M[2] >= 1) allpass_generic(out, ring[2], M[2], rp[2], N, &is_state[3]);
+        if (M[1] >= 1) allpass_generic(out, ring[1], M[1], rp[1], N, &is_state[2], wt);
+        if (M[2] >= 1) allpass_generic(out, ring[2], M[2], rp[2], N, &is_state[3], wt);
     }
 #pragma unroll
     for (int q = 0; q < REVERB_QMAX; q++) {
@@ -1597,7 +1619,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         }
     }
     __syncthreads();
-    ring_append(dl_ring, DL, &is_state[0], in, N);
+    ring_append(dl_ring, DL, &is_state[0], in, N, wt);
 }
 #endif
 
@@ -2362,9 +2384,41 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
 #endif
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
+/* ---- frames of one channel in flight on SEVERAL workgroups (WAVE) ---------------------------------------------------------------
+ * A window of W frames of a channel is W x U cells (frame f, unit u); cell (f, u) needs the frame from (f, u - 1) -- LDS of the same
+ * workgroup -- and unit u's state from (f - 1, u) -- HBM.  The walk (one workgroup per channel, frame after frame) runs the cells one
+ * at a time on one CU: fine when the channels fill the chip, 3/4 of it idle with 64 channels (a GPU's share of the 512-channel job on
+ * eight).  Here workgroup f takes frame f and meets its predecessor once per unit: before unit u touches its state it waits until the
+ * unit's cell of the channel (wave[u], HBM) says "frame f", after the unit it posts f + 1 (the window's last frame posts 0 for the
+ * next launch).  A unit still sees its frames strictly in order -- state, rings and per-call quirks exactly as in the walk, the same
+ * bits -- but unit u of frame f runs beside unit u + 1 of frame f - 1 on another CU: a window takes (sum of the units) + (W - 1) x
+ * (slowest unit) instead of W x (sum).  Release / acquire at agent scope (the workgroups of a channel may sit on different XCDs, each
+ * with an L2 of its own): every wave writes back before the barrier, one lane posts; one lane polls, every wave invalidates after the
+ * barrier.  Workgroups take their frame by TICKET (seg_kernel), so a workgroup never waits for one that has not started. */
+__device__ __forceinline__ void wave_wait(int *cell, int want) {
+    if (seg_tid() == 0) {
+        while (__hip_atomic_load(as_global(cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          /* ONE buffer_inv sc1 per workgroup: this CU's L1 (MI355X_MICROARCH.md, visibility) */
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void wave_post(int *cell, int value, bool release) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                /* every storing wave drains */
+    __syncthreads();
+    if (seg_tid() == 0) {
+        /* units whose stores for the next frame are write-through (UNIT_ARGS, wt) need no write-back; a segment with any other unit pays
+         * ONE buffer_wbl2 sc1 -- this XCD's dirty lines, 2-8 us -- per unit and frame (`release`, bit 31 of the channel's wave_mask) */
+        if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the compiler may drop the wait behind the write-back (guide, pitfall 12) */
+        __hip_atomic_store(as_global(cell), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 /* one frame of one channel: HBM -> LDS, the segment's units, LDS -> HBM */
+template <bool WAVE>
 __device__ __forceinline__ void seg_frame(const double *src, double *dst, const gdg_seg_unit *units, int unit_begin, int unit_count, int N,
-                                          const gdg_os_tables &os, int *d_error, int my_type) {
+                                          const gdg_os_tables &os, int *d_error, int my_type, int *wave = nullptr, int wf = 0, int wf_next = 0,
+                                          unsigned wave_mask = 0) {
     int tid = seg_tid();
 #ifdef SEG_FAST
     /* opaque per call: in the window walk the compiler otherwise hoists every per-thread address of the frame's load and store loops out of
@@ -2397,42 +2451,46 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         const gdg_seg_unit *U = units + unit_begin + u;
         const int type = (u < 16) ? __builtin_amdgcn_readfirstlane(s_types[u]) : U->type;
         int inplace = 0;
+        /* a unit that keeps nothing from frame to frame (a shaper without oversampling) meets nobody */
+        const bool gated = WAVE && (u >= 31 || ((wave_mask >> u) & 1u));
+        if (gated) wave_wait(wave + u, wf);
         switch (type) {
-        case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N); break;
+        case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N, WAVE); break;
         case GDG_UNIT_OVERDRIVE:
         case GDG_UNIT_DISTORTION:
 #ifdef SEG_FAST                                     /* no oversampling here: the six table pointers need not live across the unit calls */
-        case GDG_UNIT_EXCESS: { gdg_os_tables none = {}; inplace = unit_shaper(U, flip, N, none); break; }
+        case GDG_UNIT_EXCESS: { gdg_os_tables none = {}; inplace = unit_shaper(U, flip, N, WAVE, none); break; }
 #else
-        case GDG_UNIT_EXCESS: inplace = unit_shaper(U, flip, N, os); break;
+        case GDG_UNIT_EXCESS: inplace = unit_shaper(U, flip, N, WAVE, os); break;
 #endif
-        case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N); break;
-        case GDG_UNIT_CABINET: unit_cabinet(U, flip, N); break;
-        case GDG_UNIT_CHORUS: unit_chorus(U, flip, N); break;
-        case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N); break;
-        case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N); break;
-        case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N); break;
-        case GDG_UNIT_REVERB: unit_reverb(U, flip, N); break;
+        case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N, WAVE); break;
+        case GDG_UNIT_CABINET: unit_cabinet(U, flip, N, WAVE); break;
+        case GDG_UNIT_CHORUS: unit_chorus(U, flip, N, WAVE); break;
+        case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N, WAVE); break;
+        case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N, WAVE); break;
+        case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N, WAVE); break;
+        case GDG_UNIT_REVERB: unit_reverb(U, flip, N, WAVE); break;
 #ifndef SEG_FAST                                    /* units that read other threads' cells of their input after writing output, or stage a frame: two buffers */
         case GDG_UNIT_FLANGER:
-        case GDG_UNIT_PHASER: unit_flanger(U, flip, N); break;
-        case GDG_UNIT_DELAY: unit_delay(U, flip, N); break;
+        case GDG_UNIT_PHASER: unit_flanger(U, flip, N, WAVE); break;
+        case GDG_UNIT_DELAY: unit_delay(U, flip, N, WAVE); break;
         case GDG_UNIT_FUZZ:
-            if (U->jp[0] > 1) inplace = unit_fuzz_os(U, flip, N, os);
-            else unit_fuzz(U, flip, N);
+            if (U->jp[0] > 1) inplace = unit_fuzz_os(U, flip, N, WAVE, os);
+            else unit_fuzz(U, flip, N, WAVE);
             break;
-        case GDG_UNIT_AUTOYOY: unit_autoyoy(U, flip, N); break;
-        case GDG_UNIT_AUTOWAH: unit_autowah(U, flip, N); break;
-        case GDG_UNIT_BANDPASS: unit_bandpass(U, flip, N); break;
-        case GDG_UNIT_OCTAVER: unit_octaver(U, flip, N); break;
-        case GDG_UNIT_NOISEGATE: unit_noisegate(U, flip, N); break;
+        case GDG_UNIT_AUTOYOY: unit_autoyoy(U, flip, N, WAVE); break;
+        case GDG_UNIT_AUTOWAH: unit_autowah(U, flip, N, WAVE); break;
+        case GDG_UNIT_BANDPASS: unit_bandpass(U, flip, N, WAVE); break;
+        case GDG_UNIT_OCTAVER: unit_octaver(U, flip, N, WAVE); break;
+        case GDG_UNIT_NOISEGATE: unit_noisegate(U, flip, N, WAVE); break;
 #endif
         default:
             if (tid == 0) atomicExch(d_error, 1 + type);
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
             break;
         }
-        __syncthreads();
+        if (gated) wave_post(wave + u, wf_next, (wave_mask >> 31) != 0);
+        else __syncthreads();
         if (!__builtin_amdgcn_readfirstlane(inplace)) flip ^= 1;
     }
     const double *fin = flip ? s_b : s_a;
@@ -2453,21 +2511,42 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
 #else
 #define SEG_KERNEL_ATTR
 #endif
-template <bool MULTI>
+template <int MODE>             /* 0: one frame per launch; 1: the walk; 2: WAVE (a workgroup per frame, above) */
 __global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU) SEG_KERNEL_ATTR
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
-           gdg_os_tables os, int *d_error) {
-    gdg_seg_chan ch = chans[blockIdx.x];
+           gdg_os_tables os, int *d_error, int n_chans, int *ticket) {
+    constexpr bool MULTI = MODE == 1;
+    int block = blockIdx.x, wf0 = 0;
+    if (MODE == 2) {
+        /* frames are dealt in the order the workgroups START, frame-major (all channels' frame 0, then frame 1, ...): whoever a
+         * workgroup waits for holds a smaller ticket and is already running (or done), whatever the order of dispatch */
+        int *s_ticket = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32) + 16;
+        if (threadIdx.x == 0) {
+            const int t = atomicAdd(ticket, 1);
+            if (t == n_chans * n_frames - 1) __hip_atomic_store(as_global(ticket), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* everybody has drawn: ready for the next launch */
+            *s_ticket = t;
+        }
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(*s_ticket);
+        wf0 = t / n_chans;
+        block = t - wf0 * n_chans;
+    }
+    gdg_seg_chan ch = chans[block];
     if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
     if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
     const int tid = seg_tid();
     /* the unit types of this segment, fetched together with the frame (one exposed latency instead of one per unit) */
     int my_type = 0;
     if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
+    if (MODE == 2) {
+        seg_frame<true>(ch.src + (size_t)wf0 * N, ch.dst + (size_t)wf0 * N, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type,
+                        ch.wave, wf0, wf0 + 1 < n_frames ? wf0 + 1 : 0, (unsigned)ch.wave_mask);
+        return;
+    }
     /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
      * through global memory from one frame to the next exactly as from one launch to the next (same CU, same L1; a barrier between) */
     for (int wf = 0; wf < (MULTI ? n_frames : 1); wf++, ch.src += N, ch.dst += N) {
-        seg_frame(ch.src, ch.dst, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type);
+        seg_frame<false>(ch.src, ch.dst, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type);
         if (MULTI && wf + 1 < n_frames) { __threadfence_block(); __syncthreads(); }      /* state and LDS frames before the next frame touches them */
     }
 }
@@ -2497,9 +2576,11 @@ int gdg_seg_supported(int unit_type) {
 }
 
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
-                          gdg_os_tables os, int *d_error, hipStream_t s) {
+                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket) {
     if (n_chans <= 0 || n_frames <= 0) return hipSuccess;
-    if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<true>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error);
-    else hipLaunchKernelGGL(seg_kernel<false>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, 1, shift, os, d_error);
+    if (n_frames > 1 && d_wave_ticket)
+        hipLaunchKernelGGL(seg_kernel<2>, dim3(n_chans * n_frames), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, d_wave_ticket);
+    else if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<1>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, nullptr);
+    else hipLaunchKernelGGL(seg_kernel<0>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, 1, shift, os, d_error, n_chans, nullptr);
     return hipGetLastError();
 }
