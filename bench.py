@@ -124,6 +124,34 @@ def make_context(pkg, nch, frames, device, taps, channel0=0, n_distinct=0, chain
 
 # ---- CPU baseline ---------------------------------------------------------------------------------------------------------
 
+def host_cpu_info():
+    """Physical cores, sockets and model name of the host from /proc/cpuinfo (north_star: "core count stated"): distinct (physical id, core id)
+    pairs -- logical CPUs that share a pair are SMT siblings."""
+    cores, sockets, model = set(), set(), None
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "physical id":
+                    phys = val
+                elif key == "core id":
+                    core = val
+                elif key == "model name" and model is None:
+                    model = val
+                elif not key and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    sockets.add(phys)
+                    phys = core = None
+            if phys is not None and core is not None:
+                cores.add((phys, core))
+                sockets.add(phys)
+    except OSError:
+        pass
+    return {"physical_cores": len(cores) or None, "sockets": len(sockets) or None, "cpu_model": model}
+
+
 def cpu_baseline(sample_rate, frames, taps, target_seconds=12.0):
     """The oracle ("port": structure-preserving C restatement of the Go path: unpartitioned 2 * nextpow2(L)-point radix-2 FFT
     pair per block and power amp, 8 exp per sample in the tone stack ...) on the host cores THIS process may use
@@ -188,9 +216,11 @@ def cpu_baseline(sample_rate, frames, taps, target_seconds=12.0):
         # the most favourable thread count for the CPU, not the reference's own (one goroutine per channel on every logical CPU)
         "value": scaling[best_threads],
         "unit": "Msamples/s",
-        "cores": int(best_threads),
+        "cores": int(best_threads),                     # the contract's key: the threads `value` was measured with
+        "best_threads": int(best_threads),
         "kind": "port",
         "logical_cpus": cores,
+        **host_cpu_info(),
         "single_thread": single,
         "all_core": all_core,
         "parallel_efficiency_all_core": all_core / (cores * single),

@@ -43,7 +43,23 @@ ABI_SYMBOLS = [
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
     "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
     "gdg_batch_length", "gdg_batch_run", "gdg_batch_run_shard", "gdg_batch_finish_master", "gdg_batch_release", "gdg_profile_sample", "gdg_ctx_set_window", "gdg_process_window_device", "gdg_ctx_set_overlap",
+    "gdg_ctx_set_option", "gdg_ctx_get_option", "gdg_option_count", "gdg_option_name", "gdg_numa_probe",
 ]
+
+
+def option_names():
+    """The keys gdg_ctx_set_option understands."""
+    return [lib().gdg_option_name(i).decode() for i in range(lib().gdg_option_count())]
+
+
+def numa_probe(sysfs_root, pci_bus_id, capacity=4096):
+    """(node, [cpus]) of a PCI device from sysfs (gdg_numa_probe; no device needed)."""
+    node, n = C.c_int(-1), C.c_int(0)
+    cpus = (C.c_int * capacity)()
+    rc = lib().gdg_numa_probe(sysfs_root.encode(), pci_bus_id.encode(), C.byref(node), cpus, capacity, C.byref(n))
+    if rc != GDG_OK:
+        raise GdgError(rc, "gdg_numa_probe")
+    return int(node.value), [int(cpus[i]) for i in range(min(capacity, n.value))]
 
 
 class GdgError(RuntimeError):
@@ -163,6 +179,11 @@ def lib():
             "gdg_batch_run_shard": (i32, [vp, vp, i32, vp, vp, vp]),
             "gdg_batch_finish_master": (i32, [vp, i32, vp, vp, i32, vp, C.c_size_t, u32, i32, vp, vp]),
             "gdg_profile_sample": (i32, [vp, i32]),
+            "gdg_ctx_set_option": (i32, [vp, C.c_char_p, C.c_longlong]),
+            "gdg_ctx_get_option": (i32, [vp, C.c_char_p, C.POINTER(C.c_longlong)]),
+            "gdg_option_count": (i32, []),
+            "gdg_option_name": (C.c_char_p, [i32]),
+            "gdg_numa_probe": (i32, [C.c_char_p, C.c_char_p, C.POINTER(i32), C.POINTER(i32), i32, C.POINTER(i32)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -497,6 +518,15 @@ class Context:
     def set_window(self, frames_per_call):
         """Time blocking: up to `frames_per_call` (1, 2, 4, 8, 16) consecutive 8192-sample frames per channel and call."""
         self._check(lib().gdg_ctx_set_window(self._h, frames_per_call))
+
+    def set_option(self, key, value):
+        """Launch-shape options (include/gdg.h, gdg_ctx_set_option): what used to be environment variables."""
+        self._check(lib().gdg_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_longlong(0)
+        self._check(lib().gdg_ctx_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_overlap(self, groups):
         """Channel groups of the device-resident calls, free-running on streams of their own (include/gdg.h)."""

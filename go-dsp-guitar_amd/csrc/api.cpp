@@ -19,6 +19,9 @@
 #include <string.h>
 
 #include <unistd.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
 
 #include <algorithm>
 #include <atomic>
@@ -142,7 +145,18 @@ struct gdg_ctx {
      * workgroup of its own, the frames meeting unit by unit through counters in HBM -- a GPU's share of the 512-channel job on eight GPUs is 64
      * channels, and one workgroup per channel walking the window leaves 3/4 of the CUs idle (64 channels, W = 16: 417 us per segment launch,
      * 52 of the 77 us per frame).  0: never.  gdg_ctx_set_option("seg_wave_max_channels"), env GDG_SEG_WAVE_MAX. */
-    int seg_wave_max = 128;
+    int seg_wave_max = 192;                    /* 64 / 128 / 192 / 256 channels, W = 16: 77 / 102 / 128 / 146 us per frame walking, 51 / 87 / 125 / 160 in flight */
+    int scan_tables_max = 1024;                /* scan tables kept before a plan rebuild drops them all (a caller sweeping a parameter) */
+    int pcie_groups_forced = 0;                /* channel groups of the host-buffer calls; 0: by channel count */
+    int device_groups_env = 0;                 /* GDG_DEVICE_GROUPS: the debug override of gdg_ctx_set_overlap(0) */
+    int copy_threads = 8;                      /* host copy workers of the host-buffer paths (made on first use) */
+    int tuner_long = 0;                        /* 1: every analysis through the 262144-point transform pair (A/B, tests) */
+    /* NUMA placement of the host paths (option "numa", default on): the copy workers run on the CPUs of the device's NUMA node and the pinned
+     * slabs are taken from its memory -- on a two-socket node with eight GPUs, eight pools and eight sets of slabs would otherwise land
+     * wherever the scheduler put the callers (profiles/host_path_numa_r03.txt: +-15 %) */
+    int numa_mode = 1;
+    int numa_node = -1;                        /* /sys/bus/pci/devices/<bus id>/numa_node of the device, -1: unknown or a one-node host */
+    std::vector<int> numa_cpus;                /* /sys/devices/system/node/node<N>/cpulist */
     int *d_wave = nullptr;                     /* [GDG_WAVE_STEPS x GDG_WAVE_GROUPS ticket counters | one counter per unit in a segment]: zero between launches */
     size_t d_wave_cap = 0;
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
@@ -296,6 +310,149 @@ static void join_groups(gdg_ctx *ctx) {
     ctx->groups_pending = false;
 }
 
+/* ---- NUMA: where the device hangs, from sysfs ------------------------------------------------------------------------------- */
+/* "0-63,128-191" -> the CPU numbers; false on anything else */
+static bool parse_cpulist(const char *text, std::vector<int> &cpus) {
+    cpus.clear();
+    const char *p = text;
+    while (*p && *p != '\n') {
+        char *end = nullptr;
+        long a = strtol(p, &end, 10);
+        if (end == p || a < 0) return false;
+        long b = a;
+        p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); if (end == p + 1 || b < a) return false; p = end; }
+        if (b - a > 65536) return false;
+        for (long c = a; c <= b; c++) cpus.push_back((int)c);
+        if (*p == ',') p++;
+        else if (*p && *p != '\n') return false;
+    }
+    return true;
+}
+static bool read_text(const std::string &path, char *buf, size_t cap) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return n > 0;
+}
+/* node of the PCI function `pci_bus_id` ("0000:05:00.0", any case) and that node's CPUs under `sysfs_root` ("/sys") */
+int gdg_numa_probe(const char *sysfs_root, const char *pci_bus_id, int *node, int *cpus, int capacity, int *n_cpus) {
+    if (!sysfs_root || !pci_bus_id || !node) return GDG_ERR_INVALID;
+    *node = -1;
+    if (n_cpus) *n_cpus = 0;
+    std::string id(pci_bus_id);
+    for (auto &ch : id) ch = (char)tolower((unsigned char)ch);
+    char buf[4096];
+    if (!read_text(std::string(sysfs_root) + "/bus/pci/devices/" + id + "/numa_node", buf, sizeof(buf))) return GDG_OK;       /* unknown: not an error */
+    char *end = nullptr;
+    long n = strtol(buf, &end, 10);
+    if (end == buf || n < 0) return GDG_OK;                 /* "-1": the platform does not say (one node, or a VM) */
+    std::vector<int> list;
+    if (!read_text(std::string(sysfs_root) + "/devices/system/node/node" + std::to_string(n) + "/cpulist", buf, sizeof(buf)) || !parse_cpulist(buf, list) || list.empty())
+        return GDG_OK;
+    *node = (int)n;
+    if (n_cpus) *n_cpus = (int)list.size();
+    if (cpus) for (int i = 0; i < capacity && i < (int)list.size(); i++) cpus[i] = list[(size_t)i];
+    return GDG_OK;
+}
+static void numa_discover(gdg_ctx *ctx) {
+    char id[64] = { 0 };
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id), ctx->device) != hipSuccess) return;
+    int node = -1, n = 0;
+    std::vector<int> cpus(4096);
+    if (gdg_numa_probe("/sys", id, &node, cpus.data(), (int)cpus.size(), &n) != GDG_OK || node < 0) return;
+    cpus.resize((size_t)std::min(n, (int)cpus.size()));
+    ctx->numa_node = node;
+    ctx->numa_cpus = cpus;
+}
+/* the calling thread onto the device's node (copy workers) */
+static void numa_bind_thread(const std::vector<int> &cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t *set = CPU_ALLOC(4096);
+    if (!set) return;
+    const size_t bytes = CPU_ALLOC_SIZE(4096);
+    CPU_ZERO_S(bytes, set);
+    for (int c : cpus) if (c >= 0 && c < 4096) CPU_SET_S(c, bytes, set);
+    pthread_setaffinity_np(pthread_self(), bytes, set);      /* a cpuset that forbids those CPUs leaves the thread where it was */
+    CPU_FREE(set);
+}
+/* pinned host memory from the device's node: the pages are taken (and pinned) inside hipHostMalloc, under the calling thread's memory policy */
+static hipError_t pinned_alloc(gdg_ctx *ctx, void **p, size_t bytes) {
+    const bool bind = ctx->numa_mode != 0 && ctx->numa_node >= 0 && ctx->numa_node < 1024;
+    if (bind) {
+        unsigned long mask[16] = { 0 };
+        mask[ctx->numa_node / (8 * sizeof(unsigned long))] |= 1ul << (ctx->numa_node % (8 * sizeof(unsigned long)));
+        const bool policy = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul + 1) == 0;
+        hipError_t e = hipHostMalloc(p, bytes, policy ? hipHostMallocNumaUser : hipHostMallocDefault);
+        if (policy) syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+    }
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+static int numa_rebind(gdg_ctx *ctx, int mode);
+
+/* ---- options: everything that decides a launch shape, behind ONE entry point (gdg_ctx_set_option) ----------------------------------
+ * The environment variable of an option is read once, when the context is made, as a debug override of its default -- a library's behaviour
+ * should not depend on the environment of whoever loads it.  `knob` options are process-wide (their launchers have no context). */
+struct OptionDef {
+    const char *key, *env;
+    long long lo, hi;
+    int knob;                                   /* >= 0: gdg_knob_set / gdg_knob_get (process-wide) */
+    int gdg_ctx::*field;
+    bool gdg_ctx::*flag;
+    bool replans;                               /* a change invalidates the cached plan */
+};
+static const OptionDef g_options[] = {
+    /* the convolution */
+    { "fir_fused", "GDG_FIR_FUSED", -1, 1, -1, &gdg_ctx::fir_fused, nullptr, true },                  /* -1: by channel count (fir_split_max) */
+    { "fir_split_max_channels", "GDG_FIR_SPLIT_MAX", 0, 1 << 20, -1, &gdg_ctx::fir_split_max, nullptr, true },
+    { "fir_chain_adjacent_amps", "GDG_FIR_CHAIN", 0, 1, -1, nullptr, &gdg_ctx::fir_chain, true },
+    { "share_ir_spectra", "GDG_SHARE_IR_SPECTRA", 0, 1, -1, nullptr, &gdg_ctx::share_spectra, false },
+    { "fft_half_lds_mask", "GDG_FFT_HALF_LDS", 0, 63, GDG_KNOB_FFT_HALF_LDS, nullptr, nullptr, false },
+    { "fir_forward_per_channel", "GDG_FWD_PER_CHANNEL", 0, 1, GDG_KNOB_FWD_PER_CHANNEL, nullptr, nullptr, false },
+    { "fir_forward_wave_local", "GDG_WAVE_FFT", 0, 3, GDG_KNOB_WAVE_FFT, nullptr, nullptr, false },
+    { "fir_mac_variant", "GDG_MAC_VARIANT", 0, 15, GDG_KNOB_MAC_VARIANT, nullptr, nullptr, false },
+    /* the segments */
+    { "seg_two_per_cu", "GDG_SEG_FAST", 0, 1, -1, nullptr, &gdg_ctx::seg_fast, true },
+    { "seg_two_per_cu_min_channels", "GDG_SEG_FAST_MIN", 0, 1 << 20, -1, &gdg_ctx::seg_fast_min, nullptr, true },
+    { "seg_wave_max_channels", "GDG_SEG_WAVE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_max, nullptr, false },
+    { "plan_patch", "GDG_PLAN_PATCH", 0, 1, -1, nullptr, &gdg_ctx::plan_patch, false },
+    { "scan_tables_max", "GDG_SCAN_TABLES_MAX", 1, 1 << 20, -1, &gdg_ctx::scan_tables_max, nullptr, false },
+    /* host paths, tuner, profiling */
+    { "pcie_groups", "GDG_PCIE_GROUPS", 0, 16, -1, &gdg_ctx::pcie_groups_forced, nullptr, false },
+    { "device_groups_default", "GDG_DEVICE_GROUPS", 0, 16, -1, &gdg_ctx::device_groups_env, nullptr, false },
+    { "copy_threads", "GDG_COPY_THREADS", 1, 256, -1, &gdg_ctx::copy_threads, nullptr, false },
+    { "numa", "GDG_NUMA", 0, 1, -1, &gdg_ctx::numa_mode, nullptr, false },
+    { "tuner_parts", "GDG_TUNER_PARTS", 0, 24, GDG_KNOB_TUNER_PARTS, nullptr, nullptr, false },
+    { "tuner_long_transform", "GDG_TUNER_LONG", 0, 1, -1, &gdg_ctx::tuner_long, nullptr, false },
+    { "profile_attach", "GDG_PROFILE_ATTACH", 0, 1, -1, nullptr, &gdg_ctx::prof_attach, false },
+};
+static const OptionDef *find_option(const char *key) {
+    if (!key) return nullptr;
+    for (const OptionDef &o : g_options) if (strcmp(o.key, key) == 0) return &o;
+    return nullptr;
+}
+static void option_store(gdg_ctx *ctx, const OptionDef &o, long long v) {
+    if (o.knob >= 0) gdg_knob_set(o.knob, (int)v);
+    else if (o.field) ctx->*(o.field) = (int)v;
+    else ctx->*(o.flag) = v != 0;
+}
+static void options_from_env(gdg_ctx *ctx) {
+    for (const OptionDef &o : g_options) {
+        if (o.knob >= 0) continue;                      /* gdg_knob_get reads its variable itself, once */
+        const char *e = getenv(o.env);
+        if (!e) continue;
+        long long v = atoll(e);
+        if (o.flag) v = v != 0;
+        if (v < o.lo) v = o.lo;
+        if (v > o.hi) v = o.hi;
+        option_store(ctx, o, v);
+    }
+}
+
 int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     if (!out) return GDG_ERR_INVALID;
     *out = nullptr;
@@ -311,15 +468,8 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ctx->w_stride = (size_t)max_frames;
     ctx->device = device;
     ctx->chains.resize((size_t)n_channels);
-    { const char *e = getenv("GDG_SHARE_IR_SPECTRA"); if (e) ctx->share_spectra = atoi(e) != 0; }
-    { const char *e = getenv("GDG_FIR_FUSED"); if (e) ctx->fir_fused = atoi(e) != 0 ? 1 : 0; }
-    { const char *e = getenv("GDG_FIR_SPLIT_MAX"); if (e) ctx->fir_split_max = atoi(e); }
-    { const char *e = getenv("GDG_FIR_CHAIN"); if (e) ctx->fir_chain = atoi(e) != 0; }
-    { const char *e = getenv("GDG_PROFILE_ATTACH"); if (e) ctx->prof_attach = atoi(e) != 0; }
-    { const char *e = getenv("GDG_PLAN_PATCH"); if (e) ctx->plan_patch = atoi(e) != 0; }
-    { const char *e = getenv("GDG_SEG_FAST"); if (e) ctx->seg_fast = atoi(e) != 0; }
-    { const char *e = getenv("GDG_SEG_FAST_MIN"); if (e) ctx->seg_fast_min = atoi(e); }
-    { const char *e = getenv("GDG_SEG_WAVE_MAX"); if (e) ctx->seg_wave_max = atoi(e); }
+    options_from_env(ctx);                     /* debug overrides of the options' defaults (gdg_ctx_set_option) */
+    numa_discover(ctx);
     ctx->sp_az.assign((size_t)n_channels, 0.0);
     ctx->sp_dist.assign((size_t)n_channels, 0.0);
     ctx->sp_level.assign((size_t)n_channels, 1.0);
@@ -423,6 +573,32 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable) {
     ctx->share_spectra = enable != 0;       /* affects power amps prepared from now on */
     return GDG_OK;
 }
+int gdg_ctx_set_option(gdg_ctx *ctx, const char *key, long long value) {
+    if (!ctx) return GDG_ERR_INVALID;
+    const OptionDef *o = find_option(key);
+    if (!o) return fail(ctx, GDG_ERR_INVALID, "unknown option \"%s\"", key ? key : "(null)");
+    if (value < o->lo || value > o->hi) return fail(ctx, GDG_ERR_INVALID, "option %s = %lld: %lld to %lld", key, value, o->lo, o->hi);
+    enter(ctx);                                 /* free-running groups join before a launch shape changes under them */
+    if (strcmp(key, "copy_threads") == 0 && ctx->copy_pool && value != ctx->copy_threads) { destroy_copy_pool(ctx->copy_pool); ctx->copy_pool = nullptr; }
+    if (strcmp(key, "numa") == 0 && value != ctx->numa_mode) { int rc = numa_rebind(ctx, (int)value); if (rc != GDG_OK) return rc; }
+    option_store(ctx, *o, value);
+    if (o->replans) ctx->dirty = true;
+    return GDG_OK;
+}
+
+int gdg_ctx_get_option(gdg_ctx *ctx, const char *key, long long *value) {
+    if (!ctx || !value) return GDG_ERR_INVALID;
+    const OptionDef *o = find_option(key);
+    if (!o) return fail(ctx, GDG_ERR_INVALID, "unknown option \"%s\"", key ? key : "(null)");
+    if (o->knob >= 0) *value = gdg_knob_get(o->knob);
+    else if (o->field) *value = ctx->*(o->field);
+    else *value = (ctx->*(o->flag)) ? 1 : 0;
+    return GDG_OK;
+}
+
+int gdg_option_count(void) { return (int)(sizeof(g_options) / sizeof(g_options[0])); }
+const char *gdg_option_name(int index) { return (index >= 0 && index < gdg_option_count()) ? g_options[index].key : NULL; }
+
 void *gdg_ctx_stream(const gdg_ctx *ctx) {
     if (!ctx) return nullptr;
     join_groups(const_cast<gdg_ctx *>(ctx));           /* work enqueued on the returned stream from here on follows everything already submitted */
@@ -1189,8 +1365,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
      * through thousands of values would let the cache grow without bound (12 KB per tone-stack setting): past the limit everything is
      * dropped once the work in flight has drained, and this plan re-makes the few tables it needs. */
     {
-        const char *e = getenv("GDG_SCAN_TABLES_MAX");           /* read per plan: a test lowers it */
-        long limit = e ? atol(e) : 1024;
+        long limit = ctx->scan_tables_max;                         /* gdg_ctx_set_option "scan_tables_max": a test lowers it */
         if (limit < 1) limit = 1;
         if ((long)ctx->scan_tabs.size() > limit) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1233,7 +1408,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     (void)any_fir;
     /* counters of the WAVE launches: tickets per (segment step, channel group), then one frame counter per unit that sits in a segment */
     {
-        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + ctx->units.size() + (size_t)nch + 64;
+        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + 2 * ctx->units.size() + (size_t)nch + 64;
         if (need > ctx->d_wave_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             hipFree(ctx->d_wave);
@@ -1295,7 +1470,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                 s.unit_begin = (int)seg_units.size();
                 s.unit_count = (int)op.handles.size();
                 s.wave = ctx->d_wave + wave_next;
-                wave_next += op.handles.size();
+                wave_next += 2 * op.handles.size();                     /* two counters per unit: the reverb meets its predecessor frame twice */
                 {   /* which units meet their predecessor frame in a WAVE launch, and whether their stores are write-through there (seg.hip, wt) */
                     unsigned mask = 0;
                     for (size_t ui = 0; ui < op.handles.size(); ui++) {
@@ -1497,8 +1672,7 @@ int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
 static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
     join_groups(ctx);                          /* free-running channel groups may still read the descriptors */
     {
-        const char *e = getenv("GDG_SCAN_TABLES_MAX");
-        long limit = e ? atol(e) : 1024;
+        const long limit = ctx->scan_tables_max;
         if ((long)ctx->scan_tabs.size() > (limit < 1 ? 1 : limit)) { ctx->dirty = true; return GDG_OK; }       /* the rebuild trims the cache */
     }
     size_t lo = (size_t)-1, hi = 0;
@@ -1715,10 +1889,9 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     return GDG_OK;
 }
 
-/* how many channel groups a host-buffer call over n channels is split into (env GDG_PCIE_GROUPS overrides) */
-static int pcie_groups(int n) {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("GDG_PCIE_GROUPS"); forced = e ? atoi(e) : 0; }
+/* how many channel groups a host-buffer call over n channels is split into (option "pcie_groups" overrides) */
+static int pcie_groups(const gdg_ctx *ctx, int n) {
+    const int forced = ctx->pcie_groups_forced;
     int g = forced > 0 ? forced : (n >= 128 ? 2 : 1);        /* measured: profiles/host_path_rate_r01.txt */
     if (g > n) g = n;
     return g < 1 ? 1 : (g > 16 ? 16 : g);
@@ -1730,8 +1903,7 @@ static int pcie_groups(int n) {
  * ordered after the call's kernels when they run on that stream: the default is ONE group on the context's stream.
  * Measured (profiles/device_groups_r02.txt): two groups gain 7-10 % from 512 channels on, nothing below, four lose. */
 static int device_groups(const gdg_ctx *ctx) {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("GDG_DEVICE_GROUPS"); forced = e ? atoi(e) : 0; }
+    const int forced = ctx->device_groups_env;
     const int n = ctx->nch;
     int g = ctx->overlap_groups > 0 ? ctx->overlap_groups : (forced > 0 ? forced : 1);
     if (g > n) g = n;
@@ -1808,8 +1980,8 @@ static int ensure_staging(gdg_ctx *ctx) {
     size_t bytes = (size_t)std::max(ctx->nch, 2) * (size_t)ctx->max_frames * sizeof(double);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stage_in, bytes));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stage_out, bytes));
-    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_stage_in, bytes, hipHostMallocDefault));
-    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_stage_out, bytes, hipHostMallocDefault));
+    HIP_TRY(ctx, pinned_alloc(ctx, (void **)&ctx->h_stage_in, bytes));
+    HIP_TRY(ctx, pinned_alloc(ctx, (void **)&ctx->h_stage_out, bytes));
     return GDG_OK;
 }
 
@@ -1822,11 +1994,11 @@ static int ensure_staging(gdg_ctx *ctx) {
  * fork(): a child inherits the pool object but none of its threads; it finds another pid in the pool and copies inline. */
 class CopyPool {
 public:
-    explicit CopyPool(int workers) : pid_(getpid()) {
-        for (int i = 0; i < workers; i++) threads_.emplace_back([this, i]() { loop((size_t)i + 1); });
+    /* cpus: the workers' CPUs (the device's NUMA node), empty = wherever the scheduler puts them */
+    explicit CopyPool(int workers, std::vector<int> cpus = {}) : cpus_(std::move(cpus)), pid_(getpid()) {
+        for (int i = 0; i < workers; i++) threads_.emplace_back([this, i]() { numa_bind_thread(cpus_); loop((size_t)i + 1); });
     }
-    ~CopyPool() {
-        if (pid_ != getpid()) { for (auto &t : threads_) t.detach(); return; }      /* forked child: the threads do not exist here */
+    ~CopyPool() {                               /* only in the process that made the pool (destroy_copy_pool) */
         {
             std::lock_guard<std::mutex> lk(mu_);
             stop_ = true; gen_++;
@@ -1876,21 +2048,31 @@ private:
     size_t T_ = 0, pending_ = 0;
     uint64_t gen_ = 0;
     bool stop_ = false;
+    std::vector<int> cpus_;
     pid_t pid_;
 };
 
-static void destroy_copy_pool(CopyPool *p) { delete p; }
+/* A forked child inherits the pool object but none of its threads: joining or detaching std::thread handles of threads that do not exist in
+ * this process is undefined -- the child leaves the object alone (a few hundred bytes, once). */
+static void destroy_copy_pool(CopyPool *p) { if (p && p->usable()) delete p; }
 
 static CopyPool &copy_pool(gdg_ctx *ctx) {
     if (!ctx->copy_pool) {
-        const char *e = getenv("GDG_COPY_THREADS");
-        int threads = e ? atoi(e) : 8;
+        int threads = ctx->copy_threads;
         unsigned hw = std::thread::hardware_concurrency();
         if (hw > 0 && threads > (int)hw) threads = (int)hw;
         if (threads < 1) threads = 1;
-        ctx->copy_pool = new CopyPool(threads - 1);
+        ctx->copy_pool = new CopyPool(threads - 1, ctx->numa_mode ? ctx->numa_cpus : std::vector<int>());
     }
     return *ctx->copy_pool;
+}
+
+/* option "numa": the workers are re-made (bound or not) at the next host-buffer call; pinned slabs that exist stay where they are (the
+ * staging slabs' addresses are in the caller's hands), those made afterwards follow the new mode -- set it before the first call */
+static int numa_rebind(gdg_ctx *ctx, int mode) {
+    (void)mode;
+    if (ctx->copy_pool) { destroy_copy_pool(ctx->copy_pool); ctx->copy_pool = nullptr; }
+    return GDG_OK;
 }
 
 /* rows [a, b) of a host-side staging copy, spread over the copy workers (at least ~1 MiB per thread) */
@@ -1918,7 +2100,7 @@ int gdg_process_subset(gdg_ctx *ctx, const int *channels, int n, const double *c
     if (rc != GDG_OK) return rc;
     /* rows travel compactly ([i][frames]); G channel groups: group g's rows are staged and uploaded on stream g while the
      * earlier groups already compute, and copied back to the caller while the later groups still run */
-    int G = pcie_groups(n);
+    int G = pcie_groups(ctx, n);
     const std::vector<size_t> gb = pcie_group_bounds((size_t)n, &G);
     const size_t row = (size_t)frames;
     auto lo = [&](int g) { return gb[(size_t)g]; };
@@ -1984,7 +2166,7 @@ int gdg_process_staged(gdg_ctx *ctx, const int *channels, int n, int frames, uin
     const size_t stride = (size_t)ctx->max_frames;
     /* G channel groups on their own streams: uploads, kernels and downloads of different groups overlap.  One strided copy
      * per run of consecutive channels inside a group (512 single-row copies would cost ~10 us each). */
-    int G = pcie_groups(n);
+    int G = pcie_groups(ctx, n);
     const std::vector<size_t> gb = pcie_group_bounds((size_t)n, &G);
     auto lo = [&](int g) { return gb[(size_t)g]; };
     auto copy_runs = [&](int g, double *dst, const double *src, hipMemcpyKind kind, hipStream_t s) -> hipError_t {
@@ -2208,8 +2390,7 @@ int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
     enter(ctx);
     int rc = ensure_tuner(ctx);
     if (rc != GDG_OK) return rc;
-    static int force_long = -1;
-    if (force_long < 0) { const char *e = getenv("GDG_TUNER_LONG"); force_long = e ? atoi(e) : 0; }
+    const int force_long = ctx->tuner_long;
     if (!force_long && gdg_tuner_short_ok((double)ctx->tuner_sr, GDG_NOTE_FREQS[0])) {
         /* every standard rate: block-wise autocorrelation for the lags the analysis can look at; the ring is read once */
         double2 *tw4096, *tw2_4096;
@@ -2860,7 +3041,7 @@ static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes, size_t up_half_byt
             ctx->h_up[h] = nullptr;
         }
         ctx->h_up_cap = 0;
-        for (int h = 0; h < 2; h++) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_up[h], up_half_bytes, hipHostMallocDefault));
+        for (int h = 0; h < 2; h++) HIP_TRY(ctx, pinned_alloc(ctx, (void **)&ctx->h_up[h], up_half_bytes));
         ctx->h_up_cap = up_half_bytes;
     }
     if (half_bytes > ctx->h_batch_cap) {
@@ -2869,7 +3050,7 @@ static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes, size_t up_half_byt
             ctx->h_batch[h] = nullptr;
         }
         ctx->h_batch_cap = 0;
-        for (int h = 0; h < 2; h++) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_batch[h], half_bytes, hipHostMallocDefault));
+        for (int h = 0; h < 2; h++) HIP_TRY(ctx, pinned_alloc(ctx, (void **)&ctx->h_batch[h], half_bytes));
         ctx->h_batch_cap = half_bytes;
     }
     return GDG_OK;

@@ -1533,11 +1533,25 @@ static int cu_count() {
  *   channel group (593 -> 583-586 us) and a wash to +0.4 % with two (profiles/fft_half_lds_groups_r04.txt).
  * Not kept: the per-channel walk with one buffer (26 us: 512 workgroups, nothing to balance with), non-temporal spectrum stores and product
  * loads (no difference). */
-static int fft_half_lds() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GDG_FFT_HALF_LDS"); v = e ? atoi(e) : 14; }
-    return v;
+/* Launch shapes of the transforms / the tuner that the launchers (which have no context) choose between: process-wide values, set through
+ * gdg_ctx_set_option (api.cpp: the keys, what they mean, their ranges); first use takes the environment variable of the same name as a debug
+ * override, else the measured default. */
+static int g_knob[GDG_KNOB_COUNT];
+static bool g_knob_set[GDG_KNOB_COUNT];
+int gdg_knob_get(int which) {
+    static const struct { const char *env; int def; } K[GDG_KNOB_COUNT] = {
+        { "GDG_FFT_HALF_LDS", 14 }, { "GDG_FWD_PER_CHANNEL", 1 }, { "GDG_WAVE_FFT", 1 }, { "GDG_MAC_VARIANT", 0 }, { "GDG_TUNER_PARTS", 0 },
+    };
+    if (which < 0 || which >= GDG_KNOB_COUNT) return 0;
+    if (!g_knob_set[which]) { const char *e = getenv(K[which].env); g_knob[which] = e ? atoi(e) : K[which].def; g_knob_set[which] = true; }
+    return g_knob[which];
 }
+void gdg_knob_set(int which, int value) {
+    if (which < 0 || which >= GDG_KNOB_COUNT) return;
+    g_knob[which] = value;
+    g_knob_set[which] = true;
+}
+static int fft_half_lds() { return gdg_knob_get(GDG_KNOB_FFT_HALF_LDS); }
 
 /* a window of W frames of 8192 samples per channel (W in {2, 4, 8, 16}); the four launches of one power-amp step */
 template <int W, int C> static void launch_mac_tb(const gdg_fir_chan *d_chans, int n, bool shared, hipStream_t s) {
@@ -1548,8 +1562,7 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
                                  gdg_shift shift, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
     if (W != 2 && W != 4 && W != 8 && W != 16) return hipErrorInvalidValue;
-    static int per_channel = -1;
-    if (per_channel < 0) { const char *e = getenv("GDG_FWD_PER_CHANNEL"); per_channel = e ? atoi(e) : 1; }
+    const int per_channel = gdg_knob_get(GDG_KNOB_FWD_PER_CHANNEL);
     const int half = fft_half_lds();
     if (what == 0 && (half & 1)) {
         fir_fwd13wh_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2, ((half & 32) && n_chans % 8 == 0) ? 1 : 0);
@@ -1572,8 +1585,7 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
 /* 1 when a window's inverse transforms of one power amp can produce the forward transforms of the next (one workgroup per channel
  * walking the frames: needs a chip's worth of channels, like the per-channel forward kernel) */
 int gdg_fir_window_chain_ok(int n_chans, int W) {
-    static int per_channel = -1;
-    if (per_channel < 0) { const char *e = getenv("GDG_FWD_PER_CHANNEL"); per_channel = e ? atoi(e) : 1; }
+    const int per_channel = gdg_knob_get(GDG_KNOB_FWD_PER_CHANNEL);
     if ((fft_half_lds() & 8) && W >= 4) return 0;       /* two frames: the chained kernel still wins (513 against 518 us per frame) */
     return per_channel && n_chans >= cu_count();
 }
@@ -1589,8 +1601,7 @@ hipError_t gdg_launch_fir_window_chain(int W, const gdg_fir_chan *d_chans, const
 
 hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, gdg_shift shift, hipStream_t s) {
     if (n_chans <= 0) return hipSuccess;
-    static int wave_fft = -1;
-    if (wave_fft < 0) { const char *e = getenv("GDG_WAVE_FFT"); wave_fft = e ? atoi(e) : 1; }
+    const int wave_fft = gdg_knob_get(GDG_KNOB_WAVE_FFT);
     if (P == 8192 && hop == P && (fft_half_lds() & 4)) {
         fir_fwd13wh_kernel<0><<<dim3(n_chans), dim3(512), 0, s>>>(d_chans, 1, shift, d_tw, d_tw2, 0);
         return hipGetLastError();
@@ -1641,8 +1652,7 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, i
     /* IR spectra shared between channels are worth caching; private ones are read once: non-temporal like the delay line */
     if (shared_spectra) { launch_mac<8, 1, true, false, false>(P, d_chans, n_chans, s); return hipGetLastError(); }
     /* GDG_MAC_VARIANT: tuning knob for profiles/mac_variants.py; the default is the measured best */
-    static int variant = -1;
-    if (variant < 0) { const char *e = getenv("GDG_MAC_VARIANT"); variant = e ? atoi(e) : 0; }
+    const int variant = gdg_knob_get(GDG_KNOB_MAC_VARIANT);
     switch (variant) {
     case 1: launch_mac<8, 1, false>(P, d_chans, n_chans, s); break;
     case 2: launch_mac<4, 1, true>(P, d_chans, n_chans, s); break;

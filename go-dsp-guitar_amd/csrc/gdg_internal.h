@@ -62,6 +62,11 @@ struct gdg_fir_rawjob {
     int hop, pad;
 };
 
+/* process-wide launch-shape knobs of fir.hip / the tuner (their launchers have no context); set through gdg_ctx_set_option */
+enum { GDG_KNOB_FFT_HALF_LDS = 0, GDG_KNOB_FWD_PER_CHANNEL, GDG_KNOB_WAVE_FFT, GDG_KNOB_MAC_VARIANT, GDG_KNOB_TUNER_PARTS, GDG_KNOB_COUNT };
+int gdg_knob_get(int which);
+void gdg_knob_set(int which, int value);
+
 /* launchers implemented in fir.hip; all return hipError_t */
 hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
 hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, gdg_shift shift, hipStream_t s);
@@ -151,7 +156,7 @@ struct gdg_seg_chan {
     int flags;                /* GDG_SRC_IS_INPUT / GDG_DST_IS_OUTPUT */
     int wave_mask;            /* WAVE: bit u (u < 31) = unit u of the segment carries state from frame to frame (it meets its predecessor frame);
                                * bit 31 = some unit of the segment stores that state with plain stores: hand-offs write the XCD's L2 back */
-    int *wave;                /* [unit_count] frame counters of the units of this channel's segment (seg.hip, WAVE); zero between launches */
+    int *wave;                /* [2 x unit_count] frame counters of the units of this channel's segment (seg.hip, WAVE); zero between launches */
 };
 
 /* oversampling tables shared by all channels (device memory) */

@@ -358,6 +358,39 @@ __device__ __forceinline__ void st_v2d(GDG_GLOBAL seg_v2d *p, seg_v2d v, bool wt
     else *p = v;
 }
 
+/* ---- frames of one channel in flight on SEVERAL workgroups (WAVE) ---------------------------------------------------------------
+ * A window of W frames of a channel is W x U cells (frame f, unit u); cell (f, u) needs the frame from (f, u - 1) -- LDS of the same
+ * workgroup -- and unit u's state from (f - 1, u) -- HBM.  The walk (one workgroup per channel, frame after frame) runs the cells one
+ * at a time on one CU: fine when the channels fill the chip, 3/4 of it idle with 64 channels (a GPU's share of the 512-channel job on
+ * eight).  Here workgroup f takes frame f and meets its predecessor once per unit: before unit u touches its state it waits until the
+ * unit's cell of the channel (wave[u], HBM) says "frame f", after the unit it posts f + 1 (the window's last frame posts 0 for the
+ * next launch).  A unit still sees its frames strictly in order -- state, rings and per-call quirks exactly as in the walk, the same
+ * bits -- but unit u of frame f runs beside unit u + 1 of frame f - 1 on another CU: a window takes (sum of the units) + (W - 1) x
+ * (slowest unit) instead of W x (sum).  Release / acquire at agent scope (the workgroups of a channel may sit on different XCDs, each
+ * with an L2 of its own): every wave writes back before the barrier, one lane posts; one lane polls, every wave invalidates after the
+ * barrier.  Workgroups take their frame by TICKET (seg_kernel), so a workgroup never waits for one that has not started. */
+__device__ __forceinline__ void wave_wait(int *cell, int want) {
+    if (seg_tid() == 0) {
+        while (__hip_atomic_load(as_global(cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          /* ONE buffer_inv sc1 per workgroup: this CU's L1 (MI355X_MICROARCH.md, visibility) */
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void wave_post(int *cell, int value, bool release) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                /* every storing wave drains */
+    __syncthreads();
+    if (seg_tid() == 0) {
+        /* units whose stores for the next frame are write-through (UNIT_ARGS, wt) need no write-back; a segment with any other unit pays
+         * ONE buffer_wbl2 sc1 -- this XCD's dirty lines, 2-8 us -- per unit and frame (`release`, bit 31 of the channel's wave_mask) */
+        if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the compiler may drop the wait behind the write-back (guide, pitfall 12) */
+        __hip_atomic_store(as_global(cell), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+/* what a unit that meets its predecessor frame TWICE needs (the reverb: delay line, then all-pass rings): its second counter */
+struct WaveGate { int *cell; int wf, wf_next; bool release; };
+
 __device__ __forceinline__ double ring_read(const double *ring, int C, int wp, int idx) {
     int p = wp + idx;
     if (p < 0) p += C;
@@ -1509,7 +1542,11 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     }
 }
 #else
-UNIT_FN unit_reverb(UNIT_ARGS) {
+/* wt (a frame per workgroup): the unit meets its predecessor frame twice.  Delay line: entered when the caller's wait on the unit's first
+ * counter returns; the frame is appended FIRST (the ring is a frame longer than the longest tap: the cells it overwrites are the predecessor's
+ * oldest tap window, consumed by then, and no tap of this frame reads them), the taps are loaded, gate.cell - 1 is posted -- the next frame may
+ * append.  All-pass rings: wait on gate.cell, fetch, run, mix; the caller posts gate.cell.  So frame f + 1 taps while frame f runs its all-passes. */
+UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
     const int tid = seg_tid();
@@ -1527,15 +1564,19 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     {
         double *r = dl_ring + DL;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { M[k] = Uc->jp[5 + k] - 1; rp[k] = as_global(is_state)[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
+        for (int k = 0; k < 3; k++) { M[k] = Uc->jp[5 + k] - 1; rp[k] = wt ? 0 : as_global(is_state)[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
     }
     /* ring heads of the three all-passes first (in-order return: they are home before the tap loads below are consumed) */
     const bool fast = min(M[1], N) <= 3 * SEG_T && min(M[2], N) <= SEG_T;
     double pm_a[REVERB_QMAX], pm_b[3], pm_c[1];
-    if (M[0] >= 1) allpass_fetch<REVERB_QMAX>(ring[0], M[0], rp[0], N, pm_a);
-    if (fast) {
-        if (M[1] >= 1) allpass_fetch<3>(ring[1], M[1], rp[1], N, pm_b);
-        if (M[2] >= 1) allpass_fetch<1>(ring[2], M[2], rp[2], N, pm_c);
+    if (!wt) {
+        if (M[0] >= 1) allpass_fetch<REVERB_QMAX>(ring[0], M[0], rp[0], N, pm_a);
+        if (fast) {
+            if (M[1] >= 1) allpass_fetch<3>(ring[1], M[1], rp[1], N, pm_b);
+            if (M[2] >= 1) allpass_fetch<1>(ring[2], M[2], rp[2], N, pm_c);
+        }
+    } else {
+        ring_append(dl_ring, DL, &is_state[0], in, N, true);       /* dl_wp above is the write position BEFORE the frame: the taps below count from it */
     }
     double dlr[REVERB_QMAX];
     /* tapped delay line over the input history (reverb.go:65-116) */
@@ -1602,6 +1643,19 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
      * needed here anyway), then the barrier */
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    if (wt) {
+        wave_post(gate.cell - 1, gate.wf_next, gate.release);       /* the delay line is free for the next frame */
+        wave_wait(gate.cell, gate.wf);                              /* the all-pass rings are ours */
+#pragma unroll
+        for (int k = 0; k < 3; k++) rp[k] = as_global(is_state)[1 + k];
+        if (M[0] >= 1) allpass_fetch<REVERB_QMAX>(ring[0], M[0], rp[0], N, pm_a);
+        if (fast) {
+            if (M[1] >= 1) allpass_fetch<3>(ring[1], M[1], rp[1], N, pm_b);
+            if (M[2] >= 1) allpass_fetch<1>(ring[2], M[2], rp[2], N, pm_c);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();                                            /* every old ring value is in a register before anyone overwrites the rings */
+    }
     if (M[0] >= 1) allpass_chains<REVERB_QMAX>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1], wt);
     if (fast) {
         if (M[1] >= 1) allpass_chains<3>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2], wt);
@@ -1619,7 +1673,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         }
     }
     __syncthreads();
-    ring_append(dl_ring, DL, &is_state[0], in, N, wt);
+    if (!wt) ring_append(dl_ring, DL, &is_state[0], in, N);
 }
 #endif
 
@@ -2384,36 +2438,6 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
 #endif
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */
-/* ---- frames of one channel in flight on SEVERAL workgroups (WAVE) ---------------------------------------------------------------
- * A window of W frames of a channel is W x U cells (frame f, unit u); cell (f, u) needs the frame from (f, u - 1) -- LDS of the same
- * workgroup -- and unit u's state from (f - 1, u) -- HBM.  The walk (one workgroup per channel, frame after frame) runs the cells one
- * at a time on one CU: fine when the channels fill the chip, 3/4 of it idle with 64 channels (a GPU's share of the 512-channel job on
- * eight).  Here workgroup f takes frame f and meets its predecessor once per unit: before unit u touches its state it waits until the
- * unit's cell of the channel (wave[u], HBM) says "frame f", after the unit it posts f + 1 (the window's last frame posts 0 for the
- * next launch).  A unit still sees its frames strictly in order -- state, rings and per-call quirks exactly as in the walk, the same
- * bits -- but unit u of frame f runs beside unit u + 1 of frame f - 1 on another CU: a window takes (sum of the units) + (W - 1) x
- * (slowest unit) instead of W x (sum).  Release / acquire at agent scope (the workgroups of a channel may sit on different XCDs, each
- * with an L2 of its own): every wave writes back before the barrier, one lane posts; one lane polls, every wave invalidates after the
- * barrier.  Workgroups take their frame by TICKET (seg_kernel), so a workgroup never waits for one that has not started. */
-__device__ __forceinline__ void wave_wait(int *cell, int want) {
-    if (seg_tid() == 0) {
-        while (__hip_atomic_load(as_global(cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          /* ONE buffer_inv sc1 per workgroup: this CU's L1 (MI355X_MICROARCH.md, visibility) */
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void wave_post(int *cell, int value, bool release) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                /* every storing wave drains */
-    __syncthreads();
-    if (seg_tid() == 0) {
-        /* units whose stores for the next frame are write-through (UNIT_ARGS, wt) need no write-back; a segment with any other unit pays
-         * ONE buffer_wbl2 sc1 -- this XCD's dirty lines, 2-8 us -- per unit and frame (`release`, bit 31 of the channel's wave_mask) */
-        if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the compiler may drop the wait behind the write-back (guide, pitfall 12) */
-        __hip_atomic_store(as_global(cell), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 /* one frame of one channel: HBM -> LDS, the segment's units, LDS -> HBM */
 template <bool WAVE>
 __device__ __forceinline__ void seg_frame(const double *src, double *dst, const gdg_seg_unit *units, int unit_begin, int unit_count, int N,
@@ -2453,7 +2477,8 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         int inplace = 0;
         /* a unit that keeps nothing from frame to frame (a shaper without oversampling) meets nobody */
         const bool gated = WAVE && (u >= 31 || ((wave_mask >> u) & 1u));
-        if (gated) wave_wait(wave + u, wf);
+        if (gated) wave_wait(wave + 2 * u, wf);
+        int second = 0;                              /* 1: the unit posted its first counter itself and waits on the second (general reverb) */
         switch (type) {
         case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N, WAVE); break;
         case GDG_UNIT_OVERDRIVE:
@@ -2469,7 +2494,16 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N, WAVE); break;
         case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N, WAVE); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N, WAVE); break;
+#ifdef SEG_FAST
         case GDG_UNIT_REVERB: unit_reverb(U, flip, N, WAVE); break;
+#else
+        case GDG_UNIT_REVERB: {
+            const WaveGate gate = { wave + 2 * u + 1, wf, wf_next, (wave_mask >> 31) != 0 };
+            unit_reverb(U, flip, N, WAVE, gate);
+            second = WAVE ? 1 : 0;
+            break;
+        }
+#endif
 #ifndef SEG_FAST                                    /* units that read other threads' cells of their input after writing output, or stage a frame: two buffers */
         case GDG_UNIT_FLANGER:
         case GDG_UNIT_PHASER: unit_flanger(U, flip, N, WAVE); break;
@@ -2489,7 +2523,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
             break;
         }
-        if (gated) wave_post(wave + u, wf_next, (wave_mask >> 31) != 0);
+        if (gated) wave_post(wave + 2 * u + second, wf_next, (wave_mask >> 31) != 0);
         else __syncthreads();
         if (!__builtin_amdgcn_readfirstlane(inplace)) flip ^= 1;
     }

@@ -469,8 +469,7 @@ int gdg_tuner_short_ok(double sample_rate, double lowest_note_frequency) {
 /* workgroups per channel of the short-lag analysis: one from a chip's worth of channels on, else enough runs of blocks to put a workgroup
  * on every CU (at most 8: three blocks + the repeated predecessor each) */
 int gdg_tuner_short_parts(int nch) {
-    const char *e = getenv("GDG_TUNER_PARTS");                    /* read per call: a test walks through the part counts */
-    const int forced = e ? atoi(e) : 0;
+    const int forced = gdg_knob_get(GDG_KNOB_TUNER_PARTS);        /* 0: by channel count (gdg_ctx_set_option "tuner_parts") */
     int parts = forced > 0 ? forced : (nch >= cu_count() ? 1 : (cu_count() + nch - 1) / nch);
     if (parts > 8) parts = 8;
     return parts < 1 ? 1 : parts;

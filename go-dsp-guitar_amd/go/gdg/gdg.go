@@ -166,6 +166,9 @@ func (this *Context) Row(channel int, frames int) (in []float64, out []float64, 
 
 // ProcessStaged runs the chains of the listed channels on the frames deposited in the staging rows.
 func (this *Context) ProcessStaged(channels []int, frames int, sampleRate uint32) error {
+	if len(channels) == 0 {
+		return nil // nothing to run; &cs[0] of an empty slice would panic
+	}
 	cs := make([]C.int, len(channels))
 	for i, c := range channels {
 		cs[i] = C.int(c)
@@ -471,6 +474,24 @@ func (this *Context) SetWindow(frames int) error {
 // context's stream, the default; > 1: groups on streams of their own, joined by the next call of any other kind).
 func (this *Context) SetOverlap(groups int) error {
 	return this.err(C.gdg_ctx_set_overlap(this.ctx, C.int(groups)))
+}
+
+// SetOption / Option: the library's launch-shape options (gdg_ctx_set_option in include/gdg.h lists the keys) -- what used to be
+// environment variables of the process.  The drop-in needs none of them; they are here for deployments that tune a node
+// ("numa", "copy_threads", "seg_wave_max_channels", ...).
+func (this *Context) SetOption(key string, value int64) error {
+	k := C.CString(key)
+	defer C.free(unsafe.Pointer(k))
+	return this.err(C.gdg_ctx_set_option(this.ctx, k, C.longlong(value)))
+}
+func (this *Context) Option(key string) (int64, error) {
+	k := C.CString(key)
+	defer C.free(unsafe.Pointer(k))
+	var v C.longlong
+	if e := this.err(C.gdg_ctx_get_option(this.ctx, k, &v)); e != nil {
+		return 0, e
+	}
+	return int64(v), nil
 }
 
 // BatchInput: one input file of the batch run -- the data section of a RIFF/WAVE file (wave.go:840-1100 parses the header and

@@ -79,6 +79,45 @@ int gdg_ctx_channels(const gdg_ctx *ctx);
  * bit-identical either way.
  */
 int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
+/*
+ * Launch-shape options of a context -- everything that used to be an environment variable of the process that loads the library.  The
+ * variables still exist as DEBUG overrides of the defaults, read once when the context is made; a value set here wins.  Results never depend
+ * on an option beyond the last bits (which association a sum takes); unknown keys and values out of range are GDG_ERR_INVALID.
+ *   key                          values      meaning (default)
+ *   fir_fused                    -1, 0, 1    spectrum multiply-accumulate inside the inverse transform's kernel: by channel count / never / always (-1)
+ *   fir_split_max_channels       >= 0        with fir_fused = -1: launches of up to this many channels take the bin-tiled multiply-accumulate (96)
+ *   fir_chain_adjacent_amps      0, 1        a power amp's inverse transform also makes the forward transform of the amp behind it (1)
+ *   share_ir_spectra             0, 1        = gdg_ctx_share_ir_spectra (1)
+ *   seg_two_per_cu               0, 1        segments of in-place units on 8192-sample frames take the 512-thread kernel, two workgroups per CU (1)
+ *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (257)
+ *   seg_wave_max_channels        >= 0        windows (gdg_ctx_set_window) of up to this many channels per call: one workgroup per FRAME and channel, the
+ *                                            frames of a channel meeting unit by unit -- fills the chip when the channels alone do not (192; 0: never)
+ *   plan_patch                   0, 1        parameter changes patch the device descriptors in place instead of rebuilding the plan (1)
+ *   scan_tables_max              >= 1        scan tables (one per distinct coefficient set) kept before a plan rebuild drops them all (1024)
+ *   pcie_groups                  0 .. 16     channel groups of the host-buffer calls, 0 = by channel count (0)
+ *   device_groups_default        0 .. 16     what gdg_ctx_set_overlap(ctx, 0) means, 0 = one group (0)
+ *   copy_threads                 1 .. 256    host copy workers of the host-buffer paths and the batch run (8)
+ *   numa                         0, 1        copy workers on the CPUs, pinned slabs from the memory, of the device's NUMA node (1; before the first host-buffer call)
+ *   tuner_long_transform         0, 1        every tuner analysis through the reference's 262144-point transform pair (0)
+ *   profile_attach               0, 1        the fused convolution launch records its own begin / end events (1)
+ * Process-wide (the transforms' and the tuner's launchers have no context; set them before the first call that uses them):
+ *   fft_half_lds_mask            0 .. 63     which 8192-point transforms run through ONE LDS buffer, two workgroups per CU (14)
+ *   fir_forward_per_channel      0, 1        a window's forward transforms as one workgroup per channel from a chip's worth of channels on (1)
+ *   fir_forward_wave_local       0 .. 3      8 x 1024 forward transform with wave-local sub-transforms (1)
+ *   fir_mac_variant              0 .. 15     tile shape of the stand-alone multiply-accumulate (0)
+ *   tuner_parts                  0 .. 24     workgroups per channel of the short-lag analysis, 0 = by channel count (0)
+ * gdg_option_count / gdg_option_name enumerate the keys.
+ */
+int gdg_ctx_set_option(gdg_ctx *ctx, const char *key, long long value);
+int gdg_ctx_get_option(gdg_ctx *ctx, const char *key, long long *value);
+int gdg_option_count(void);
+const char *gdg_option_name(int index);
+/*
+ * Where a PCI device hangs, from sysfs (what option "numa" uses): *node = <sysfs_root>/bus/pci/devices/<pci_bus_id>/numa_node (-1 when the
+ * platform does not say), cpus[0 .. min(capacity, *n_cpus)) = the CPUs of <sysfs_root>/devices/system/node/node<N>/cpulist.  sysfs_root is
+ * "/sys" outside tests.  No device needed.
+ */
+int gdg_numa_probe(const char *sysfs_root, const char *pci_bus_id, int *node, int *cpus, int capacity, int *n_cpus);
 /* The hipStream_t all of this context's work is enqueued on (as void*), for event timing. */
 void *gdg_ctx_stream(const gdg_ctx *ctx);
 /* Block until everything enqueued so far has finished. */

@@ -22,16 +22,59 @@ UNIT = {name: i for i, name in enumerate(UNIT_NAMES)}
 SCALING_DEFAULT, SCALING_ORTHONORMAL, MODE_STANDARD, MODE_INPLACE = 0, 1, 2, 3
 
 
-def build(force=False):
-    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+_JITTER_PATH = os.path.join(_HERE, "libgdg_oracle_jitter.so")
+
+
+def build(force=False, jitter=False):
+    """Compile the oracle with gcc (recipe: oracle/Makefile).  jitter: the second build whose transcendental functions are perturbed by a
+    seeded +-2 ulp (libm_jitter.h) -- what another libm (Go's math, ocml) may return for the same argument."""
+    path, target = (_JITTER_PATH, "libgdg_oracle_jitter.so") if jitter else (_LIB_PATH, "libgdg_oracle.so")
     srcs = [f for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
     newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in srcs)
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libgdg_oracle.so"])
-    return _LIB_PATH
+    if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
+        subprocess.check_call(["make", "-s", "-C", _HERE, target])
+    return path
 
 
 _lib = None
+_plain_lib = None
+_jitter_lib = None
+
+
+class jittered:
+    """with oracle.jittered(seed): every oracle object made AND used inside runs on the build whose exp / sin / cos / atan / pow / log10 / log2
+    results are moved by a seeded -2 .. +2 ulp.  Objects must not cross the boundary (they are destroyed by the library that made them)."""
+
+    def __init__(self, seed=1):
+        self.seed = seed
+
+    def __enter__(self):
+        global _lib, _plain_lib, _jitter_lib
+        lib()
+        _plain_lib = _lib
+        if _jitter_lib is None:
+            build(jitter=True)
+            L = C.CDLL(_JITTER_PATH)
+            _declare(L)
+            L.gdgo_jitter_seed.restype = None
+            L.gdgo_jitter_seed.argtypes = [C.c_uint64]
+            L.gdgo_jitter_calls.restype = C.c_uint64
+            L.gdgo_jitter_calls.argtypes = []
+            _jitter_lib = L
+        _jitter_lib.gdgo_jitter_seed(self.seed)
+        _lib = _jitter_lib
+        return self
+
+    def calls(self):
+        return int(_jitter_lib.gdgo_jitter_calls())
+
+    def __exit__(self, *exc):
+        global _lib
+        import gc
+        gc.collect()                       # objects of this block die under the library that made them
+        _lib = _plain_lib
+        return False
+
 _dp = C.POINTER(C.c_double)
 
 
@@ -44,6 +87,13 @@ def lib():
     if _lib is None:
         build()
         L = C.CDLL(_LIB_PATH)
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def _declare(L):
+    if True:
         vp = C.c_void_p
         sig = {
             "gdgo_fft_create": (vp, []),
@@ -118,8 +168,6 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
 
 
 def _f64(a):

@@ -6,6 +6,7 @@
 #include "gdg_oracle.h"
 #include "go_consts.h"
 #include <math.h>
+#include "libm_jitter.h"
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>

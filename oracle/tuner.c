@@ -9,6 +9,7 @@
 #include "gdg_oracle.h"
 #include "notes.inc"
 #include <math.h>
+#include "libm_jitter.h"
 #include <stdlib.h>
 #include <string.h>
 

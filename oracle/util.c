@@ -5,6 +5,7 @@
  */
 #include "gdg_oracle.h"
 #include <math.h>
+#include "libm_jitter.h"
 #include <stdlib.h>
 #include <string.h>
 

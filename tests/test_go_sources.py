@@ -376,3 +376,250 @@ def test_tuner_overlay_keeps_the_reference_s_two_locks():
     assert "ctx" not in proc and "gdg." not in proc and "mutexAnalyze" not in proc
     ana = re.search(r"func \(this \*tunerStruct\) Analyze\(.*?^\}", code, flags=re.S | re.M).group(0)
     assert ana.index("mutexAnalyze.Lock()") < ana.index("mutexBuffer.RLock()") < ana.index("Retrieve(") < ana.index("mutexBuffer.RUnlock()") < ana.index("TunerEnqueueStaged(") < ana.index("TunerAnalyze(")
+
+
+# ---- cgo argument TYPES: what the cgo type checker refuses second ---------------------------------------------------------------
+
+def _c_type_to_cgo(ctype):
+    """A parameter type of include/gdg.h as cgo spells it in Go ("const double *const *" -> "**C.double")."""
+    t = re.sub(r"\bconst\b", " ", ctype)
+    t = re.sub(r"\b(restrict|__restrict__)\b", " ", t)
+    stars = t.count("*")
+    base = " ".join(t.replace("*", " ").split())
+    names = {"int": "C.int", "unsigned": "C.uint", "unsigned int": "C.uint", "double": "C.double", "char": "C.char", "long long": "C.longlong",
+             "size_t": "C.size_t", "uint32_t": "C.uint32_t", "int32_t": "C.int32_t", "uint8_t": "C.uint8_t", "int8_t": "C.int8_t", "uint64_t": "C.uint64_t"}
+    if base == "void":
+        assert stars >= 1, ctype
+        return "*" * (stars - 1) + "unsafe.Pointer"
+    if base in names:
+        return "*" * stars + names[base]
+    assert re.fullmatch(r"gdg_[a-z0-9_]+", base), "unknown C type %r" % ctype
+    return "*" * stars + "C." + base
+
+
+def _header_prototypes():
+    """name -> (return type as cgo, [parameter types as cgo]); struct name -> {field: cgo type}"""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gdg.h")).read(), flags=re.S)
+    protos, structs = {}, {}
+    for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(gdg_[a-z0-9_]+)\s*;", header, flags=re.S):
+        fields = {}
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *more = [d.strip() for d in decl.split(",")]
+            mm = re.match(r"(.*?)(\**)\s*([A-Za-z_][A-Za-z0-9_]*)$", first)
+            base = mm.group(1).strip()
+            fields[mm.group(3)] = _c_type_to_cgo(base + mm.group(2))
+            for extra in more:
+                mm2 = re.match(r"(\**)\s*([A-Za-z_][A-Za-z0-9_]*)$", extra)
+                fields[mm2.group(2)] = _c_type_to_cgo(base + mm2.group(1))
+        structs[m.group(2)] = fields
+    body = re.sub(r"typedef\s+struct\s*\{.*?\}\s*gdg_[a-z0-9_]+\s*;", "", header, flags=re.S)
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(gdg_[a-z0-9_]+)\s*\(", body):
+        ret = m.group(1).strip()
+        if not ret or ret.startswith("#") or "return" in ret or "typedef" in ret:
+            continue
+        args = _call_args(body, m.end() - 1).strip()
+        params = []
+        if args not in ("", "void"):
+            for a in _split_top_level(args):
+                a = re.sub(r"\s*=\s*[^,]+$", "", a.strip())
+                mm = re.match(r"(.*?)([A-Za-z_][A-Za-z0-9_]*)?$", a)
+                typ = mm.group(1).strip() if (mm.group(2) and mm.group(1).strip()) else a
+                params.append(_c_type_to_cgo(typ))
+        protos[m.group(2)] = (None if ret == "void" else _c_type_to_cgo(ret), params)
+    return protos, structs
+
+
+def _go_functions(src):
+    """(name, body text, parameter text) of every function of a stripped Go source"""
+    out = []
+    for m in re.finditer(r"^func\s*(\([^)]*\))?\s*([A-Za-z_][A-Za-z0-9_]*)\s*\(", src, flags=re.M):
+        params = _call_args(src, m.end() - 1)
+        brace = src.index("{", m.end() - 1 + len(params) + 1)
+        depth = 0
+        for i in range(brace, len(src)):
+            if src[i] == "{":
+                depth += 1
+            elif src[i] == "}":
+                depth -= 1
+                if depth == 0:
+                    out.append((m.group(2), src[brace:i + 1], params, brace))
+                    break
+    return out
+
+
+_CAST = r"(?:C\.[A-Za-z0-9_]+|unsafe\.Pointer)"
+
+
+def _type_of_expr(expr, body, upto, structs, ctx_fields):
+    """cgo type of an argument expression, or None for an untyped constant / nil (fits any numeric / any pointer)."""
+    e = expr.strip()
+    if e == "nil":
+        return "nil"
+    if re.fullmatch(r"-?\d+", e):
+        return "const"
+    m = re.match(r"\((\*+)(%s)\)\s*\(" % _CAST, e)
+    if m:
+        return m.group(1) + m.group(2)
+    m = re.match(r"(%s)\s*\(" % _CAST, e)
+    if m:
+        return m.group(1)
+    m = re.match(r"([a-z][A-Za-z0-9_]*)\s*\(", e)                       # a Go helper of the file (cbool): its single result
+    if m and m.group(1) in _GO_RESULTS and len(_GO_RESULTS[m.group(1)]) == 1:
+        return _GO_RESULTS[m.group(1)][0]
+    if re.fullmatch(r"(this|c)\.ctx", e):
+        return "*C.gdg_ctx"
+    if re.fullmatch(r"&(this|c)\.ctx", e):
+        return "**C.gdg_ctx"
+    m = re.fullmatch(r"(this|c)\.([a-z_]+)", e)
+    if m and m.group(2) in ctx_fields:
+        return ctx_fields[m.group(2)]
+    amp = e.startswith("&")
+    core = e[1:] if amp else e
+    m = re.fullmatch(r"([A-Za-z_][A-Za-z0-9_]*)(\[[^\]]*\])?(?:\.([a-z_]+))?", core)
+    if not m:
+        return "?" + e
+    name, index, field = m.group(1), m.group(2), m.group(3)
+    t = _declared_type(name, body[:upto])
+    if t is None:
+        return "?" + e
+    if index:
+        if not t.startswith("[]"):
+            return "?" + e
+        t = t[2:]
+    if field:
+        sname = t.replace("C.", "")
+        if sname not in structs or field not in structs[sname]:
+            return "?" + e
+        t = structs[sname][field]
+    return ("*" + t) if amp else t
+
+
+_GO_RESULTS = {}
+
+
+def _go_results(src):
+    """Go function name -> list of result types (from `func name(...) (T1, T2)` / `func name(...) T`)"""
+    out = {}
+    for m in re.finditer(r"^func\s*(?:\([^)]*\))?\s*([A-Za-z_][A-Za-z0-9_]*)\s*\(", src, flags=re.M):
+        params = _call_args(src, m.end() - 1)
+        rest = src[m.end() + len(params) + 1:]
+        rest = rest[:rest.index("{")].strip()
+
+        def norm(r):
+            r = r.strip()
+            mm = re.match(r"[A-Za-z_][A-Za-z0-9_]*\s+(.*)$", r)            # a named result: drop the name
+            if mm and not r.startswith("func"):
+                r = mm.group(1).strip()
+            return re.sub(r"^\*\[[^\]]*\]", "[]", r)                      # pointer to an array: indexes like a slice
+        if rest.startswith("("):
+            out[m.group(1)] = [norm(r) for r in _split_top_level(rest[1:rest.rindex(")")])]
+        elif rest:
+            out[m.group(1)] = [norm(rest)]
+    return out
+
+
+def _declared_type(name, before):
+    """type of the local `name` from its LAST declaration in the text before its use"""
+    best, pos = None, -1
+    for mm in re.finditer(r"((?:[A-Za-z_][A-Za-z0-9_]*\s*,\s*)*[A-Za-z_][A-Za-z0-9_]*)\s*:=\s*([a-z][A-Za-z0-9_]*)\s*\(", before):
+        lhs = [x.strip() for x in mm.group(1).split(",")]
+        if name in lhs and mm.group(2) in _GO_RESULTS and len(_GO_RESULTS[mm.group(2)]) == len(lhs):
+            t = _GO_RESULTS[mm.group(2)][lhs.index(name)]
+            if re.fullmatch(r"\**(?:\[\])?\**%s" % _CAST, t) and mm.start() > pos:
+                best, pos = t, mm.start()
+    m = None
+    for m in re.finditer(r"\b%s\s*:=\s*C\.CString\s*\(" % re.escape(name), before):
+        pass
+    if m:
+        best, pos = "*C.char", m.start()                # C.CString returns *C.char
+    for mm in re.finditer(r"((?:[A-Za-z_][A-Za-z0-9_]*\s*,\s*)+[A-Za-z_][A-Za-z0-9_]*)\s*:=\s*([^\n]+)", before):     # a, b := X, Y
+        lhs = [x.strip() for x in mm.group(1).split(",")]
+        rhs = _split_top_level(mm.group(2))
+        if name in lhs and len(rhs) == len(lhs) and mm.start() > pos:
+            r = rhs[lhs.index(name)].strip()
+            if re.match(r"C\.(malloc|calloc|CBytes)\s*\(", r):
+                best, pos = "unsafe.Pointer", mm.start()
+    for mm in re.finditer(r"\b%s\s*:=\s*C\.(malloc|calloc|CBytes)\s*\(" % re.escape(name), before):
+        if mm.start() > pos:
+            best, pos = "unsafe.Pointer", mm.start()
+    pats = [
+        (r"\bvar\s+(?:[A-Za-z_][A-Za-z0-9_]*\s*,\s*)*%s\b(?:\s*,\s*[A-Za-z_][A-Za-z0-9_]*)*\s+(\**(?:\[\])?\**%s)" % (re.escape(name), _CAST), lambda m: m.group(1)),
+        (r"\b%s\s*:=\s*make\(\s*(\[\]\**%s)" % (re.escape(name), _CAST), lambda m: m.group(1)),
+        (r"\b%s\s*:=\s*(%s)\s*\{" % (re.escape(name), _CAST), lambda m: m.group(1)),
+        (r"\b%s\s*:=\s*(C\.(?!gdg_|CString\b)[A-Za-z0-9_]+|unsafe\.Pointer)\s*\(" % re.escape(name), lambda m: m.group(1)),
+        (r"\b%s\s*:=\s*\((\*+%s)\)\s*\(" % (re.escape(name), _CAST), lambda m: m.group(1)),
+        (r"\b%s\s*:=\s*\(\*\[[^\]]*\](\**%s)\)\s*\(" % (re.escape(name), _CAST), lambda m: "[]" + m.group(1)),      # pointer to an array: indexes like a slice
+        (r"\b%s\s*:=\s*&([A-Za-z_][A-Za-z0-9_]*)\b" % re.escape(name), None),
+        (r"\b%s\s*:=\s*(C\.gdg_[a-z0-9_]+)\s*\(" % re.escape(name), "call"),
+    ]
+    for pat, fn in pats:
+        for m in re.finditer(pat, before):
+            if m.start() > pos:
+                if fn is None:
+                    inner = _declared_type(m.group(1), before[:m.start()])
+                    if inner is None:
+                        continue
+                    best, pos = "*" + inner, m.start()
+                elif fn == "call":
+                    best, pos = ("ret:" + m.group(1)[2:]), m.start()
+                else:
+                    best, pos = fn(m), m.start()
+    return best
+
+
+def test_every_c_call_of_the_binding_passes_the_prototype_s_types():
+    """cgo maps every C type to ONE Go type and converts nothing implicitly: C.int where the header says size_t, *C.int where it says
+    const int32_t *, a Go int where it says int -- each is a compile error.  So: the cgo type of every argument of every C.gdg_* call, inferred
+    from its conversion (C.int(x), (*C.double)(p), unsafe.Pointer(p)), from `nil` / an untyped constant, or from the declaration of the local it
+    names (var x C.int, make([]C.gdg_batch_input, n), &arr[0], o.out_format ...), against the prototype; and every result against its use
+    (this.err takes C.int, C.GoString takes *C.char).  An argument the test cannot type is a failure, not a pass."""
+    protos, structs = _header_prototypes()
+    raw = open(os.path.join(GO, "gdg", "gdg.go")).read()
+    src = _strip(raw)
+    _GO_RESULTS.clear()
+    _GO_RESULTS.update(_go_results(src))
+    # fields of the Go struct `Context` that hold C values
+    ctx_fields = {}
+    m = re.search(r"type Context struct \{(.*?)\n\}", src, flags=re.S)
+    for line in m.group(1).splitlines():
+        mm = re.match(r"\s*([a-z_, ]+?)\s+(\**(?:%s|unsafe\.Pointer))\s*$" % _CAST, line)
+        if mm:
+            for nm in mm.group(1).split(","):
+                ctx_fields[nm.strip()] = mm.group(2)
+    # the helper every status goes through
+    m = re.search(r"func \(this \*Context\) err\(rc (C\.[a-z0-9_]+)\)", src)
+    assert m and m.group(1) == "C.int", "Context.err must take C.int: every gdg_* status is an int"
+    checked = 0
+    for fname, body, params, _ in _go_functions(src):
+        for m in re.finditer(r"\bC\.(gdg_[a-z0-9_]+)\s*\(", body):
+            name = m.group(1)
+            if name not in protos:
+                continue                                   # C.gdg_batch_input{...} / a conversion
+            ret, want = protos[name]
+            args = _split_top_level(_call_args(body, m.end() - 1))
+            assert len(args) == len(want), (fname, name)
+            for k, (a, w) in enumerate(zip(args, want)):
+                got = _type_of_expr(a, body, m.start(), structs, ctx_fields)
+                where = "%s: argument %d of %s (%s)" % (fname, k + 1, name, a.strip())
+                assert not got.startswith("?"), "cannot type " + where
+                if got.startswith("ret:"):
+                    got = protos[got[4:]][0]
+                if got == "nil":
+                    assert w.startswith("*") or w == "unsafe.Pointer", where + ": nil for " + w
+                elif got == "const":
+                    assert not w.startswith("*") and w != "unsafe.Pointer", where + ": a constant for " + w
+                else:
+                    assert got == w, where + ": %s, the header wants %s" % (got, w)
+                checked += 1
+            # the result's use
+            pre = body[max(0, m.start() - 40):m.start()]
+            if re.search(r"\.err\(\s*$", pre):
+                assert ret == "C.int", (fname, name, ret)
+            if re.search(r"C\.GoString\(\s*$", pre):
+                assert ret == "*C.char", (fname, name, ret)
+            if re.search(r"\bint\(\s*$", pre):
+                assert ret in ("C.int", "C.size_t"), (fname, name, ret)
+    assert checked > 150, checked

@@ -50,8 +50,7 @@ def test_tuner_matches_oracle_on_string_tones(pkg, oracle, sr, frames):
 def test_tuner_analysis_split_over_workgroups_agrees(pkg, oracle):
     """Fewer channels than CUs: a channel's 24 blocks are transformed by up to 8 workgroups (runs of blocks, each repeating its predecessor
     for the cross term), the partial sums added in part order.  Every split gives the note, the cents and -- to rounding -- the frequency of
-    the one-workgroup analysis and of the oracle (GDG_TUNER_PARTS forces the count; the default picks it from the channel count)."""
-    import os
+    the one-workgroup analysis and of the oracle (option "tuner_parts" forces the count; 0 = the default picks it from the channel count)."""
     sr, frames = 192000, 8192
     nch = len(STRINGS)
     total = 96000 + 5 * frames
@@ -66,10 +65,10 @@ def test_tuner_analysis_split_over_workgroups_agrees(pkg, oracle):
     results = {}
     try:
         for parts in (1, 2, 3, 5, 8):
-            os.environ["GDG_TUNER_PARTS"] = str(parts)
+            ctx.set_option("tuner_parts", parts)
             results[parts] = ctx.tuner_analyze()
     finally:
-        os.environ.pop("GDG_TUNER_PARTS", None)
+        ctx.set_option("tuner_parts", 0)                # process-wide: back to "by channel count" for the tests that follow
     results["auto"] = ctx.tuner_analyze()
     ctx.close()
     for c in range(nch):
