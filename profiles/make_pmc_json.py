@@ -20,14 +20,15 @@ JSON_PATH = os.path.join(ROOT, "profiles", "pmc_fir_mac.json")
 KERNELS = {
     "fir_inv_kernel<13, 1, false>": None,                 # the roofline kernel: top level
     "fir_inv_kernel<13, 1, true>": "chained_variant",
-    "segf_kernel<false>": "segment_kernel",
-    "fir_fwd13w_kernel<0>": "forward_kernel",
+    "segf_kernel<0>": "segment_kernel",                   # one frame per launch (round 4's summaries print segf_kernel<false>)
+    "fir_fwd13wh_kernel<0>": "forward_kernel",            # (round 4: fir_fwd13w_kernel<0>)
 }
+OLD_NAMES = {"segf_kernel<false>": "segf_kernel<0>", "fir_fwd13w_kernel<0>": "fir_fwd13wh_kernel<0>"}
 DESCRIPTION = {
     None: "fir_inv_kernel<13, 1, false> (spectrum multiply-accumulate fused into the inverse FFT; the plain variant = amp 2 of the benchmark chain)",
     "chained_variant": "fir_inv_kernel<13, 1, true> (amp 1: + the forward transform of amp 2)",
-    "segment_kernel": "segf_kernel<false> (seg.hip compiled with SEG_FAST: 512 threads, one LDS frame buffer, two workgroups per CU; average over the two segment launches of a step)",
-    "forward_kernel": "fir_fwd13w_kernel<0> (forward transform of amp 1's frame)",
+    "segment_kernel": "segf_kernel<0> (seg.hip compiled with SEG_FAST: 512 threads, one LDS frame buffer, two workgroups per CU; average over the two segment launches of a step)",
+    "forward_kernel": "fir_fwd13wh_kernel<0> (forward transform of amp 1's frame, one LDS buffer)",
 }
 
 
@@ -40,13 +41,14 @@ def parse_summary(path):
         for line in f:
             m = traffic.match(line)
             if m:
-                k = m.group(1).strip()
+                k = OLD_NAMES.get(m.group(1).strip(), m.group(1).strip())
                 out.setdefault(k, {}).update(read_bytes=float(m.group(2)) * 1e6, write_bytes=float(m.group(3)) * 1e6,
                                              traffic_bytes_per_launch=float(m.group(4)) * 1e6)
                 continue
             m = table.match(line)
-            if m and m.group(1).strip() in KERNELS and "avg_us" not in out.get(m.group(1).strip(), {}):
-                out.setdefault(m.group(1).strip(), {}).update(calls=int(m.group(3)), avg_us=float(m.group(5)))
+            k = OLD_NAMES.get(m.group(1).strip(), m.group(1).strip()) if m else None
+            if m and k in KERNELS and "avg_us" not in out.get(k, {}):
+                out.setdefault(k, {}).update(calls=int(m.group(3)), avg_us=float(m.group(5)))
     return out
 
 
