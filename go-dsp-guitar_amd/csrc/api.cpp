@@ -151,12 +151,16 @@ struct gdg_ctx {
     int device_groups_env = 0;                 /* GDG_DEVICE_GROUPS: the debug override of gdg_ctx_set_overlap(0) */
     int copy_threads = 8;                      /* host copy workers of the host-buffer paths (made on first use) */
     int tuner_long = 0;                        /* 1: every analysis through the 262144-point transform pair (A/B, tests) */
-    /* NUMA placement of the host paths (option "numa", default on): the copy workers run on the CPUs of the device's NUMA node and the pinned
-     * slabs are taken from its memory -- on a two-socket node with eight GPUs, eight pools and eight sets of slabs would otherwise land
-     * wherever the scheduler put the callers (profiles/host_path_numa_r03.txt: +-15 %) */
-    int numa_mode = 1;
+    /* NUMA placement of the host paths (option "numa").  The CPU side of a host-buffer call is copying between the CALLER's pageable buffers
+     * and the pinned slabs; the GPU's DMA engines reach either socket's memory at PCIe speed.  So the default (2) puts the copy workers and
+     * the pinned slabs on the node the caller runs on when they are made; 1 puts them on the device's node (deterministic per GPU, but a
+     * caller on the other socket then has every byte read across the socket link: batch run 56 -> 73 ms); 0 leaves both to the scheduler and
+     * to hipHostMalloc's default (profiles/host_path_numa_r05.txt: both sockets within 1 % for the batch run and 4 % for the staged call at 2,
+     * 30 % / 1 % apart at 1, 0 % / 10 % at 0). */
+    int numa_mode = 2;                         /* 0: nothing; 1: the device's node; 2: the node the CALLER runs on when the pool / a slab is made */
     int numa_node = -1;                        /* /sys/bus/pci/devices/<bus id>/numa_node of the device, -1: unknown or a one-node host */
     std::vector<int> numa_cpus;                /* /sys/devices/system/node/node<N>/cpulist */
+    std::vector<std::vector<int>> node_cpus;   /* every node's CPUs (mode 2) */
     int *d_wave = nullptr;                     /* [GDG_WAVE_STEPS x GDG_WAVE_GROUPS ticket counters | one counter per unit in a segment]: zero between launches */
     size_t d_wave_cap = 0;
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
@@ -366,6 +370,24 @@ static void numa_discover(gdg_ctx *ctx) {
     cpus.resize((size_t)std::min(n, (int)cpus.size()));
     ctx->numa_node = node;
     ctx->numa_cpus = cpus;
+    for (int n = 0; n < 64; n++) {                      /* every node's CPU list, for "the caller's node" */
+        char buf[4096];
+        std::vector<int> list;
+        if (!read_text("/sys/devices/system/node/node" + std::to_string(n) + "/cpulist", buf, sizeof(buf)) || !parse_cpulist(buf, list)) break;
+        ctx->node_cpus.push_back(list);
+    }
+}
+/* the node and CPUs option "numa" points at right now: the device's (1) or the calling thread's (2); node < 0: bind nothing */
+static int numa_target(const gdg_ctx *ctx, const std::vector<int> **cpus) {
+    static const std::vector<int> none;
+    *cpus = &none;
+    if (ctx->numa_mode == 1 && ctx->numa_node >= 0) { *cpus = &ctx->numa_cpus; return ctx->numa_node; }
+    if (ctx->numa_mode == 2) {
+        const int cpu = sched_getcpu();
+        for (size_t n = 0; n < ctx->node_cpus.size(); n++)
+            if (std::find(ctx->node_cpus[n].begin(), ctx->node_cpus[n].end(), cpu) != ctx->node_cpus[n].end()) { *cpus = &ctx->node_cpus[n]; return (int)n; }
+    }
+    return -1;
 }
 /* the calling thread onto the device's node (copy workers) */
 static void numa_bind_thread(const std::vector<int> &cpus) {
@@ -380,10 +402,12 @@ static void numa_bind_thread(const std::vector<int> &cpus) {
 }
 /* pinned host memory from the device's node: the pages are taken (and pinned) inside hipHostMalloc, under the calling thread's memory policy */
 static hipError_t pinned_alloc(gdg_ctx *ctx, void **p, size_t bytes) {
-    const bool bind = ctx->numa_mode != 0 && ctx->numa_node >= 0 && ctx->numa_node < 1024;
+    const std::vector<int> *unused;
+    const int node = numa_target(ctx, &unused);
+    const bool bind = node >= 0 && node < 1024;
     if (bind) {
         unsigned long mask[16] = { 0 };
-        mask[ctx->numa_node / (8 * sizeof(unsigned long))] |= 1ul << (ctx->numa_node % (8 * sizeof(unsigned long)));
+        mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
         const bool policy = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul + 1) == 0;
         hipError_t e = hipHostMalloc(p, bytes, policy ? hipHostMallocNumaUser : hipHostMallocDefault);
         if (policy) syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
@@ -425,7 +449,7 @@ static const OptionDef g_options[] = {
     { "pcie_groups", "GDG_PCIE_GROUPS", 0, 16, -1, &gdg_ctx::pcie_groups_forced, nullptr, false },
     { "device_groups_default", "GDG_DEVICE_GROUPS", 0, 16, -1, &gdg_ctx::device_groups_env, nullptr, false },
     { "copy_threads", "GDG_COPY_THREADS", 1, 256, -1, &gdg_ctx::copy_threads, nullptr, false },
-    { "numa", "GDG_NUMA", 0, 1, -1, &gdg_ctx::numa_mode, nullptr, false },
+    { "numa", "GDG_NUMA", 0, 2, -1, &gdg_ctx::numa_mode, nullptr, false },
     { "tuner_parts", "GDG_TUNER_PARTS", 0, 24, GDG_KNOB_TUNER_PARTS, nullptr, nullptr, false },
     { "tuner_long_transform", "GDG_TUNER_LONG", 0, 1, -1, &gdg_ctx::tuner_long, nullptr, false },
     { "profile_attach", "GDG_PROFILE_ATTACH", 0, 1, -1, nullptr, &gdg_ctx::prof_attach, false },
@@ -2062,7 +2086,9 @@ static CopyPool &copy_pool(gdg_ctx *ctx) {
         unsigned hw = std::thread::hardware_concurrency();
         if (hw > 0 && threads > (int)hw) threads = (int)hw;
         if (threads < 1) threads = 1;
-        ctx->copy_pool = new CopyPool(threads - 1, ctx->numa_mode ? ctx->numa_cpus : std::vector<int>());
+        const std::vector<int> *cpus;
+        numa_target(ctx, &cpus);
+        ctx->copy_pool = new CopyPool(threads - 1, *cpus);
     }
     return *ctx->copy_pool;
 }

@@ -97,7 +97,9 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   pcie_groups                  0 .. 16     channel groups of the host-buffer calls, 0 = by channel count (0)
  *   device_groups_default        0 .. 16     what gdg_ctx_set_overlap(ctx, 0) means, 0 = one group (0)
  *   copy_threads                 1 .. 256    host copy workers of the host-buffer paths and the batch run (8)
- *   numa                         0, 1        copy workers on the CPUs, pinned slabs from the memory, of the device's NUMA node (1; before the first host-buffer call)
+ *   numa                         0, 1, 2     copy workers on the CPUs, pinned slabs from the memory, of a NUMA node: 2 the node the caller runs on when
+ *                                            they are made, 1 the device's node, 0 wherever the scheduler and hipHostMalloc put them (2; set it before
+ *                                            the first host-buffer call -- slabs that exist stay where they are)
  *   tuner_long_transform         0, 1        every tuner analysis through the reference's 262144-point transform pair (0)
  *   profile_attach               0, 1        the fused convolution launch records its own begin / end events (1)
  * Process-wide (the transforms' and the tuner's launchers have no context; set them before the first call that uses them):
