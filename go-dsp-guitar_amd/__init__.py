@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "gdg_meter_configure", "gdg_meter_set_enabled", "gdg_meter_process", "gdg_meter_process_device", "gdg_meter_analyze", "gdg_meter_state",
     "gdg_metronome_set_tick", "gdg_metronome_set_tock", "gdg_metronome_configure", "gdg_metronome_process", "gdg_metronome_process_device",
     "gdg_batch_length", "gdg_batch_run", "gdg_batch_run_shard", "gdg_batch_finish_master", "gdg_batch_release", "gdg_profile_sample", "gdg_ctx_set_window", "gdg_process_window_device", "gdg_ctx_set_overlap",
-    "gdg_ctx_set_option", "gdg_ctx_get_option", "gdg_option_count", "gdg_option_name", "gdg_numa_probe",
+    "gdg_ctx_set_option", "gdg_ctx_get_option", "gdg_option_count", "gdg_option_name", "gdg_numa_probe", "gdg_ctx_trim", "gdg_tuner_replace",
 ]
 
 
@@ -181,6 +181,8 @@ def lib():
             "gdg_profile_sample": (i32, [vp, i32]),
             "gdg_ctx_set_option": (i32, [vp, C.c_char_p, C.c_longlong]),
             "gdg_ctx_get_option": (i32, [vp, C.c_char_p, C.POINTER(C.c_longlong)]),
+            "gdg_ctx_trim": (i32, [vp]),
+            "gdg_tuner_replace": (i32, [vp, i32, vp, i32, u32]),
             "gdg_option_count": (i32, []),
             "gdg_option_name": (C.c_char_p, [i32]),
             "gdg_numa_probe": (i32, [C.c_char_p, C.c_char_p, C.POINTER(i32), C.POINTER(i32), i32, C.POINTER(i32)]),
@@ -518,6 +520,15 @@ class Context:
     def set_window(self, frames_per_call):
         """Time blocking: up to `frames_per_call` (1, 2, 4, 8, 16) consecutive 8192-sample frames per channel and call."""
         self._check(lib().gdg_ctx_set_window(self._h, frames_per_call))
+
+    def tuner_replace(self, channel, samples, sample_rate):
+        """One channel's whole 96000-sample ring, oldest first (gdg_tuner_replace)."""
+        a = np.ascontiguousarray(samples, dtype=np.float64)
+        self._check(lib().gdg_tuner_replace(self._h, channel, a.ctypes.data, a.size, sample_rate))
+
+    def trim(self):
+        """Give spare device memory back (gdg_ctx_trim); blocks."""
+        self._check(lib().gdg_ctx_trim(self._h))
 
     def set_option(self, key, value):
         """Launch-shape options (include/gdg.h, gdg_ctx_set_option): what used to be environment variables."""

@@ -500,6 +500,7 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     size_t row = (size_t)n_channels * (size_t)max_frames * sizeof(double);
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ctx->arena.stream = ctx->stream;
+    ctx->arena.defer_trim = true;               /* hipFree waits for the device: chunks go back in build_plan / gdg_ctx_trim, never inside a patch (arena.h) */
     ok = ok && hipMalloc((void **)&ctx->d_w0, row) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_w1, row) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_scratch, row) == hipSuccess;
@@ -1515,6 +1516,10 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                     int rc = prepare_unit(ctx, ctx->units[(size_t)h], frames, sample_rate, du, step_fast ? GDG_CHK_FAST : GDG_CHK);
                     t_unit += pnow() - tq;
                     if (rc != GDG_OK) return rc;
+                    /* both reverbs that append the frame BEFORE they tap (two-per-CU kernel; general kernel in a WAVE launch) rely on a delay
+                     * line exactly one batch frame longer than the longest tap (seg.hip): a change of one side without the other stops here */
+                    if (du.type == GDG_UNIT_REVERB && du.jp[4] != std::max(std::max(du.jp[0], du.jp[1]), std::max(du.jp[2], du.jp[3])) + GDG_MAX_FRAMES)
+                        return fail(ctx, GDG_ERR_INVALID, "reverb delay line of %d cells, expected the longest tap + %d", du.jp[4], GDG_MAX_FRAMES);
                     ctx->plan_unit_slot[(size_t)h] = (int)seg_units.size();
                     ctx->plan_unit_fast[(size_t)h] = step_fast ? 1 : 0;
                     ctx->plan_unit_fast_ok[(size_t)h] = segf_unit_ok(ctx->units[(size_t)h], frames, sample_rate) ? 1 : 0;
@@ -1594,6 +1599,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
         /* the previous plan may still be in use by launches in flight */
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    ctx->arena.trim();                         /* the stream is drained: the one place where giving spare chunks back stalls nobody */
     if (!ctx->blob.empty())
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, ctx->blob.data(), ctx->blob.size(), hipMemcpyHostToDevice, ctx->stream));
     ctx->plan_frames = frames;
@@ -1990,6 +1996,15 @@ static int check_device_error(gdg_ctx *ctx) {
         hipMemsetAsync(ctx->d_error, 0, sizeof(int), ctx->stream);
         return fail(ctx, GDG_ERR_UNSUPPORTED, "segment kernel met unit type %d without a HIP implementation", e - 1);
     }
+    return GDG_OK;
+}
+
+int gdg_ctx_trim(gdg_ctx *ctx) {
+    if (!ctx) return GDG_ERR_INVALID;
+    enter(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->arena.trim_pending = true;
+    ctx->arena.trim();
     return GDG_OK;
 }
 
@@ -2408,6 +2423,24 @@ int gdg_tuner_enqueue_staged(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
     rc = gdg_tuner_enqueue_device(ctx, ctx->d_stage_in, frames, sample_rate);
     if (rc != GDG_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GDG_OK;
+}
+
+/* circular.Buffer.Retrieve -> the device ring in ONE call: the n = 96000 samples of a channel's ring, oldest first, replace the whole ring */
+int gdg_tuner_replace(gdg_ctx *ctx, int channel, const double *samples, int n, uint32_t sample_rate) {
+    if (!ctx || !samples) return GDG_ERR_INVALID;
+    if (channel < 0 || channel >= ctx->nch) return fail(ctx, GDG_ERR_INVALID, "channel %d out of range", channel);
+    if (n != GDG_TUNER_RING) return fail(ctx, GDG_ERR_INVALID, "%d samples do not replace a ring of %d (tuner/tuner.go:16 NUM_SAMPLES)", n, GDG_TUNER_RING);
+    enter(ctx);
+    int rc = ensure_tuner(ctx);
+    if (rc != GDG_OK) return rc;
+    /* the oldest sample sits at the write position (shared by the context's channels): two pieces around the ring's end */
+    double *ring = ctx->d_tuner_ring + (size_t)channel * GDG_TUNER_RING;
+    const int wp = ctx->tuner_wp, head = GDG_TUNER_RING - wp;
+    HIP_TRY(ctx, hipMemcpyAsync(ring + wp, samples, (size_t)head * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (wp > 0) HIP_TRY(ctx, hipMemcpyAsync(ring, samples + head, (size_t)wp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));           /* the caller's buffer is free again */
+    ctx->tuner_sr = sample_rate;
     return GDG_OK;
 }
 

@@ -19,8 +19,13 @@
  * ZEROS.  Almost every block starts out as zeros (unit state, history rings, delay lines), and one hipMemsetAsync per block was 14 338
  * fill dispatches -- a third of the GPU time of a 512-channel context's set-up trace.  A chunk is zeroed ONCE, when it is made, and
  * remembers how far it has been handed out (`virgin`): alloc_zeroed() on space beyond that mark is free, only recycled space is filled. */
-/* Chunks after the first that become entirely free are given back to the device, all but the latest one (a run of 1M-tap filters does
- * not pin its gigabytes for the life of the context); the first chunk stays. */
+/* Chunks after the first that become entirely free are given back to the device, all but one (a run of 1M-tap filters does not pin its
+ * gigabytes for the life of the context); the first chunk stays.  WHEN: freeing device memory waits for the whole device, so a context
+ * that serves a live stream must not do it inside a process call.  With `defer_trim` (the device arena of api.cpp) release() only notes
+ * that there is something to give back and trim() does it -- api.cpp calls trim() where it has just drained the stream anyway (a plan
+ * rebuild, gdg_ctx_trim, the context's end), never on the parameter-patch path of a process call.  What CAN still stall a patch: a history
+ * that outgrows every hole makes a new chunk (one device malloc + one fill of up to 1 GiB, waited for); gdg.h says so at
+ * gdg_unit_set_param. */
 template <class B>
 struct ArenaT {
     using err_t = typename B::err_t;
@@ -38,6 +43,8 @@ struct ArenaT {
     size_t big_align = 4096;
     size_t first_chunk = (size_t)4 << 20;
     bool direct = false, sync_release = false;
+    bool defer_trim = false, trim_pending = false;
+    size_t spare_hint = 0;                                                             /* the chunk that became free last: the spare trim() keeps */
     ArenaT() {
         if (const char *e = getenv("GDG_ARENA_ALIGN")) { size_t a = (size_t)atoll(e); if (a >= 256 && (a & (a - 1)) == 0) big_align = a; }
         if (const char *e = getenv("GDG_ARENA")) direct = atoi(e) == 0;
@@ -122,14 +129,28 @@ struct ArenaT {
         /* this chunk is now entirely free: it stays as the ONE spare (a temporary that lives alone in a chunk must not cost a device
          * malloc + free per use); an older spare goes back to the device */
         if (c > 0 && entirely_free(ch)) {
-            for (size_t d = 1; d < chunks.size(); d++) {
-                if (d == c || !entirely_free(chunks[d])) continue;
-                B::free(chunks[d].base);                                               /* waits for the device, like any free of device memory */
-                total -= chunks[d].size;
-                trimmed++;
-                chunks[d] = Chunk{ nullptr, 0, {}, 0 };
-            }
+            if (defer_trim) { trim_pending = true; spare_hint = c; return; }
+            give_back_all_but(c);
         }
+    }
+    /* give the entirely free chunks back, all but `keep` (the spare) */
+    void give_back_all_but(size_t keep) {
+        for (size_t d = 1; d < chunks.size(); d++) {
+            if (d == keep || !entirely_free(chunks[d])) continue;
+            B::free(chunks[d].base);                                               /* waits for the device, like any free of device memory */
+            total -= chunks[d].size;
+            trimmed++;
+            chunks[d] = Chunk{ nullptr, 0, {}, 0 };
+        }
+    }
+    /* deferred trimming: call where waiting for the device costs nothing (the caller has just drained it).  Keeps the chunk that became
+     * free last (what the immediate mode keeps), or, if that one has been taken again, the first free one it finds. */
+    void trim() {
+        if (!trim_pending) return;
+        trim_pending = false;
+        size_t keep = (spare_hint > 0 && spare_hint < chunks.size() && entirely_free(chunks[spare_hint])) ? spare_hint : 0;
+        for (size_t d = 1; d < chunks.size() && keep == 0; d++) if (entirely_free(chunks[d])) keep = d;
+        if (keep) give_back_all_but(keep);
     }
     static bool entirely_free(const Chunk &ch) {
         return ch.base && ch.holes.size() == 1 && ch.holes.begin()->first == 0 && ch.holes.begin()->second == ch.size;

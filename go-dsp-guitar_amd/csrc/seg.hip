@@ -1433,9 +1433,20 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         const int npairs = (taps[3] - taps[0] + N + 1) / 2; /* pair k = values (rtop - 2 k - 1, rtop - 2 k) */
         auto fetch = [&](int k) -> seg_v2d {
             const int kk = min(k, npairs - 1);
-            int pl = dl_wp + (rtop - 2 * kk - 1);            /* ring cell of the pair's older value; >= -DL */
+            const int r_old = rtop - 2 * kk - 1;            /* the pair's older value, relative to the frame's start */
+            int pl = dl_wp + r_old;                         /* its ring cell; >= -DL - 1 */
             if (pl < 0) pl += DL;
             seg_v2d v;
+            /* a union of an odd number of values: the last pair's older half would be value -taps[3] - 1 -- with DL = taps[3] + N that is the
+             * cell this frame's sample N - 1 has just been stored to: never consumed (no tap reaches it), but a load racing a store all the
+             * same.  Only the newer half is fetched then. */
+            if (r_old < -taps[3]) {
+                int pn = pl + 1;
+                if (pn >= DL) pn -= DL;
+                v.x = 0.0;
+                v.y = g[pn];
+                return v;
+            }
             if (pl + 1 < DL) v = *(const GDG_GLOBAL seg_v2d *)(g + pl);
             else { v.x = g[pl]; v.y = g0; }
             return v;

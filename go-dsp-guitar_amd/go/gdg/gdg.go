@@ -189,6 +189,15 @@ func (this *Context) TunerEnqueueStaged(frames int, sampleRate uint32) error {
 	return this.err(C.gdg_tuner_enqueue_staged(this.ctx, C.int(frames), C.uint32_t(sampleRate)))
 }
 
+// TunerReplace: the whole ring of one channel at once -- len(samples) must be the ring's length (tuner.NUM_SAMPLES = 96000, oldest
+// sample first: what circular.Buffer.Retrieve hands out); anything else is an error from the library, never a partial upload.
+func (this *Context) TunerReplace(channel int, samples []float64, sampleRate uint32) error {
+	if len(samples) == 0 {
+		return fmt.Errorf("gdg: an empty ring")
+	}
+	return this.err(C.gdg_tuner_replace(this.ctx, C.int(channel), (*C.double)(unsafe.Pointer(&samples[0])), C.int(len(samples)), C.uint32_t(sampleRate)))
+}
+
 // TunerAnalyze: tuner.Analyze for every channel of the context.
 func (this *Context) TunerAnalyze() ([]TunerResult, error) {
 	n := this.channels

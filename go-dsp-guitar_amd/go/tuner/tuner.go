@@ -102,20 +102,9 @@ func (this *tunerStruct) Analyze() (Result, error) {
 	if err != nil {
 		return nil, fmt.Errorf("Failed to retrieve contents of circular buffer: %s", err.Error())
 	}
-	// the whole ring, oldest first, into the device ring (NUM_SAMPLES enqueued samples replace all of it)
-	for at := 0; at < n; at += blockSize {
-		m := n - at
-		if m > blockSize {
-			m = blockSize
-		}
-		row, _, err := ctx.Row(0, m)
-		if err != nil {
-			return nil, fmt.Errorf("Failed to analyze: %s", err.Error())
-		}
-		copy(row, this.snapshot[at:at+m]) // Go memory -> pinned C slab
-		if err := ctx.TunerEnqueueStaged(m, sampleRate); err != nil {
-			return nil, fmt.Errorf("Failed to analyze: %s", err.Error())
-		}
+	// the whole ring, oldest first, replaces the device ring in ONE upload (the library refuses any length but NUM_SAMPLES)
+	if err := ctx.TunerReplace(0, this.snapshot, sampleRate); err != nil {
+		return nil, fmt.Errorf("Failed to analyze: %s", err.Error())
 	}
 	res, err := ctx.TunerAnalyze()
 	if err != nil {

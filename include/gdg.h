@@ -124,6 +124,10 @@ int gdg_numa_probe(const char *sysfs_root, const char *pci_bus_id, int *node, in
 void *gdg_ctx_stream(const gdg_ctx *ctx);
 /* Block until everything enqueued so far has finished. */
 int gdg_ctx_synchronize(gdg_ctx *ctx);
+/* Give device memory the context no longer uses back to the device (entirely free chunks of the per-unit state arena, all but one spare).
+ * Freeing device memory waits for the whole device, so the library never does it inside a process call; it happens here and whenever a plan
+ * is rebuilt.  Blocks. */
+int gdg_ctx_trim(gdg_ctx *ctx);
 
 /* ---- effects units: effects.CreateUnit / Set*Value / state ----------------------------------- */
 
@@ -133,7 +137,13 @@ int gdg_unit_destroy(gdg_ctx *ctx, int handle);
 /* Resolved value of one parameter (the host side has already done effects.go:144-384's checks).  Effective from the next process call, like the
  * reference's setter (effects/effects.go:283-345: a store under a mutex).  Cheap on a live context: the call itself stores the value; the next
  * process call re-derives that unit's constants and patches its descriptor on the device in place -- the launch plan is only rebuilt by changes of
- * a chain's layout (gdg_chain_set), of the frame size or rate, or by new filter taps. */
+ * a chain's layout (gdg_chain_set), of the frame size or rate, or by new filter taps.
+ * "Cheap" has exceptions, all at the NEXT process call: (1) a value that moves the unit to another kernel -- oversampling switched on or off,
+ * a reverb leaving the in-place shape -- rebuilds the plan (~0.5 ms for 512 channels); (2) more than `scan_tables_max` distinct coefficient
+ * sets since the last plan (a caller sweeping a tone stack through a thousand settings) rebuilds it once to drop the table cache; (3) a unit
+ * whose constants cannot be derived (prepare fails) rebuilds it to report the error; (4) a value that re-makes a history the way the reference
+ * does (a longer delay, a new band-pass order) waits for the stream and may take a new arena chunk: one device malloc and one fill of up to
+ * 1 GiB, waited for.  Device memory is never FREED on this path (gdg_ctx_trim). */
 int gdg_unit_set_param(gdg_ctx *ctx, int handle, int param_index, int32_t value);
 int gdg_unit_get_param(gdg_ctx *ctx, int handle, int param_index, int32_t *value);
 /*
@@ -303,6 +313,11 @@ int gdg_tuner_enqueue_device(gdg_ctx *ctx, const double *d_samples, int frames, 
 /* the same from the pinned INPUT slab of gdg_staging_buffers (row c = channel c): for hosts that may not hand over their own
  * pointers (the Go overlay of tuner.Tuner copies in[tunerChannel] into row 0 of a one-channel context) */
 int gdg_tuner_enqueue_staged(gdg_ctx *ctx, int frames, uint32_t sample_rate);
+/* One channel's whole ring at once: `n` must be the ring's length, 96000 (tuner/tuner.go:16 NUM_SAMPLES; anything else is GDG_ERR_INVALID),
+ * samples oldest first -- what circular.Buffer.Retrieve hands out (tuner.go:392-399).  For a host that keeps the ring itself and only
+ * analyses on the device (the Go overlay of tuner.Tuner: Process stays a host-side enqueue under the reference's lock): one upload per
+ * analysis instead of twelve staged blocks.  Host buffer, blocks until it is consumed. */
+int gdg_tuner_replace(gdg_ctx *ctx, int channel, const double *samples, int n, uint32_t sample_rate);
 /* tuner.Analyze for every channel; results has n_channels entries.  Blocks. */
 int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results);
 const char *gdg_tuner_note_name(int note_index);

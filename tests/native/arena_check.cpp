@@ -3,7 +3,8 @@
  *   - live blocks never overlap (every block carries its own byte pattern until it is released),
  *   - blocks of a page or more start on the page alignment,
  *   - entirely free chunks go back (all but one spare and the first), and everything is returned at destroy.
- * usage: arena_check <seed> <operations>; prints "OK ..." or the first violation (exit 1). */
+ * usage: arena_check <seed> <operations> [defer]; prints "OK ..." or the first violation (exit 1).
+ * defer = 1: the device arena's mode (api.cpp): release() frees no chunk, trim() -- called every 997 operations here -- does. */
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -38,6 +39,7 @@ int main(int argc, char **argv) {
     std::mt19937 rng(seed);
     ArenaT<HostBackend> arena;
     arena.first_chunk = 64 << 10;
+    arena.defer_trim = argc > 3 && atoi(argv[3]) != 0;
     std::vector<Block> blocks;
     size_t peak_chunks = 0;
     auto fail = [&](const char *what, int op) { printf("FAIL seed %u op %d: %s\n", seed, op, what); return 1; };
@@ -74,12 +76,21 @@ int main(int argc, char **argv) {
         if (arena.live.size() != blocks.size()) return fail("live count", op);
         size_t spare = 0;
         for (size_t c = 1; c < arena.chunks.size(); c++) spare += ArenaT<HostBackend>::entirely_free(arena.chunks[c]);
-        if (spare > 1) return fail("more than one spare chunk", op);
+        if (arena.defer_trim) {
+            const long before = HostBackend::outstanding;
+            if (op % 997 == 996) {
+                arena.trim();
+                spare = 0;
+                for (size_t c = 1; c < arena.chunks.size(); c++) spare += ArenaT<HostBackend>::entirely_free(arena.chunks[c]);
+                if (spare > 1) return fail("more than one spare chunk after trim()", op);
+            } else if (HostBackend::outstanding < before) return fail("a deferred arena gave a chunk back outside trim()", op);
+        } else if (spare > 1) return fail("more than one spare chunk", op);
     }
     for (auto &k : blocks) {
         for (size_t j = 0; j < k.n; j++) if (k.p[j] != k.tag) return fail("a live block was overwritten (overlap)", ops);
         arena.release(k.p);
     }
+    arena.trim();
     if (arena.chunks_held() > 2) return fail("free chunks kept", ops);
     const size_t held = arena.chunks_held();
     arena.destroy();

@@ -22,3 +22,11 @@ def test_arena_churn_on_the_host(arena_check, seed):
     page alignment of large blocks, at most one spare chunk, nothing leaked."""
     r = subprocess.run([arena_check, str(seed), "12000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_deferred_trimming_frees_only_in_trim(arena_check, seed):
+    """The device arena's mode: freeing a chunk waits for the whole device, so release() -- reachable from a process call through a
+    parameter patch -- must never do it; trim() does, where the caller has drained the stream anyway."""
+    r = subprocess.run([arena_check, str(seed), "12000", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr

@@ -375,7 +375,8 @@ def test_tuner_overlay_keeps_the_reference_s_two_locks():
     assert "mutexBuffer.Lock()" in proc and "Enqueue(" in proc
     assert "ctx" not in proc and "gdg." not in proc and "mutexAnalyze" not in proc
     ana = re.search(r"func \(this \*tunerStruct\) Analyze\(.*?^\}", code, flags=re.S | re.M).group(0)
-    assert ana.index("mutexAnalyze.Lock()") < ana.index("mutexBuffer.RLock()") < ana.index("Retrieve(") < ana.index("mutexBuffer.RUnlock()") < ana.index("TunerEnqueueStaged(") < ana.index("TunerAnalyze(")
+    assert ana.index("mutexAnalyze.Lock()") < ana.index("mutexBuffer.RLock()") < ana.index("Retrieve(") < ana.index("mutexBuffer.RUnlock()") < ana.index("TunerReplace(") < ana.index("TunerAnalyze(")
+    assert "TunerEnqueueStaged(" not in ana            # ONE upload of the whole ring (gdg_tuner_replace refuses any length but NUM_SAMPLES)
 
 
 # ---- cgo argument TYPES: what the cgo type checker refuses second ---------------------------------------------------------------

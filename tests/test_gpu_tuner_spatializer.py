@@ -149,3 +149,32 @@ def test_spatializer_wide_shard(pkg, oracle):
         wl, wr = ref.process(x)
         assert rms(gl - wl) <= TOL_RMS and rms(gr - wr) <= TOL_RMS, b
     ctx.close()
+
+
+def test_tuner_replace_is_twelve_enqueues_in_one(pkg, oracle):
+    """gdg_tuner_replace: the whole ring of ONE channel, oldest first (what circular.Buffer.Retrieve hands the Go overlay), whatever the write
+    position the context's channels share -- same analysis as feeding the samples block by block; any length but 96000 is refused."""
+    sr, frames = 192000, 8192
+    nch = 3
+    total = 96000 + 5 * frames
+    x = np.stack([tone(f, total, sr, detune_cents=3.0 * i, phase=0.1 * i) for i, (_, f) in enumerate(STRINGS[:nch])])
+    ctx = pkg.Context(nch, frames)
+    for b in range(0, 2 * frames + 100, frames):                       # leave the shared write position somewhere inside the ring
+        ctx.tuner_enqueue(x[:, b:b + frames][:, :min(frames, 2 * frames + 100 - b)], sr)
+    refs = []
+    for c in range(nch):
+        ring = x[c, total - 96000:]
+        ctx.tuner_replace(c, ring, sr)
+        t = oracle.Tuner()
+        for b in range(0, 96000, frames):
+            t.process(ring[b:b + frames], sr)
+        refs.append(t.analyze())
+    got = ctx.tuner_analyze()
+    for c in range(nch):
+        assert got[c]["note"] == refs[c]["note"] and got[c]["cents"] == refs[c]["cents"], c
+        assert abs(got[c]["frequency"] - refs[c]["frequency"]) / refs[c]["frequency"] <= 1e-9, c
+    with pytest.raises(pkg.GdgError):
+        ctx.tuner_replace(0, x[0, :95999], sr)
+    with pytest.raises(pkg.GdgError):
+        ctx.tuner_replace(nch, x[0, :96000], sr)
+    ctx.close()
