@@ -108,6 +108,7 @@ struct StepDesc {
     bool chain_next = false;          /* FIR step whose every channel feeds another power amp next (the following step): that amp's forward
                                        * transform rides on this step's inverse (fir_inv_kernel CHAIN) in per-frame calls */
     bool fast = false;                /* segment step: every unit of every channel works in place on 8192-sample frames -> the two-per-CU kernel (segf) */
+    bool premac_ok = false;           /* FIR step: split shape (few channels), 8192-sample frames, every channel with K >= 2: the terms k >= 1 can be summed ahead */
     int wave_tickets = -1;            /* segment step: first of its GDG_WAVE_GROUPS ticket counters in d_wave (seg.hip, WAVE), -1: none */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
@@ -161,6 +162,19 @@ struct gdg_ctx {
     int numa_node = -1;                        /* /sys/bus/pci/devices/<bus id>/numa_node of the device, -1: unknown or a one-node host */
     std::vector<int> numa_cpus;                /* /sys/devices/system/node/node<N>/cpulist */
     std::vector<std::vector<int>> node_cpus;   /* every node's CPUs (mode 2) */
+    /* Small shards, per-frame calls (one GPU's share of a job split over several): the convolution's multiply-accumulate is the one kernel
+     * of the step that does not depend on the frame for 7/8 of its work -- the terms k = K - 1 .. 1 of Y = sum_k FDL[pos - k] H[k] only need
+     * frames that are already in the delay line.  So when a call ends, that part of the NEXT frame's sum is launched on a stream of its own
+     * (the "premac": fir_mac_kernel with k_lo = 1 into Y) and runs beside the call's last segment and the next call's first (64 workgroups
+     * on a 256-CU chip); the next call's inverse kernel adds the newest term and transforms (fir_inv_kernel FUSED = 4): 2 spectra per channel
+     * on the critical path instead of 2 K.  Every multiply-accumulate kernel sums k DESCENDING, so the split sum has the bits of the whole one.
+     * The premac is speculative: any library call but a process call drops it (the next call then runs the whole sum). */
+    int fir_premac = 1;                        /* option "fir_premac": 0 never */
+    int fir_premac_min = 48;                   /* fewest channels of a launch worth it: 16 channels lose 10 us per step to the two cross-stream hops */
+    hipStream_t premac_stream = nullptr;
+    hipEvent_t ev_fir_done = nullptr, ev_premac = nullptr;
+    bool premac_valid = false;                 /* Y of every premac step holds the terms k >= 1 of the plan's NEXT frame */
+    bool premac_outstanding = false;           /* ... and the context's stream has not been ordered behind that launch yet */
     int *d_wave = nullptr;                     /* [GDG_WAVE_STEPS x GDG_WAVE_GROUPS ticket counters | one counter per unit in a segment]: zero between launches */
     size_t d_wave_cap = 0;
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */
@@ -266,9 +280,18 @@ static int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {
 /* Device-resident calls may leave their channel groups running on streams of their own (process_rows, `free_run`); whatever
  * touches the context next -- any entry point -- first makes the context's stream wait for them. */
 static void join_groups(gdg_ctx *ctx);
-static void enter(gdg_ctx *ctx) {
+/* the context's stream behind the premac launch; `keep` = the caller changes no state (synchronize, stream, profiling): the sums stay usable */
+static void join_premac(gdg_ctx *ctx, bool keep) {
+    if (ctx->premac_outstanding) {
+        hipStreamWaitEvent(ctx->stream, ctx->ev_premac, 0);
+        ctx->premac_outstanding = false;
+    }
+    if (!keep) ctx->premac_valid = false;
+}
+static void enter(gdg_ctx *ctx, bool read_only = false) {
     hipSetDevice(ctx->device);
     join_groups(ctx);
+    join_premac(ctx, read_only);
 }
 
 #define HIP_TRY(ctx, call)                                                                          \
@@ -434,6 +457,8 @@ static const OptionDef g_options[] = {
     { "fir_fused", "GDG_FIR_FUSED", -1, 1, -1, &gdg_ctx::fir_fused, nullptr, true },                  /* -1: by channel count (fir_split_max) */
     { "fir_split_max_channels", "GDG_FIR_SPLIT_MAX", 0, 1 << 20, -1, &gdg_ctx::fir_split_max, nullptr, true },
     { "fir_chain_adjacent_amps", "GDG_FIR_CHAIN", 0, 1, -1, nullptr, &gdg_ctx::fir_chain, true },
+    { "fir_premac", "GDG_FIR_PREMAC", 0, 1, -1, &gdg_ctx::fir_premac, nullptr, true },
+    { "fir_premac_min_channels", "GDG_FIR_PREMAC_MIN", 1, 1 << 20, -1, &gdg_ctx::fir_premac_min, nullptr, true },
     { "share_ir_spectra", "GDG_SHARE_IR_SPECTRA", 0, 1, -1, nullptr, &gdg_ctx::share_spectra, false },
     { "fft_half_lds_mask", "GDG_FFT_HALF_LDS", 0, 63, GDG_KNOB_FFT_HALF_LDS, nullptr, nullptr, false },
     { "fir_forward_per_channel", "GDG_FWD_PER_CHANNEL", 0, 1, GDG_KNOB_FWD_PER_CHANNEL, nullptr, nullptr, false },
@@ -549,6 +574,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     if (!ctx) return GDG_ERR_INVALID;
     enter(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->premac_stream) { hipStreamSynchronize(ctx->premac_stream); hipStreamDestroy(ctx->premac_stream); hipEventDestroy(ctx->ev_fir_done); hipEventDestroy(ctx->ev_premac); }
     for (auto &u : ctx->units) if (u.alive) free_unit(ctx, u);
     ctx->spectra.clear();
     if (const char *e = getenv("GDG_ARENA_TRACE")) if (atoi(e))
@@ -627,6 +653,7 @@ const char *gdg_option_name(int index) { return (index >= 0 && index < gdg_optio
 void *gdg_ctx_stream(const gdg_ctx *ctx) {
     if (!ctx) return nullptr;
     join_groups(const_cast<gdg_ctx *>(ctx));           /* work enqueued on the returned stream from here on follows everything already submitted */
+    join_premac(const_cast<gdg_ctx *>(ctx), true);
     return (void *)ctx->stream;
 }
 
@@ -1386,6 +1413,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
     double t_fir = 0.0, t_unit = 0.0;
     const double t_plan0 = pnow();
     join_groups(ctx);                 /* a new plan replaces descriptors (and possibly unit state) the group streams may still be reading */
+    join_premac(ctx, false);          /* ... and the sums made ahead belong to the old plan's next frame */
     /* Scan tables live as long as some plan's descriptors point at them -- there is one plan, this one.  A caller that sweeps a parameter
      * through thousands of values would let the cache grow without bound (12 KB per tone-stack setting): past the limit everything is
      * dropped once the work in flight has drained, and this plan re-makes the few tables it needs. */
@@ -1552,6 +1580,10 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
             for (auto &f : fd) hp.push_back(f.H);
             std::sort(hp.begin(), hp.end());
             st.shared_spectra = std::adjacent_find(hp.begin(), hp.end()) != hp.end();
+            /* the terms k >= 1 ahead of the frame (premac): the split launch shape of few channels, one group, batch frames, every channel K >= 2 */
+            const bool split = ctx->fir_fused < 0 ? (st.n <= ctx->fir_split_max) : (ctx->fir_fused == 0);
+            st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && (int)fd.size() >= ctx->fir_premac_min;
+            for (auto &f : fd) if (f.K < 2 || f.hop != frames) st.premac_ok = false;
         }
         ctx->steps.push_back(st);
         seg_descs.push_back(sd);
@@ -1675,7 +1707,7 @@ int gdg_profile_sample(gdg_ctx *ctx, int every) {
 
 int gdg_profile_read(gdg_ctx *ctx, int kind, double *total_ms, int *launches) {
     if (!ctx || kind < 0 || kind >= GDG_K_COUNT) return GDG_ERR_INVALID;
-    enter(ctx);
+    enter(ctx, true);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     double total = 0.0;
     int n = 0;
@@ -1812,6 +1844,8 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     const bool free_run = G > 1 && !before && !after;
     if (!free_run) join_groups(ctx);      /* (a change of the group count rebuilds the plan, and build_plan joins every stream there is) */
     const int P2 = fir_transform_size(frames);
+    /* sums made ahead by the previous call (premac) are this call's if nothing has touched the context since and the plan still fits */
+    bool use_pre = ctx->premac_valid && window == 1 && G == 1;
     std::vector<size_t> bounds;
     if (group_bounds_in && (int)group_bounds_in->size() == G + 1) bounds = *group_bounds_in;
     else bounds = equal_group_bounds(active.size(), G);
@@ -1822,6 +1856,9 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
         int rc = apply_patches(ctx, frames, sample_rate);            /* knob moves: the affected descriptors only (may fall back to dirty) */
         if (rc != GDG_OK) return rc;
     }
+    if (!plan_fits) use_pre = false;
+    if (!use_pre) join_premac(ctx, false);       /* an unused premac still writes Y: this call's launches go behind it */
+    ctx->premac_valid = false;                   /* consumed by this call or dropped; the call's end makes the next one */
     if (ctx->dirty || ctx->plan_frames != frames || ctx->plan_sr != sample_rate ||
         ctx->plan_active != active || ctx->plan_stride != stride || ctx->plan_stride_out != stride_out || ctx->plan_by_channel != rows_by_channel ||
         ctx->plan_groups != G || ctx->plan_bounds != bounds) {
@@ -1846,6 +1883,14 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
     for (auto &st : ctx->steps)
         if (st.is_fir && st.n) { int rc = fir_tables(ctx, fir_transform_size(frames), &tw, &tw2); if (rc != GDG_OK) return rc; break; }
     if (G > 1) {
+        /* HIP streams share a few hardware queues (two on this runtime: profiles/groups_overlap_r04.txt); an idle premac stream left over from
+         * one-group calls takes a slot and the two group streams end up behind one another (64 channels: 149 -> 274 us per step) */
+        if (ctx->premac_stream) {
+            join_premac(ctx, false);
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->premac_stream));
+            hipStreamDestroy(ctx->premac_stream); hipEventDestroy(ctx->ev_fir_done); hipEventDestroy(ctx->ev_premac);
+            ctx->premac_stream = nullptr; ctx->ev_fir_done = nullptr; ctx->ev_premac = nullptr;
+        }
         while ((int)ctx->gstreams.size() < G) {
             hipStream_t s = nullptr;
             hipEvent_t e = nullptr;
@@ -1856,6 +1901,16 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
         }
         if (!ctx->gfork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->gfork, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventRecord(ctx->gfork, ctx->stream));            /* the plan upload and earlier work on the main stream */
+    }
+    /* premac: which step is the call's last power amp, and is there anything to sum ahead */
+    bool premac_here = false;
+    size_t premac_after = 0;
+    if (window == 1 && G == 1 && P2 == GDG_MAX_FRAMES && !ctx->profiling && !before && !after) {
+        for (size_t sj = 0; sj < ctx->steps.size(); sj++) {
+            if (!ctx->steps[sj].is_fir || !ctx->steps[sj].n) continue;
+            premac_after = sj;
+            premac_here = premac_here || ctx->steps[sj].premac_ok;
+        }
     }
     for (int g = 0; g < G; g++) {
         hipStream_t s = G > 1 ? ctx->gstreams[(size_t)g] : ctx->stream;
@@ -1895,9 +1950,23 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
                      * variant, which also makes the next amp's forward transform, under a kind of its own) */
                     ProfScope ps(ctx, d_next ? GDG_K_FIR_MAC_CHAIN : GDG_K_FIR_MAC, s, ctx->prof_attach);
                     HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, st.shared_spectra ? 2 : 1, shift, s, d_next, ps.attached ? ps.a : nullptr, ps.attached ? ps.b : nullptr));
+                } else if (use_pre && st.premac_ok) {
+                    /* the terms k >= 1 are in Y already (the previous call's premac): the newest term + the inverse transform */
+                    if (ctx->premac_outstanding) { HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_premac, 0)); ctx->premac_outstanding = false; }
+                    ProfScope ps(ctx, GDG_K_FIR_INV, s);
+                    HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 4, shift, s, d_next));
                 } else {
                     { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(P2, d, n, st.shared_spectra ? 1 : 0, s)); }
                     { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, shift, s, d_next)); }
+                }
+                /* behind the call's LAST power amp the next frame's sums can start (premac, below): mark the place in the stream */
+                if (premac_here && si == premac_after) {
+                    if (!ctx->premac_stream) {
+                        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->premac_stream, hipStreamNonBlocking));
+                        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fir_done, hipEventDisableTiming));
+                        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_premac, hipEventDisableTiming));
+                    }
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_fir_done, s));
                 }
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
@@ -1910,6 +1979,19 @@ static int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const doub
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));
+        if (premac_here) {
+            /* every launch of the call is in the context's stream: now the side stream's share (the host must not keep the main stream
+             * waiting for its next kernel while it enqueues these: 6 us per step) */
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->premac_stream, ctx->ev_fir_done, 0));
+            for (auto &sx : ctx->steps) {
+                if (!sx.is_fir || !sx.premac_ok || !sx.n) continue;
+                const gdg_fir_chan *dx = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + sx.offset);
+                HIP_TRY(ctx, gdg_launch_fir_mac(P2, dx, sx.n, sx.shared_spectra ? 1 : 0, ctx->premac_stream, 1));
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_premac, ctx->premac_stream));
+            ctx->premac_valid = true;
+            ctx->premac_outstanding = true;
+        }
         if (free_run) ctx->groups_pending = true;
         else if (G > 1) {
             HIP_TRY(ctx, hipEventRecord(ctx->gjoin[(size_t)g], s));
@@ -2010,7 +2092,7 @@ int gdg_ctx_trim(gdg_ctx *ctx) {
 
 int gdg_ctx_synchronize(gdg_ctx *ctx) {
     if (!ctx) return GDG_ERR_INVALID;
-    enter(ctx);
+    enter(ctx, true);
     return check_device_error(ctx);
 }
 

@@ -718,7 +718,7 @@ __device__ __forceinline__ cplx mac_load(const cplx *p) {
 
 template <int UNROLL, int BPT, bool NT, bool SWAP = false, bool HNT = NT>
 __global__ void __launch_bounds__(1024)
-fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
+fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P, int k_lo) {
 #pragma clang fp contract(off)      /* the sums of products as the reference forms them (no fused multiply-add): all three multiply-accumulate kernels give the same bits */
     gdg_fir_chan ch = chans[SWAP ? blockIdx.x : blockIdx.y];
     const int b0 = ((SWAP ? blockIdx.y : blockIdx.x) * blockDim.x + threadIdx.x) * BPT;
@@ -730,17 +730,21 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
     double ar[BPT], ai[BPT], br = 0.0, bi = 0.0;       /* complex product sums; component-wise sum for bin 0 */
 #pragma unroll
     for (int q = 0; q < BPT; q++) { ar[q] = 0.0; ai[q] = 0.0; }
-    int k = 0;
-    for (; k + UNROLL <= K; k += UNROLL) {
+    /* THE ORDER OF THE SUM (all three multiply-accumulate kernels, and what makes their results bit-identical): k DESCENDING, K - 1 first,
+     * the newest partition (k = 0, the frame that has just been transformed) LAST.  Every prefix of that order is computable before the
+     * frame exists: k = K - 1 .. K_LO with K_LO = 1 is the "premac" launch that runs beside the previous call's last segment, and the
+     * inverse kernel then only adds the k = 0 term (fir_inv_kernel, FUSED = 4) -- the same additions in the same order, the same bits. */
+    int k = K - 1;
+    for (; k - (UNROLL - 1) >= k_lo; k -= UNROLL) {
         cplx x[UNROLL][BPT], h[UNROLL][BPT];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            int slot = cur - (k + u);
+            int slot = cur - (k - u);
             if (slot < 0) slot += R;
 #pragma unroll
             for (int q = 0; q < BPT; q++) {
                 x[u][q] = mac_load<NT>(fdl + (size_t)slot * P + q);
-                h[u][q] = mac_load<HNT>(H + (size_t)(k + u) * P + q);
+                h[u][q] = mac_load<HNT>(H + (size_t)(k - u) * P + q);
             }
         }
 #pragma unroll
@@ -754,7 +758,7 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
             bi += x[u][0].y * h[u][0].y;
         }
     }
-    for (; k < K; k++) {
+    for (; k >= k_lo; k--) {
         int slot = cur - k;
         if (slot < 0) slot += R;
 #pragma unroll
@@ -800,10 +804,12 @@ __device__ __forceinline__ void inv_head_store(int k, cplx yk, cplx yn, double *
 
 /* The fused head: the workgroup walks ONE partition at a time through all its bins (partition-major), accumulating the
  * thread's eight bin pairs in registers.  Per partition it reads the delay-line slot and the IR partition front to back
- * (k ascending from 0, n descending from N - 1): two long sequential streams per workgroup.  The bin-major order (all K
+ * (bins k ascending from 0, n descending from N - 1): two long sequential streams per workgroup.  The bin-major order (all K
  * partitions of one bin pair at once) had 32 interleaved streams per workgroup, 8192 on the chip, and lost 25 % of the
  * bandwidth to DRAM page conflicts (profiles/experiments/README.md). */
-template <int LOGN, bool HNT>
+/* PRE: the terms k = K - 1 .. 1 are already summed in Y (the premac launch, fir_mac_kernel with k_lo = 1): the sums start from there and
+ * only the newest partition is added -- two spectra per channel instead of 2 K on the critical path of a small shard. */
+template <int LOGN, bool HNT, bool PRE = false>
 __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int tid, double *sre, double *sim, const cplx *__restrict__ tw2) {
 #pragma clang fp contract(off)
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
@@ -811,7 +817,16 @@ __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int ti
     double kr[ITER], ki[ITER], nr[ITER], ni[ITER], br = 0.0, bi = 0.0;
 #pragma unroll
     for (int i = 0; i < ITER; i++) { kr[i] = 0.0; ki[i] = 0.0; nr[i] = 0.0; ni[i] = 0.0; }
-    for (int u = 0; u < K; u++) {
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < ITER; i++) {
+            const int k = tid + T * i, n = (k == 0) ? N / 2 : N - k;
+            const cplx yk = gload(ch.Y + k), yn = gload(ch.Y + n);
+            if (k == 0) { br = yk.x; bi = yk.y; } else { kr[i] = yk.x; ki[i] = yk.y; }
+            nr[i] = yn.x; ni[i] = yn.y;
+        }
+    }
+    for (int u = PRE ? 0 : K - 1; u >= 0; u--) {        /* k descending: the order of the sum (fir_mac_kernel) */
         int slot = cur - u;
         if (slot < 0) slot += ch.R;
         const cplx *__restrict__ x = ch.fdl + (size_t)slot * N;
@@ -848,7 +863,8 @@ __device__ __forceinline__ void mac_head(const gdg_fir_chan &ch, int cur, int ti
     }
 }
 
-/* FUSED 0: Y comes from fir_mac_kernel.  FUSED 1 / 2: the multiply-accumulate runs here, straight into the inverse's
+/* FUSED 4: Y holds the sum of the terms k = K - 1 .. 1 (fir_mac_kernel with k_lo = 1, launched ahead of the frame); the newest term is added here.
+ * FUSED 0: Y comes from fir_mac_kernel.  FUSED 1 / 2: the multiply-accumulate runs here, straight into the inverse's
  * first stage (no Y round trip through HBM: the 6 % of extra bytes cost the separate MAC 20 % of its time, see
  * profiles/probes/); 2 = the IR spectra are shared between channels and read with cacheable loads. */
 /* CHAIN (8192-point frames only): the NEXT unit of every channel is a power amp too (the benchmark chain: cabinet IR, then reverb IR).
@@ -873,10 +889,11 @@ fir_inv_kernel(const gdg_fir_chan *__restrict__ chans, int W, gdg_shift shift, c
     gdg_fir_chan ch = chans[(FUSED == 3) ? blockIdx.x / (unsigned)W : blockIdx.x];
     const cplx *__restrict__ Y = ch.Y + (size_t)jw * N;
     int cur = 0;
-    if constexpr (FUSED == 1 || FUSED == 2) cur = (*ch.pos) % ch.R;
+    if constexpr (FUSED == 1 || FUSED == 2 || FUSED == 4) cur = (*ch.pos) % ch.R;
 
     if constexpr (FUSED == 1) mac_head<LOGN, true>(ch, cur, tid, sre, sim, tw2);
     else if constexpr (FUSED == 2) mac_head<LOGN, false>(ch, cur, tid, sre, sim, tw2);
+    else if constexpr (FUSED == 4) mac_head<LOGN, false, true>(ch, cur, tid, sre, sim, tw2);       /* Y holds the terms k >= 1 (premac) */
     else {
         constexpr int ITER = (N / 2) / T;
 #pragma unroll
@@ -1129,7 +1146,7 @@ fir_raw_inv_kernel(const gdg_fir_rawjob *__restrict__ jobs, double scale, const 
  *
  * One thread per bin.  Partitions are walked in chunks of C (= W up to 8, 8 for W = 16): a chunk needs C IR partitions and the
  * W + C - 1 delay-line slots they meet, all loaded before the C x W multiply-adds, whose indices are compile-time constants.
- * Every Y_j accumulates its terms in ascending k -- the order of the per-frame kernels -- and, like them, without fused
+ * Every Y_j accumulates its terms in DESCENDING k -- the order of the per-frame kernels (fir_mac_kernel) -- and, like them, without fused
  * multiply-adds (`fp contract(off)` in all three multiply-accumulate kernels): the results are bit-identical to W single-frame calls.
  * ---------------------------------------------------------------------------------------------- */
 template <int W, int C, bool HNT>
@@ -1147,7 +1164,7 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
 #pragma unroll
     for (int j = 0; j < W; j++) { ar[j] = 0.0; ai[j] = 0.0; }
     /* partitions in chunks of C: chunk c0 needs H[c0 .. c0 + C - 1] and the W + C - 1 slots X[t0 - c0 + d - (C - 1)], d = 0 .. W + C - 2 */
-    for (int c0 = 0; c0 < K; c0 += C) {
+    for (int c0 = ((K - 1) / C) * C; c0 >= 0; c0 -= C) {      /* k descending: the order of the sum (fir_mac_kernel) */
         cplx x[W + C - 1], h[C];
 #pragma unroll
         for (int d = 0; d < W + C - 1; d++) {
@@ -1161,7 +1178,7 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
             h[i] = (k < K) ? mac_load<HNT>(H + (size_t)k * P) : make_double2(0.0, 0.0);
         }
 #pragma unroll
-        for (int i = 0; i < C; i++) {
+        for (int i = C - 1; i >= 0; i--) {
             if (c0 + i < K) {
 #pragma unroll
                 for (int j = 0; j < W; j++) {
@@ -1176,12 +1193,12 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
 #pragma unroll
         for (int j = 0; j < W; j++) gstore_nt(ch.Y + (size_t)j * P + b, make_double2(ar[j], ai[j]));
     }
-    /* bin 0 = (DC, Nyquist) as two reals: component-wise products, the same ascending order.  Lane j of the channel's first workgroup
+    /* bin 0 = (DC, Nyquist) as two reals: component-wise products, the same descending order.  Lane j of the channel's first workgroup
      * takes frame j: its operands were loaded a moment ago (cache), eight partitions' worth are issued before they are consumed */
     if (blockIdx.x == 0 && threadIdx.x < W) {
         const int j = threadIdx.x;
         double br = 0.0, bi = 0.0;
-        for (int k0 = 0; k0 < K; k0 += 8) {
+        for (int k0 = ((K - 1) / 8) * 8; k0 >= 0; k0 -= 8) {
             cplx xv[8], hv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -1192,7 +1209,7 @@ fir_mac_tb_kernel(const gdg_fir_chan *__restrict__ chans, int P) {
                 hv[u] = gload(ch.H + (size_t)k * P);
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 7; u >= 0; u--) {
                 if (k0 + u < K) {
                     br += xv[u].x * hv[u].x;
                     bi += xv[u].y * hv[u].y;
@@ -1499,12 +1516,14 @@ template <int LG> static void launch_inv(const gdg_fir_chan *d_chans, int n, con
     if constexpr (LG == 13) {
         if (d_next) {       /* the next unit of every channel is a power amp: its forward transform rides along */
             if (fused == 0) GDG_LAUNCH_INV((fir_inv_kernel<13, 0, true>), d_chans, 1, shift, tw, tw2, d_next);
+            else if (fused == 4) GDG_LAUNCH_INV((fir_inv_kernel<13, 4, true>), d_chans, 1, shift, tw, tw2, d_next);
             else if (fused == 1) GDG_LAUNCH_INV((fir_inv_kernel<13, 1, true>), d_chans, 1, shift, tw, tw2, d_next);
             else GDG_LAUNCH_INV((fir_inv_kernel<13, 2, true>), d_chans, 1, shift, tw, tw2, d_next);
             return;
         }
     }
     if (fused == 0) GDG_LAUNCH_INV((fir_inv_kernel<LG, 0>), d_chans, 1, shift, tw, tw2, none);
+    else if (fused == 4) { if constexpr (LG == 13) GDG_LAUNCH_INV((fir_inv_kernel<13, 4>), d_chans, 1, shift, tw, tw2, none); }
     else if (fused == 1) GDG_LAUNCH_INV((fir_inv_kernel<LG, 1>), d_chans, 1, shift, tw, tw2, none);
     else GDG_LAUNCH_INV((fir_inv_kernel<LG, 2>), d_chans, 1, shift, tw, tw2, none);
 }
@@ -1638,19 +1657,20 @@ hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_job
 }
 
 template <int UNROLL, int BPT, bool NT, bool SWAP = false, bool HNT = NT>
-static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s, int block = 256) {
+static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s, int block = 256, int k_lo = 0) {
     int per_block = block * BPT;
     int threads = P < per_block ? (P / BPT) : block;
     if (threads < 1) threads = 1;
     unsigned tiles = (unsigned)((P + threads * BPT - 1) / (threads * BPT));
     dim3 grid = SWAP ? dim3((unsigned)n_chans, tiles) : dim3(tiles, (unsigned)n_chans);
-    fir_mac_kernel<UNROLL, BPT, NT, SWAP, HNT><<<grid, dim3(threads), 0, s>>>(d_chans, P);
+    fir_mac_kernel<UNROLL, BPT, NT, SWAP, HNT><<<grid, dim3(threads), 0, s>>>(d_chans, P, k_lo);
 }
 
-hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s) {
+hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s, int k_lo) {
     if (n_chans <= 0) return hipSuccess;
     /* IR spectra shared between channels are worth caching; private ones are read once: non-temporal like the delay line */
-    if (shared_spectra) { launch_mac<8, 1, true, false, false>(P, d_chans, n_chans, s); return hipGetLastError(); }
+    if (shared_spectra) { launch_mac<8, 1, true, false, false>(P, d_chans, n_chans, s, 256, k_lo); return hipGetLastError(); }
+    if (k_lo > 0) { launch_mac<8, 1, true>(P, d_chans, n_chans, s, 256, k_lo); return hipGetLastError(); }       /* the premac: the measured best shape */
     /* GDG_MAC_VARIANT: tuning knob for profiles/mac_variants.py; the default is the measured best */
     const int variant = gdg_knob_get(GDG_KNOB_MAC_VARIANT);
     switch (variant) {
@@ -1674,12 +1694,13 @@ hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, i
     return hipGetLastError();
 }
 
-/* fused: 0 = inverse only (Y from gdg_launch_fir_mac), 1 = MAC + inverse, 2 = MAC + inverse with shared (cacheable) IR spectra */
+/* fused: 0 = inverse only (Y from gdg_launch_fir_mac), 1 = MAC + inverse, 2 = MAC + inverse with shared (cacheable) IR spectra,
+ * 4 (P = 8192 only) = Y from gdg_launch_fir_mac(.., k_lo = 1) + the newest partition's term + inverse */
 hipError_t gdg_launch_fir_inv(int P, const gdg_fir_chan *d_chans, int n_chans, const cplx *d_tw, const cplx *d_tw2, int fused, gdg_shift shift, hipStream_t s,
                               const gdg_fir_chan *d_next_chans, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (n_chans <= 0) return hipSuccess;
     int L = ilog2_exact(P);
-    if (d_next_chans && L != 13) return hipErrorInvalidValue;
+    if ((d_next_chans || fused == 4) && L != 13) return hipErrorInvalidValue;
     GDG_DISPATCH_LOGN(L, launch_inv<LG>(d_chans, n_chans, d_tw, d_tw2, fused, shift, s, d_next_chans, ev_begin, ev_end));
     return hipGetLastError();
 }

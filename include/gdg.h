@@ -87,6 +87,11 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   fir_fused                    -1, 0, 1    spectrum multiply-accumulate inside the inverse transform's kernel: by channel count / never / always (-1)
  *   fir_split_max_channels       >= 0        with fir_fused = -1: launches of up to this many channels take the bin-tiled multiply-accumulate (96)
  *   fir_chain_adjacent_amps      0, 1        a power amp's inverse transform also makes the forward transform of the amp behind it (1)
+ *   fir_premac                   0, 1        per-frame calls of few channels (the split launch shape): when a call ends, the sums of the NEXT frame's
+ *                                            convolution over the partitions that are already in the delay line (7 of 8 at 65536 taps) are launched on a
+ *                                            stream of their own and run beside the segments; the next call adds the newest term.  Speculative: any library
+ *                                            call but a process call, gdg_ctx_synchronize and gdg_ctx_stream drops them.  Same bits either way (1)
+ *   fir_premac_min_channels      >= 1        ... from this many channels per launch on (48: below, the two cross-stream hops cost more than they hide)
  *   share_ir_spectra             0, 1        = gdg_ctx_share_ir_spectra (1)
  *   seg_two_per_cu               0, 1        segments of in-place units on 8192-sample frames take the 512-thread kernel, two workgroups per CU (1)
  *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (257)
