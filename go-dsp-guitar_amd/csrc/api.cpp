@@ -170,7 +170,9 @@ struct gdg_ctx {
      * on the critical path instead of 2 K.  Every multiply-accumulate kernel sums k DESCENDING, so the split sum has the bits of the whole one.
      * The premac is speculative: any library call but a process call drops it (the next call then runs the whole sum). */
     int fir_premac = 1;                        /* option "fir_premac": 0 never */
-    int fir_premac_min = 48;                   /* fewest channels of a launch worth it: 16 channels lose 10 us per step to the two cross-stream hops */
+    int fir_premac_min = 384;                  /* fewest partitions (sum of K over a launch's channels) worth it: the two cross-stream hops and the
+                                                * three extra spectra of the inverse kernel cost ~20 us per step -- the multiply-accumulate of 48 x 8
+                                                * partitions takes that long (16 x 8: 113.7 -> 123.4 us per step with it, 64 x 4 (config 3): 137 -> 141) */
     hipStream_t premac_stream = nullptr;
     hipEvent_t ev_fir_done = nullptr, ev_premac = nullptr;
     bool premac_valid = false;                 /* Y of every premac step holds the terms k >= 1 of the plan's NEXT frame */
@@ -458,7 +460,7 @@ static const OptionDef g_options[] = {
     { "fir_split_max_channels", "GDG_FIR_SPLIT_MAX", 0, 1 << 20, -1, &gdg_ctx::fir_split_max, nullptr, true },
     { "fir_chain_adjacent_amps", "GDG_FIR_CHAIN", 0, 1, -1, nullptr, &gdg_ctx::fir_chain, true },
     { "fir_premac", "GDG_FIR_PREMAC", 0, 1, -1, &gdg_ctx::fir_premac, nullptr, true },
-    { "fir_premac_min_channels", "GDG_FIR_PREMAC_MIN", 1, 1 << 20, -1, &gdg_ctx::fir_premac_min, nullptr, true },
+    { "fir_premac_min_partitions", "GDG_FIR_PREMAC_MIN", 1, 1 << 24, -1, &gdg_ctx::fir_premac_min, nullptr, true },
     { "share_ir_spectra", "GDG_SHARE_IR_SPECTRA", 0, 1, -1, nullptr, &gdg_ctx::share_spectra, false },
     { "fft_half_lds_mask", "GDG_FFT_HALF_LDS", 0, 63, GDG_KNOB_FFT_HALF_LDS, nullptr, nullptr, false },
     { "fir_forward_per_channel", "GDG_FWD_PER_CHANNEL", 0, 1, GDG_KNOB_FWD_PER_CHANNEL, nullptr, nullptr, false },
@@ -1533,7 +1535,7 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
                         if (shaper && wu.params[os_param] == 0) continue;                       /* memoryless: no state, no meeting */
                         if (ui < 31) mask |= 1u << ui;
                         const bool write_through = wu.type == GDG_UNIT_COMPRESSOR || wu.type == GDG_UNIT_TONESTACK || wu.type == GDG_UNIT_CABINET ||
-                                                   wu.type == GDG_UNIT_CHORUS || (wu.type == GDG_UNIT_REVERB && !step_fast);
+                                                   wu.type == GDG_UNIT_CHORUS || (wu.type == GDG_UNIT_REVERB && !step_fast) || (shaper && !step_fast);
                         if (!write_through) mask |= 1u << 31;
                     }
                     s.wave_mask = (int)mask;
@@ -1582,7 +1584,9 @@ static int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double
             st.shared_spectra = std::adjacent_find(hp.begin(), hp.end()) != hp.end();
             /* the terms k >= 1 ahead of the frame (premac): the split launch shape of few channels, one group, batch frames, every channel K >= 2 */
             const bool split = ctx->fir_fused < 0 ? (st.n <= ctx->fir_split_max) : (ctx->fir_fused == 0);
-            st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && (int)fd.size() >= ctx->fir_premac_min;
+            long partitions = 0;
+            for (auto &f : fd) partitions += f.K;
+            st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && partitions >= ctx->fir_premac_min;
             for (auto &f : fd) if (f.K < 2 || f.hop != frames) st.premac_ok = false;
         }
         ctx->steps.push_back(st);

@@ -769,7 +769,7 @@ __device__ __forceinline__ void os_decimate(const double *stage, const GDG_CONST
  * call = phase r of input slot i -- also goes to `dbg_up`, so that oversampling_test.go's vectors meet these tiles directly */
 template <int F, bool DBG = false>
 __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, double *stage, double *scr, double *hist_generic,
-                                                   const double *taps_generic, const double *lw_generic, int N, double *dbg_up = nullptr) {
+                                                   const double *taps_generic, const double *lw_generic, int N, double *dbg_up = nullptr, bool wt = false) {
     constexpr int TAPS = OsCfg<F>::TAPS, BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, TILE = OsCfg<F>::S, PH = OsCfg<F>::PH;
     /* wave-uniform table pointers in SGPRs + constant address space: the taps arrive through scalar loads */
     const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(taps_generic);      /* phase-major, zero padded */
@@ -826,7 +826,7 @@ __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, 
                 const int m = F * N - (TAPS - 1) + q;
                 const int i = (m >= 0) ? m / F : -((-m + F - 1) / F);
                 const int r = m - i * F;
-                hist[8 + q] = stage[r * PH + (i - I0)];       /* i >= I0 always: F * BACK >= TAPS - 1 */
+                st_f64(hist + 8 + q, stage[r * PH + (i - I0)], wt);       /* i >= I0 always: F * BACK >= TAPS - 1 */
             }
         }
         if (R * tid < S_out) {
@@ -838,7 +838,7 @@ __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, 
         }
         __syncthreads();
     }
-    if (tid < 8) hist[tid] = keep;
+    if (tid < 8) st_f64(hist + tid, keep, wt);
 }
 
 /* returns 1 when the result is in the INPUT buffer (oversampled: in place), 0 when it is in the other one */
@@ -858,8 +858,8 @@ __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tab
         return 0;
     }
 #ifndef SEG_FAST                                    /* the oversampled shapers stage a whole output frame in the second buffer */
-    if (f == 2) shaper_oversampled<2>(S, in, out, scr, U->hist, os.tapsP2, os.lanczos2, N);
-    else shaper_oversampled<4>(S, in, out, scr, U->hist, os.tapsP4, os.lanczos4, N);
+    if (f == 2) shaper_oversampled<2>(S, in, out, scr, U->hist, os.tapsP2, os.lanczos2, N, nullptr, wt);
+    else shaper_oversampled<4>(S, in, out, scr, U->hist, os.tapsP4, os.lanczos4, N, nullptr, wt);
 #endif
     return 1;
 }

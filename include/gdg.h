@@ -91,7 +91,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *                                            convolution over the partitions that are already in the delay line (7 of 8 at 65536 taps) are launched on a
  *                                            stream of their own and run beside the segments; the next call adds the newest term.  Speculative: any library
  *                                            call but a process call, gdg_ctx_synchronize and gdg_ctx_stream drops them.  Same bits either way (1)
- *   fir_premac_min_channels      >= 1        ... from this many channels per launch on (48: below, the two cross-stream hops cost more than they hide)
+ *   fir_premac_min_partitions    >= 1        ... for launches of at least this many partitions (channels x ceil(taps / 8192)) (384 = 48 channels x 65536
+ *                                            taps: below, the two cross-stream hops cost more than they hide)
  *   share_ir_spectra             0, 1        = gdg_ctx_share_ir_spectra (1)
  *   seg_two_per_cu               0, 1        segments of in-place units on 8192-sample frames take the 512-thread kernel, two workgroups per CU (1)
  *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (257)

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_premac.py tests/test_gpu_overlap.py tests/test_gpu_boundary.py tests/test_options_numa.py -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r05e_tests.txt
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > gpurun_out/r05c_pytest_gpu.txt
 P=profiles/probes/small_ctx.py
 {
-NCH=64 MODE=frame NGROUPS_LIST=1,2,1 KINDS=0 timeout 300 python $P
-} > gpurun_out/r05e_premac.txt 2>&1
+NCH=64 MODE=window CHAIN=config3 NGROUPS_LIST=1 KINDS=0 timeout 300 python $P
+NCH=64 MODE=frame CHAIN=config3 NGROUPS_LIST=1 KINDS=0 timeout 300 python $P
+} > gpurun_out/r05f_config3.txt 2>&1

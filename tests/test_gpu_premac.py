@@ -25,7 +25,7 @@ def oracle():
 def build(pkg, nch, frames, taps, premac, two_amps=True):
     ctx = pkg.Context(nch, frames)
     ctx.set_option("fir_premac", 1 if premac else 0)
-    ctx.set_option("fir_premac_min_channels", 1)
+    ctx.set_option("fir_premac_min_partitions", 1)
     for c in range(nch):
         ctx.append_unit(c, "compressor")
         ctx.append_unit(c, "power_amp", fir=synth_ir(taps, seed=100 + c))
@@ -58,7 +58,7 @@ def test_premac_is_dropped_by_whatever_touches_the_context(pkg, oracle):
     used), a new filter, a bypass, a frame-size change, a host-buffer call -- the stream must follow the oracle through all of them."""
     nch, frames, sr = 2, 8192, 96000
     ctx = pkg.Context(nch, frames)
-    ctx.set_option("fir_premac_min_channels", 1)
+    ctx.set_option("fir_premac_min_partitions", 1)
     pairs = []
     for c in range(nch):
         p = ChainPair(ctx, c, oracle)
