@@ -1,4 +1,4 @@
-/* arena.h -- sub-allocator for the device memory of the per-unit state (api.cpp).  Written against a small backend (malloc / free /
+/* arena.h -- sub-allocator for the device memory of the per-unit state (ctx.h, api_plan.cpp).  Written against a small backend (malloc / free /
  * fill / wait) so that the book-keeping can be exercised on the host: tests/native/arena_check.cpp runs it over plain memory. */
 #pragma once
 #include <algorithm>
@@ -21,8 +21,8 @@
  * remembers how far it has been handed out (`virgin`): alloc_zeroed() on space beyond that mark is free, only recycled space is filled. */
 /* Chunks after the first that become entirely free are given back to the device, all but one (a run of 1M-tap filters does not pin its
  * gigabytes for the life of the context); the first chunk stays.  WHEN: freeing device memory waits for the whole device, so a context
- * that serves a live stream must not do it inside a process call.  With `defer_trim` (the device arena of api.cpp) release() only notes
- * that there is something to give back and trim() does it -- api.cpp calls trim() where it has just drained the stream anyway (a plan
+ * that serves a live stream must not do it inside a process call.  With `defer_trim` (the device arena of the api_*.cpp files) release() only notes
+ * that there is something to give back and trim() does it -- api_plan.cpp / api_process.cpp call trim() where it has just drained the stream anyway (a plan
  * rebuild, gdg_ctx_trim, the context's end), never on the parameter-patch path of a process call.  What CAN still stall a patch: a history
  * that outgrows every hole makes a new chunk (one device malloc + one fill of up to 1 GiB, waited for); gdg.h says so at
  * gdg_unit_set_param. */

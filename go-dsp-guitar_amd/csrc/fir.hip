@@ -1553,7 +1553,7 @@ static int cu_count() {
  * Not kept: the per-channel walk with one buffer (26 us: 512 workgroups, nothing to balance with), non-temporal spectrum stores and product
  * loads (no difference). */
 /* Launch shapes of the transforms / the tuner that the launchers (which have no context) choose between: process-wide values, set through
- * gdg_ctx_set_option (api.cpp: the keys, what they mean, their ranges); first use takes the environment variable of the same name as a debug
+ * gdg_ctx_set_option (api_ctx.cpp: the keys, what they mean, their ranges); first use takes the environment variable of the same name as a debug
  * override, else the measured default. */
 static int g_knob[GDG_KNOB_COUNT];
 static bool g_knob_set[GDG_KNOB_COUNT];

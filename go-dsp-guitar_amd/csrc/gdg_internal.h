@@ -1,5 +1,5 @@
 /*
- * gdg_internal.h -- structures shared by the host side (api.cpp) and the HIP kernels.
+ * gdg_internal.h -- structures shared by the host side (api_*.cpp, ctx.h) and the HIP kernels.
  * Not part of the ABI.
  */
 #ifndef GDG_INTERNAL_H
@@ -71,7 +71,7 @@ void gdg_knob_set(int which, int value);
 hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
 hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, gdg_shift shift, hipStream_t s);
 /* k_lo: the partitions k = K - 1 .. k_lo are summed (descending: the order of every multiply-accumulate kernel).  0 = the whole sum;
- * 1 = everything but the newest partition, i.e. what can be computed BEFORE the frame exists (the premac of small shards, api.cpp) */
+ * 1 = everything but the newest partition, i.e. what can be computed BEFORE the frame exists (the premac of small shards, api_process.cpp) */
 hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s, int k_lo = 0);
 /* time blocking: a window of W (2, 4, 8 or 16) consecutive 8192-sample frames per channel; what = 0 forward transforms, 1 multiply-accumulate
  * (reads every spectrum once for the W frames), 2 inverse transforms, 3 history + frame counter.  chans[].src / dst: frame 0 of the
@@ -117,7 +117,7 @@ struct gdg_seg_unit {
                                * host at plan time -- they depend on the coefficients only -- and shared by all units with the same ones */
 };
 
-/* scan tables (seg.hip: lin_scan / lin2_scan); layouts shared with the host builder in api.cpp.  A thread's chunk has GDG_CHK samples:
+/* scan tables (seg.hip: lin_scan / lin2_scan); layouts shared with the host builder in api_plan.cpp.  A thread's chunk has GDG_CHK samples:
  * 8 in the general segment kernel (1024 threads per frame), 16 in the two-per-CU kernel for the batch block size (512 threads,
  * seg.hip compiled with -DSEG_FAST); the layouts below take the chunk size as a parameter because the host builds both. */
 #ifndef GDG_CHK

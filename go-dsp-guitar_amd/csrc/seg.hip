@@ -232,12 +232,12 @@ __device__ __forceinline__ double apply_map(double A, double B, double s) {
  *     frame in lane 0, so lane w holds the state entering wave w;
  *   - start state of the thread's chunk = exclusive in-wave value (wave_shr:1) + A^lane * (state entering the wave).
  * One workgroup barrier per scan (the exchange slots alternate).  The tables depend on the coefficient only: the host builds them at
- * plan time (api.cpp: scan_tables) and the unit copies them from HBM into LDS.  The exact replay from the start state is unchanged,
+ * plan time (api_plan.cpp: scan_tables) and the unit copies them from HBM into LDS.  The exact replay from the start state is unchanged,
  * so only that start state carries the scan's rounding (~1e-16 relative), as before.
  * 2 x 2 variant (tone stack band = high-pass feeding a low-pass): the pair (h, l) evolves linearly with the constant
  * lower-triangular matrix [[1-aH, 0], [-aL, 1-aL]] per sample, so ONE scan of vectors replaces two scans and one of the
  * three passes. */
-/* table layout (LT_*, L2_*): gdg_internal.h -- the tables are built on the host at plan time (api.cpp scan_tables) */
+/* table layout (LT_*, L2_*): gdg_internal.h -- the tables are built on the host at plan time (api_plan.cpp scan_tables) */
 #define LX_SLOT 17                /* exchange slot: [state before the frame | 16 wave totals] */
 
 template <int CTRL, int ROWMASK>
@@ -1378,7 +1378,7 @@ __device__ __attribute__((noinline)) void allpass_generic(double *buf, double *r
 }
 
 #ifdef SEG_FAST
-/* The reverb IN PLACE (one frame buffer), for the shape the host checks (gdg_segf_supported + api.cpp segf_unit_ok): N = 8192, every tap
+/* The reverb IN PLACE (one frame buffer), for the shape the host checks (gdg_segf_supported + api_plan.cpp segf_unit_ok): N = 8192, every tap
  * at least a frame back (rates from 42.7 kHz), all-pass rings of at most 16 / 6 / 2 values per thread.  Same arithmetic as below; what moves
  * is WHERE values wait: the tapped sums and dry * x stay in registers while the all-passes run in the buffer, the frame joins the delay
  * line (from registers) as soon as every thread has consumed its taps, and the tap loads come in two batches (16 sixteen-byte loads in
@@ -2594,7 +2594,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
 
 int gdg_seg_supported(int unit_type) {
 #ifdef SEG_FAST
-    /* by type; the host adds the per-unit conditions (no oversampling, the reverb's shape: api.cpp segf_unit_ok) */
+    /* by type; the host adds the per-unit conditions (no oversampling, the reverb's shape: api_plan.cpp segf_unit_ok) */
     switch (unit_type) {
     case GDG_UNIT_COMPRESSOR: case GDG_UNIT_OVERDRIVE: case GDG_UNIT_DISTORTION: case GDG_UNIT_EXCESS: case GDG_UNIT_TONESTACK:
     case GDG_UNIT_CABINET: case GDG_UNIT_CHORUS: case GDG_UNIT_RINGMODULATOR: case GDG_UNIT_TREMOLO: case GDG_UNIT_SIGNALGENERATOR:

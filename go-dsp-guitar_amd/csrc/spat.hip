@@ -7,7 +7,7 @@
  * association changes the result by ~1e-16 * N, far inside the 1e-9 RMS bar.  Across shards the host adds
  * the partial pairs and the aux buffer, spatializer.go:300-310.)
  * Per-channel gains, delays and interpolation weights are computed on the host in the reference's
- * arithmetic (api.cpp), including its quirk that the delay is always computed for 96 kHz.
+ * arithmetic (api_tuner_spat.cpp), including its quirk that the delay is always computed for 96 kHz.
  */
 #include "gdg_internal.h"
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the per-unit state's placement (DevArena in api.cpp): one hipMalloc per block vs the arena at several alignments.
+"""A/B of the per-unit state's placement (DevArena in ctx.h): one hipMalloc per block vs the arena at several alignments.
 Runs itself once per setting in a child process (the knobs are read when a context is created)."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

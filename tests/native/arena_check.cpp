@@ -4,7 +4,7 @@
  *   - blocks of a page or more start on the page alignment,
  *   - entirely free chunks go back (all but one spare and the first), and everything is returned at destroy.
  * usage: arena_check <seed> <operations> [defer]; prints "OK ..." or the first violation (exit 1).
- * defer = 1: the device arena's mode (api.cpp): release() frees no chunk, trim() -- called every 997 operations here -- does. */
+ * defer = 1: the device arena's mode (ctx.h): release() frees no chunk, trim() -- called every 997 operations here -- does. */
 #include <cstdio>
 #include <cstring>
 #include <random>

@@ -1,5 +1,5 @@
 """csrc/arena.h on the host: the sub-allocator behind every unit's device state, run over plain memory (tests/native/arena_check.cpp).
-No GPU: the book-keeping is a template over a four-call backend, and the HIP backend in api.cpp adds nothing to it."""
+No GPU: the book-keeping is a template over a four-call backend, and the HIP backend in ctx.h adds nothing to it."""
 import os
 import subprocess
 

@@ -1,4 +1,4 @@
-"""Parameter changes on a live context are patched into the plan's descriptors in place (api.cpp apply_patches; round-3 review, item 7): the
+"""Parameter changes on a live context are patched into the plan's descriptors in place (api_process.cpp apply_patches; round-3 review, item 7): the
 next call must behave exactly as if the whole plan had been rebuilt (GDG_PLAN_PATCH=0, round 3's behaviour) -- same bits -- and follow the
 oracle, whose setters are the reference's (effects/effects.go:283-345: a store under a mutex, effective from the next Process)."""
 import json

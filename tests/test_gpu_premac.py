@@ -1,5 +1,5 @@
 """Small shards, per-frame calls: the sums of the NEXT frame's convolution over the partitions already in the delay line are launched when a call
-ends (premac, api.cpp) and the next call only adds the newest term.  Every multiply-accumulate kernel sums k descending, so the split sum must
+ends (premac, api_process.cpp) and the next call only adds the newest term.  Every multiply-accumulate kernel sums k descending, so the split sum must
 have the bits of the whole one -- and anything that touches the context between two calls must drop the speculative part."""
 import numpy as np
 import pytest

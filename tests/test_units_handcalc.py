@@ -184,7 +184,7 @@ def test_hip_oversampler_tiles_follow_the_oracle_object(oracle, factor, sizes):
     for k, n in enumerate(sizes):
         x = rng.uniform(-1.2, 1.2, n)                        # beyond full scale: the decimator's clip takes part
         if k > 0 and n != sizes[k - 1]:
-            state[:8] = 0.0                                   # bufferPreUpsampling is re-made when the frame size changes (oversampling.go:86-89; api.cpp does the same)
+            state[:8] = 0.0                                   # bufferPreUpsampling is re-made when the frame size changes (oversampling.go:86-89; api_plan.cpp does the same)
         up, down = ctx.debug_oversample_decimate(factor, x, state)
         up_want = osd.oversample(x)
         down_want = osd.decimate(up_want)
