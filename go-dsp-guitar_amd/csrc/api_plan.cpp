@@ -692,7 +692,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     (void)any_fir;
     /* counters of the WAVE launches: tickets per (segment step, channel group), then one frame counter per unit that sits in a segment */
     {
-        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + 2 * ctx->units.size() + (size_t)nch + 64;
+        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + 8 * ctx->units.size() + (size_t)nch + 64;
         if (need > ctx->d_wave_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             hipFree(ctx->d_wave);
@@ -754,7 +754,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
                 s.unit_begin = (int)seg_units.size();
                 s.unit_count = (int)op.handles.size();
                 s.wave = ctx->d_wave + wave_next;
-                wave_next += 2 * op.handles.size();                     /* two counters per unit: the reverb meets its predecessor frame twice */
+                wave_next += 8 * op.handles.size();                     /* GDG_WAVE_CELLS counters per unit (seg.hip) */
                 {   /* which units meet their predecessor frame in a WAVE launch, and whether their stores are write-through there (seg.hip, wt) */
                     unsigned mask = 0;
                     for (size_t ui = 0; ui < op.handles.size(); ui++) {

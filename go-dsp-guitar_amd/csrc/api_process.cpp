@@ -250,8 +250,9 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                 /* one launch per window: a channel's workgroup walks its frames in order, the units' state runs through them */
                 /* ... unless the channels are few: then a workgroup per frame, the frames of a channel meeting unit by unit (seg.hip, WAVE) */
                 int *tickets = (window > 1 && n <= ctx->seg_wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
-                if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets));
-                else HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets));
+                const int epoch = tickets ? (ctx->wave_epoch = (ctx->wave_epoch % 0x3ffffff) + 1) : 0;          /* epoch * 32 + frame fits an int */
+                if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch));
+                else HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch));
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));

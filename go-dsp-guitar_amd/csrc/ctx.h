@@ -176,6 +176,7 @@ struct gdg_ctx {
     hipEvent_t ev_fir_done = nullptr, ev_premac = nullptr;
     bool premac_valid = false;                 /* Y of every premac step holds the terms k >= 1 of the plan's NEXT frame */
     bool premac_outstanding = false;           /* ... and the context's stream has not been ordered behind that launch yet */
+    int wave_epoch = 0;                        /* a number per WAVE launch (seg.hip: "done" marks carry it) */
     int *d_wave = nullptr;                     /* [GDG_WAVE_STEPS x GDG_WAVE_GROUPS ticket counters | one counter per unit in a segment]: zero between launches */
     size_t d_wave_cap = 0;
     std::vector<int> patch_units;              /* units whose parameters changed since the plan was built: their descriptors are patched in place */

@@ -1583,8 +1583,13 @@ hipError_t gdg_launch_fir_window(int W, const gdg_fir_chan *d_chans, int n_chans
     if (W != 2 && W != 4 && W != 8 && W != 16) return hipErrorInvalidValue;
     const int per_channel = gdg_knob_get(GDG_KNOB_FWD_PER_CHANNEL);
     const int half = fft_half_lds();
-    if (what == 0 && (half & 1)) {
-        fir_fwd13wh_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2, ((half & 32) && n_chans % 8 == 0) ? 1 : 0);
+    if (what == 0 && ((half & 1) || n_chans < cu_count())) {
+        /* one buffer, two workgroups per CU.  Off by default for a chip's worth of channels (the walk leaves room for the other channel group's
+         * multiply-accumulate, see above); below that there is no second group to make room for and the (channel, frame) grid of one-buffer
+         * workgroups, dealt XCD by XCD so that a frame's second read meets its first in L2, is the fastest forward launch:
+         * 64 channels 8.3 -> 6.2 us per frame, the window 51.5 -> 49.8; 128 channels 87.1 -> 83.4 (profiles/small_shards_r05.txt) */
+        const bool deal = n_chans % 8 == 0 && ((half & 32) || n_chans < cu_count());
+        fir_fwd13wh_kernel<1><<<dim3(n_chans * W), dim3(512), 0, s>>>(d_chans, W, shift, d_tw, d_tw2, deal ? 1 : 0);
     } else if (what == 0) {
         /* one workgroup per channel needs a chip's worth of channels; below that the (channel, frame) grid fills the CUs better
          * (64 channels: 9.7 vs 18.8 us per frame) */

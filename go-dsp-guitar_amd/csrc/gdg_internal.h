@@ -158,7 +158,7 @@ struct gdg_seg_chan {
     int flags;                /* GDG_SRC_IS_INPUT / GDG_DST_IS_OUTPUT */
     int wave_mask;            /* WAVE: bit u (u < 31) = unit u of the segment carries state from frame to frame (it meets its predecessor frame);
                                * bit 31 = some unit of the segment stores that state with plain stores: hand-offs write the XCD's L2 back */
-    int *wave;                /* [2 x unit_count] frame counters of the units of this channel's segment (seg.hip, WAVE); zero between launches */
+    int *wave;                /* [8 x unit_count] frame counters of the units of this channel's segment (seg.hip, WAVE); zero between launches */
 };
 
 /* oversampling tables shared by all channels (device memory) */
@@ -179,14 +179,15 @@ struct gdg_os_tables {
 #define GDG_OS_PADLO(F) (GDG_OS_NC - 1 - GDG_OS_BACK(F))
 #define GDG_OS_NE(F) (GDG_OS_NC + GDG_OS_R(F) - 1 + 1)              /* table entries per phase (+1: even) */
 
-/* d_wave_ticket != NULL and n_frames > 1: a workgroup per FRAME and channel, the frames of a channel meeting unit by unit (seg.hip, WAVE) --
+/* epoch: a number no other WAVE launch of the context carries (marks that must not be mistaken for an earlier launch's).
+ * d_wave_ticket != NULL and n_frames > 1: a workgroup per FRAME and channel, the frames of a channel meeting unit by unit (seg.hip, WAVE) --
  * for windows of channel counts that leave most of the chip idle; the counter (zero before the first launch, zero after every launch)
  * belongs to this launch slot alone */
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
-                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr);
+                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0);
 /* the same for segments that only hold units the two-per-CU kernel runs (gdg_segf_supported) on frames of 8192 samples */
 hipError_t gdg_launch_segf(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
-                           gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr);
+                           gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0);
 int gdg_segf_supported(int unit_type);
 hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_hist, double *d_up, double *d_down, gdg_os_tables os, hipStream_t s);
 /* 1 when seg.hip implements the unit type */

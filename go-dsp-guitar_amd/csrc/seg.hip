@@ -389,7 +389,8 @@ __device__ __forceinline__ void wave_post(int *cell, int value, bool release) {
 }
 
 /* what a unit that meets its predecessor frame TWICE needs (the reverb: delay line, then all-pass rings): its second counter */
-struct WaveGate { int *cell; int wf, wf_next; bool release; };
+struct WaveGate { int *cell; int wf, wf_next; bool release; int epoch; };
+#define GDG_WAVE_CELLS 8      /* counters per unit: [0] the unit's, [1] its second meeting (reverb), [2..5] "frame f is done" marks (chorus), spare */
 
 __device__ __forceinline__ double ring_read(const double *ring, int C, int wp, int idx) {
     int p = wp + idx;
@@ -1050,7 +1051,14 @@ UNIT_FN unit_cabinet(UNIT_ARGS) {
  * ring[(wp + t) & mask] whether it lies in the frame or before it -- one 16-byte load fetches the two neighbours of a fractional
  * delay, no LDS-or-ring branch, no modulo.  (The first version branched per tap between LDS and ring and between pair and
  * single loads: ~60 instructions and 6 branches per tap, 300 per sample.) */
-UNIT_FN unit_chorus(UNIT_ARGS) {
+/* wt (a frame per workgroup): what the next frame needs from this one is the appended ring and the two state cells -- both known as soon
+ * as the frame is in the ring.  So the unit posts its counter right there and the next frame's chorus runs beside this one's taps: the
+ * unit's serial part shrinks from the whole unit (10 us) to the append (2 us).  What bounds the overlap is the ring: the append of frame
+ * f + s + 1 reaches cells frame f's taps may still read once (s + 2) N + C + 1 >= capacity, so a frame waits for frame f - s - 1 to be DONE
+ * before it appends (s = 1 at 192 kHz: 32768 cells, C = 9600; s = 0, i.e. no overlap and the plain hand-off, at 96 kHz).  "Done" marks are
+ * per frame (cell 2 + (f & 3)) and carry the launch's epoch, so a mark left by an earlier launch never passes for this one's.
+ * *posted says to the caller that the unit's counter has been posted. */
+UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
     const double depth = Uc->dp[0], angular = Uc->dp[1], sr = Uc->dp[2];
@@ -1060,6 +1068,13 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
     GDG_GLOBAL double *ds = as_global(Uc->ds);
     const int wp = is[0];
     const double prev = ds[0];
+    if (wt) {
+        const int s_ok = ((mask + 1) - C - 2) / N - 1;
+        if (s_ok >= 1 && s_ok <= 2 && gate.wf - s_ok - 1 >= 0) {
+            const int fd = gate.wf - s_ok - 1;                        /* the frame whose taps this frame's append would run into */
+            wave_wait(gate.cell + 1 + (fd & 3), gate.epoch * 32 + fd + 1);
+        }
+    }
     /* 1. append the frame (pairs where possible); cell 0 is mirrored into the guard cell mask + 1 */
     if ((N & 1) == 0 && (wp & 1) == 0) {
         for (int i = 2 * (int)seg_tid(); i < N; i += 2 * SEG_T) {
@@ -1078,6 +1093,17 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
     }
     if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the sc1 pair stores are inline assembly: the compiler does not wait for them */
     __syncthreads();                                                /* the frame is in the ring (visible to the whole workgroup) */
+    /* (this frame's taps read t = -C - 1 .. N - 1 relative to wp; frame f + j appends at wp + j N ..) */
+    const int slack = wt ? ((mask + 1) - C - 2) / N - 1 : 0;        /* s: how many later frames may append while this one still reads */
+    const bool early = wt && slack >= 1 && slack <= 2;
+    if (early) {
+        if (seg_tid() == 0) {
+            st_f64(ds, fmod(prev + (angular * ((double)C / sr)), GO_MATH_TWO_PI), true);      /* the end-of-unit update below, same expression */
+            st_i32(is, (wp + N) & mask, true);
+        }
+        wave_post(gate.cell - 1, gate.wf_next, gate.release);
+        *posted = 1;
+    }
     /* sin(zero_phase + j 2pi/5) by the angle-addition formula from ONE sincos (the five LFOs are 72 degrees apart):
      * differs from the reference's sin(fmod(zero_phase + j 2pi/5, 2pi)) by ~1e-16, i.e. ~1e-13 samples of delay */
     const double cj[5] = { 1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410, 0.30901699437494742410 };
@@ -1164,11 +1190,12 @@ UNIT_FN unit_chorus(UNIT_ARGS) {
             samples(idx, (i + SEG_T < N) ? 2 : 1);
         }
     }
-    if (seg_tid() == 0) {
+    if (seg_tid() == 0 && !early) {
         double buffer_time = (double)C / sr;          /* quirk: advances by the buffer length, not by N */
         st_f64(ds, fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI), wt);
         st_i32(is, (wp + N) & mask, wt);
     }
+    if (early) wave_post(gate.cell + 1 + (gate.wf & 3), gate.epoch * 32 + gate.wf + 1, false);      /* this frame's taps are done (nothing to publish: no release) */
 }
 
 #ifndef SEG_FAST
@@ -2449,7 +2476,7 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
 template <bool WAVE>
 __device__ __forceinline__ void seg_frame(const double *src, double *dst, const gdg_seg_unit *units, int unit_begin, int unit_count, int N,
                                           const gdg_os_tables &os, int *d_error, int my_type, int *wave = nullptr, int wf = 0, int wf_next = 0,
-                                          unsigned wave_mask = 0) {
+                                          unsigned wave_mask = 0, int epoch = 0) {
     int tid = seg_tid();
 #ifdef SEG_FAST
     /* opaque per call: in the window walk the compiler otherwise hoists every per-thread address of the frame's load and store loops out of
@@ -2484,8 +2511,9 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         int inplace = 0;
         /* a unit that keeps nothing from frame to frame (a shaper without oversampling) meets nobody */
         const bool gated = WAVE && (u >= 31 || ((wave_mask >> u) & 1u));
-        if (gated) wave_wait(wave + 2 * u, wf);
+        if (gated) wave_wait(wave + GDG_WAVE_CELLS * u, wf);
         int second = 0;                              /* 1: the unit posted its first counter itself and waits on the second (general reverb) */
+        bool skip_post = false;                      /* the unit posted its counter itself and has no second one (chorus) */
         switch (type) {
         case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N, WAVE); break;
         case GDG_UNIT_OVERDRIVE:
@@ -2497,7 +2525,13 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
 #endif
         case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N, WAVE); break;
         case GDG_UNIT_CABINET: unit_cabinet(U, flip, N, WAVE); break;
-        case GDG_UNIT_CHORUS: unit_chorus(U, flip, N, WAVE); break;
+        case GDG_UNIT_CHORUS: {
+            const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch };
+            int posted = 0;
+            unit_chorus(U, flip, N, WAVE, gate, &posted);
+            skip_post = WAVE && __builtin_amdgcn_readfirstlane(posted);
+            break;
+        }
         case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N, WAVE); break;
         case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N, WAVE); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N, WAVE); break;
@@ -2505,7 +2539,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         case GDG_UNIT_REVERB: unit_reverb(U, flip, N, WAVE); break;
 #else
         case GDG_UNIT_REVERB: {
-            const WaveGate gate = { wave + 2 * u + 1, wf, wf_next, (wave_mask >> 31) != 0 };
+            const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch };
             unit_reverb(U, flip, N, WAVE, gate);
             second = WAVE ? 1 : 0;
             break;
@@ -2530,7 +2564,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
             break;
         }
-        if (gated) wave_post(wave + 2 * u + second, wf_next, (wave_mask >> 31) != 0);
+        if (gated && !skip_post) wave_post(wave + GDG_WAVE_CELLS * u + second, wf_next, (wave_mask >> 31) != 0);
         else __syncthreads();
         if (!__builtin_amdgcn_readfirstlane(inplace)) flip ^= 1;
     }
@@ -2555,7 +2589,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
 template <int MODE>             /* 0: one frame per launch; 1: the walk; 2: WAVE (a workgroup per frame, above) */
 __global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU) SEG_KERNEL_ATTR
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
-           gdg_os_tables os, int *d_error, int n_chans, int *ticket) {
+           gdg_os_tables os, int *d_error, int n_chans, int *ticket, int epoch) {
     constexpr bool MULTI = MODE == 1;
     int block = blockIdx.x, wf0 = 0;
     if (MODE == 2) {
@@ -2581,7 +2615,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
     if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
     if (MODE == 2) {
         seg_frame<true>(ch.src + (size_t)wf0 * N, ch.dst + (size_t)wf0 * N, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type,
-                        ch.wave, wf0, wf0 + 1 < n_frames ? wf0 + 1 : 0, (unsigned)ch.wave_mask);
+                        ch.wave, wf0, wf0 + 1 < n_frames ? wf0 + 1 : 0, (unsigned)ch.wave_mask, epoch);
         return;
     }
     /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
@@ -2617,11 +2651,11 @@ int gdg_seg_supported(int unit_type) {
 }
 
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
-                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket) {
+                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket, int epoch) {
     if (n_chans <= 0 || n_frames <= 0) return hipSuccess;
     if (n_frames > 1 && d_wave_ticket)
-        hipLaunchKernelGGL(seg_kernel<2>, dim3(n_chans * n_frames), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, d_wave_ticket);
-    else if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<1>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, nullptr);
-    else hipLaunchKernelGGL(seg_kernel<0>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, 1, shift, os, d_error, n_chans, nullptr);
+        hipLaunchKernelGGL(seg_kernel<2>, dim3(n_chans * n_frames), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, d_wave_ticket, epoch);
+    else if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<1>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, nullptr, 0);
+    else hipLaunchKernelGGL(seg_kernel<0>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, 1, shift, os, d_error, n_chans, nullptr, 0);
     return hipGetLastError();
 }
