@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
+P=profiles/probes/small_ctx.py
 {
-echo "== WAVE (default)"; NCH=64 python profiles/seg_breakdown.py --window=16 "(copy)" compressor overdrive tone_stack chorus cabinet reverb "seg0 of bench" "seg1 of bench" 2>&1 | grep -v "^chain"
-echo "== walk (GDG_SEG_WAVE_MAX=0)"; GDG_SEG_WAVE_MAX=0 NCH=64 python profiles/seg_breakdown.py --window=16 "(copy)" compressor overdrive tone_stack chorus cabinet reverb "seg0 of bench" "seg1 of bench" 2>&1 | grep -v "^chain"
-} > gpurun_out/r05h_seg_window_64.txt 2>&1
+NCH=128 MODE=frame NGROUPS_LIST=1,1 timeout 300 python $P
+NCH=256 MODE=frame NGROUPS_LIST=1 timeout 300 python $P
+} > gpurun_out/r05i_128.txt 2>&1
