@@ -762,7 +762,9 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
                         const bool shaper = wu.type == GDG_UNIT_OVERDRIVE || wu.type == GDG_UNIT_DISTORTION || wu.type == GDG_UNIT_EXCESS;
                         const int os_param = wu.type == GDG_UNIT_OVERDRIVE ? 5 : (wu.type == GDG_UNIT_DISTORTION ? 3 : 2);
                         if (shaper && wu.params[os_param] == 0) continue;                       /* memoryless: no state, no meeting */
-                        if (ui < 31) mask |= 1u << ui;
+                        if (ui < 15) mask |= 1u << ui;
+                        if (ui < 15 && (wu.type == GDG_UNIT_COMPRESSOR || wu.type == GDG_UNIT_TONESTACK || wu.type == GDG_UNIT_CABINET))
+                            mask |= 1u << (16 + ui);                                              /* all their state is a few cells, read past the L1 */
                         const bool write_through = wu.type == GDG_UNIT_COMPRESSOR || wu.type == GDG_UNIT_TONESTACK || wu.type == GDG_UNIT_CABINET ||
                                                    wu.type == GDG_UNIT_CHORUS || (wu.type == GDG_UNIT_REVERB && !step_fast) || (shaper && !step_fast);
                         if (!write_through) mask |= 1u << 31;

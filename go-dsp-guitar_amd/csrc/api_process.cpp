@@ -353,6 +353,11 @@ int check_device_error(gdg_ctx *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (e != 0) {
         hipMemsetAsync(ctx->d_error, 0, sizeof(int), ctx->stream);
+        if (e == 0x57415645) {                  /* seg.hip GDG_WAVE_TIMEOUT_CODE: a frame waited ~1 s for its predecessor's counter */
+            ctx->dirty = true;                  /* the next plan starts from fresh counters */
+            if (ctx->d_wave) hipMemsetAsync(ctx->d_wave, 0, ctx->d_wave_cap * sizeof(int), ctx->stream);
+            return fail(ctx, GDG_ERR_HIP, "a window's segment launch timed out waiting for a frame counter (results of that window are invalid)");
+        }
         return fail(ctx, GDG_ERR_UNSUPPORTED, "segment kernel met unit type %d without a HIP implementation", e - 1);
     }
     return GDG_OK;

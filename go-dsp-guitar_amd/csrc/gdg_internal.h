@@ -156,8 +156,9 @@ struct gdg_seg_chan {
     int unit_begin;
     int unit_count;
     int flags;                /* GDG_SRC_IS_INPUT / GDG_DST_IS_OUTPUT */
-    int wave_mask;            /* WAVE: bit u (u < 31) = unit u of the segment carries state from frame to frame (it meets its predecessor frame);
-                               * bit 31 = some unit of the segment stores that state with plain stores: hand-offs write the XCD's L2 back */
+    int wave_mask;            /* WAVE: bit u (u < 15) = unit u of the segment carries state from frame to frame (it meets its predecessor frame; units
+                               * from the 16th on always do); bit 16 + u = it reads that state through sc1 loads only (no acquire fence at its
+                               * hand-off); bit 31 = some unit of the segment stores that state with plain stores: hand-offs write the XCD's L2 back */
     int *wave;                /* [8 x unit_count] frame counters of the units of this channel's segment (seg.hip, WAVE); zero between launches */
 };
 

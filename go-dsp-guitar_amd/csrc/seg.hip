@@ -349,6 +349,13 @@ __device__ __forceinline__ void st_f64(GDG_GLOBAL double *p, double v, bool wt) 
     if (wt) __hip_atomic_store((GDG_GLOBAL unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
+/* ... and the matching load of a state cell: sc1 (past this CU's L1, which no other CU's store refreshes) when the producer stored sc1 -- a
+ * unit whose whole state is read this way needs no acquire fence at its hand-off (MI355X_MICROARCH.md: "sc1 loads may replace the acquire
+ * only when the producer stored sc1") */
+__device__ __forceinline__ double ld_f64(const GDG_GLOBAL double *p, bool wt) {
+    if (wt) return __longlong_as_double((long long)__hip_atomic_load((const GDG_GLOBAL unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
 __device__ __forceinline__ void st_i32(GDG_GLOBAL int *p, int v, bool wt) {
     if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
@@ -369,10 +376,19 @@ __device__ __forceinline__ void st_v2d(GDG_GLOBAL seg_v2d *p, seg_v2d v, bool wt
  * (slowest unit) instead of W x (sum).  Release / acquire at agent scope (the workgroups of a channel may sit on different XCDs, each
  * with an L2 of its own): every wave writes back before the barrier, one lane posts; one lane polls, every wave invalidates after the
  * barrier.  Workgroups take their frame by TICKET (seg_kernel), so a workgroup never waits for one that has not started. */
-__device__ __forceinline__ void wave_wait(int *cell, int want) {
+/* light: the unit reads everything its predecessor frame left it through sc1 loads (ld_f64): no acquire fence (1.7 us) */
+/* Every spin is BOUNDED (~1 s): a counter that never comes -- a launch that broke the protocol, a workgroup that died -- must end as an error
+ * code in the context's error word (the next call reports it), never as a hung device. */
+#define GDG_WAVE_SPIN_LIMIT (1 << 23)
+#define GDG_WAVE_TIMEOUT_CODE 0x57415645           /* "WAVE" */
+__device__ __forceinline__ void wave_wait(int *cell, int want, bool light = false, int *d_error = nullptr) {
     if (seg_tid() == 0) {
-        while (__hip_atomic_load(as_global(cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          /* ONE buffer_inv sc1 per workgroup: this CU's L1 (MI355X_MICROARCH.md, visibility) */
+        int spins = 0;
+        while (__hip_atomic_load(as_global(cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > GDG_WAVE_SPIN_LIMIT) { if (d_error) atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
+        }
+        if (!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          /* ONE buffer_inv sc1 per workgroup: this CU's L1 (MI355X_MICROARCH.md, visibility) */
     }
     __syncthreads();
 }
@@ -389,7 +405,7 @@ __device__ __forceinline__ void wave_post(int *cell, int value, bool release) {
 }
 
 /* what a unit that meets its predecessor frame TWICE needs (the reverb: delay line, then all-pass rings): its second counter */
-struct WaveGate { int *cell; int wf, wf_next; bool release; int epoch; };
+struct WaveGate { int *cell; int wf, wf_next; bool release; int epoch; int *d_error; };
 #define GDG_WAVE_CELLS 8      /* counters per unit: [0] the unit's, [1] its second meeting (reverb), [2..5] "frame f is done" marks (chorus), spare */
 
 __device__ __forceinline__ double ring_read(const double *ring, int C, int wp, int idx) {
@@ -609,7 +625,7 @@ __device__ __forceinline__ const GDG_CONST gdg_seg_unit *uniform_unit(const gdg_
 template <class C>
 __device__ __forceinline__ void compressor_body(const gdg_seg_unit *U, int flip, int N, const C &c, const bool wt) {
     UNIT_PROLOGUE
-    double s = U->ds[0];
+    double s = ld_f64(as_global(U->ds), wt);
     double x[CHK], e[CHK];
     chunk_load(in, c, x);
     __syncthreads();                                /* everybody holds the old state before the last thread rewrites it */
@@ -633,7 +649,7 @@ __device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip
     const int follow = U->ip[0];
     const double d_inv = U->dp[2], d = U->dp[3], limit = U->dp[0], target = U->dp[1];
     GDG_GLOBAL double *ds = as_global(U->ds);
-    if (tid == 0) st[0] = ds[0];
+    if (tid == 0) st[0] = ld_f64(ds, wt);
     tab_fetch(scr, U->tab, LT_SIZE);
     const ChunkT<true> c = full_chunk();
     double x[CHK], e[CHK];
@@ -871,7 +887,7 @@ template <class C>
 __device__ __forceinline__ void tonestack_body(const gdg_seg_unit *U, int flip, int N, const C &c, const bool wt) {
     UNIT_PROLOGUE
     double *st = tmp + SEG_STASH;                    /* the eight capacitor voltages, stashed in LDS (not in live registers) */
-    if (seg_tid() < 8) st[seg_tid()] = U->ds[seg_tid()];
+    if (seg_tid() < 8) st[seg_tid()] = ld_f64(as_global(U->ds) + seg_tid(), wt);
     double x[CHK];
     chunk_load(in, c, x);
     __syncthreads();
@@ -948,7 +964,7 @@ __device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip,
     double *st = tmp + SEG_STASH;                    /* [0..7] the capacitor voltages, [16..27] factors and coefficients */
     const int tid = seg_tid();
     GDG_GLOBAL double *ds = as_global(U->ds);
-    if (tid < 8) st[tid] = ds[tid];
+    if (tid < 8) st[tid] = ld_f64(ds + tid, wt);
     if (tid < 12) st[16 + tid] = U->dp[tid];
     tab_fetch(scr, U->tab, 4 * L2_SIZE);
     const ChunkT<true> c = full_chunk();
@@ -992,7 +1008,7 @@ template <class C>
 __device__ __forceinline__ void cabinet_body(const gdg_seg_unit *U, int flip, int N, const C &c, const bool wt) {
     UNIT_PROLOGUE
     double *st = tmp + SEG_STASH;                    /* the seven capacitor voltages, fetched once, kept in LDS */
-    if (seg_tid() < 7) st[seg_tid()] = U->ds[seg_tid()];
+    if (seg_tid() < 7) st[seg_tid()] = ld_f64(as_global(U->ds) + seg_tid(), wt);
     double v[CHK];
     chunk_load(in, c, v);
     __syncthreads();
@@ -1015,7 +1031,7 @@ __device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip, c
     double *st = tmp + SEG_STASH;                    /* [0..6] the capacitor voltages, [16..22] the coefficients */
     const int tid = seg_tid();
     GDG_GLOBAL double *ds = as_global(U->ds);
-    if (tid < 7) { st[tid] = ds[tid]; st[16 + tid] = U->dp[tid]; }
+    if (tid < 7) { st[tid] = ld_f64(ds + tid, wt); st[16 + tid] = U->dp[tid]; }
     tab_fetch(scr, U->tab, 7 * LT_SIZE);
     const ChunkT<true> c = full_chunk();
     double v[CHK];
@@ -1072,7 +1088,7 @@ UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
         const int s_ok = ((mask + 1) - C - 2) / N - 1;
         if (s_ok >= 1 && s_ok <= 2 && gate.wf - s_ok - 1 >= 0) {
             const int fd = gate.wf - s_ok - 1;                        /* the frame whose taps this frame's append would run into */
-            wave_wait(gate.cell + 1 + (fd & 3), gate.epoch * 32 + fd + 1);
+            wave_wait(gate.cell + 1 + (fd & 3), gate.epoch * 32 + fd + 1, false, gate.d_error);
         }
     }
     /* 1. append the frame (pairs where possible); cell 0 is mirrored into the guard cell mask + 1 */
@@ -1679,7 +1695,7 @@ UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
     __syncthreads();
     if (wt) {
         wave_post(gate.cell - 1, gate.wf_next, gate.release);       /* the delay line is free for the next frame */
-        wave_wait(gate.cell, gate.wf);                              /* the all-pass rings are ours */
+        wave_wait(gate.cell, gate.wf, false, gate.d_error);         /* the all-pass rings are ours */
 #pragma unroll
         for (int k = 0; k < 3; k++) rp[k] = as_global(is_state)[1 + k];
         if (M[0] >= 1) allpass_fetch<REVERB_QMAX>(ring[0], M[0], rp[0], N, pm_a);
@@ -2510,8 +2526,8 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         const int type = (u < 16) ? __builtin_amdgcn_readfirstlane(s_types[u]) : U->type;
         int inplace = 0;
         /* a unit that keeps nothing from frame to frame (a shaper without oversampling) meets nobody */
-        const bool gated = WAVE && (u >= 31 || ((wave_mask >> u) & 1u));
-        if (gated) wave_wait(wave + GDG_WAVE_CELLS * u, wf);
+        const bool gated = WAVE && (u >= 15 || ((wave_mask >> u) & 1u));
+        if (gated) wave_wait(wave + GDG_WAVE_CELLS * u, wf, u < 15 && ((wave_mask >> (16 + u)) & 1u), d_error);
         int second = 0;                              /* 1: the unit posted its first counter itself and waits on the second (general reverb) */
         bool skip_post = false;                      /* the unit posted its counter itself and has no second one (chorus) */
         switch (type) {
@@ -2526,7 +2542,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         case GDG_UNIT_TONESTACK: unit_tonestack(U, flip, N, WAVE); break;
         case GDG_UNIT_CABINET: unit_cabinet(U, flip, N, WAVE); break;
         case GDG_UNIT_CHORUS: {
-            const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch };
+            const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch, d_error };
             int posted = 0;
             unit_chorus(U, flip, N, WAVE, gate, &posted);
             skip_post = WAVE && __builtin_amdgcn_readfirstlane(posted);
@@ -2539,7 +2555,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         case GDG_UNIT_REVERB: unit_reverb(U, flip, N, WAVE); break;
 #else
         case GDG_UNIT_REVERB: {
-            const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch };
+            const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch, d_error };
             unit_reverb(U, flip, N, WAVE, gate);
             second = WAVE ? 1 : 0;
             break;

@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT
-P=profiles/probes/small_ctx.py
-{
-NCH=128 MODE=frame NGROUPS_LIST=1,1 timeout 300 python $P
-NCH=256 MODE=frame NGROUPS_LIST=1 timeout 300 python $P
-} > gpurun_out/r05i_128.txt 2>&1
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r05c_pytest_gpu.txt
+for NCH in 64; do NCH=$NCH MODE=window NGROUPS_LIST=1 KINDS=0 timeout 300 python profiles/probes/small_ctx.py; done > gpurun_out/r05j_light.txt 2>&1
