@@ -281,9 +281,9 @@ def leg_on_one_gpu(pkg, nch, frames, sr, taps, device, steps, channel0=0, chain=
     return st
 
 
-def window_leg_on_one_gpu(pkg, nch, frames, sr, taps, device, W=16, windows=2, channel0=0):
+def window_leg_on_one_gpu(pkg, nch, frames, sr, taps, device, W=16, windows=2, channel0=0, chain=CHAIN, second_amp=True):
     """Seconds per frame with W consecutive frames per call (batch mode, time blocked) over `windows` windows resident in HBM."""
-    ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0)
+    ctx = make_context(pkg, nch, frames, device, taps, channel0=channel0, chain=chain, second_amp=second_amp)
     ctx.set_window(W)
     n = W * windows * frames
     d_in, d_out = ctx.alloc(nch, n), ctx.alloc(nch, n)
@@ -433,6 +433,10 @@ def other_configs(pkg, device):
         dt = st["median"]
         out[key] = {"value": nch * frames / dt / 1e6, "unit": "Msamples/s", "us_per_block": dt * 1e6, "realtime_factor": frames / sr / dt,
                     "timing": us_stats(st)}
+    # config 3 in batch mode (whole files in HBM: windows of 16 frames per call)
+    stw = window_leg_on_one_gpu(pkg, 64, 8192, 96000, 32768, device, chain=chain3, second_amp=False)
+    out["config3_64ch_96k_4xOS_32ktaps"]["batch_mode_window_16"] = {"us_per_frame": stw["median"] * 1e6, "value": 64 * 8192 / stw["median"] / 1e6,
+                                                                    "realtime_factor": 8192 / 96000 / stw["median"], "timing": us_stats(stw)}
     # the ends of the power amp's range (effects/poweramp.go:303-329): the DEFAULT filter order, 1 048 576 taps = 128 partitions at the batch block
     # size, and a 9600-tap filter at the live path's 64-sample hops = 150 partitions; one power amp per chain, 64 channels, 4 distinct IRs
     # (the spectra of 64 private 1M-tap IRs alone would be 2 GiB of synthetic data to make on the host)
@@ -648,6 +652,8 @@ def main():
     # same box, profiles/probes/bisect_g1.py), as a batch caller that only touches the results through the library would
     headline_groups = args.channel_groups if args.channel_groups > 0 else (2 if nch >= 384 else 1)
     ctx.set_overlap(headline_groups)
+    # the launch-shape options in force (gdg_ctx_set_option: defaults unless an environment variable overrode one at context creation)
+    library_options = {k: ctx.get_option(k) for k in pkg.option_names()}
     # the steps walk round robin through INPUT_BLOCKS distinct consecutive blocks of the stream (delay lines of identical spectra would be
     # a special case; the traffic is the same either way)
     x_host = synth_blocks(nch, frames, sr, channel0=channel0)
@@ -845,7 +851,10 @@ def main():
                                                                    "predicted_job_value": args.channels * frames / dtw / 1e6,
                                                                    "predicted_realtime_factor": frames / sr / dtw}
                 extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
-                                                       "(channels are independent: the job's step time is the slowest shard's step time)",
+                                                       "(channels are independent: the job's step time is the slowest shard's step time); launch shapes "
+                                                       "are the library's own by channel count: per-frame calls of <= 96 channels run the split multiply-accumulate with "
+                                                       "the sums over the partitions already in the delay line made ahead of the frame (option fir_premac), windows of "
+                                                       "<= 192 channels run a workgroup per frame and channel (option seg_wave_max_channels)",
                                                "legs": legs}
                 if frames == 8192:
                     extras["sharded_batch"] = sharded_batch_one_gpu(pkg, local_rank, args.channels, 2, sr, taps)
@@ -918,6 +927,7 @@ def main():
                 "inputs": "SURVEY 8(d): two sines + 0.05 x the reference LCG (random/random.go) seeded 1337 + channel; IRs (1 - 2 r) exp(-6.9 k / L) on the "
                           "LCG seeded 4242 + 2 channel (cabinet) / 4243 + 2 channel (reverb), unit energy",
                 "channel_groups": headline_groups,
+                "library_options": library_options,
                 "channel_groups_note": "opt-in through gdg_ctx_set_overlap (free-running groups; the library's default is 1, ordered on the context's stream)",
                 "control_plane": "gloo barrier + max of one scalar; no RCCL, no data-path collective",
             },

@@ -275,7 +275,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error); hipFree(ctx->d_wave);
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
-    hipFree(ctx->d_note_freqs); hipFree(ctx->d_tuner_out); hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_part); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
+    hipFree(ctx->d_note_freqs); /* d_tuner_out is the device view of h_tuner_out */ hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_part); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);
     hipFree(ctx->d_sp_chan); hipFree(ctx->d_sp_out); hipFree(ctx->d_io[0]); hipFree(ctx->d_io[1]); hipFree(ctx->d_meter); hipFree(ctx->d_tick); hipFree(ctx->d_tock);
     for (auto st : ctx->gstreams) hipStreamDestroy(st);
     for (auto e : ctx->gjoin) hipEventDestroy(e);

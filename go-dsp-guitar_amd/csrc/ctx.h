@@ -224,7 +224,7 @@ struct gdg_ctx {
     int tuner_wp = 0;
     uint32_t tuner_sr = 0;
     double *d_note_freqs = nullptr;
-    gdg_tuner_out *d_tuner_out = nullptr, *h_tuner_out = nullptr;      /* results on the device / in pinned host memory */
+    gdg_tuner_out *d_tuner_out = nullptr, *h_tuner_out = nullptr;      /* results: pinned host memory the kernels write directly (d_ = its device-side address) */
     double2 *d_tuner_work = nullptr, *d_tuner_twn = nullptr, *d_tuner_twm = nullptr;
     double2 *d_tuner_part = nullptr;           /* partial sums of a short-lag analysis split over several workgroups per channel */
     std::vector<double> sp_az, sp_dist, sp_level;

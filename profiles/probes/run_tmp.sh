@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r05c_pytest_gpu.txt
-for NCH in 64; do NCH=$NCH MODE=window NGROUPS_LIST=1 KINDS=0 timeout 300 python profiles/probes/small_ctx.py; done > gpurun_out/r05j_light.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_tuner_spatializer.py tests/test_gpu_fuzz.py tests/test_host_mirror.py -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r05k_tests.txt
+python profiles/probes/tuner_channels.py > gpurun_out/r05k_tuner.txt 2>&1
