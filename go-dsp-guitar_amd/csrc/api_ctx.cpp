@@ -154,6 +154,7 @@ static const OptionDef g_options[] = {
     { "seg_two_per_cu", "GDG_SEG_FAST", 0, 1, -1, nullptr, &gdg_ctx::seg_fast, true },
     { "seg_two_per_cu_min_channels", "GDG_SEG_FAST_MIN", 0, 1 << 20, -1, &gdg_ctx::seg_fast_min, nullptr, true },
     { "seg_wave_max_channels", "GDG_SEG_WAVE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_max, nullptr, false },
+    { "seg_os_tiles_max_channels", "GDG_SEG_OS_TILES_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_os_tiles_max, nullptr, true },
     { "plan_patch", "GDG_PLAN_PATCH", 0, 1, -1, nullptr, &gdg_ctx::plan_patch, false },
     { "scan_tables_max", "GDG_SCAN_TABLES_MAX", 1, 1 << 20, -1, &gdg_ctx::scan_tables_max, nullptr, false },
     /* host paths, tuner, profiling */
@@ -398,7 +399,10 @@ int gdg_unit_set_param(gdg_ctx *ctx, int handle, int param_index, int32_t value)
          * (apply_patches) -- chain shape, launches and every other descriptor stay.  A power amp's parameters only matter through its
          * taps (gdg_unit_set_fir), and a unit that is not in the plan (bypassed, or in no chain) has nothing on the device to update.
          * Layout changes (gdg_chain_set), frame size, rate and new filters still rebuild the plan. */
-        if (ctx->dirty || !ctx->plan_patch) ctx->dirty = true;
+        /* a shaper's oversampling factor decides which LAUNCHES the plan holds (a segment cut at the unit, os_tiles_kernel<2 / 4>): a new plan */
+        const bool shaper = u->type == GDG_UNIT_OVERDRIVE || u->type == GDG_UNIT_DISTORTION || u->type == GDG_UNIT_EXCESS;
+        const bool os_changed = shaper && param_index == (u->type == GDG_UNIT_OVERDRIVE ? 5 : (u->type == GDG_UNIT_DISTORTION ? 3 : 2));
+        if (ctx->dirty || !ctx->plan_patch || os_changed) ctx->dirty = true;
         else if (u->type != GDG_UNIT_POWERAMP && (size_t)handle < ctx->plan_unit_slot.size() && ctx->plan_unit_slot[(size_t)handle] >= 0) {
             if (std::find(ctx->patch_units.begin(), ctx->patch_units.end(), handle) == ctx->patch_units.end()) ctx->patch_units.push_back(handle);
         }

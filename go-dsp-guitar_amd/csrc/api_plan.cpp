@@ -668,25 +668,41 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     std::vector<int> row_of((size_t)nch, -1);
     for (size_t i = 0; i < active.size(); i++) row_of[(size_t)active[i]] = rows_by_channel ? active[i] : (int)i;
     bool any_fir = false;
+    /* Slots: the ops of all channels are laid on one grid so that one launch takes the same op of every channel that has it.  Power amp number k
+     * of a channel sits at slot_key(k, 63, fir); what stands between power amps k - 1 and k is segment pieces (kind 0) and -- when the channels
+     * are too few to fill the chip -- oversampled shapers as launches of their own (kinds 2 / 3 for 2 x / 4 x: seg.hip os_tiles_kernel), numbered
+     * j = 0, 1, 2 ... in the order they come.  A channel without such a shaper has ONE piece (j = 0), as before. */
+    enum { K_SEG = 0, K_FIR = 1, K_OS2 = 2, K_OS4 = 3 };
+    auto slot_key = [](int k, int j, int kind) { return (k * 64 + j) * 4 + kind; };
+    const bool os_tiles = ctx->seg_os_tiles_max > 0 && (int)active.size() <= ctx->seg_os_tiles_max && frames == GDG_MAX_FRAMES;
     for (int c : active) {
         std::vector<int> seg;
-        int k = 0, count = 0;
+        int k = 0, j = 0, count = 0;
+        auto close_seg = [&]() { if (!seg.empty()) { by_slot[slot_key(k, j, K_SEG)].push_back({ c, Op{ false, seg } }); seg.clear(); count++; j++; } };
         for (auto &s : ctx->chains[(size_t)c]) {
             if (s.bypass) continue;                                   /* signal.go:390-401 */
             Unit &u = ctx->units[(size_t)s.handle];
             if (u.type == GDG_UNIT_POWERAMP) {
-                if (!seg.empty()) { by_slot[2 * k].push_back({ c, Op{ false, seg } }); seg.clear(); count++; }
-                by_slot[2 * k + 1].push_back({ c, Op{ true, { s.handle } } });
+                close_seg();
+                by_slot[slot_key(k, 63, K_FIR)].push_back({ c, Op{ true, { s.handle } } });
                 count++;
                 k++;
+                j = 0;
                 any_fir = true;
             } else {
                 if (!gdg_seg_supported(u.type)) return fail(ctx, GDG_ERR_UNSUPPORTED, "unit type %d has no HIP implementation yet", u.type);
-                seg.push_back(s.handle);
+                const bool shaper = u.type == GDG_UNIT_OVERDRIVE || u.type == GDG_UNIT_DISTORTION || u.type == GDG_UNIT_EXCESS;
+                const int os_index = !shaper ? 0 : u.params[u.type == GDG_UNIT_OVERDRIVE ? 5 : (u.type == GDG_UNIT_DISTORTION ? 3 : 2)];      /* 0 none, 1 "2", 2 "4" */
+                if (os_tiles && os_index > 0 && j < 60) {
+                    close_seg();
+                    by_slot[slot_key(k, j, os_index == 1 ? K_OS2 : K_OS4)].push_back({ c, Op{ false, { s.handle } } });
+                    count++;
+                    j++;
+                } else seg.push_back(s.handle);
             }
         }
-        if (!seg.empty()) { by_slot[2 * k].push_back({ c, Op{ false, seg } }); count++; }
-        if (count == 0) { by_slot[0].push_back({ c, Op{ false, {} } }); count = 1; }     /* empty chain: copy */
+        close_seg();
+        if (count == 0) { by_slot[slot_key(0, 0, K_SEG)].push_back({ c, Op{ false, {} } }); count = 1; }     /* empty chain: copy */
         n_ops[(size_t)c] = count;
     }
     (void)any_fir;
@@ -717,11 +733,12 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     ctx->plan_unit_fast.assign(ctx->units.size(), 0);
     ctx->plan_unit_fast_ok.assign(ctx->units.size(), 0);
     for (auto &kv : by_slot) {
-        bool is_fir = (kv.first & 1) != 0;
+        const int kind = kv.first & 3;
+        const bool is_fir = kind == K_FIR, is_os = kind == K_OS2 || kind == K_OS4;
         std::vector<gdg_seg_chan> sd;
         std::vector<gdg_fir_chan> fd;
         /* a segment step goes to the two-per-CU kernel when EVERY unit of EVERY channel in it can (one launch per step) */
-        bool step_fast = !is_fir && ctx->seg_fast && frames == GDG_MAX_FRAMES && (int)active.size() >= ctx->seg_fast_min;
+        bool step_fast = !is_fir && !is_os && ctx->seg_fast && frames == GDG_MAX_FRAMES && (int)active.size() >= ctx->seg_fast_min;
         if (step_fast)
             for (auto &entry : kv.second)
                 for (int h : entry.second.handles) if (!segf_unit_ok(ctx->units[(size_t)h], frames, sample_rate)) { step_fast = false; break; }
@@ -793,10 +810,12 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         }
         StepDesc st;
         st.is_fir = is_fir;
+        st.os_factor = is_os ? (kind == K_OS2 ? 2 : 4) : 0;
         st.fast = step_fast;
         st.n = is_fir ? (int)fd.size() : (int)sd.size();
         st.offset = 0;
         if (!is_fir && seg_steps < GDG_WAVE_STEPS && G <= GDG_WAVE_GROUPS) st.wave_tickets = GDG_WAVE_GROUPS * seg_steps++;
+        if (is_os) { st.os_flags = (int)wave_next; wave_next += sd.size(); }                /* one flag per channel of the launch (os_tiles_kernel) */
         /* descriptors are in `active` order, so every channel group owns one contiguous run of them */
         st.group_range.assign((size_t)G, std::make_pair(0, 0));
         {

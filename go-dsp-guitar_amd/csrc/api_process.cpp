@@ -244,6 +244,12 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                     }
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_fir_done, s));
                 }
+            } else if (st.os_factor) {
+                /* an oversampled shaper of few channels: a workgroup per (channel, frame, tile) instead of one per channel */
+                const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
+                ProfScope ps(ctx, GDG_K_SEGMENT, s);
+                const int epoch = (ctx->wave_epoch = (ctx->wave_epoch % 0x3ffffff) + 1);
+                HIP_TRY(ctx, gdg_launch_os_tiles(st.os_factor, d, n, d_units, frames, window, shift, ctx->os, ctx->d_wave + st.os_flags + first, epoch, ctx->d_error, s));
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);

@@ -109,6 +109,8 @@ struct StepDesc {
                                        * transform rides on this step's inverse (fir_inv_kernel CHAIN) in per-frame calls */
     bool fast = false;                /* segment step: every unit of every channel works in place on 8192-sample frames -> the two-per-CU kernel (segf) */
     bool premac_ok = false;           /* FIR step: split shape (few channels), 8192-sample frames, every channel with K >= 2: the terms k >= 1 can be summed ahead */
+    int os_factor = 0;                /* 2 / 4: the step is ONE oversampled shaper per channel, run as a launch of its own (seg.hip os_tiles_kernel) */
+    int os_flags = -1;                /* ... and its per-channel flags start here in d_wave */
     int wave_tickets = -1;            /* segment step: first of its GDG_WAVE_GROUPS ticket counters in d_wave (seg.hip, WAVE), -1: none */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
@@ -145,6 +147,8 @@ struct gdg_ctx {
      * workgroup of its own, the frames meeting unit by unit through counters in HBM -- a GPU's share of the 512-channel job on eight GPUs is 64
      * channels, and one workgroup per channel walking the window leaves 3/4 of the CUs idle (64 channels, W = 16: 417 us per segment launch,
      * 52 of the 77 us per frame).  0: never.  gdg_ctx_set_option("seg_wave_max_channels"), env GDG_SEG_WAVE_MAX. */
+    int seg_os_tiles_max = 192;                /* calls of up to this many channels run oversampled shapers as launches of their own, a workgroup per tile
+                                                * (option "seg_os_tiles_max_channels"; 0: never) */
     int seg_wave_max = 192;                    /* 64 / 128 / 192 / 256 channels, W = 16: 77 / 102 / 128 / 146 us per frame walking, 51 / 87 / 125 / 160 in flight */
     int scan_tables_max = 1024;                /* scan tables kept before a plan rebuild drops them all (a caller sweeping a parameter) */
     int pcie_groups_forced = 0;                /* channel groups of the host-buffer calls; 0: by channel count */

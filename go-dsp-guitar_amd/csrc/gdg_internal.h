@@ -190,6 +190,10 @@ hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_se
 hipError_t gdg_launch_segf(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
                            gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0);
 int gdg_segf_supported(int unit_type);
+/* an oversampled shaper (overdrive / distortion / excess at 2 x or 4 x) as a launch of its own, one workgroup per (channel, frame, tile): the
+ * descriptors are segment descriptors whose unit_begin names the shaper; d_flags: one int per channel, any value but `epoch` (seg.hip) */
+hipError_t gdg_launch_os_tiles(int factor, const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames,
+                               gdg_shift shift, gdg_os_tables os, int *d_flags, int epoch, int *d_error, hipStream_t s);
 hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_hist, double *d_up, double *d_down, gdg_os_tables os, hipStream_t s);
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);

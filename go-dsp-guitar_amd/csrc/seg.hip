@@ -2485,6 +2485,131 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+
+/* ---- an oversampled shaper as a launch of its own: one workgroup per TILE (round 5) -----------------------------------------------------------
+ * The oversampled overdrive / distortion / excess is the one unit of the chains that is heavy (46 us per frame on one CU at 4 x: 32768
+ * exp + a 155-tap decimator) AND feed-forward: a tile of 2048 (4 x) / 4096 (2 x) outputs needs the inputs below it and nothing a neighbour
+ * computes.  With the chip full that does not matter; with 64 channels (a GPU's share of a split job, BASELINE config 3) the unit runs on
+ * 64 of 256 CUs for 1/3 of the step.  The plan then cuts the segment at the unit (api_plan.cpp) and this kernel runs one workgroup per
+ * (channel, frame of the window, tile): the tile's inputs and the BACK + 6 samples below them come straight from the caller's row in HBM
+ * (frames of a window are consecutive in it, so the previous frame's tail is simply below the frame), the oversampled, shaped stream is
+ * made in LDS in the same polyphase layout by the same code (os_decimate, shape) as the in-segment unit, the outputs go to the output row.
+ * What the in-segment unit keeps as STATE between frames -- the last 8 inputs and the last TAPS - 1 shaped oversampled samples -- is
+ * recomputed here from the previous frame's inputs for every frame but a call's first (the same expressions on the same operands: the same
+ * bits); the call's first frame reads the unit's state, its last frame writes it.  One flag per channel orders that pair: the last
+ * workgroup does not store before the first has loaded (a bounded spin; both are in flight together in every launch that has both). */
+template <int F>
+__global__ void __launch_bounds__(SEG_T)
+os_tiles_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
+                gdg_os_tables os, int *__restrict__ flags, int epoch, int *d_error) {
+    constexpr int TAPS = OsCfg<F>::TAPS, BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, TILE = OsCfg<F>::S, PH = OsCfg<F>::PH, HALO = BACK + 6;
+    static_assert(TILE + HALO + 8 <= 8192 + 256, "a tile's inputs fit one frame buffer");
+    const int tid = seg_tid();
+    const int tiles = (N + TILE - 1) / TILE;
+    const int f = blockIdx.x / tiles, tile = blockIdx.x - f * tiles;
+    gdg_seg_chan ch = chans[blockIdx.y];
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
+    if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
+    const gdg_seg_unit *U = units + ch.unit_begin;
+    Shaper S;
+    S.type = U->type; S.valve = U->ip[4];
+    S.gain = U->dp[0]; S.drive = U->dp[1]; S.clean = U->dp[2]; S.level = U->dp[3];
+    const GDG_CONST double *taps = (const GDG_CONST double *)uniform_ptr(F == 2 ? os.tapsP2 : os.tapsP4);
+    const GDG_CONST double *lw = (const GDG_CONST double *)uniform_ptr(F == 2 ? os.lanczos2 : os.lanczos4);
+    GDG_GLOBAL double *hist = as_global(U->hist);
+    const GDG_GLOBAL double *src = as_global(ch.src) + (size_t)f * N;      /* sample 0 of this frame; negative indices: the previous frame of the row */
+    GDG_GLOBAL double *dst = as_global(ch.dst) + (size_t)f * N;
+    double *sin_ = s_a, *stage = s_b, *scr = s_scr;
+    const bool first = f == 0, last = f == n_frames - 1 && tile == tiles - 1;
+    const int o0 = tile * TILE, S_out = min(TILE, N - o0), I0 = o0 - BACK, b0 = I0 - 6;       /* b0: the lowest input index the tile touches */
+    /* inputs b0 .. o0 + S_out - 1 -> sin_[0 ..]; below the call's first frame: the unit's 8-sample history, older ones are never used */
+    for (int k = tid; k < S_out + HALO; k += SEG_T) {
+        const int i = b0 + k;
+        double v;
+        if (i >= 0 || !first) v = src[i];
+        else v = (i >= -8) ? hist[8 + i] : 0.0;
+        sin_[LX(k)] = v;
+    }
+    if (first && tile == 0) for (int q = tid; q < TAPS - 1; q += SEG_T) scr[q] = hist[8 + q];      /* the previous call's oversampled tail */
+    double keep = 0.0;
+    if (last && tid < 8) {                                  /* the last 8 inputs of the call (older frames of the row, or the old history, when N < 8 never happens: N = 8192) */
+        keep = src[N - 8 + tid];
+    }
+    __syncthreads();
+    if (first && tile == 0 && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* the state is in LDS / registers: the call's last workgroup may replace it */
+        __hip_atomic_store(as_global(flags + blockIdx.y), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    auto s_at = [&](int k) -> double { return sin_[LX(k - b0)]; };
+    const int slots = S_out + BACK;
+    for (int idx = tid; idx < min(slots + OsCfg<F>::NC, PH); idx += SEG_T) {
+        const int i = I0 + idx;
+        if (idx >= slots) {
+#pragma unroll
+            for (int r = 0; r < F; r++) stage[r * PH + idx] = 0.0;
+        } else if (i < 0 && first) {
+            /* oversampled samples of the previous CALL: the stored tail (older than it: never read) */
+#pragma unroll
+            for (int r = 0; r < F; r++) {
+                const int m = F * i + r;
+                stage[r * PH + idx] = (m >= -(TAPS - 1)) ? scr[(TAPS - 1) + m] : 0.0;
+            }
+        } else {
+            /* (i < 0 in a later frame of the window: the previous frame's samples, made again from its inputs) */
+            double w6[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) w6[t] = s_at(i - 6 + t);
+            stage[idx] = shape(S, w6[2]);
+#pragma unroll
+            for (int r = 1; r < F; r++) {
+                double up = 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; t++) up += w6[t] * lw[(r - 1) * 6 + t];
+                stage[r * PH + idx] = shape(S, up);
+            }
+        }
+    }
+    __syncthreads();
+    if (last) {
+        /* the call's new state, once the call's first workgroup has read the old one */
+        if (tid == 0 && !(first && tile == 0)) {
+            int spins = 0;
+            while (__hip_atomic_load(as_global(flags + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > GDG_WAVE_SPIN_LIMIT) { atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < TAPS - 1; q += SEG_T) {
+            const int m = F * N - (TAPS - 1) + q;
+            const int i = m / F, r = m - i * F;             /* m >= 0: N = 8192 */
+            hist[8 + q] = stage[r * PH + (i - I0)];
+        }
+        if (tid < 8) hist[tid] = keep;
+    }
+    if (R * tid < S_out) {
+        double acc[R];
+        os_decimate<F>(stage, taps, tid, acc);
+#pragma unroll
+        for (int j = 0; j < R; j += 2) {
+            seg_v2d v = { ATTENUATION_HALF_DECIBEL * clip1(acc[j]), ATTENUATION_HALF_DECIBEL * clip1(acc[j + 1]) };
+            *(GDG_GLOBAL seg_v2d *)(dst + o0 + R * tid + j) = v;
+        }
+    }
+}
+
+/* n_chans x (n_frames x tiles) workgroups; d_flags: one int per channel of the launch (any value but this launch's epoch) */
+hipError_t gdg_launch_os_tiles(int factor, const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames,
+                               gdg_shift shift, gdg_os_tables os, int *d_flags, int epoch, int *d_error, hipStream_t s) {
+    if (n_chans <= 0 || n_frames <= 0) return hipSuccess;
+    if (frames != GDG_MAX_FRAMES) return hipErrorInvalidValue;
+    if (factor == 2)
+        hipLaunchKernelGGL(os_tiles_kernel<2>, dim3(n_frames * (frames / OsCfg<2>::S), n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_flags, epoch, d_error);
+    else if (factor == 4)
+        hipLaunchKernelGGL(os_tiles_kernel<4>, dim3(n_frames * (frames / OsCfg<4>::S), n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_flags, epoch, d_error);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
 #endif
 
 /* ---- the segment kernel ------------------------------------------------------------------------------------------ */

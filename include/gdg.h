@@ -98,6 +98,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (257)
  *   seg_wave_max_channels        >= 0        windows (gdg_ctx_set_window) of up to this many channels per call: one workgroup per FRAME and channel, the
  *                                            frames of a channel meeting unit by unit -- fills the chip when the channels alone do not (192; 0: never)
+ *   seg_os_tiles_max_channels    >= 0        calls of up to this many channels run every 2 x / 4 x oversampled shaper as a launch of its own, one workgroup
+ *                                            per (channel, frame, tile of 4096 / 2048 samples) instead of one per channel (192; 0: never)
  *   plan_patch                   0, 1        parameter changes patch the device descriptors in place instead of rebuilding the plan (1)
  *   scan_tables_max              >= 1        scan tables (one per distinct coefficient set) kept before a plan rebuild drops them all (1024)
  *   pcie_groups                  0 .. 16     channel groups of the host-buffer calls, 0 = by channel count (0)
@@ -144,8 +146,8 @@ int gdg_unit_destroy(gdg_ctx *ctx, int handle);
  * reference's setter (effects/effects.go:283-345: a store under a mutex).  Cheap on a live context: the call itself stores the value; the next
  * process call re-derives that unit's constants and patches its descriptor on the device in place -- the launch plan is only rebuilt by changes of
  * a chain's layout (gdg_chain_set), of the frame size or rate, or by new filter taps.
- * "Cheap" has exceptions, all at the NEXT process call: (1) a value that moves the unit to another kernel -- oversampling switched on or off,
- * a reverb leaving the in-place shape -- rebuilds the plan (~0.5 ms for 512 channels); (2) more than `scan_tables_max` distinct coefficient
+ * "Cheap" has exceptions, all at the NEXT process call: (1) a value that moves the unit to another kernel -- any change of an oversampling
+ * factor, a reverb leaving the in-place shape -- rebuilds the plan (~0.5 ms for 512 channels); (2) more than `scan_tables_max` distinct coefficient
  * sets since the last plan (a caller sweeping a tone stack through a thousand settings) rebuilds it once to drop the table cache; (3) a unit
  * whose constants cannot be derived (prepare fails) rebuilds it to report the error; (4) a value that re-makes a history the way the reference
  * does (a longer delay, a new band-pass order) waits for the stream and may take a new arena chunk: one device malloc and one fill of up to

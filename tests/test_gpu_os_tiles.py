@@ -1,0 +1,106 @@
+"""Calls of few channels run every 2 x / 4 x oversampled shaper as a launch of its own, a workgroup per (channel, frame, tile) -- seg.hip
+os_tiles_kernel, option seg_os_tiles_max_channels.  What the in-segment unit keeps as state between frames is recomputed there from the previous
+frame's inputs, so the two forms must give the same BITS, frame by frame and in windows, through changes of the factor and of the call shape."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from helpers import synth_ir, synth_signal, rms, TOL_RMS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return entry.load_package()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    o = entry.load_oracle()
+    o.build()
+    return o
+
+
+CHAINS = {
+    "overdrive4": [("compressor", None), ("overdrive", [0, 20, 100, 0, 1, 2]), ("tone_stack", None), ("chorus", None)],
+    "distortion2_first": [("distortion", [0, 20, -3, 1]), ("cabinet", None)],
+    "excess4_last_after_fir": [("tone_stack", None), ("power_amp", "ir"), ("excess", [12, -6, 2])],
+    "two_shapers": [("overdrive", [5, 10, 50, -6, 0, 1]), ("distortion", [10, 10, 0, 2]), ("reverb", None)],
+    "shaper_only": [("overdrive", [0, 20, 100, 0, 1, 2])],
+}
+
+
+def build(pkg, nch, frames, chain, tiles):
+    ctx = pkg.Context(nch, frames)
+    ctx.set_option("seg_os_tiles_max_channels", 192 if tiles else 0)
+    for c in range(nch):
+        for name, p in chain:
+            if p == "ir":
+                ctx.append_unit(c, name, fir=synth_ir(9000, seed=3 + c))
+            else:
+                ctx.append_unit(c, name, params=p)
+    return ctx
+
+
+@pytest.mark.parametrize("name", sorted(CHAINS))
+def test_tiles_give_the_bits_of_the_in_segment_unit_and_follow_the_oracle(pkg, oracle, name):
+    nch, frames, sr, blocks = 3, 8192, 96000, 6
+    chain = CHAINS[name]
+    x = np.stack([synth_signal(c + 1, frames * blocks, sr) * (1.0 if c else 0.3) for c in range(nch)])
+    outs = {}
+    for tiles in (False, True):
+        ctx = build(pkg, nch, frames, chain, tiles)
+        got = np.zeros_like(x)
+        d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
+        for b in range(blocks):
+            d_in.upload(x[:, b * frames:(b + 1) * frames])
+            ctx.process_device(d_in, d_out, frames, sr)
+            got[:, b * frames:(b + 1) * frames] = d_out.download()
+        outs[tiles] = got
+        ctx.close()
+    np.testing.assert_array_equal(outs[True], outs[False])
+    for c in range(nch):
+        ref = oracle.Chain()
+        for uname, p in chain:
+            if p == "ir":
+                ref.append_unit(uname, fir=synth_ir(9000, seed=3 + c))
+            else:
+                ref.append_unit(uname, params=p)
+        want = np.concatenate([ref.process(x[c, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+        assert rms(outs[True][c] - want) <= TOL_RMS, (name, c)
+
+
+def test_windows_frames_and_a_change_of_factor_are_one_stream(pkg):
+    """frames 0-1 per call, 2-5 as a window of 4, 6 per call, 7-10 as a window of 4 with the factor changed from 4 x to 2 x before it, 11 per call:
+    the tiles' recomputed tails, the state they leave and the state they find must be the in-segment unit's, bit for bit"""
+    nch, frames, sr, blocks = 2, 8192, 192000, 12
+    chain = CHAINS["overdrive4"]
+    x = np.stack([synth_signal(c + 5, frames * blocks, sr) for c in range(nch)])
+    outs = {}
+    for tiles in (False, True):
+        ctx = build(pkg, nch, frames, chain, tiles)
+        ctx.set_window(4)
+        got = np.zeros_like(x)
+        d_in, d_out = ctx.alloc(nch, 4 * frames), ctx.alloc(nch, 4 * frames)
+
+        def per_frame(b):
+            blk = np.zeros((nch, 4 * frames))
+            blk[:, :frames] = x[:, b * frames:(b + 1) * frames]
+            d_in.upload(blk)
+            ctx.process_window_device(d_in.ptr, d_out.ptr, 4 * frames, 1, sr)
+            got[:, b * frames:(b + 1) * frames] = d_out.download()[:, :frames]
+
+        def window(b):
+            d_in.upload(x[:, b * frames:(b + 4) * frames])
+            ctx.process_window_device(d_in.ptr, d_out.ptr, 4 * frames, 4, sr)
+            got[:, b * frames:(b + 4) * frames] = d_out.download()
+
+        per_frame(0); per_frame(1); window(2); per_frame(6)
+        for c in range(nch):
+            ctx.unit_set_param(ctx._chains[c][1][0], 5, 1)       # the channel's overdrive (second unit of its chain): oversampling "2"
+        window(7); per_frame(11)
+        outs[tiles] = got
+        ctx.close()
+    np.testing.assert_array_equal(outs[True], outs[False])
+    assert np.isfinite(outs[True]).all() and np.abs(outs[True]).max() > 0.01
