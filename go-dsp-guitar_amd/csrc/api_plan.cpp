@@ -738,7 +738,9 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         std::vector<gdg_seg_chan> sd;
         std::vector<gdg_fir_chan> fd;
         /* a segment step goes to the two-per-CU kernel when EVERY unit of EVERY channel in it can (one launch per step) */
-        bool step_fast = !is_fir && !is_os && ctx->seg_fast && frames == GDG_MAX_FRAMES && (int)active.size() >= ctx->seg_fast_min;
+        const int n_act = (int)active.size();
+        const int fast_min = ctx->seg_fast_min;
+        bool step_fast = !is_fir && !is_os && ctx->seg_fast && frames == GDG_MAX_FRAMES && n_act >= fast_min;
         if (step_fast)
             for (auto &entry : kv.second)
                 for (int h : entry.second.handles) if (!segf_unit_ok(ctx->units[(size_t)h], frames, sample_rate)) { step_fast = false; break; }
@@ -783,7 +785,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
                         if (ui < 15 && (wu.type == GDG_UNIT_COMPRESSOR || wu.type == GDG_UNIT_TONESTACK || wu.type == GDG_UNIT_CABINET))
                             mask |= 1u << (16 + ui);                                              /* all their state is a few cells, read past the L1 */
                         const bool write_through = wu.type == GDG_UNIT_COMPRESSOR || wu.type == GDG_UNIT_TONESTACK || wu.type == GDG_UNIT_CABINET ||
-                                                   wu.type == GDG_UNIT_CHORUS || (wu.type == GDG_UNIT_REVERB && !step_fast) || (shaper && !step_fast);
+                                                   wu.type == GDG_UNIT_CHORUS || wu.type == GDG_UNIT_REVERB || (shaper && !step_fast);
                         if (!write_through) mask |= 1u << 31;
                     }
                     s.wave_mask = (int)mask;

@@ -255,7 +255,8 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);
                 /* one launch per window: a channel's workgroup walks its frames in order, the units' state runs through them */
                 /* ... unless the channels are few: then a workgroup per frame, the frames of a channel meeting unit by unit (seg.hip, WAVE) */
-                int *tickets = (window > 1 && n <= ctx->seg_wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
+                /* (by the CALL's channel count, not the group's: two groups of 256 channels fill the chip like one launch of 512) */
+                int *tickets = (window > 1 && (int)active.size() <= ctx->seg_wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
                 const int epoch = tickets ? (ctx->wave_epoch = (ctx->wave_epoch % 0x3ffffff) + 1) : 0;          /* epoch * 32 + frame fits an int */
                 if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch));
                 else HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch));

@@ -138,18 +138,22 @@ struct gdg_ctx {
     std::vector<char> plan_unit_fast;          /* ... and whether its segment runs on the two-per-CU kernel (scan tables for 16-sample chunks) */
     std::vector<char> plan_unit_fast_ok;       /* ... and whether the unit itself could (segf_unit_ok at plan time): a change of that rebuilds the plan */
     bool seg_fast = true;                      /* GDG_SEG_FAST=0: every segment on the general kernel (A/B measurements, bit-identity tests) */
-    int seg_fast_min = 257;                    /* GDG_SEG_FAST_MIN: fewest channels of a call that take the two-per-CU kernel.  Up to a chip's worth of
-                                                * channels (256 CUs) the general kernel's 1024 threads per channel run in ONE round and finish a frame
-                                                * sooner (64 channels: 158 vs 163 us per step, 128: 214 vs 217, 256: 301 vs 305; W = 16: 77 / 102 / 147 vs
-                                                * 83 / 108 / 152 us per frame); beyond that it needs a second round and the two-per-CU kernel wins
-                                                * (512: 75-81 vs 60-65 us per segment launch; profiles/fast_min_ab_r04.txt) */
+    int seg_fast_min = 128;                    /* GDG_SEG_FAST_MIN: fewest channels of a call that take the two-per-CU kernel.  Per-frame calls of up to a chip's
+                                                * worth of channels finish a frame 1-3 % sooner on the general kernel (one round of 1024-thread workgroups; 128
+                                                * channels 214 vs 217 us per step, 256: 301 vs 305; profiles/fast_min_ab_r04.txt) -- but windows of few channels
+                                                * run a workgroup per frame (WAVE, below), and there twice the frames in flight are worth 7-13 % from 128 channels
+                                                * on (W = 16: 96 channels 65.1 vs 63.0 us per frame, 128: 83.1 vs 76.8, 256: 159 vs 137.6; not from 96: per-frame
+                                                * calls of 96 channels lose 13 % -- pairs of 512-thread workgroups land on one CU beside the premac).  ONE threshold for both
+                                                * kinds of call: the two builds differ in the association of their scans (~1e-16), and a window has to give the
+                                                * bits of the same frames called one by one. */
     /* Windows of few channels (seg.hip, WAVE): up to this many channels per launch a window's segment launch puts every FRAME of a channel on a
      * workgroup of its own, the frames meeting unit by unit through counters in HBM -- a GPU's share of the 512-channel job on eight GPUs is 64
      * channels, and one workgroup per channel walking the window leaves 3/4 of the CUs idle (64 channels, W = 16: 417 us per segment launch,
      * 52 of the 77 us per frame).  0: never.  gdg_ctx_set_option("seg_wave_max_channels"), env GDG_SEG_WAVE_MAX. */
     int seg_os_tiles_max = 192;                /* calls of up to this many channels run oversampled shapers as launches of their own, a workgroup per tile
                                                 * (option "seg_os_tiles_max_channels"; 0: never) */
-    int seg_wave_max = 192;                    /* 64 / 128 / 192 / 256 channels, W = 16: 77 / 102 / 128 / 146 us per frame walking, 51 / 87 / 125 / 160 in flight */
+    int seg_wave_max = 448;                    /* W = 16, us per frame, walk -> a workgroup per frame: 64 channels 77 -> 48, 128: 102 -> 77, 256: 146 -> 138, 384: 222 -> 206;
+                                                * 512: 259 -> 263 (the walk wins once two workgroups per CU are all busy anyway) */
     int scan_tables_max = 1024;                /* scan tables kept before a plan rebuild drops them all (a caller sweeping a parameter) */
     int pcie_groups_forced = 0;                /* channel groups of the host-buffer calls; 0: by channel count */
     int device_groups_env = 0;                 /* GDG_DEVICE_GROUPS: the debug override of gdg_ctx_set_overlap(0) */

@@ -1426,7 +1426,9 @@ __device__ __attribute__((noinline)) void allpass_generic(double *buf, double *r
  * is WHERE values wait: the tapped sums and dry * x stay in registers while the all-passes run in the buffer, the frame joins the delay
  * line (from registers) as soon as every thread has consumed its taps, and the tap loads come in two batches (16 sixteen-byte loads in
  * flight per lane instead of 32: the register file is shared by two workgroups). */
-UNIT_FN unit_reverb(UNIT_ARGS) {
+/* wt (a frame per workgroup, WAVE): the two meetings of the general build's reverb (below) -- the delay line is handed on once this frame's
+ * pairs are in it and its taps are loaded, the all-pass rings are waited for separately */
+UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
     const int tid = seg_tid();
@@ -1444,7 +1446,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
     {
         double *r = dl_ring + DL;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { M[k] = Uc->jp[5 + k] - 1; rp[k] = as_global(is_state)[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
+        for (int k = 0; k < 3; k++) { M[k] = Uc->jp[5 + k] - 1; rp[k] = wt ? 0 : as_global(is_state)[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
     }
     constexpr int QA = REVERB_QMAX, QB = 3 * 1024 / SEG_T, QC = 1024 / SEG_T, NP = REVERB_QMAX / 2;      /* NP sample pairs per thread */
     GDG_GLOBAL double *g = as_global(dl_ring);
@@ -1468,8 +1470,8 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
             const double x0 = in[LX(i0)], x1 = in[LX(i0 + 1)];
             int p = dl_wp + i0;                             /* dl_wp < DL, i0 < N <= DL */
             if (p >= DL) p -= DL;
-            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
-            else { g[p] = x0; g[0] = x1; }
+            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; st_v2d((GDG_GLOBAL seg_v2d *)(g + p), v, wt); }
+            else { st_f64(g + p, x0, wt); st_f64(g, x1, wt); }
         }
         __syncthreads();                                    /* every thread has its pair out of the buffer: tap 0 may overwrite it */
         const int rtop = N - 1 - taps[0];                   /* the newest value any tap of this frame reads (negative) */
@@ -1542,8 +1544,8 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
             const double x0 = in[LX(i0)], x1 = in[LX(i0 + 1)];
             int p = dl_wp + i0;                             /* dl_wp < DL, i0 < N <= DL */
             if (p >= DL) p -= DL;
-            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
-            else { g[p] = x0; g[0] = x1; }
+            if (p + 1 < DL) { seg_v2d v = { x0, x1 }; st_v2d((GDG_GLOBAL seg_v2d *)(g + p), v, wt); }
+            else { st_f64(g + p, x0, wt); st_f64(g, x1, wt); }
             double pre0 = 0.0, pre1 = 0.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1557,7 +1559,15 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         }
     }
     }
-    if (tid == 0) as_global(is_state)[0] = (dl_wp + N) % DL;
+    if (tid == 0) st_i32(as_global(is_state), (dl_wp + N) % DL, wt);
+    if (wt) {
+        /* every tap of this frame is in registers / in the buffer (the union path ends on a barrier; the batches consumed their loads before
+         * they stored): the delay line goes to the next frame, the all-pass rings are waited for */
+        wave_post(gate.cell - 1, gate.wf_next, gate.release);
+        wave_wait(gate.cell, gate.wf, false, gate.d_error);
+#pragma unroll
+        for (int k = 0; k < 3; k++) rp[k] = as_global(is_state)[1 + k];
+    }
     /* 2. ring heads of the three all-passes, and the tapped sums back into registers (own cells, written above: the mix wants them after
      * the all-passes have replaced them in the buffer) */
     double pm_a[QA], pm_b[QB], pm_c[QC];
@@ -1571,8 +1581,8 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
      * completes the buffer) */
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    allpass_chains<QA>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1]);
-    allpass_chains<QB>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2]);
+    allpass_chains<QA>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1], wt);
+    allpass_chains<QB>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2], wt);
     /* the dry samples come back from the delay line (this thread's own stores of step 1) while the last all-pass runs */
     seg_v2d xr[NP];
 #pragma unroll
@@ -1582,7 +1592,7 @@ UNIT_FN unit_reverb(UNIT_ARGS) {
         if (p + 1 < DL) xr[q] = *(const GDG_GLOBAL seg_v2d *)(g + p);
         else { xr[q].x = g[p]; xr[q].y = g[0]; }
     }
-    allpass_chains<QC>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3]);
+    allpass_chains<QC>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3], wt);
 #pragma unroll
     for (int q = 0; q < REVERB_QMAX; q++) {
         const int i = 2 * (tid + (q >> 1) * SEG_T) + (q & 1);
@@ -2676,16 +2686,12 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N, WAVE); break;
         case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N, WAVE); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N, WAVE); break;
-#ifdef SEG_FAST
-        case GDG_UNIT_REVERB: unit_reverb(U, flip, N, WAVE); break;
-#else
         case GDG_UNIT_REVERB: {
             const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch, d_error };
             unit_reverb(U, flip, N, WAVE, gate);
             second = WAVE ? 1 : 0;
             break;
         }
-#endif
 #ifndef SEG_FAST                                    /* units that read other threads' cells of their input after writing output, or stage a frame: two buffers */
         case GDG_UNIT_FLANGER:
         case GDG_UNIT_PHASER: unit_flanger(U, flip, N, WAVE); break;

@@ -95,9 +95,9 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *                                            taps: below, the two cross-stream hops cost more than they hide)
  *   share_ir_spectra             0, 1        = gdg_ctx_share_ir_spectra (1)
  *   seg_two_per_cu               0, 1        segments of in-place units on 8192-sample frames take the 512-thread kernel, two workgroups per CU (1)
- *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (257)
+ *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (128)
  *   seg_wave_max_channels        >= 0        windows (gdg_ctx_set_window) of up to this many channels per call: one workgroup per FRAME and channel, the
- *                                            frames of a channel meeting unit by unit -- fills the chip when the channels alone do not (192; 0: never)
+ *                                            frames of a channel meeting unit by unit -- fills the chip when the channels alone do not (448; 0: never)
  *   seg_os_tiles_max_channels    >= 0        calls of up to this many channels run every 2 x / 4 x oversampled shaper as a launch of its own, one workgroup
  *                                            per (channel, frame, tile of 4096 / 2048 samples) instead of one per channel (192; 0: never)
  *   plan_patch                   0, 1        parameter changes patch the device descriptors in place instead of rebuilding the plan (1)

@@ -1,5 +1,5 @@
 """The two-per-CU segment kernel (seg.hip compiled with SEG_FAST: 512 threads per channel, ONE LDS frame buffer, every unit in place) takes over
-segments of 8192-sample frames from 257 channels on.  Here it is forced on for small contexts (GDG_SEG_FAST_MIN=0) and held against the oracle
+segments of 8192-sample frames from 128 channels on.  Here it is forced on for small contexts (GDG_SEG_FAST_MIN=0) and held against the oracle
 (1e-9 RMS), against the general kernel (same arithmetic, another association of the workgroup scans: ~1e-16) and against itself in windows
 (bit for bit); streams that move between the two kernels -- frame-size changes, a unit that loses its eligibility -- must stay continuous:
 both kernels share one state layout in HBM."""
@@ -126,7 +126,7 @@ def test_a_stream_moves_between_the_two_kernels_without_a_seam(oracle, monkeypat
 
 
 def test_small_contexts_stay_on_the_general_kernel_by_default(monkeypatch):
-    """up to 256 channels per call the general kernel finishes a frame sooner (one round of 1024-thread workgroups): same bits as GDG_SEG_FAST=0"""
+    """below 128 channels per call the general kernel is the default (one round of 1024-thread workgroups; the two-per-CU build takes over where windows of a workgroup per frame gain from twice the frames in flight): same bits as GDG_SEG_FAST=0"""
     pkg = package()
     sr = 48000
     x = np.stack([0.7 * synth_signal(c, 2 * B, sr) for c in range(2)])
