@@ -854,7 +854,8 @@ def main():
                                                        "(channels are independent: the job's step time is the slowest shard's step time); launch shapes "
                                                        "are the library's own by channel count: per-frame calls of <= 96 channels run the split multiply-accumulate with "
                                                        "the sums over the partitions already in the delay line made ahead of the frame (option fir_premac), windows of "
-                                                       "<= 192 channels run a workgroup per frame and channel (option seg_wave_max_channels)",
+                                                       "<= 448 channels run a workgroup per frame and channel (option seg_wave_max_channels), oversampled shapers of calls of <= 192 channels "
+                                                       "run as launches of their own, a workgroup per tile (option seg_os_tiles_max_channels)",
                                                "legs": legs}
                 if frames == 8192:
                     extras["sharded_batch"] = sharded_batch_one_gpu(pkg, local_rank, args.channels, 2, sr, taps)
