@@ -215,7 +215,9 @@ struct gdg_ctx {
      * as its own bin-tiled kernel (32 workgroups per channel) followed by the inverse (profiles/channels_sweep_r02.txt).
      * GDG_FIR_FUSED=0 / 1 forces one shape (A/B measurements). */
     int fir_fused = -1;
-    int fir_split_max = 96;           /* GDG_FIR_SPLIT_MAX: largest launch (channels) that takes the split shape */
+    int fir_split_max = 128;          /* largest launch (channels) that takes the split shape.  Round 2 measured the two shapes equal at 128 channels
+                                       * (220 us per step either way) and set 96; with the sums made ahead of the frame (premac, below) the split shape
+                                       * takes 207 us there, at 192 channels the fused kernel wins again (252 vs 274) */
     bool fir_chain = true;            /* GDG_FIR_CHAIN=0: adjacent power amps keep separate launches (A/B measurements, bit-identity tests) */
     double *d_os = nullptr;
     gdg_os_tables os;

@@ -85,7 +85,7 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  * on an option beyond the last bits (which association a sum takes); unknown keys and values out of range are GDG_ERR_INVALID.
  *   key                          values      meaning (default)
  *   fir_fused                    -1, 0, 1    spectrum multiply-accumulate inside the inverse transform's kernel: by channel count / never / always (-1)
- *   fir_split_max_channels       >= 0        with fir_fused = -1: launches of up to this many channels take the bin-tiled multiply-accumulate (96)
+ *   fir_split_max_channels       >= 0        with fir_fused = -1: launches of up to this many channels take the bin-tiled multiply-accumulate (128)
  *   fir_chain_adjacent_amps      0, 1        a power amp's inverse transform also makes the forward transform of the amp behind it (1)
  *   fir_premac                   0, 1        per-frame calls of few channels (the split launch shape): when a call ends, the sums of the NEXT frame's
  *                                            convolution over the partitions that are already in the delay line (7 of 8 at 65536 taps) are launched on a
