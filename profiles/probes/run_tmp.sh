@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r05p_pytest_gpu.txt 2>&1
-for n in 96 128 160; do NCH=$n MODE=frame NGROUPS_LIST=1 KINDS=0 timeout 300 python profiles/probes/small_ctx.py; done > gpurun_out/r05p_small.txt 2>&1
+timeout 600 python -m pytest tests/test_gpu_tuner_spatializer.py -x -q > gpurun_out/r05s_tuner_tests.txt 2>&1
+timeout 600 python profiles/probes/tuner_pairs.py > gpurun_out/r05s_tuner_pairs.txt 2>&1
