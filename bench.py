@@ -477,6 +477,16 @@ def other_configs(pkg, device):
         gbs = (nbytes / (avg * 1e-3) / 1e9) if avg else None
         roof[name] = {"bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg, "launches": n, "achieved": gbs, "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None}
+    if roof["tuner"]["avg_launch_ms"]:
+        # The short-lag analysis is FP64-issue bound, not HBM bound (profiles/experiments/README.md, r05): ~460 000 vector lane-operations per
+        # 4096-sample block (4096-point transform with its twiddle powers, un-packing, accumulation), 24 blocks + the inverse per analysis;
+        # a CU issues 64 FP64 lanes per clock (16 per SIMD) at 2.4 GHz.
+        lane_ops = nch * 25 * 460e3
+        peak = 256 * 64 * 2.4e9
+        roof["tuner"]["fp64_issue"] = {"lane_operations_per_launch": lane_ops, "peak_lane_operations_per_s": peak,
+                                       "achieved": lane_ops / (roof["tuner"]["avg_launch_ms"] * 1e-3),
+                                       "frac": lane_ops / (roof["tuner"]["avg_launch_ms"] * 1e-3) / peak,
+                                       "note": "estimate from the instruction mix; the bound that applies to this kernel (`frac` above is against HBM)"}
     d_x.free()
     d_lr.free()
     ctx.close()
