@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_tuner_spatializer.py -x -q > gpurun_out/r05s_tuner_tests.txt 2>&1
-timeout 600 python profiles/probes/tuner_pairs.py > gpurun_out/r05s_tuner_pairs.txt 2>&1
+timeout 900 python profiles/probes/fuzz_soak.py 6000 700 > gpurun_out/r05t_fuzz_soak2.txt 2>&1
+echo "exit $?" >> gpurun_out/r05t_fuzz_soak2.txt
