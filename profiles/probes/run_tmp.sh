@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python profiles/probes/fuzz_soak.py 6000 700 > gpurun_out/r05t_fuzz_soak2.txt 2>&1
-echo "exit $?" >> gpurun_out/r05t_fuzz_soak2.txt
+s=$(date +%s.%N)
+timeout 900 python bench.py > gpurun_out/bench_r05_final.json 2> gpurun_out/bench_r05_final.err
+e=$(date +%s.%N)
+echo "bench.py wall: $(echo "$e - $s" | bc) s, exit $?" > gpurun_out/bench_r05_final.time
