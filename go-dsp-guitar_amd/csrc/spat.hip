@@ -43,8 +43,15 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
         }
         return;
     }
+    /* Workgroups are dealt to the eight XCDs round robin, and a tile reads three places of every channel row: its own 32 samples and the two
+     * neighbours of the delayed sample, up to H samples back -- other tiles' samples.  With tile = blockIdx a cache line's three readers sat on
+     * three XCDs, each fetching its own copy into its own L2; dealt so that an XCD works on a contiguous run of tiles (tiles / 8 of them = 1024
+     * samples at the batch block size) they share one: 11.5-12.1 -> 10.6-10.9 us per launch (same box, profiles/spat_shapes_r05.txt; wider tiles
+     * and more threads all lose: 64 x 8 15 us, 64 x 16 17, 128 x 4 23, 16 x 32 17). */
+    const int bx = (int)blockIdx.x;
+    const int tile = (tiles % 8 == 0) ? (bx & 7) * (tiles >> 3) + (bx >> 3) : bx;
     const int s = tid & (SPAT_TILE - 1), q = tid / SPAT_TILE;
-    const int j = min((int)blockIdx.x * SPAT_TILE + s, frames - 1);      /* lanes past the end repeat the last sample and are not stored */
+    const int j = min(tile * SPAT_TILE + s, frames - 1);                 /* lanes past the end repeat the last sample and are not stored */
     const int groups = (nch + SPAT_GROUP - 1) / SPAT_GROUP;
     /* the channel descriptors, once per workgroup, into LDS (behind the partials); very wide shards read them from HBM instead */
     gdg_spat_chan *l_ch = reinterpret_cast<gdg_spat_chan *>(part + (size_t)groups * 2 * SPAT_TILE);
@@ -53,7 +60,7 @@ spat_kernel(const gdg_spat_chan *__restrict__ chans, int nch, const double *__re
         __syncthreads();
     }
 #define s_ch (LDS_DESC ? (const gdg_spat_chan *)l_ch : chans)
-    const int side = tid / SPAT_TILE, jj = blockIdx.x * SPAT_TILE + s;      /* the 2 x 32 finishing threads: (side, sample) */
+    const int side = tid / SPAT_TILE, jj = tile * SPAT_TILE + s;            /* the 2 x 32 finishing threads: (side, sample) */
     double acc = 0.0;
     for (int g0 = 0; g0 < groups; g0 += SPAT_MAX_GROUPS) {
     const int g1 = min(groups, g0 + SPAT_MAX_GROUPS);
