@@ -4,6 +4,7 @@
  * There is no CPU compute path here: every sample is produced by a HIP kernel.
  */
 #include "ctx.h"
+#include <future>
 
 #define GDG_BLOCK_SIZE 8192           /* controller/controller.go:36 */
 
@@ -55,6 +56,7 @@ static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes, size_t up_half_byt
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_ready[h], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_moved[h], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_up_ready[h], hipEventDisableTiming));
+            for (int c = 0; c < 4; c++) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->batch_chunk[h][c], hipEventDisableTiming));
         }
     }
     if (up_half_bytes > ctx->h_up_cap) {
@@ -80,11 +82,11 @@ static int ensure_batch_pipe(gdg_ctx *ctx, size_t half_bytes, size_t up_half_byt
 
 /* host memcpy pieces (dst, src, bytes), spread over the copy threads */
 struct BatchPiece { unsigned char *dst; const unsigned char *src; size_t bytes; };
-static void move_pieces(gdg_ctx *ctx, const std::vector<BatchPiece> &pieces) {
+static void move_pieces(gdg_ctx *ctx, const std::vector<BatchPiece> &pieces, int which = 0) {
     size_t total = 0;
     for (auto &p : pieces) total += p.bytes;
     copy_rows_parallel(ctx, 0, pieces.size(), [&](size_t i) { memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); },
-                       pieces.empty() ? 0 : total / pieces.size());
+                       pieces.empty() ? 0 : total / pieces.size(), which);
 }
 
 /*
@@ -241,34 +243,55 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
         if (ctx->all_channels.empty()) for (int c = 0; c < ctx->nch; c++) ctx->all_channels.push_back(c);
         struct Step { size_t off; int w; };
         std::vector<Step> steps;
-        for (size_t off = 0; off < length;) {
+        /* A long run opens with a quarter window and a half window: the device has nothing to do until the first step's bytes are gathered and uploaded (16 blocks
+         * of 512 files: 1.9 + 2.4 ms), and what it computes first comes down and is scattered while nothing else waits for the host.  The blocks
+         * that step leaves over make the tail shorter the same way (W/2, W/4: the last download and scatter are a quarter step's).  Window sizes
+         * only change the time blocking, never a sample (tests/test_gpu_window.py). */
+        size_t off0 = 0;
+        if (W >= 8 && length >= (size_t)3 * W * B) {                             /* W/4, W/2, then whole windows: each step's upload fits behind the step before */
+            steps.push_back({ 0, W / 4 });
+            steps.push_back({ (size_t)(W / 4) * B, W / 2 });
+            off0 = (size_t)(W / 4 + W / 2) * B;
+        }
+        for (size_t off = off0; off < length;) {
             int w = W;
             while ((size_t)w * B > length - off) w >>= 1;                        /* the tail: windows of W/2, W/4 .. 1 */
             steps.push_back({ off, w });
             off += (size_t)w * B;
         }
-        auto scatter = [&](size_t i) {                                           /* step i's bytes from its pinned half into the files */
+        /* A step comes down in `chunks` pieces of whole rows (the float64 rows of a shard ride with the last one), an event behind each: the
+         * scatter of piece c runs while piece c + 1 is on the bus -- the run's tail (last download, then last scatter) and its head are that
+         * much shorter; in between the device sets the pace either way. */
+        auto chunks_of = [&](size_t i) { return (steps[i].w >= 4 && enc_rows >= 8) ? 4 : 1; };
+        auto chunk_rows = [&](size_t i, int c) { return (size_t)enc_rows * (size_t)c / (size_t)chunks_of(i); };      /* first encoded row of piece c */
+        auto scatter = [&](size_t i) -> int {                                    /* step i's bytes from its pinned half into the files */
             const unsigned char *src = ctx->h_batch[i & 1];
             const size_t wb = (size_t)steps[i].w * B, row_bytes = wb * out_width, at = steps[i].off * out_width;
             const size_t f64_at = ((size_t)enc_rows * row_bytes + 15) & ~(size_t)15;
-            copy_rows_parallel(ctx, 0, (size_t)enc_rows + (size_t)f64_rows, [&](size_t o) {
-                if (o < (size_t)enc_rows) {
-                    /* NULL: "skipping output" (:3143); a shard's row N is the metronome track */
-                    void *dst = (sharded && o == (size_t)N) ? shard->metronome_bytes : out_bytes[o];
-                    if (dst) memcpy(static_cast<unsigned char *>(dst) + at, src + o * row_bytes, row_bytes);
-                } else {
-                    const size_t k = o - (size_t)enc_rows;
-                    double *dst = k == 0 ? shard->master_left : (k == 1 ? shard->master_right : shard->metronome);
-                    memcpy(dst + steps[i].off, src + f64_at + k * wb * sizeof(double), wb * sizeof(double));
-                }
-            }, row_bytes);
+            const int K = chunks_of(i);
+            for (int c = 0; c < K; c++) {
+                HIP_TRY(ctx, hipEventSynchronize(ctx->batch_chunk[i & 1][c]));    /* piece c has landed */
+                const size_t o0 = chunk_rows(i, c), o1 = (c + 1 == K) ? (size_t)enc_rows + (size_t)f64_rows : chunk_rows(i, c + 1);
+                copy_rows_parallel(ctx, o0, o1, [&](size_t o) {
+                    if (o < (size_t)enc_rows) {
+                        /* NULL: "skipping output" (:3143); a shard's row N is the metronome track */
+                        void *dst = (sharded && o == (size_t)N) ? shard->metronome_bytes : out_bytes[o];
+                        if (dst) memcpy(static_cast<unsigned char *>(dst) + at, src + o * row_bytes, row_bytes);
+                    } else {
+                        const size_t k = o - (size_t)enc_rows;
+                        double *dst = k == 0 ? shard->master_left : (k == 1 ? shard->master_right : shard->metronome);
+                        memcpy(dst + steps[i].off, src + f64_at + k * wb * sizeof(double), wb * sizeof(double));
+                    }
+                }, row_bytes);
+            }
+            return GDG_OK;
         };
         /* the streamed inputs of step i: gathered into a pinned half by the copy threads, moved and decoded on the upload stream while
          * the block loop is busy with the steps before */
         HIP_TRY(ctx, hipEventRecord(ctx->batch_begin, ctx->stream));             /* rows zeroed, whole-file inputs decoded */
         if (n_streamed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_up_stream, ctx->batch_begin, 0));
         int up_used[2] = { 0, 0 };
-        auto stage = [&](size_t i) -> int {
+        auto stage = [&](size_t i, int pool = 0) -> int {                        /* pool 1: from the helper thread, with the upload side's copy workers */
             if (!n_streamed || i >= steps.size()) return GDG_OK;
             const int h = (int)(i & 1);
             if (up_used[h]) HIP_TRY(ctx, hipEventSynchronize(ctx->batch_up_ready[h]));     /* step i - 2 has left this half */
@@ -293,7 +316,7 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
             }
             up_used[h] = 1;
             if (n_rows) {
-                move_pieces(ctx, pieces);
+                move_pieces(ctx, pieces, pool);
                 HIP_TRY(ctx, hipMemcpyAsync(db, hb, cur, hipMemcpyHostToDevice, ctx->batch_up_stream));
                 HIP_TRY(ctx, gdg_launch_wave_decode_rows(reinterpret_cast<const gdg_decode_row *>(db), n_rows, max_count, ctx->batch_up_stream));
             }
@@ -347,8 +370,14 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
             const int h = (int)(i & 1), wb = steps[i].w * B;
             unsigned char *enc = d_enc + h * enc_bytes;
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->batch_stream, ctx->batch_ready[h], 0));
-            const size_t down = (((size_t)enc_rows * wb * out_width + 15) & ~(size_t)15) + (size_t)f64_rows * wb * sizeof(double);
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h], enc, sharded ? down : (size_t)NO * wb * out_width, hipMemcpyDeviceToHost, ctx->batch_stream));
+            const size_t row_bytes = (size_t)wb * out_width;
+            const size_t down = sharded ? (((size_t)enc_rows * row_bytes + 15) & ~(size_t)15) + (size_t)f64_rows * wb * sizeof(double) : (size_t)NO * row_bytes;
+            const int K = chunks_of(i);
+            for (int c = 0; c < K; c++) {
+                const size_t b0 = chunk_rows(i, c) * row_bytes, b1 = (c + 1 == K) ? down : chunk_rows(i, c + 1) * row_bytes;
+                if (b1 > b0) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_batch[h] + b0, enc + b0, b1 - b0, hipMemcpyDeviceToHost, ctx->batch_stream));
+                HIP_TRY(ctx, hipEventRecord(ctx->batch_chunk[h][c], ctx->batch_stream));
+            }
             HIP_TRY(ctx, hipEventRecord(ctx->batch_moved[h], ctx->batch_stream));
             return GDG_OK;
         };
@@ -357,24 +386,54 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
          * of 16 blocks where the device needs 5.7 (GDG_BATCH_TRACE).  Now step i + 2 is enqueued as soon as step i's download has finished (before
          * its bytes are scattered), while step i + 1 is already queued behind step i on the device. */
         if (trace) fprintf(stderr, "[batch] set-up %.2f ms\n", now_ms() - t_begin);
-        for (size_t i = 0; i < 2 && i < steps.size(); i++) {
-            if ((r = stage(i)) != GDG_OK) return r;
-            if ((r = enqueue_compute(i)) != GDG_OK || (r = enqueue_down(i)) != GDG_OK) return r;
+        /* Gathering step i + 2's input bytes (1.9 ms of 16 blocks x 512 files) and scattering step i's output bytes (3.0 ms) were one thread's
+         * work, one after the other: 4.8 ms per step beside the device's 4.7 -- the host set the pace half of the time.  With windows of four
+         * blocks or more the gather runs on a helper thread with copy workers of its own (copy_pool_up), one step further ahead (step i + 3 while
+         * step i is scattered; its pinned half and its device half were step i + 1's, whose upload and decode are long done -- stage() waits
+         * for their event): the host's step is the scatter alone and the device sets the pace. */
+        const bool helper = n_streamed && ws >= (size_t)4 * B && steps.size() > 3;
+        std::future<int> staged;
+        struct Join { std::future<int> &f; ~Join() { if (f.valid()) f.wait(); } } join_on_exit{ staged };     /* stage() captures this frame by reference */
+        auto on_helper = [&](size_t first, size_t last) {                        /* stage(first .. last), one after the other, on the helper thread */
+            if (first >= steps.size()) return;
+            staged = std::async(std::launch::async, [&, first, last]() -> int {
+                if (hipSetDevice(ctx->device) != hipSuccess) return GDG_ERR_HIP;
+                for (size_t k = first; k <= last && k < steps.size(); k++) { const int rr = stage(k, 1); if (rr != GDG_OK) return rr; }
+                return GDG_OK;
+            });
+        };
+        auto stage_async = [&](size_t i) { on_helper(i, i); };
+        if (helper) {
+            /* the head: step 0 is gathered here; steps 1 and 2 on the helper meanwhile, so that the first whole window's bytes are on the bus
+             * while the quarter and the half window compute */
+            if ((r = stage(0)) != GDG_OK) return r;
+            on_helper(1, 2);
+            if ((r = enqueue_compute(0)) != GDG_OK || (r = enqueue_down(0)) != GDG_OK) return r;
+            if ((r = staged.get()) != GDG_OK) return r;
+            if ((r = enqueue_compute(1)) != GDG_OK || (r = enqueue_down(1)) != GDG_OK) return r;
+        } else {
+            for (size_t i = 0; i < 2 && i < steps.size(); i++) {
+                if ((r = stage(i)) != GDG_OK) return r;
+                if ((r = enqueue_compute(i)) != GDG_OK || (r = enqueue_down(i)) != GDG_OK) return r;
+            }
         }
         if (trace) fprintf(stderr, "[batch] steps 0 and 1 staged and enqueued at %.2f ms\n", now_ms() - t_begin);
         for (size_t i = 0; i < steps.size(); i++) {
             const double t_it = now_ms();
-            if ((r = stage(i + 2)) != GDG_OK) return r;                          /* while steps i, i + 1 run: the inputs of step i + 2 go up ... */
+            if (helper) {
+                if (staged.valid() && (r = staged.get()) != GDG_OK) return r;     /* step i + 2's inputs are on their way up (i = 0: since the head) */
+                stage_async(i + 3);
+            } else if ((r = stage(i + 2)) != GDG_OK) return r;                   /* while steps i, i + 1 run: the inputs of step i + 2 go up ... */
             const double t_st = now_ms();
-            HIP_TRY(ctx, hipEventSynchronize(ctx->batch_moved[i & 1]));          /* ... step i comes down ... */
-            const double t_wait = now_ms();
-            /* step i + 2 needs step i's half of `enc` (free now) but not its pinned half: it goes onto the compute stream BEFORE the scatter, so
-             * the loop compute -> download -> compute spans 5.7 + 4.0 ms per two steps and the device, not the host, sets the pace */
+            const double t_wait = t_st;
+            /* step i + 2 needs step i's half of `enc` (the compute stream waits for its download itself) but not its pinned half: it goes onto
+             * the compute stream BEFORE the scatter, so the loop compute -> download -> compute spans 5.7 + 4.0 ms per two steps and the device,
+             * not the host, sets the pace */
             if (i + 2 < steps.size() && (r = enqueue_compute(i + 2)) != GDG_OK) return r;
             const double t_enq = now_ms();
-            scatter(i);                                                          /* ... and goes into the files */
+            if ((r = scatter(i)) != GDG_OK) return r;                            /* ... step i comes down and goes into the files, piece by piece */
             if (i + 2 < steps.size() && (r = enqueue_down(i + 2)) != GDG_OK) return r;     /* its pinned half is free again */
-            if (trace) fprintf(stderr, "[batch] step %zu: stage %zu %.2f | wait for the download %.2f | enqueue %zu %.2f | scatter %.2f  (at %.2f ms)\n", i, i + 2,
+            if (trace) fprintf(stderr, "[batch] step %zu: stage %zu %.2f | (%.2f) | enqueue %zu %.2f | download + scatter %.2f  (at %.2f ms)\n", i, i + 2,
                                t_st - t_it, t_wait - t_st, i + 2, t_enq - t_wait, now_ms() - t_enq, now_ms() - t_begin);
         }
         return check_device_error(ctx);

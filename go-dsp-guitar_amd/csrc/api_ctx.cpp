@@ -285,6 +285,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
         if (ctx->h_batch[h]) hipHostFree(ctx->h_batch[h]);
         if (ctx->batch_ready[h]) hipEventDestroy(ctx->batch_ready[h]);
         if (ctx->batch_moved[h]) hipEventDestroy(ctx->batch_moved[h]);
+        for (int c = 0; c < 4; c++) if (ctx->batch_chunk[h][c]) hipEventDestroy(ctx->batch_chunk[h][c]);
     }
     if (ctx->batch_stream) hipStreamDestroy(ctx->batch_stream);
     for (int h = 0; h < 2; h++) {
@@ -299,6 +300,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     if (ctx->h_stage_out) hipHostFree(ctx->h_stage_out);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     destroy_copy_pool(ctx->copy_pool);
+    destroy_copy_pool(ctx->copy_pool_up);
     delete ctx;
     return GDG_OK;
 }
@@ -317,7 +319,10 @@ int gdg_ctx_set_option(gdg_ctx *ctx, const char *key, long long value) {
     if (!o) return fail(ctx, GDG_ERR_INVALID, "unknown option \"%s\"", key ? key : "(null)");
     if (value < o->lo || value > o->hi) return fail(ctx, GDG_ERR_INVALID, "option %s = %lld: %lld to %lld", key, value, o->lo, o->hi);
     enter(ctx);                                 /* free-running groups join before a launch shape changes under them */
-    if (strcmp(key, "copy_threads") == 0 && ctx->copy_pool && value != ctx->copy_threads) { destroy_copy_pool(ctx->copy_pool); ctx->copy_pool = nullptr; }
+    if (strcmp(key, "copy_threads") == 0 && value != ctx->copy_threads) {
+        if (ctx->copy_pool) { destroy_copy_pool(ctx->copy_pool); ctx->copy_pool = nullptr; }
+        if (ctx->copy_pool_up) { destroy_copy_pool(ctx->copy_pool_up); ctx->copy_pool_up = nullptr; }
+    }
     if (strcmp(key, "numa") == 0 && value != ctx->numa_mode) { int rc = numa_rebind(ctx, (int)value); if (rc != GDG_OK) return rc; }
     option_store(ctx, *o, value);
     if (o->replans) ctx->dirty = true;

@@ -400,7 +400,19 @@ int ensure_staging(gdg_ctx *ctx) {
  * this process is undefined -- the child leaves the object alone (a few hundred bytes, once). */
 void destroy_copy_pool(CopyPool *p) { if (p && p->usable()) delete p; }
 
-static CopyPool &copy_pool(gdg_ctx *ctx) {
+static CopyPool &copy_pool(gdg_ctx *ctx, int which = 0) {
+    if (which == 1) {
+        if (!ctx->copy_pool_up) {
+            int threads = ctx->copy_threads;
+            unsigned hw = std::thread::hardware_concurrency();
+            if (hw > 0 && threads > (int)hw) threads = (int)hw;
+            if (threads < 1) threads = 1;
+            const std::vector<int> *cpus;
+            numa_target(ctx, &cpus);
+            ctx->copy_pool_up = new CopyPool(threads - 1, *cpus);
+        }
+        return *ctx->copy_pool_up;
+    }
     if (!ctx->copy_pool) {
         int threads = ctx->copy_threads;
         unsigned hw = std::thread::hardware_concurrency();
@@ -418,14 +430,15 @@ static CopyPool &copy_pool(gdg_ctx *ctx) {
 int numa_rebind(gdg_ctx *ctx, int mode) {
     (void)mode;
     if (ctx->copy_pool) { destroy_copy_pool(ctx->copy_pool); ctx->copy_pool = nullptr; }
+    if (ctx->copy_pool_up) { destroy_copy_pool(ctx->copy_pool_up); ctx->copy_pool_up = nullptr; }
     return GDG_OK;
 }
 
 /* rows [a, b) of a host-side staging copy, spread over the copy workers (at least ~1 MiB per thread) */
-void copy_rows_parallel(gdg_ctx *ctx, size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes) {
+void copy_rows_parallel(gdg_ctx *ctx, size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes, int which) {
     size_t n = b > a ? b - a : 0;
     if (n == 0) return;
-    CopyPool &pool = copy_pool(ctx);
+    CopyPool &pool = copy_pool(ctx, which);
     size_t T = std::min(pool.slots(), n * row_bytes / (1u << 20) + 1);
     if (T <= 1 || n < 2 || !pool.usable()) { for (size_t i = a; i < b; i++) copy_row(i); return; }
     pool.run(T, [&](size_t t) { for (size_t i = a + n * t / T; i < a + n * (t + 1) / T; i++) copy_row(i); });

@@ -254,6 +254,7 @@ struct gdg_ctx {
     size_t h_batch_cap = 0;
     hipStream_t batch_stream = nullptr;
     hipEvent_t batch_ready[2] = { nullptr, nullptr }, batch_moved[2] = { nullptr, nullptr };
+    hipEvent_t batch_chunk[2][4] = {};         /* a step's download in four pieces: the scatter into the caller's files starts when the first has landed */
     /* ... and the streamed upload of the inputs that need no resampling: two more pinned halves, a stream, events */
     unsigned char *h_up[2] = { nullptr, nullptr };
     size_t h_up_cap = 0;
@@ -273,6 +274,7 @@ struct gdg_ctx {
     std::vector<hipEvent_t> gjoin;
     hipEvent_t gfork = nullptr;
     CopyPool *copy_pool = nullptr;             /* host copy workers of the host-buffer paths, made on first use */
+    CopyPool *copy_pool_up = nullptr;          /* ... a second set for the batch run's upload side: the next step's bytes are gathered while this step's are scattered */
     /* metronome (metronome/metronome.go): sounds in HBM, the two counters on the host */
     double *d_tick = nullptr, *d_tock = nullptr;
     uint32_t n_tick = 0, n_tock = 0;
@@ -442,7 +444,7 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                         int window = 1, int stride_out = 0, const std::vector<size_t> *group_bounds_in = nullptr);
 int spatialize_rows(gdg_ctx *ctx, const double *d_in, int in_stride, double *d_left, int out_stride, int frames);
 int tuner_enqueue_rows(gdg_ctx *ctx, const double *d_samples, size_t stride, int frames, uint32_t sample_rate);
-void copy_rows_parallel(gdg_ctx *ctx, size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes);
+void copy_rows_parallel(gdg_ctx *ctx, size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes, int which = 0);      /* which: 1 = the upload side's workers */
 void destroy_copy_pool(CopyPool *p);
 
 #pragma GCC visibility pop
