@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_end_to_end.py tests/test_host_mirror.py -x -q -m gpu > gpurun_out/r05x_tests.txt 2>&1
-timeout 600 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu -k "batch" >> gpurun_out/r05x_tests.txt 2>&1
-GDG_BATCH_TRACE=1 timeout 300 python profiles/probes/batch_kinds.py > gpurun_out/r05x_batch_trace.txt 2>&1
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r05z_pytest_gpu.txt 2>&1
+timeout 900 python bench.py > gpurun_out/bench_r05_final2.json 2> gpurun_out/bench_r05_final2.err
