@@ -383,6 +383,64 @@ def test_batch_run_streams_every_format_bit_exact(oracle):
             assert not got[lengths[c]:].any(), (W, FORMATS[c])
 
 
+@pytest.mark.parametrize("W,blocks", [(8, 31), (16, 50), (4, 14)])
+def test_long_batch_run_in_windows_gives_the_bytes_of_the_block_by_block_run(oracle, W, blocks):
+    """A run long enough for everything the batch loop does to keep the device busy (api_batch.cpp): it opens with a quarter and a half window,
+    the inputs of step i + 3 are gathered on a helper thread while step i is scattered, every step comes down in four pieces with the scatter
+    behind each, the tail runs in windows of W/2 .. 1.  None of that may change a byte: the N + 3 output files, the meters and the tuners are
+    those of the same context run block by block (W = 1: the reference's loop, compared with the oracle in the tests above).  Files of
+    different formats and lengths (zero padding from different steps on), metronome in the master mix."""
+    pkg = package()
+    rate, nch = 48000, 7                                                   # 7 + 3 rows: the four-piece download needs >= 8
+    rng = np.random.default_rng(100 + W)
+    irs = [synth_ir(1500, seed=60 + c) for c in range(nch)]
+    fmts = ["lpcm16", "lpcm24", "ieee64", "lpcm8", "lpcm32", "ieee32", "lpcm16"]
+    lengths = [blocks * BLOCK, blocks * BLOCK - 5, (blocks - 3) * BLOCK + 100, 2 * BLOCK + 1, blocks * BLOCK - BLOCK // 2, 9 * BLOCK, blocks * BLOCK]
+    files = []
+    for c in range(nch):
+        x = 0.6 * synth_signal(70 + c, lengths[c], rate)
+        files.append((oracle.wave_encode(fmts[c], x), fmts[c], rate))
+    tick, tock = rng.uniform(-0.5, 0.5, 900), rng.uniform(-0.5, 0.5, 500)
+
+    def run(window):
+        ctx = pkg.Context(nch, BLOCK)
+        for c in range(nch):
+            for name, p in CHAIN:
+                ctx.append_unit(c, name, fir=irs[c]) if p == "ir" else ctx.append_unit(c, name, params=p)
+        ctx.spatializer_set_sample_rate(rate)
+        for c in range(nch):
+            ctx.spatializer_set_position(c, 25.0 * (c - 3), 0.5 + 0.7 * c, 0.3 + 0.1 * c)
+        ctx.metronome_set_sounds(tick, tock)
+        ctx.metronome_configure(4, 170, rate)
+        ctx.meter_configure(2 * nch + 3)
+        ctx.meter_set_enabled(True)
+        ctx.set_window(window)
+        outs = [ctx.batch_run(files, rate, "lpcm24", metronome_to_master=True, run_meters=True, tuner_enqueue=True)]
+        outs.append(ctx.batch_run(files, rate, "lpcm24", metronome_to_master=True, run_meters=False, tuner_enqueue=False))   # state carries on
+        meters, tuned = ctx.meter_analyze(), ctx.tuner_analyze()
+        # ... and as ONE SHARD of a larger job (its partial master mix and the metronome leave the device as float64 behind the last piece)
+        shard = ctx.batch_run_shard(files, rate, "lpcm16", metronome=True)
+        ctx.close()
+        return outs, meters, tuned, shard
+
+    (a1, a2), am, at, ash = run(W)
+    (b1, b2), bm, bt, bsh = run(1)
+    for r in range(nch):
+        np.testing.assert_array_equal(ash[0][r], bsh[0][r], err_msg="shard output %d" % r)
+    for k in (1, 2, 3, 4):                                                 # partial left, right, metronome bytes, metronome float64
+        np.testing.assert_array_equal(ash[k], bsh[k], err_msg="shard part %d" % k)
+    assert ash[1].any() and ash[3].any() and ash[4].any()
+    assert len(a1) == nch + 3
+    for got, want in ((a1, b1), (a2, b2)):
+        for r in range(nch + 3):
+            assert got[r].size == blocks * BLOCK * 3
+            np.testing.assert_array_equal(got[r], want[r], err_msg="output %d" % r)
+    assert any(a1[r].any() for r in range(nch)) and a1[nch].any() and a1[nch + 2].any()
+    assert all(np.array_equal(x, y) for x, y in zip(am, bm))
+    assert [(t["note_index"], t["cents"]) for t in at] == [(t["note_index"], t["cents"]) for t in bt]
+    assert np.array_equal([t["frequency"] for t in at], [t["frequency"] for t in bt], equal_nan=True)      # the silent channel has no pitch
+
+
 def test_batch_release_and_reuse():
     """The batch run keeps its device buffers between runs (larger, then smaller batches reuse them); gdg_batch_release frees them and the
     next run allocates again.  Same bytes every time."""
