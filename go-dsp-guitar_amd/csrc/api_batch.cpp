@@ -396,11 +396,19 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
         struct Join { std::future<int> &f; ~Join() { if (f.valid()) f.wait(); } } join_on_exit{ staged };     /* stage() captures this frame by reference */
         auto on_helper = [&](size_t first, size_t last) {                        /* stage(first .. last), one after the other, on the helper thread */
             if (first >= steps.size()) return;
-            staged = std::async(std::launch::async, [&, first, last]() -> int {
-                if (hipSetDevice(ctx->device) != hipSuccess) return GDG_ERR_HIP;
-                for (size_t k = first; k <= last && k < steps.size(); k++) { const int rr = stage(k, 1); if (rr != GDG_OK) return rr; }
-                return GDG_OK;
-            });
+            try {
+                staged = std::async(std::launch::async, [&, first, last]() -> int {
+                    if (hipSetDevice(ctx->device) != hipSuccess) return GDG_ERR_HIP;
+                    for (size_t k = first; k <= last && k < steps.size(); k++) { const int rr = stage(k, 1); if (rr != GDG_OK) return rr; }
+                    return GDG_OK;
+                });
+            } catch (...) {                                                    /* no thread to be had: gather here, as the short runs do */
+                int rr = GDG_OK;
+                for (size_t k = first; k <= last && k < steps.size() && rr == GDG_OK; k++) rr = stage(k, 0);
+                std::promise<int> done;
+                done.set_value(rr);
+                staged = done.get_future();
+            }
         };
         auto stage_async = [&](size_t i) { on_helper(i, i); };
         if (helper) {
