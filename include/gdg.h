@@ -426,6 +426,11 @@ int gdg_batch_length(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, 
  * controller.go:3123-3219; NULL = "skipping output") of gdg_batch_length() * gdg_wave_bytes_per_sample(out_format) bytes each.
  * Only file bytes cross PCIe: the samples stay in HBM from decode to encode.  Chains, spatializer positions, metronome and meters
  * are whatever was configured on the context; their state carries on from earlier calls, like the reference's.
+ * The block loop runs in steps of up to gdg_ctx_set_window() blocks (a long run opens with a quarter and a half window, its tail
+ * runs in halves down to one block: step sizes change the time blocking, never a sample).  The host side of the call -- gathering the
+ * next steps' input bytes, scattering a finished step's output bytes -- runs beside the device on the calling thread, on the
+ * context's copy workers (option copy_threads; two sets) and, for runs of more than three steps of four blocks or more, on ONE
+ * helper thread that lives for the call; inputs and out_bytes are only read / written during the call.
  */
 int gdg_batch_run(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inputs, const gdg_batch_options *options, void *const *out_bytes);
 /*

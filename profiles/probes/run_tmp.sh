@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_end_to_end.py -x -q > gpurun_out/r05x_tests.txt 2>&1
+for g in 1 2; do echo "NGROUPS=$g"; NGROUPS=$g timeout 300 python profiles/probes/batch_kinds.py 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r05z_batch_groups.txt
