@@ -281,13 +281,17 @@ struct gdg_ctx {
     uint32_t met_sample_counter = 0, met_tick_counter = 0, met_beats = 4, met_bpm = 120, met_sr = 96000;
 };
 
-static inline int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {
+inline int fail(const gdg_ctx *ctx, int code, const char *fmt, ...) {       /* one definition, one mutex, for all files */
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        static std::mutex mu;                      /* the batch run's helper thread may fail beside the calling thread (api_batch.cpp) */
+        std::lock_guard<std::mutex> lk(mu);
+        ctx->err = buf;
+    }
     return code;
 }
 
