@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-SECONDS=100 timeout 400 python profiles/probes/wave_soak.py > gpurun_out/r05_soak_long.txt 2>&1
-echo "exit $?" >> gpurun_out/r05_soak_long.txt
+timeout 600 python -m pytest tests/test_gpu_tuner_spatializer.py tests/test_gpu_fuzz.py -x -q -k "tuner" > gpurun_out/r05_tuner_tests.txt 2>&1
+timeout 300 python profiles/probes/tuner_channels.py > gpurun_out/r05_tuner_channels.txt 2>&1
