@@ -572,8 +572,10 @@ def parity_gate(ctx_step, read_output, x_blocks, n_calls, nch, channel0, frames,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the chip needs ~10 ms of work before its step time settles (3 warm-up steps: 0.556-0.563 ms per step in the timed region, 25: 0.536,
+    # the same as runs that follow; profiles/small_shards_r05.txt section 11) -- a batch job runs for seconds, so the settled figure is the one to quote
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--channels", type=int, default=512, help="channels per GPU (weak scaling, the default)")
     ap.add_argument("--total-channels", type=int, default=0,
                     help="strong scaling: this many channels in total, split over the GPUs in contiguous blocks (0 = weak mode)")

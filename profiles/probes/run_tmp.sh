@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_tuner_spatializer.py tests/test_gpu_fuzz.py -x -q -k "tuner" > gpurun_out/r05_tuner_tests.txt 2>&1
-timeout 300 python profiles/probes/tuner_channels.py > gpurun_out/r05_tuner_channels.txt 2>&1
+timeout 900 python bench.py > gpurun_out/bench_r05_final3.json 2> gpurun_out/bench_r05_final3.err
