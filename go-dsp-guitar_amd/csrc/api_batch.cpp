@@ -394,10 +394,16 @@ static int batch_run_impl(gdg_ctx *ctx, const gdg_batch_input *inputs, int n_inp
         const bool helper = n_streamed && ws >= (size_t)4 * B && steps.size() > 3;
         std::future<int> staged;
         struct Join { std::future<int> &f; ~Join() { if (f.valid()) f.wait(); } } join_on_exit{ staged };     /* stage() captures this frame by reference */
+        /* the upload side's copy workers are made HERE, by the caller's thread, and the helper thread goes where they go: with option "numa" = 2
+         * workers are bound to the node of the thread that makes them, and a helper the scheduler happened to start on the other socket would
+         * put the gather's workers a socket away from the caller's buffers and the pinned halves */
+        const std::vector<int> *helper_cpus = nullptr;
+        if (helper) { ensure_copy_pool(ctx, 1); numa_target(ctx, &helper_cpus); }
         auto on_helper = [&](size_t first, size_t last) {                        /* stage(first .. last), one after the other, on the helper thread */
             if (first >= steps.size()) return;
             try {
                 staged = std::async(std::launch::async, [&, first, last]() -> int {
+                    if (helper_cpus) numa_bind_thread(*helper_cpus);
                     if (hipSetDevice(ctx->device) != hipSuccess) return GDG_ERR_HIP;
                     for (size_t k = first; k <= last && k < steps.size(); k++) { const int rr = stage(k, 1); if (rr != GDG_OK) return rr; }
                     return GDG_OK;

@@ -425,6 +425,8 @@ static CopyPool &copy_pool(gdg_ctx *ctx, int which = 0) {
     return *ctx->copy_pool;
 }
 
+void ensure_copy_pool(gdg_ctx *ctx, int which) { (void)copy_pool(ctx, which); }
+
 /* option "numa": the workers are re-made (bound or not) at the next host-buffer call; pinned slabs that exist stay where they are (the
  * staging slabs' addresses are in the caller's hands), those made afterwards follow the new mode -- set it before the first call */
 int numa_rebind(gdg_ctx *ctx, int mode) {

@@ -450,6 +450,7 @@ int spatialize_rows(gdg_ctx *ctx, const double *d_in, int in_stride, double *d_l
 int tuner_enqueue_rows(gdg_ctx *ctx, const double *d_samples, size_t stride, int frames, uint32_t sample_rate);
 void copy_rows_parallel(gdg_ctx *ctx, size_t a, size_t b, const std::function<void(size_t)> &copy_row, size_t row_bytes, int which = 0);      /* which: 1 = the upload side's workers */
 void destroy_copy_pool(CopyPool *p);
+void ensure_copy_pool(gdg_ctx *ctx, int which);     /* makes the pool NOW, on the calling thread (option "numa" = 2 binds the workers to the node of the thread that makes them) */
 
 #pragma GCC visibility pop
 
