@@ -13,14 +13,18 @@ spectra in HBM (d = 1).  Channels are independent: N GPUs 
 collective on the data path, no RCCL (the barrier and the max-over-ranks of the elapsed time go
 through a gloo group).
 
-Two ways to spread the job over N GPUs, both reported:
-  * default ("scaling": "weak"): 512 channels on EVERY GPU -- the headline line;
-  * --total-channels T ("scaling": "strong"): the reference's `-channels T` is a fixed job
-    (controller.go:3262-3269, :3333-3341); rank r takes the contiguous block
-    shard.channel_shard(T, N, r) and IRs / inputs are seeded by GLOBAL channel number.
-    A default run with N > 1 also times this split for T = 512 ("strong_split" in the JSON);
-    a default run with N = 1 times the per-GPU legs of that split (64 / 128 / 256 channels on
-    the one GPU: "strong_split_legs").
+The job is FIXED, like the reference's `-channels 512` (controller.go:3262-3269, :3333-3341) -- "scaling": "strong":
+  * default: the 512 channels are split over the N GPUs in contiguous blocks, rank r taking shard.channel_shard(512, N, r)
+    (BASELINE config 4 at N = 8: 64 channels per GPU; at N = 1 the whole job on the one GPU); IRs and inputs are seeded by GLOBAL
+    channel number.  `value` = 512 x frames x K / MAX-over-ranks time.
+    With N > 1 the line also carries `one_gpu_alone` (rank 0's shard stepping alone: the one-GPU prediction of this split, next to
+    the measurement), the split's batch-mode legs, `weak_scaling` (512 channels on EVERY GPU) and `config5_sharded` (256 tuners and
+    the 256 -> 2 mixdown split the same way, partial mixes added on rank 0's host); with N = 1 the per-GPU legs of the split
+    (64 / 128 / 256 channels on the one GPU: `strong_split_legs`).
+  * --weak ("scaling": "weak"): 512 channels on EVERY GPU as the headline, the strong split as the extra leg `strong_split`.
+  * --total-channels T: another fixed job, headline only.
+When --steps / --warmup are shorter than the settled default (40 after 25), `settled` carries the same context's rate after 25 more
+warm-up steps over 40 steps, so one line holds the caller's figure and the settled one.
 
 Prints ONE JSON line (rank 0) with the metric, the roofline of the dominant kernel measured with
 HIP events over the timed region, the PCIe-inclusive host-buffer rates ("end_to_end"), the other
@@ -41,6 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+METRIC = "Msamples/s through full chain incl. 64k-tap cab IR, 512ch@192kHz; %HBM roofline"
 PROFILE_EVERY = 4             # timed region: HIP events around the dominant kernel on every 4th step
 
 CHAIN = [
@@ -509,6 +514,100 @@ def other_configs(pkg, device):
     return out
 
 
+def split_job_legs(pkg, torch, dist, shard, sctx, sx, n_loc, c0, T, frames, sr, rank, ssync):
+    """The batch-mode legs of the job split over the ranks, on a rank's own shard context `sctx` (n_loc channels from global channel c0;
+    `sx`: one resident block): windows of 16 frames per call, and the batch run proper (gdg_batch_run_shard + the gather of the partial
+    master mixes on rank 0's host + gdg_batch_finish_master).  Every timing is the MAX over ranks."""
+    res = {}
+    if frames == 8192:
+        # the same split in batch mode: 16 consecutive frames per call, time blocked (every rank walks 2 windows of its shard)
+        W, windows = 16, 2
+        sctx.set_window(W)
+        wx = sx.repeat(1, W * windows).contiguous()
+        wy = torch.empty_like(wx)
+
+        def wstep():
+            for b in range(0, W * windows, W):
+                sctx.process_window_device(wx.data_ptr() + 8 * b * frames, wy.data_ptr() + 8 * b * frames, W * windows * frames, W, sr)
+        wstep()
+        w_elapsed = shard.timed_steps(wstep, 1, ssync, dist, None) / (W * windows)
+        res["batch_mode_window_16"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
+                                                         "realtime_factor": frames / sr / w_elapsed}
+        del wx, wy
+        # ... and as the batch run proper: file bytes in, file bytes out, every rank its shard (gdg_batch_run_shard), the float64
+        # partial master mixes gathered on rank 0's HOST over gloo (SURVEY 8e: "the host adds the partials") and finished there
+        blocks = 32
+        n = blocks * frames
+        for c in range(n_loc):
+            sctx.spatializer_set_position(c, -90.0 + 180.0 * (c0 + c) / max(T - 1, 1), 1.0 + 0.01 * (c0 + c), 0.5)
+        files = batch_files(n_loc, sr, blocks, channel0=c0)
+        bcall, bres = sctx.batch_shard_prepared(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0))
+        bcall()
+        held = {"r": bres}
+
+        def bstep():
+            bcall()
+        b_elapsed = shard.timed_steps(bstep, 1, ssync, dist, None)
+        dist.barrier()
+        t0 = time.perf_counter()
+        lefts, rights = shard.gather_master_partials(held["r"][1], held["r"][2], dist, dst=0)
+        master_ok = None
+        if rank == 0:
+            ml, mr = sctx.batch_finish_master("lpcm24", lefts, rights, aux=None)
+            master_ok = bool(ml.any() and mr.any())
+        t_finish = time.perf_counter() - t0
+        res["batch_run_sharded"] = {
+            "blocks": blocks, "window": W, "files_in": "lpcm16", "files_out": "lpcm24", "shard_ms_max_over_ranks": b_elapsed * 1e3,
+            "gather_and_finish_master_ms": t_finish * 1e3, "value": T * n / (b_elapsed + t_finish) / 1e6, "unit": "Msamples/s",
+            "realtime_factor": n / sr / (b_elapsed + t_finish), "master_nonzero": master_ok,
+            "what": "gdg_batch_run_shard on every rank (file bytes to file bytes, PCIe inside), partial master mixes gathered on "
+                    "rank 0's host over gloo, gdg_batch_finish_master there"}
+    return res
+
+
+def config5_sharded(pkg, torch, dist, shard, device, world, rank, total=256, frames=8192, sr=192000):
+    """BASELINE config 5 over the ranks: 256 tuners and the 256 -> 2 mixdown, rank r holding the contiguous block channel_shard(256, N, r).
+    Tuners are independent (three scalars per channel come back); the spatializer gives one partial L/R pair per rank, added in rank order on
+    rank 0's HOST (spatializer/spatializer.go:300-310) -- no device collective.  Timings are the MAX over ranks."""
+    c0, n_loc = shard.channel_shard(total, world, rank)
+    ctx = pkg.Context(n_loc, frames, device)
+    d_x = ctx.alloc(n_loc, frames)
+    d_x.upload(synth_block(n_loc, frames, sr, channel0=c0))
+    d_lr = ctx.alloc(2, frames)
+    ctx.spatializer_set_sample_rate(sr)
+    for c in range(n_loc):
+        g = c0 + c
+        ctx.spatializer_set_position(c, -90.0 + 180.0 * g / (total - 1), 0.5 + 0.01 * g, 0.5)
+    for _ in range(13):
+        ctx.tuner_enqueue_device(d_x, frames, sr)
+    ctx.spatialize_device(d_x, d_lr, frames)
+    ctx.tuner_analyze()
+    reps_an, reps_sp = 5, 20
+    for _ in range(2):
+        t_an = shard.timed_steps(lambda: ctx.tuner_analyze(raw=True), reps_an, ctx.synchronize, dist, None) / reps_an
+        t_sp = shard.timed_steps(lambda: ctx.spatialize_device(d_x, d_lr, frames), reps_sp, ctx.synchronize, dist, None) / reps_sp
+    # the mixdown's one exchange: the partial pair of every rank to rank 0's host, added there in rank order
+    ctx.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    part = d_lr.download()
+    lefts, rights = shard.gather_master_partials(part[0], part[1], dist, dst=0)
+    mix_ok = None
+    if rank == 0:
+        left, right = shard.combine_spatializer_partials(list(zip(lefts, rights)))
+        mix_ok = bool(np.isfinite(left).all() and np.isfinite(right).all() and left.any() and right.any())
+    t_mix = time.perf_counter() - t0
+    d_x.free()
+    d_lr.free()
+    ctx.close()
+    return {"tuners_total": total, "tuners_per_gpu": n_loc, "n_gpus": world,
+            "tuner": {"value": total / t_an, "unit": "analyses/s", "us_per_round_of_analyses_max_over_ranks": t_an * 1e6},
+            "spatializer": {"value": total * frames / t_sp / 1e6, "unit": "Msamples/s", "us_per_block_max_over_ranks": t_sp * 1e6,
+                            "gather_partials_and_host_sum_us": t_mix * 1e6, "mix_nonzero_and_finite": mix_ok},
+            "what": "config 5 split over the ranks in contiguous channel blocks: tuner analyses at the C boundary, the spatializer's partial L/R per rank "
+                    "(device-resident), the partials gathered over gloo and added on rank 0's host in rank order"}
+
+
 # ---- parity gate (SURVEY 8d: in the same run) ---------------------------------------------------------------------------------
 
 PARITY_TOL_RMS = 1e-9          # north_star: output matches the float64 reference within 1e-9 RMS
@@ -576,9 +675,11 @@ def main():
     # the same as runs that follow; profiles/small_shards_r05.txt section 11) -- a batch job runs for seconds, so the settled figure is the one to quote
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=25)
-    ap.add_argument("--channels", type=int, default=512, help="channels per GPU (weak scaling, the default)")
-    ap.add_argument("--total-channels", type=int, default=0,
-                    help="strong scaling: this many channels in total, split over the GPUs in contiguous blocks (0 = weak mode)")
+    ap.add_argument("--channels", type=int, default=512, help="the job's channels (default run: BASELINE's 512, split over the N GPUs); with --weak: channels per GPU")
+    ap.add_argument("--total-channels", type=int, default=-1,
+                    help="strong scaling: this many channels in total, split over the GPUs in contiguous blocks (default -1 = --channels; 0 = --weak)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --channels on EVERY GPU (a default run with N > 1 reports it as the extra leg `weak_scaling`)")
+    ap.add_argument("--plan-only", action="store_true", help="print the job's shape (ranks, scaling, channels per GPU) and stop: needs no GPU")
     ap.add_argument("--sample-rate", type=int, default=192000)
     ap.add_argument("--frames", type=int, default=8192)
     ap.add_argument("--taps", type=int, default=65536)
@@ -621,6 +722,29 @@ def main():
     distributed = world > 1
     one_device = bool(os.environ.get("GDG_BENCH_ONE_DEVICE"))     # harness self-test on a one-GPU box: every rank shares device 0
     try:
+        shape = shard.job_shape(world, rank, args.channels, args.total_channels, args.weak)
+    except shard.LaunchError as e:
+        sys.stderr.write("bench.py: %s\n" % e.msg)
+        raise
+    if args.plan_only:
+        # the job's shape as the ranks themselves derive it (no device touched): what a CPU test of the N > 1 default can check
+        shapes = [shape]
+        if distributed:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+            shapes = [None] * world
+            dist.all_gather_object(shapes, shape)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"plan_only": True, "metric": METRIC, "unit": "Msamples/s", "n_gpus": world, "n_gpus_requested": args.gpus,
+                              "scaling": shape["scaling"], "steps": args.steps, "warmup": args.warmup,
+                              "config": {"total_channels": shape["total_channels"], "channels_per_gpu": shape["channels_per_gpu"],
+                                         "channel_blocks": [[sh["channel0"], sh["channels_per_gpu"]] for sh in shapes],
+                                         "sample_rate": args.sample_rate, "frames": args.frames, "ir_taps": args.taps}}))
+        return
+    try:
         local_rank = shard.pick_device(args.gpus, local_rank, torch.cuda.device_count(), one_device)
     except shard.LaunchError as e:
         sys.stderr.write("bench.py: %s\n" % e.msg)
@@ -649,13 +773,11 @@ def main():
             raise
 
     frames, sr, taps = args.frames, args.sample_rate, args.taps
-    strong = args.total_channels > 0
-    if strong:
-        channel0, nch = shard.channel_shard(args.total_channels, world, rank)
-        total_channels = args.total_channels
-    else:
-        channel0, nch = rank * args.channels, args.channels
-        total_channels = world * args.channels
+    # the job: BASELINE's 512 channels, split over the N GPUs in contiguous blocks (config 4 at N = 8; the headline configuration itself at
+    # N = 1) -- shard.job_shape; --weak puts 512 channels on every GPU instead
+    strong = shape["scaling"] == "strong"
+    channel0, nch, total_channels = shape["channel0"], shape["channels_per_gpu"], shape["total_channels"]
+    default_job = strong and args.total_channels < 0          # the driver's own command line: every extra leg belongs to it
     # every channel has its OWN impulse responses (d = 1): identical filters would share one copy of the spectra
     n_distinct = args.distinct_irs
     ctx = make_context(pkg, nch, frames, local_rank, taps, channel0=channel0, n_distinct=n_distinct)
@@ -715,6 +837,24 @@ def main():
     ms_c, n_c = ctx.profile_read(pkg.K_FIR_MAC_CHAIN)
     timed_chain = {"ms_total": ms_c, "launches": n_c, "avg_ms": (ms_c / n_c) if n_c else None}
 
+    # The chip needs ~10 ms of work before its step time settles; a batch job runs for seconds.  When the caller's K / W are shorter than the
+    # settled default (40 steps after 25 warm-ups), the same context runs 25 more warm-up steps and 40 timed ones (same bracketing as the timed
+    # region, max over ranks), so ONE line carries the driver's figure and the settled one
+    settled = None
+    if args.steps < 40 or args.warmup < 25:
+        for _ in range(25):
+            step()
+        ctx.profile_sample(PROFILE_EVERY)
+        if os.environ.get("GDG_BENCH_TIMED_PROFILE", "1") != "0":
+            ctx.profile_enable(kinds=[pkg.K_FIR_MAC])
+        st_elapsed = shard.timed_steps(step, 40, synchronize, dist if distributed else None, None)
+        settled = {"steps": 40, "warmup_before": args.warmup + 3 * args.steps + 25, "ms_per_step": st_elapsed / 40 * 1e3,
+                   "value": total_channels * frames * 40 / st_elapsed / 1e6, "unit": "Msamples/s",
+                   "what": "the same context after 25 more warm-up steps, 40 timed steps with the timed region's bracketing (max over ranks): the rate a job "
+                           "that runs for seconds sees; `value` at the top is the caller's own --steps / --warmup"}
+        ctx.profile_enable(False)
+        ctx.profile_sample(1)
+        ctx.profile_read(pkg.K_FIR_MAC)                 # (discarded: the roofline's launches are the timed region's)
     groups = headline_groups
     # Second pass: the SAME steps with one channel group and the dominant kernel (both variants) bracketed on every step, then once more
     # with every launch bracketed.  With --channel-groups > 1 a launch of the timed region shares the chip with the other group's kernels
@@ -770,18 +910,57 @@ def main():
 
     extras = {}
     # the extra legs may not take the headline with them: whatever goes wrong in one is reported in the line, not instead of it
+    run_extras = not args.no_extras and (default_job or not strong)
     try:
-        if not args.no_extras and not strong:
+        if run_extras:
             if world == 1:
                 extras["end_to_end"] = end_to_end(pkg, ctx, nch, frames, sr)
                 if frames == 8192:
                     extras["end_to_end"]["batch_run"] = batch_run(pkg, ctx, nch, sr)
                     extras["time_blocked"] = time_blocked(pkg, ctx, nch, frames, sr)
+            elif strong:
+                # rank 0's shard ALONE on the node (the other ranks wait at the barrier): the step time one GPU predicts for this split,
+                # next to the measured max over N ranks running together (host threads, PCIe and power are shared; the GPUs are not)
+                dist.barrier()
+                if rank == 0:
+                    t_al = shard.timed_steps(step, args.steps, synchronize, None, None)
+                    extras["one_gpu_alone"] = {"channels": nch, "ms_per_step": t_al / args.steps * 1e3,
+                                               "predicted_job_value": total_channels * frames * args.steps / t_al / 1e6, "unit": "Msamples/s",
+                                               "measured_over_predicted": (t_al / elapsed) if elapsed else None,
+                                               "what": "rank 0's shard stepping alone, the other ranks idle at a barrier: the one-GPU prediction "
+                                                       "of this split's step time; the headline `value` is the measurement (max over ranks, all running)"}
+                dist.barrier()
+                extras.update(split_job_legs(pkg, torch, dist, shard, ctx, x[0], nch, channel0, total_channels, frames, sr, rank, synchronize))
         ctx.close()
         del x, y
-        if not args.no_extras and not strong:
-            if world > 1:
-                # the strong split of the same 512-channel job over these N GPUs (BASELINE config 4: 64 channels per GPU at N = 8)
+        if run_extras:
+            if world > 1 and strong:
+                # the weak-scaling leg: --channels on EVERY GPU (what the default measured up to round 5)
+                wctx = make_context(pkg, args.channels, frames, local_rank, taps, channel0=rank * args.channels)
+                wctx.set_overlap(2 if args.channels >= 384 else 1)
+                wx = torch.from_numpy(synth_block(args.channels, frames, sr, channel0=rank * args.channels)).to(dev)
+                wy = torch.empty_like(wx)
+
+                def wwstep():
+                    wctx.process_device(wx.data_ptr(), wy.data_ptr(), frames, sr)
+
+                def wwsync():
+                    wctx.synchronize()
+                    torch.cuda.synchronize()
+
+                for _ in range(max(args.warmup, 1)):
+                    wwstep()
+                ww_elapsed = shard.timed_steps(wwstep, args.steps, wwsync, dist, None)
+                extras["weak_scaling"] = {"scaling": "weak", "channels_per_gpu": args.channels, "total_channels": world * args.channels, "n_gpus": world,
+                                          "value": world * args.channels * frames * args.steps / ww_elapsed / 1e6, "unit": "Msamples/s",
+                                          "ms_per_step": ww_elapsed / args.steps * 1e3,
+                                          "realtime_factor": frames * args.steps / ww_elapsed / sr}
+                wctx.close()
+                del wx, wy
+                if frames == 8192:
+                    extras["config5_sharded"] = config5_sharded(pkg, torch, dist, shard, local_rank, world, rank)
+            elif world > 1:
+                # --weak: the strong split of the same 512-channel job over these N GPUs as the extra leg
                 T = args.channels
                 c0, n_loc = shard.channel_shard(T, world, rank)
                 sctx = make_context(pkg, n_loc, frames, local_rank, taps, channel0=c0)
@@ -803,49 +982,7 @@ def main():
                     "value": T * frames * args.steps / s_elapsed / 1e6, "unit": "Msamples/s",
                     "ms_per_step": s_elapsed / args.steps * 1e3, "realtime_factor": frames * args.steps / s_elapsed / sr,
                 }
-                if frames == 8192:
-                    # the same split in batch mode: 16 consecutive frames per call, time blocked (every rank walks 2 windows of its shard)
-                    W, windows = 16, 2
-                    sctx.set_window(W)
-                    wx = sx.repeat(1, W * windows).contiguous()
-                    wy = torch.empty_like(wx)
-
-                    def wstep():
-                        for b in range(0, W * windows, W):
-                            sctx.process_window_device(wx.data_ptr() + 8 * b * frames, wy.data_ptr() + 8 * b * frames, W * windows * frames, W, sr)
-                    wstep()
-                    w_elapsed = shard.timed_steps(wstep, 1, ssync, dist, None) / (W * windows)
-                    extras["strong_split"]["batch_mode_window_16"] = {"us_per_frame": w_elapsed * 1e6, "value": T * frames / w_elapsed / 1e6,
-                                                                     "realtime_factor": frames / sr / w_elapsed}
-                    del wx, wy
-                    # ... and as the batch run proper: file bytes in, file bytes out, every rank its shard (gdg_batch_run_shard), the float64
-                    # partial master mixes gathered on rank 0's HOST over gloo ("the host adds the partials") and finished there
-                    blocks = 32
-                    n = blocks * frames
-                    for c in range(n_loc):
-                        sctx.spatializer_set_position(c, -90.0 + 180.0 * (c0 + c) / max(T - 1, 1), 1.0 + 0.01 * (c0 + c), 0.5)
-                    files = batch_files(n_loc, sr, blocks, channel0=c0)
-                    bcall, bres = sctx.batch_shard_prepared(files, sr, "lpcm24", job_samples=n, metronome=(rank == 0))
-                    bcall()
-                    held = {"r": bres}
-
-                    def bstep():
-                        bcall()
-                    b_elapsed = shard.timed_steps(bstep, 1, ssync, dist, None)
-                    dist.barrier()
-                    t0 = time.perf_counter()
-                    lefts, rights = shard.gather_master_partials(held["r"][1], held["r"][2], dist, dst=0)
-                    master_ok = None
-                    if rank == 0:
-                        ml, mr = sctx.batch_finish_master("lpcm24", lefts, rights, aux=None)
-                        master_ok = bool(ml.any() and mr.any())
-                    t_finish = time.perf_counter() - t0
-                    extras["strong_split"]["batch_run_sharded"] = {
-                        "blocks": blocks, "window": W, "files_in": "lpcm16", "files_out": "lpcm24", "shard_ms_max_over_ranks": b_elapsed * 1e3,
-                        "gather_and_finish_master_ms": t_finish * 1e3, "value": T * n / (b_elapsed + t_finish) / 1e6, "unit": "Msamples/s",
-                        "realtime_factor": n / sr / (b_elapsed + t_finish), "master_nonzero": master_ok,
-                        "what": "gdg_batch_run_shard on every rank (file bytes to file bytes, PCIe inside), partial master mixes gathered on "
-                                "rank 0's host over gloo, gdg_batch_finish_master there"}
+                extras["strong_split"].update(split_job_legs(pkg, torch, dist, shard, sctx, sx, n_loc, c0, T, frames, sr, rank, ssync))
                 sctx.close()
             elif rank == 0:
                 legs = {}
@@ -914,7 +1051,7 @@ def main():
             pass
         value = total_channels * frames * args.steps / elapsed / 1e6
         out = {
-            "metric": "Msamples/s through full chain incl. 64k-tap cab IR, 512ch@192kHz; %HBM roofline",
+            "metric": METRIC,
             "value": value,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -983,6 +1120,13 @@ def main():
             if "batch_mode_window_16" in ss:
                 out["strong_batch_mode_value"] = ss["batch_mode_window_16"]["value"]
                 out["strong_batch_mode_realtime_factor"] = ss["batch_mode_window_16"]["realtime_factor"]
+        ws = extras.get("weak_scaling")
+        if ws:
+            # the weak leg (512 channels on EVERY GPU) in top-level keys next to the strong headline
+            out["weak_value"], out["weak_unit"], out["weak_ms_per_step"] = ws["value"], ws["unit"], ws["ms_per_step"]
+            out["weak_total_channels"], out["weak_channels_per_gpu"] = ws["total_channels"], ws["channels_per_gpu"]
+        if settled is not None:
+            out["settled"] = settled
         cfg = extras.get("configs") or {}
         for key, name in (("config5_256_tuners", "tuner"), ("config5_spatializer_256_to_2", "spatializer")):
             if key in cfg and "roofline" in cfg[key]:

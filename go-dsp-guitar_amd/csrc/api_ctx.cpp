@@ -118,9 +118,15 @@ hipError_t pinned_alloc(gdg_ctx *ctx, void **p, size_t bytes) {
     if (bind) {
         unsigned long mask[16] = { 0 };
         mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-        const bool policy = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul + 1) == 0;
+        /* the caller's own policy (numactl --membind / --interleave, set_mempolicy by the host program) is put back afterwards; a thread whose
+         * policy cannot be read keeps it: no binding then */
+        int old_mode = 0;
+        unsigned long old_mask[16] = { 0 };
+        const bool saved = syscall(SYS_get_mempolicy, &old_mode, old_mask, 1024ul + 1, nullptr, 0ul) == 0;
+        const bool policy = saved && syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul + 1) == 0;
         hipError_t e = hipHostMalloc(p, bytes, policy ? hipHostMallocNumaUser : hipHostMallocDefault);
-        if (policy) syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+        if (policy && syscall(SYS_set_mempolicy, old_mode, old_mode == 0 ? nullptr : old_mask, old_mode == 0 ? 0ul : 1024ul + 1) != 0)
+            syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
         if (e == hipSuccess) return e;
         (void)hipGetLastError();
     }

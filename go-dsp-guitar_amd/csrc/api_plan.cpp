@@ -708,7 +708,8 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     (void)any_fir;
     /* counters of the WAVE launches: tickets per (segment step, channel group), then one frame counter per unit that sits in a segment */
     {
-        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + 8 * ctx->units.size() + (size_t)nch + 64;
+        /* 8 cells per unit in a segment + one flag per oversampled shaper that is a launch of its own (each such unit is one descriptor of one step) */
+        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + 9 * ctx->units.size() + (size_t)nch + 64;
         if (need > ctx->d_wave_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             hipFree(ctx->d_wave);
@@ -888,6 +889,10 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->arena.trim();                         /* the stream is drained: the one place where giving spare chunks back stalls nobody */
+    /* The counters are laid out afresh by every plan: a cell of this layout may sit on a word the previous layout used for something else (an
+     * os_tiles flag keeps its launch's epoch, a chorus "done" mark keeps epoch * 32 + f + 1).  Every stream is joined and drained here. */
+    if (wave_next > ctx->d_wave_cap) return fail(ctx, GDG_ERR_INVALID, "counter layout of %zu words exceeds the %zu allocated", wave_next, ctx->d_wave_cap);
+    if (ctx->d_wave) HIP_TRY(ctx, hipMemsetAsync(ctx->d_wave, 0, ctx->d_wave_cap * sizeof(int), ctx->stream));
     if (!ctx->blob.empty())
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, ctx->blob.data(), ctx->blob.size(), hipMemcpyHostToDevice, ctx->stream));
     ctx->plan_frames = frames;

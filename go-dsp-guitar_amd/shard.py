@@ -15,6 +15,22 @@ def channel_shard(n_total, world, rank):
     return start, stop - start
 
 
+def job_shape(world, rank, channels, total_channels=-1, weak=False):
+    """What `bench.py --gpus N` runs on rank `rank`.  The reference's `-channels T` is a FIXED job (controller/controller.go:3262-3269): the
+    default is therefore the strong split of `channels` (BASELINE's 512) over the N GPUs in contiguous blocks -- config 4 at N = 8, the
+    headline configuration itself at N = 1.  `weak` (or total_channels = 0) puts `channels` on EVERY GPU instead; total_channels > 0 names
+    another fixed job.  Returns scaling, total_channels, channel0 and channels_per_gpu of this rank."""
+    if total_channels == 0:
+        weak = True
+    if weak:
+        return {"scaling": "weak", "total_channels": world * channels, "channel0": rank * channels, "channels_per_gpu": channels}
+    total = channels if total_channels < 0 else total_channels
+    if total < world:
+        raise LaunchError("%d channels cannot be split over %d GPUs" % (total, world))
+    start, count = channel_shard(total, world, rank)
+    return {"scaling": "strong", "total_channels": total, "channel0": start, "channels_per_gpu": count}
+
+
 def timed_steps(step, steps, synchronize, dist=None, device=None):
     """Barrier + synchronize, run `step` exactly `steps` times, synchronize; returns the MAX over ranks of the
     elapsed seconds (the same number on every rank)."""

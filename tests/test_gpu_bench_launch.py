@@ -22,7 +22,9 @@ def test_plain_python_bench_gpus_2_prints_a_two_rank_line():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["n_gpus_requested"] == 2
     assert [d["rank"] for d in line["devices"]] == [0, 1] and all(d["pci_bus_id"] for d in line["devices"])
-    assert line["config"]["total_channels"] == 128 and line["config"]["channels_per_gpu"] == 64
+    # the default job is FIXED (the reference's `-channels T`, controller.go:3262-3269): --channels 64 over two ranks = 32 each, strong scaling
+    assert line["scaling"] == "strong" and line["config"]["total_channels"] == 64 and line["config"]["channels_per_gpu"] == 32
+    assert line["settled"]["steps"] == 40 and line["settled"]["value"] > 0          # --steps 4: the settled figure rides on the same line
     assert line["parity"]["ok"] and line["parity"]["rms_max_all_ranks"] <= 1e-9
     assert line["value"] > 0 and line["roofline"]["frac"] is not None
 

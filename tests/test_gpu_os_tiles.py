@@ -104,3 +104,40 @@ def test_windows_frames_and_a_change_of_factor_are_one_stream(pkg):
         ctx.close()
     np.testing.assert_array_equal(outs[True], outs[False])
     assert np.isfinite(outs[True]).all() and np.abs(outs[True]).max() > 0.01
+
+
+def test_switching_oversampling_off_and_on_in_window_mode_relays_the_counters(pkg):
+    """ADVICE r05 (api_plan.cpp, d_wave): switching oversampling OFF merges [tiles launch | segment] into one segment, so the counters of its
+    gated units move onto words the old layout used for tile flags (which keep their launch's epoch) -- every plan must start from zeroed
+    counters.  64 channels of [distortion 4 x, tone stack, chorus] in windows, oversampling off, on (2 x), off again: no stall, no error word,
+    and the bits of the per-frame walk of the same stream."""
+    nch, frames, sr, W = 64, 8192, 192000, 4
+    chain = [("distortion", [0, 20, -3, 2]), ("tone_stack", None), ("chorus", None)]
+    x = np.stack([synth_signal(c + 1, frames * W * 4, sr) for c in range(nch)])
+    outs = {}
+    for windowed in (False, True):
+        ctx = build(pkg, nch, frames, chain, True)
+        ctx.set_window(W)
+        got = np.zeros_like(x)
+        d_in, d_out = ctx.alloc(nch, W * frames), ctx.alloc(nch, W * frames)
+        for w, os_index in enumerate((2, 0, 1, 0)):
+            for c in range(nch):
+                ctx.unit_set_param(ctx._chains[c][0][0], 3, os_index)
+            lo = w * W * frames
+            if windowed:
+                d_in.upload(x[:, lo:lo + W * frames])
+                ctx.process_window_device(d_in.ptr, d_out.ptr, W * frames, W, sr)
+                ctx.synchronize()                                    # raises on the device error word
+                got[:, lo:lo + W * frames] = d_out.download()
+            else:
+                for f in range(W):
+                    blk = np.zeros((nch, W * frames))
+                    blk[:, :frames] = x[:, lo + f * frames:lo + (f + 1) * frames]
+                    d_in.upload(blk)
+                    ctx.process_window_device(d_in.ptr, d_out.ptr, W * frames, 1, sr)
+                    got[:, lo + f * frames:lo + (f + 1) * frames] = d_out.download()[:, :frames]
+                ctx.synchronize()
+        outs[windowed] = got
+        ctx.close()
+    np.testing.assert_array_equal(outs[True], outs[False])
+    assert np.isfinite(outs[True]).all() and np.abs(outs[True]).max() > 0.01

@@ -166,3 +166,36 @@ def test_plain_python_bench_gpus_2_spawns_two_ranks():
     assert "rank 0 of 2 started" in r.stderr and "rank 1 of 2 started" in r.stderr, r.stderr[-2000:]      # BOTH ranks ran
     assert r.stderr.count("no HIP device visible") >= 1, r.stderr[-2000:]    # (the launcher may kill the second rank before it says so too)
     assert '"n_gpus"' not in r.stdout
+
+
+def test_job_shape_defaults_to_the_strong_split_of_the_fixed_job():
+    """round-5 review: `bench.py --gpus 8` ran 8 x 512 channels (weak scaling); BASELINE config 4 is 512 channels SPLIT over the GPUs"""
+    entry.load_package()
+    from go_dsp_guitar_amd import shard
+    assert shard.job_shape(1, 0, 512) == {"scaling": "strong", "total_channels": 512, "channel0": 0, "channels_per_gpu": 512}
+    blocks = [shard.job_shape(8, r, 512) for r in range(8)]
+    assert all(b["scaling"] == "strong" and b["total_channels"] == 512 and b["channels_per_gpu"] == 64 for b in blocks)
+    assert [b["channel0"] for b in blocks] == list(range(0, 512, 64))
+    assert shard.job_shape(4, 3, 512, weak=True) == {"scaling": "weak", "total_channels": 2048, "channel0": 1536, "channels_per_gpu": 512}
+    assert shard.job_shape(4, 3, 512, total_channels=0)["scaling"] == "weak"
+    assert shard.job_shape(2, 1, 512, total_channels=100) == {"scaling": "strong", "total_channels": 100, "channel0": 50, "channels_per_gpu": 50}
+    with pytest.raises(shard.LaunchError):
+        shard.job_shape(8, 0, 4)
+
+
+def test_two_rank_bench_reports_the_strong_split_of_512_channels():
+    """`python bench.py --gpus 2 --plan-only`: the real launch path (self re-exec under torch.distributed.run, gloo group, the ranks' own
+    job_shape, rank 0's line) without touching a device -- the line a 2-GPU SCALE run would carry says strong / 512 / 256"""
+    import json
+    r = _bench(["--gpus", "2", "--plan-only", "--steps", "20", "--warmup", "5"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["total_channels"] == 512 and line["config"]["channels_per_gpu"] == 256
+    assert line["config"]["channel_blocks"] == [[0, 256], [256, 256]]
+    assert "512ch@192kHz" in line["metric"]
+    r = _bench(["--gpus", "2", "--plan-only", "--weak"], {})
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["scaling"] == "weak" and line["config"]["total_channels"] == 1024 and line["config"]["channels_per_gpu"] == 512
