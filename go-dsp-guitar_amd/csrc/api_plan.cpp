@@ -113,6 +113,12 @@ bool segf_unit_ok(const Unit &u, int frames, uint32_t sample_rate) {
     }
 }
 
+/* May the wet path of a reverb be made ahead of the frame's own samples (seg.hip, REVERB_AHEAD)?  The batch block size, and every tap at least
+ * a frame back, so that the tapped sums need nothing of the frame itself (rates from 42.7 kHz). */
+bool reverb_ahead_ok(int frames, uint32_t sample_rate) {
+    return frames == GDG_MAX_FRAMES && (uint32_t)round(0.19196 * (double)sample_rate) >= (uint32_t)frames;
+}
+
 /* Fill the device-side description of one non-FIR unit; (re)build its history for this rate / frame size. */
 int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate, gdg_seg_unit &d, int chk) {
     memset(&d, 0, sizeof(d));
@@ -287,6 +293,9 @@ int prepare_unit(gdg_ctx *ctx, Unit &u, int frames, uint32_t sample_rate, gdg_se
             d.jp[5 + i] = D;
             len += (size_t)(D > 1 ? D - 1 : 0);
         }
+        /* behind the rings (even offset): the sums  tapped + all-passed  of a frame whose wet path an earlier launch of the call makes (seg.hip, REVERB_AHEAD) */
+        len = ((len + 1) & ~(size_t)1) + GDG_MAX_FRAMES;
+        d.ip[7] = 0;                    /* 1: an earlier launch of the call makes the unit's wet path (build_plan decides) */
         /* the reference rebuilds every reverb buffer when the sample rate changes (reverb.go:207-271) */
         if (u.hist_key != (long long)sample_rate) rc = zero_is(ctx, u, 0, 4);
         if (rc == GDG_OK) rc = ensure_hist(ctx, u, len, (long long)sample_rate);
@@ -723,6 +732,9 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     int seg_steps = 0;
     /* blob layout: [step 0 descs][step 1 descs]...[seg units] */
     std::vector<gdg_seg_unit> seg_units;
+    std::vector<std::vector<int>> ahead_lists; /* per step: reverbs of later steps (indices into seg_units) whose wet path the step's launch makes (seg.hip REVERB_AHEAD) */
+    int ahead_host = -1;                       /* the general-kernel segment step, among those already laid out, that hosts them */
+    double ahead_host_weight = 0.0;
     std::vector<std::vector<gdg_seg_chan>> seg_descs;
     std::vector<std::vector<gdg_fir_chan>> fir_descs;
     std::vector<int> done((size_t)nch, 0);
@@ -801,6 +813,13 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
                      * line exactly one batch frame longer than the longest tap (seg.hip): a change of one side without the other stops here */
                     if (du.type == GDG_UNIT_REVERB && du.jp[4] != std::max(std::max(du.jp[0], du.jp[1]), std::max(du.jp[2], du.jp[3])) + GDG_MAX_FRAMES)
                         return fail(ctx, GDG_ERR_INVALID, "reverb delay line of %d cells, expected the longest tap + %d", du.jp[4], GDG_MAX_FRAMES);
+                    /* a reverb behind an earlier general-kernel segment launch of the same call: that launch makes its wet path beside its own
+                     * channels (extra workgroups: the channels are too few to fill the chip), the unit itself only mixes */
+                    if (du.type == GDG_UNIT_REVERB && !step_fast && !is_os && ahead_host >= 0 && n_act <= ctx->seg_reverb_ahead_max &&
+                        reverb_ahead_ok(frames, sample_rate)) {
+                        du.ip[7] = 1;
+                        ahead_lists[(size_t)ahead_host].push_back((int)seg_units.size());
+                    }
                     ctx->plan_unit_slot[(size_t)h] = (int)seg_units.size();
                     ctx->plan_unit_fast[(size_t)h] = step_fast ? 1 : 0;
                     ctx->plan_unit_fast_ok[(size_t)h] = segf_unit_ok(ctx->units[(size_t)h], frames, sample_rate) ? 1 : 0;
@@ -842,6 +861,24 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
             st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && partitions >= ctx->fir_premac_min;
             for (auto &f : fd) if (f.K < 2 || f.hop != frames) st.premac_ok = false;
         }
+        if (!is_fir && !is_os && !step_fast && !sd.empty()) {
+            /* the host of later reverbs' wet paths: the earlier general-kernel launch that lives longest (the extra workgroups take ~15 us at
+             * 192 kHz; behind a short launch -- a lone compressor -- they would BE the launch).  Rough unit times in us, one workgroup per CU
+             * (profiles/seg_latency_by_channels_r04.txt) */
+            double w = 0.0;
+            for (int h : kv.second[0].second.handles) {
+                switch (ctx->units[(size_t)h].type) {
+                case GDG_UNIT_COMPRESSOR: w += 2.6; break;
+                case GDG_UNIT_TONESTACK: case GDG_UNIT_CABINET: w += 6.5; break;
+                case GDG_UNIT_CHORUS: w += 9.2; break;
+                case GDG_UNIT_REVERB: w += 18.0; break;
+                case GDG_UNIT_AUTOWAH: w += 14.0; break;
+                default: w += 4.0; break;
+                }
+            }
+            if (ahead_host < 0 || w > ahead_host_weight) { ahead_host = (int)ctx->steps.size(); ahead_host_weight = w; }
+        }
+        ahead_lists.emplace_back();
         ctx->steps.push_back(st);
         seg_descs.push_back(sd);
         fir_descs.push_back(fd);
@@ -878,6 +915,10 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         else ctx->steps[i].offset = append(seg_descs[i].data(), seg_descs[i].size() * sizeof(gdg_seg_chan));
     }
     ctx->units_offset = append(seg_units.data(), seg_units.size() * sizeof(gdg_seg_unit));
+    for (size_t i = 0; i < ctx->steps.size(); i++) {
+        ctx->steps[i].ahead_n = (int)ahead_lists[i].size();
+        if (ctx->steps[i].ahead_n) ctx->steps[i].ahead_offset = append(ahead_lists[i].data(), ahead_lists[i].size() * sizeof(int));
+    }
     if (ctx->blob.size() > ctx->d_blob_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         hipFree(ctx->d_blob);

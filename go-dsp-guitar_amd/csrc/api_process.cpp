@@ -29,6 +29,7 @@ static int apply_patches(gdg_ctx *ctx, int frames, uint32_t sample_rate) {
         int rc = prepare_unit(ctx, *u, frames, sample_rate, du, fast ? GDG_CHK_FAST : GDG_CHK);
         if (rc != GDG_OK) { ctx->dirty = true; return rc; }
         const size_t off = ctx->units_offset + (size_t)slot * sizeof(gdg_seg_unit);
+        if (du.type == GDG_UNIT_REVERB) du.ip[7] = reinterpret_cast<const gdg_seg_unit *>(ctx->blob.data() + off)->ip[7];      /* the plan's decision (build_plan: wet path made by an earlier launch) */
         memcpy(ctx->blob.data() + off, &du, sizeof(du));
         lo = std::min(lo, off); hi = std::max(hi, off + sizeof(du));
     }
@@ -98,6 +99,15 @@ static std::vector<size_t> pcie_group_bounds(size_t n, int *G_io) {
     }
     b[(size_t)G] = n;
     return b;
+}
+
+/* the side stream of the sums made ahead of the next frame (premac) and its events */
+static int ensure_side_stream(gdg_ctx *ctx) {
+    if (ctx->premac_stream) return GDG_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->premac_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fir_done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_premac, hipEventDisableTiming));
+    return GDG_OK;
 }
 
 int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
@@ -237,11 +247,7 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                 }
                 /* behind the call's LAST power amp the next frame's sums can start (premac, below): mark the place in the stream */
                 if (premac_here && si == premac_after) {
-                    if (!ctx->premac_stream) {
-                        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->premac_stream, hipStreamNonBlocking));
-                        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fir_done, hipEventDisableTiming));
-                        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_premac, hipEventDisableTiming));
-                    }
+                    { int rc = ensure_side_stream(ctx); if (rc != GDG_OK) return rc; }
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_fir_done, s));
                 }
             } else if (st.os_factor) {
@@ -259,7 +265,13 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                 int *tickets = (window > 1 && (int)active.size() <= ctx->seg_wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
                 const int epoch = tickets ? (ctx->wave_epoch = (ctx->wave_epoch % 0x3ffffff) + 1) : 0;          /* epoch * 32 + frame fits an int */
                 if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch));
-                else HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch));
+                else {
+                    /* one frame per launch: the launch also makes the wet paths of the reverbs of LATER segment steps (extra workgroups beside
+                     * the channels'; seg.hip REVERB_AHEAD), and reverbs whose wet path an earlier launch of this call made only mix */
+                    const bool piggy = window == 1 && G == 1;
+                    const int *d_ahead = piggy && st.ahead_n > 0 ? reinterpret_cast<const int *>(ctx->d_blob + st.ahead_offset) : nullptr;
+                    HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch, piggy ? 1 : 0, d_ahead, d_ahead ? st.ahead_n : 0));
+                }
             }
         }
         if (after) HIP_TRY(ctx, (*after)(g, s));

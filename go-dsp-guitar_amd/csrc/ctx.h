@@ -111,6 +111,8 @@ struct StepDesc {
     bool premac_ok = false;           /* FIR step: split shape (few channels), 8192-sample frames, every channel with K >= 2: the terms k >= 1 can be summed ahead */
     int os_factor = 0;                /* 2 / 4: the step is ONE oversampled shaper per channel, run as a launch of its own (seg.hip os_tiles_kernel) */
     int os_flags = -1;                /* ... and its per-channel flags start here in d_wave */
+    int ahead_n = 0;                  /* segment step (general kernel, one frame per launch): it also makes the wet paths of this many reverbs of LATER steps ... */
+    size_t ahead_offset = 0;          /* ... whose indices into the plan's unit array start here in the blob (seg.hip REVERB_AHEAD) */
     int wave_tickets = -1;            /* segment step: first of its GDG_WAVE_GROUPS ticket counters in d_wave (seg.hip, WAVE), -1: none */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
@@ -184,6 +186,9 @@ struct gdg_ctx {
     hipEvent_t ev_fir_done = nullptr, ev_premac = nullptr;
     bool premac_valid = false;                 /* Y of every premac step holds the terms k >= 1 of the plan's NEXT frame */
     bool premac_outstanding = false;           /* ... and the context's stream has not been ordered behind that launch yet */
+    /* reverbs' wet paths ahead of the frame (seg.hip REVERB_AHEAD): made by extra workgroups of an EARLIER segment launch of the same call */
+    int seg_reverb_ahead_max = 80;             /* most channels of a call that does it: 64 channels 156 -> 142 us per step, 96 channels 168 -> 175 (twice the
+                                                * workgroups in the first segment launch, and the premac's share of the chip with them) */
     int wave_epoch = 0;                        /* a number per WAVE launch (seg.hip: "done" marks carry it) */
     int *d_wave = nullptr;                     /* [GDG_WAVE_STEPS x GDG_WAVE_GROUPS ticket counters | one counter per unit in a segment]: zero between launches */
     size_t d_wave_cap = 0;
@@ -431,6 +436,7 @@ private:
 
 Unit *get_unit(gdg_ctx *ctx, int handle);
 bool segf_unit_ok(const Unit &u, int frames, uint32_t sample_rate);
+bool reverb_ahead_ok(int frames, uint32_t sample_rate);
 hipError_t pinned_alloc(gdg_ctx *ctx, void **p, size_t bytes);
 int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in, double *d_out, int frames, uint32_t sample_rate,
                       int stride, int stride_out, bool rows_by_channel, int G, const std::vector<size_t> &bounds);

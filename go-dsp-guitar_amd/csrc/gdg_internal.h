@@ -185,10 +185,15 @@ struct gdg_os_tables {
  * for windows of channel counts that leave most of the chip idle; the counter (zero before the first launch, zero after every launch)
  * belongs to this launch slot alone */
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
-                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0);
+                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0, int ahead = 0,
+                          const int *d_ahead_list = nullptr, int n_ahead = 0);
+/* one frame per launch (n_frames == 1), general kernel: d_ahead_list names n_ahead reverbs (indices into d_units) of LATER segment steps of the
+ * call whose wet path this launch makes with extra workgroups (seg.hip REVERB_AHEAD); ahead != 0: reverbs whose descriptor says so (ip[7])
+ * only mix -- an earlier launch of the call made theirs */
 /* the same for segments that only hold units the two-per-CU kernel runs (gdg_segf_supported) on frames of 8192 samples */
 hipError_t gdg_launch_segf(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
-                           gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0);
+                           gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0, int ahead = 0,
+                           const int *d_ahead_list = nullptr, int n_ahead = 0);
 int gdg_segf_supported(int unit_type);
 /* an oversampled shaper (overdrive / distortion / excess at 2 x or 4 x) as a launch of its own, one workgroup per (channel, frame, tile): the
  * descriptors are segment descriptors whose unit_begin names the shaper; d_flags: one int per channel, any value but `epoch` (seg.hip) */

@@ -1428,7 +1428,7 @@ __device__ __attribute__((noinline)) void allpass_generic(double *buf, double *r
  * flight per lane instead of 32: the register file is shared by two workgroups). */
 /* wt (a frame per workgroup, WAVE): the two meetings of the general build's reverb (below) -- the delay line is handed on once this frame's
  * pairs are in it and its taps are loaded, the all-pass rings are waited for separately */
-UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
+UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate, const int /* ahead: general build only */ = 0) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
     const int tid = seg_tid();
@@ -1606,7 +1606,21 @@ UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
  * counter returns; the frame is appended FIRST (the ring is a frame longer than the longest tap: the cells it overwrites are the predecessor's
  * oldest tap window, consumed by then, and no tap of this frame reads them), the taps are loaded, gate.cell - 1 is posted -- the next frame may
  * append.  All-pass rings: wait on gate.cell, fetch, run, mix; the caller posts gate.cell.  So frame f + 1 taps while frame f runs its all-passes. */
-UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
+/* The wet path AHEAD of the frame (round 6).  With every tap at least a frame back (rates from 42.7 kHz at the batch block size) the tapped
+ * sums of a frame -- and with them the three all-passes, whose only input they are -- depend on EARLIER frames' inputs alone: all the unit
+ * needs of the frame itself is the final mix  clip(dry x + 0.5 wet (tapped + all-passed))  (reverb.go:300-317).  Per-frame calls of few
+ * channels leave 3/4 of the chip idle, and the reverb is the longest unit of its segment (18 of the 33 us a cabinet > reverb workgroup lives).
+ * So the FIRST segment launch of such a call carries extra workgroups, one per reverb of the call's later segment steps, that make
+ * tapped + all-passed  for this very frame (REVERB_AHEAD: the same expressions in the same order as the unit itself) beside the channels'
+ * own workgroups, and the unit, when its turn comes behind the power amps, only mixes (REVERB_CONSUME).  Everything stays inside one call and
+ * one stream: nothing speculative, no event.  (A side stream that made the NEXT call's wet paths cost more in cross-stream hops than the
+ * unit takes: 153 -> 172 us per step at 64 channels, profiles/experiments/README.md r06.)  The extra workgroup leaves the all-pass rings
+ * exactly as the whole unit would (nobody but this unit reads them, and its mix comes later in the same call) and the sums
+ * tapped + all-passed  in a staging area behind the rings (even offset, 8192 values); the frame joins the delay line at the mix.
+ * The host decides (api_plan.cpp reverb_ahead_ok, build_plan). */
+enum { REVERB_FULL = 0, REVERB_AHEAD = 1, REVERB_CONSUME = 2 };
+template <int MODE>
+static __device__ __forceinline__ void reverb_general(UNIT_ARGS, const WaveGate &gate) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
     const int tid = seg_tid();
@@ -1621,10 +1635,27 @@ UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
     const int dl_wp = as_global(is_state)[0];
     int M[3], rp[3];
     double *ring[3];
+    double *ahead;                                      /* the staging area (see above) */
     {
         double *r = dl_ring + DL;
 #pragma unroll
         for (int k = 0; k < 3; k++) { M[k] = Uc->jp[5 + k] - 1; rp[k] = wt ? 0 : as_global(is_state)[1 + k]; ring[k] = r; r += (M[k] > 0 ? M[k] : 0); }
+        ahead = dl_ring + (((r - dl_ring) + 1) & ~(ptrdiff_t)1);
+    }
+    if (MODE == REVERB_CONSUME) {
+        /* the sums made ahead (16-byte pairs, the mapping of the pair path below), the mix, the frame into the delay line */
+        seg_v2d sm[REVERB_QMAX / 2];
+#pragma unroll
+        for (int q = 0; q < REVERB_QMAX / 2; q++) sm[q] = *(const GDG_GLOBAL seg_v2d *)(as_global(ahead) + 2 * (tid + q * SEG_T));
+#pragma unroll
+        for (int q = 0; q < REVERB_QMAX; q++) {
+            const int i = 2 * (tid + (q >> 1) * SEG_T) + (q & 1);
+            const double sum = (q & 1) ? sm[q >> 1].y : sm[q >> 1].x;
+            out[LX(i)] = clip1((dry * in[LX(i)]) + (half_wet * sum));
+        }
+        __syncthreads();
+        ring_append(dl_ring, DL, &is_state[0], in, N);
+        return;
     }
     /* ring heads of the three all-passes first (in-order return: they are home before the tap loads below are consumed) */
     const bool fast = min(M[1], N) <= 3 * SEG_T && min(M[2], N) <= SEG_T;
@@ -1724,6 +1755,16 @@ UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
         if (M[1] >= 1) allpass_generic(out, ring[1], M[1], rp[1], N, &is_state[2], wt);
         if (M[2] >= 1) allpass_generic(out, ring[2], M[2], rp[2], N, &is_state[3], wt);
     }
+    if (MODE == REVERB_AHEAD) {
+        /* tapped + all-passed, the first addition of the mix (reverb.go:303), for the frame to come */
+#pragma unroll
+        for (int q = 0; q < REVERB_QMAX / 2; q++) {
+            const int i0 = 2 * (tid + q * SEG_T);
+            seg_v2d v = { dlr[2 * q] + out[LX(i0)], dlr[2 * q + 1] + out[LX(i0 + 1)] };
+            *(GDG_GLOBAL seg_v2d *)(as_global(ahead) + i0) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < REVERB_QMAX; q++) {
         int i = pairs ? 2 * (tid + (q >> 1) * SEG_T) + (q & 1) : tid + q * SEG_T;
@@ -1734,6 +1775,11 @@ UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate) {
     }
     __syncthreads();
     if (!wt) ring_append(dl_ring, DL, &is_state[0], in, N);
+}
+/* ahead: one frame per launch (kernel argument); ip[7]: an earlier launch of this call made the unit's wet path (api_plan.cpp build_plan) */
+UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate, const int ahead = 0) {
+    if (!wt && ahead && uniform_unit(U)->ip[7]) reverb_general<REVERB_CONSUME>(U, flip, N, false, gate);
+    else reverb_general<REVERB_FULL>(U, flip, N, wt, gate);
 }
 #endif
 
@@ -2627,7 +2673,7 @@ hipError_t gdg_launch_os_tiles(int factor, const gdg_seg_chan *d_chans, int n_ch
 template <bool WAVE>
 __device__ __forceinline__ void seg_frame(const double *src, double *dst, const gdg_seg_unit *units, int unit_begin, int unit_count, int N,
                                           const gdg_os_tables &os, int *d_error, int my_type, int *wave = nullptr, int wf = 0, int wf_next = 0,
-                                          unsigned wave_mask = 0, int epoch = 0) {
+                                          unsigned wave_mask = 0, int epoch = 0, int ahead = 0) {
     int tid = seg_tid();
 #ifdef SEG_FAST
     /* opaque per call: in the window walk the compiler otherwise hoists every per-thread address of the frame's load and store loops out of
@@ -2688,7 +2734,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N, WAVE); break;
         case GDG_UNIT_REVERB: {
             const WaveGate gate = { wave + GDG_WAVE_CELLS * u + 1, wf, wf_next, (wave_mask >> 31) != 0, epoch, d_error };
-            unit_reverb(U, flip, N, WAVE, gate);
+            unit_reverb(U, flip, N, WAVE, gate, ahead);
             second = WAVE ? 1 : 0;
             break;
         }
@@ -2736,9 +2782,17 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
 template <int MODE>             /* 0: one frame per launch; 1: the walk; 2: WAVE (a workgroup per frame, above) */
 __global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU) SEG_KERNEL_ATTR
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
-           gdg_os_tables os, int *d_error, int n_chans, int *ticket, int epoch) {
+           gdg_os_tables os, int *d_error, int n_chans, int *ticket, int epoch, int ahead, const int *__restrict__ ahead_list) {
     constexpr bool MULTI = MODE == 1;
     int block = blockIdx.x, wf0 = 0;
+#ifndef SEG_FAST
+    if (MODE == 0 && block >= n_chans) {
+        /* an extra workgroup: the wet path of a reverb of a LATER segment step of this call (reverb_general, REVERB_AHEAD) */
+        const WaveGate none = {};
+        reverb_general<REVERB_AHEAD>(units + ahead_list[block - n_chans], 0, GDG_MAX_FRAMES, false, none);
+        return;
+    }
+#endif
     if (MODE == 2) {
         /* frames are dealt in the order the workgroups START, frame-major (all channels' frame 0, then frame 1, ...): whoever a
          * workgroup waits for holds a smaller ticket and is already running (or done), whatever the order of dispatch */
@@ -2768,7 +2822,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
     /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
      * through global memory from one frame to the next exactly as from one launch to the next (same CU, same L1; a barrier between) */
     for (int wf = 0; wf < (MULTI ? n_frames : 1); wf++, ch.src += N, ch.dst += N) {
-        seg_frame<false>(ch.src, ch.dst, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type);
+        seg_frame<false>(ch.src, ch.dst, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type, nullptr, 0, 0, 0, 0, MODE == 0 ? ahead : 0);
         if (MULTI && wf + 1 < n_frames) { __threadfence_block(); __syncthreads(); }      /* state and LDS frames before the next frame touches them */
     }
 }
@@ -2798,11 +2852,17 @@ int gdg_seg_supported(int unit_type) {
 }
 
 hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames, gdg_shift shift,
-                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket, int epoch) {
+                          gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket, int epoch, int ahead, const int *d_ahead_list, int n_ahead) {
     if (n_chans <= 0 || n_frames <= 0) return hipSuccess;
     if (n_frames > 1 && d_wave_ticket)
-        hipLaunchKernelGGL(seg_kernel<2>, dim3(n_chans * n_frames), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, d_wave_ticket, epoch);
-    else if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<1>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, nullptr, 0);
-    else hipLaunchKernelGGL(seg_kernel<0>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, 1, shift, os, d_error, n_chans, nullptr, 0);
+        hipLaunchKernelGGL(seg_kernel<2>, dim3(n_chans * n_frames), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, d_wave_ticket, epoch, 0, nullptr);
+    else if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<1>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, nullptr, 0, 0, nullptr);
+    else {
+#ifdef SEG_FAST
+        n_ahead = 0;
+#endif
+        if (!d_ahead_list || frames != GDG_MAX_FRAMES) n_ahead = 0;
+        hipLaunchKernelGGL(seg_kernel<0>, dim3(n_chans + n_ahead), dim3(SEG_T), 0, s, d_chans, d_units, frames, 1, shift, os, d_error, n_chans, nullptr, 0, ahead, d_ahead_list);
+    }
     return hipGetLastError();
 }

@@ -100,6 +100,11 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *                                            frames of a channel meeting unit by unit -- fills the chip when the channels alone do not (448; 0: never)
  *   seg_os_tiles_max_channels    >= 0        calls of up to this many channels run every 2 x / 4 x oversampled shaper as a launch of its own, one workgroup
  *                                            per (channel, frame, tile of 4096 / 2048 samples) instead of one per channel (192; 0: never)
+ *   seg_reverb_ahead_max_channels >= 0       per-frame calls of up to this many channels: the call's first segment launch also makes, with extra
+ *                                            workgroups beside the channels' own, the wet path of every reverb of its LATER segment steps -- tapped
+ *                                            sums and all-passes need nothing of the frame itself when every tap lies at least a frame back
+ *                                            (8192-sample frames, 42.7 .. 194.9 kHz) -- and the reverb behind the power amps only mixes.  Same bits
+ *                                            either way (80; 0: never)
  *   plan_patch                   0, 1        parameter changes patch the device descriptors in place instead of rebuilding the plan (1)
  *   scan_tables_max              >= 1        scan tables (one per distinct coefficient set) kept before a plan rebuild drops them all (1024)
  *   pcie_groups                  0 .. 16     channel groups of the host-buffer calls, 0 = by channel count (0)

@@ -21,7 +21,11 @@ if os.environ.get("CHAIN", "") == "config3":
 else:
     sr, taps, second, chain = 192000, 65536, True, bench.CHAIN
 ctx = bench.make_context(pkg, nch, frames, 0, taps, chain=chain, second_amp=second)
-tag = "%s %d ch %s hwq=%s" % (os.environ.get("CHAIN", "bench"), nch, mode, os.environ.get("GPU_MAX_HW_QUEUES", "default"))
+opts = os.environ.get("OPTIONS", "")                 # "key=value,key=value": gdg_ctx_set_option before the first call
+for kv in [o for o in opts.split(",") if o]:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
+tag = "%s %d ch %s hwq=%s%s" % (os.environ.get("CHAIN", "bench"), nch, mode, os.environ.get("GPU_MAX_HW_QUEUES", "default"), (" [" + opts + "]") if opts else "")
 if mode == "frame":
     d_in, d_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
     d_in.upload(bench.synth_block(nch, frames, sr))
