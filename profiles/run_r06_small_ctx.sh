@@ -9,9 +9,11 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 P="$REPO/profiles/probes/small_ctx.py"
 {
-  for NCH in 32 64 96 127; do
+  for NCH in 32 64 80 96 127; do
     for A in 0 200; do
-      NCH=$NCH MODE=frame NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A" python $P
+      for H in 0 1; do
+        NCH=$NCH MODE=frame NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A,fir_premac_hosted=$H" python $P
+      done
     done
   done
   for A in 0 200; do NCH=64 MODE=frame CHAIN=config3 NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A" python $P; done
@@ -19,10 +21,10 @@ P="$REPO/profiles/probes/small_ctx.py"
 for A in 0 200; do
   WHICH=$([ $A = 0 ] && echo before || echo after)
   rm -rf /tmp/prof_s
-  NCH=64 MODE=frame NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A" rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $P > /tmp/s.log 2>&1
+  NCH=64 MODE=frame NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A,fir_premac_hosted=$([ $A = 0 ] && echo 0 || echo 1)" rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $P > /tmp/s.log 2>&1
   DB=$(find /tmp/prof_s -name '*.db' | head -1)
   {
-    echo "# NCH=64 MODE=frame OPTIONS=seg_reverb_ahead_max_channels=$A rocprofv3 --kernel-trace --stats -- python profiles/probes/small_ctx.py  (bench chain, 2 x 65536 taps, 192 kHz)"
+    echo "# NCH=64 MODE=frame OPTIONS=seg_reverb_ahead_max_channels=$A,fir_premac_hosted=$([ $A = 0 ] && echo 0 || echo 1) rocprofv3 --kernel-trace --stats -- python profiles/probes/small_ctx.py  (bench chain, 2 x 65536 taps, 192 kHz)"
     grep "groups:" /tmp/s.log
     python "$REPO/profiles/summarize_rocprof.py" "$DB"
   } > "$OUT/${TAG}_64ch_frame_rocprof_${WHICH}.txt" 2>&1
