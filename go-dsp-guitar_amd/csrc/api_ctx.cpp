@@ -162,6 +162,8 @@ static const OptionDef g_options[] = {
     { "seg_wave_max_channels", "GDG_SEG_WAVE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_max, nullptr, true },
     { "seg_os_tiles_max_channels", "GDG_SEG_OS_TILES_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_os_tiles_max, nullptr, true },
     { "seg_reverb_ahead_max_channels", "GDG_SEG_REVERB_AHEAD_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_reverb_ahead_max, nullptr, true },
+    { "wave_spin_limit_ms", "GDG_WAVE_SPIN_LIMIT_MS", 1, 600000, -1, &gdg_ctx::wave_spin_ms, nullptr, false },
+    { "debug_stall_unit", "GDG_DEBUG_STALL_UNIT", -1, 1 << 30, -1, &gdg_ctx::debug_stall_unit, nullptr, false },
     { "plan_patch", "GDG_PLAN_PATCH", 0, 1, -1, nullptr, &gdg_ctx::plan_patch, false },
     { "scan_tables_max", "GDG_SCAN_TABLES_MAX", 1, 1 << 20, -1, &gdg_ctx::scan_tables_max, nullptr, false },
     /* host paths, tuner, profiling */
@@ -223,8 +225,9 @@ int gdg_ctx_create(int n_channels, int max_frames, int device, gdg_ctx **out) {
     ok = ok && hipMalloc((void **)&ctx->d_w0, row) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_w1, row) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_scratch, row) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_error, sizeof(int)) == hipSuccess;
-    ok = ok && hipMemset(ctx->d_error, 0, sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_error, 4 * sizeof(int)) == hipSuccess;       /* [error word | wave_spin_limit_ms | spare] */
+    ok = ok && hipMemset(ctx->d_error, 0, 4 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->d_error + 1, &ctx->wave_spin_ms, sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     /* oversampling tables: 77 + 155 taps, 6 + 18 Lanczos-3 weights (resample.go:36-66 evaluated once per phase) */
     const size_t os_base = 77 + 155 + 6 + 18;
     std::vector<double> tab(os_base + 2 * GDG_OS_NE(2) + 4 * GDG_OS_NE(4), 0.0);
@@ -333,6 +336,8 @@ int gdg_ctx_set_option(gdg_ctx *ctx, const char *key, long long value) {
     if (strcmp(key, "numa") == 0 && value != ctx->numa_mode) { int rc = numa_rebind(ctx, (int)value); if (rc != GDG_OK) return rc; }
     option_store(ctx, *o, value);
     if (o->replans) ctx->dirty = true;
+    if (strcmp(key, "wave_spin_limit_ms") == 0)       /* the kernels read it from the context's error block (seg.hip wave_spin_expired) */
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_error + 1, &ctx->wave_spin_ms, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     return GDG_OK;
 }
 

@@ -264,7 +264,12 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                 /* (by the CALL's channel count, not the group's: two groups of 256 channels fill the chip like one launch of 512) */
                 int *tickets = (window > 1 && (int)active.size() <= ctx->seg_wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
                 const int epoch = tickets ? (ctx->wave_epoch = (ctx->wave_epoch % 0x3ffffff) + 1) : 0;          /* epoch * 32 + frame fits an int */
-                if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch));
+                /* option debug_stall_unit: in a WAVE launch frame 0 of that unit's channel withholds the unit's counter (seg.hip) */
+                int stall = 0;
+                if (tickets && ctx->debug_stall_unit >= 0 && (size_t)ctx->debug_stall_unit < ctx->plan_unit_slot.size() &&
+                    ctx->plan_unit_slot[(size_t)ctx->debug_stall_unit] >= 0) stall = 1 + ctx->plan_unit_slot[(size_t)ctx->debug_stall_unit];
+                if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch, stall));
+                else if (tickets) HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch, stall));
                 else {
                     /* one frame per launch: the launch also makes the wet paths of the reverbs of LATER segment steps (extra workgroups beside
                      * the channels'; seg.hip REVERB_AHEAD), and reverbs whose wet path an earlier launch of this call made only mix */

@@ -189,6 +189,8 @@ struct gdg_ctx {
     /* reverbs' wet paths ahead of the frame (seg.hip REVERB_AHEAD): made by extra workgroups of an EARLIER segment launch of the same call */
     int seg_reverb_ahead_max = 80;             /* most channels of a call that does it: 64 channels 156 -> 142 us per step, 96 channels 168 -> 175 (twice the
                                                 * workgroups in the first segment launch, and the premac's share of the chip with them) */
+    int wave_spin_ms = 1000;                   /* how long a frame waits for its predecessor's counter before the launch gives up (seg.hip wave_spin_expired; d_error[1]) */
+    int debug_stall_unit = -1;                 /* test hook: this unit's first counter of a WAVE launch stays away, so that the bounded wait expires */
     int wave_epoch = 0;                        /* a number per WAVE launch (seg.hip: "done" marks carry it) */
     int *d_wave = nullptr;                     /* [GDG_WAVE_STEPS x GDG_WAVE_GROUPS ticket counters | one counter per unit in a segment]: zero between launches */
     size_t d_wave_cap = 0;

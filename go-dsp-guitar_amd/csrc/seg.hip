@@ -377,16 +377,25 @@ __device__ __forceinline__ void st_v2d(GDG_GLOBAL seg_v2d *p, seg_v2d v, bool wt
  * with an L2 of its own): every wave writes back before the barrier, one lane posts; one lane polls, every wave invalidates after the
  * barrier.  Workgroups take their frame by TICKET (seg_kernel), so a workgroup never waits for one that has not started. */
 /* light: the unit reads everything its predecessor frame left it through sc1 loads (ld_f64): no acquire fence (1.7 us) */
-/* Every spin is BOUNDED (~1 s): a counter that never comes -- a launch that broke the protocol, a workgroup that died -- must end as an error
- * code in the context's error word (the next call reports it), never as a hung device. */
-#define GDG_WAVE_SPIN_LIMIT (1 << 23)
+/* Every spin is BOUNDED IN TIME (1 s unless option wave_spin_limit_ms says otherwise: the context's error block, d_error[1]): a counter that never
+ * comes -- a launch that broke the protocol, a workgroup that died -- must end as an error code in the context's error word (the next
+ * synchronize reports it), never as a hung device.  The clock is the constant 100 MHz one (s_memrealtime), read every 1024th poll; the first
+ * 1024 polls (~1 ms) are free. */
 #define GDG_WAVE_TIMEOUT_CODE 0x57415645           /* "WAVE" */
+__device__ __forceinline__ bool wave_spin_expired(int &spins, unsigned long long &t0, int *d_error) {
+    if ((++spins & 1023) != 0) return false;
+    const unsigned long long now = wall_clock64();
+    if (spins == 1024) { t0 = now; return false; }
+    const int ms = d_error ? __hip_atomic_load(as_global(d_error) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    return now - t0 > (unsigned long long)(ms > 0 ? ms : 1000) * 100000ull;
+}
 __device__ __forceinline__ void wave_wait(int *cell, int want, bool light = false, int *d_error = nullptr) {
     if (seg_tid() == 0) {
         int spins = 0;
+        unsigned long long t0 = 0;
         while (__hip_atomic_load(as_global(cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > GDG_WAVE_SPIN_LIMIT) { if (d_error) atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
+            if (wave_spin_expired(spins, t0, d_error)) { if (d_error) atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
         }
         if (!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          /* ONE buffer_inv sc1 per workgroup: this CU's L1 (MI355X_MICROARCH.md, visibility) */
     }
@@ -2630,9 +2639,10 @@ os_tiles_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__re
         /* the call's new state, once the call's first workgroup has read the old one */
         if (tid == 0 && !(first && tile == 0)) {
             int spins = 0;
+            unsigned long long t0 = 0;
             while (__hip_atomic_load(as_global(flags + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > GDG_WAVE_SPIN_LIMIT) { atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
+                if (wave_spin_expired(spins, t0, d_error)) { atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
             }
         }
         __syncthreads();
@@ -2673,7 +2683,7 @@ hipError_t gdg_launch_os_tiles(int factor, const gdg_seg_chan *d_chans, int n_ch
 template <bool WAVE>
 __device__ __forceinline__ void seg_frame(const double *src, double *dst, const gdg_seg_unit *units, int unit_begin, int unit_count, int N,
                                           const gdg_os_tables &os, int *d_error, int my_type, int *wave = nullptr, int wf = 0, int wf_next = 0,
-                                          unsigned wave_mask = 0, int epoch = 0, int ahead = 0) {
+                                          unsigned wave_mask = 0, int epoch = 0, int ahead = 0, int stall = 0) {
     int tid = seg_tid();
 #ifdef SEG_FAST
     /* opaque per call: in the window walk the compiler otherwise hoists every per-thread address of the frame's load and store loops out of
@@ -2757,7 +2767,8 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
             for (int i = tid; i < N; i += SEG_T) out[LX(i)] = 0.0;
             break;
         }
-        if (gated && !skip_post) wave_post(wave + GDG_WAVE_CELLS * u + second, wf_next, (wave_mask >> 31) != 0);
+        /* (stall: option debug_stall_unit -- frame 0 withholds this unit's counter, so that frame 1's bounded wait can be seen to expire) */
+        if (gated && !skip_post && !(WAVE && stall == unit_begin + u + 1 && wf == 0)) wave_post(wave + GDG_WAVE_CELLS * u + second, wf_next, (wave_mask >> 31) != 0);
         else __syncthreads();
         if (!__builtin_amdgcn_readfirstlane(inplace)) flip ^= 1;
     }
@@ -2816,7 +2827,7 @@ seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restric
     if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
     if (MODE == 2) {
         seg_frame<true>(ch.src + (size_t)wf0 * N, ch.dst + (size_t)wf0 * N, units, ch.unit_begin, ch.unit_count, N, os, d_error, my_type,
-                        ch.wave, wf0, wf0 + 1 < n_frames ? wf0 + 1 : 0, (unsigned)ch.wave_mask, epoch);
+                        ch.wave, wf0, wf0 + 1 < n_frames ? wf0 + 1 : 0, (unsigned)ch.wave_mask, epoch, 0, ahead /* WAVE: the debug stall (launcher) */);
         return;
     }
     /* a window of n_frames consecutive frames (gdg_process_window_device): the workgroup walks them in order, the units' state going
@@ -2855,7 +2866,8 @@ hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_se
                           gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket, int epoch, int ahead, const int *d_ahead_list, int n_ahead) {
     if (n_chans <= 0 || n_frames <= 0) return hipSuccess;
     if (n_frames > 1 && d_wave_ticket)
-        hipLaunchKernelGGL(seg_kernel<2>, dim3(n_chans * n_frames), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, d_wave_ticket, epoch, 0, nullptr);
+        hipLaunchKernelGGL(seg_kernel<2>, dim3(n_chans * n_frames), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, d_wave_ticket, epoch,
+                           ahead /* a WAVE launch has no use for it: 1 + the plan index of the unit whose first counter stays away (option debug_stall_unit) */, nullptr);
     else if (n_frames > 1) hipLaunchKernelGGL(seg_kernel<1>, dim3(n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_error, n_chans, nullptr, 0, 0, nullptr);
     else {
 #ifdef SEG_FAST

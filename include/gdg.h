@@ -105,6 +105,13 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *                                            sums and all-passes need nothing of the frame itself when every tap lies at least a frame back
  *                                            (8192-sample frames, 42.7 .. 194.9 kHz) -- and the reverb behind the power amps only mixes.  Same bits
  *                                            either way (80; 0: never)
+ *   wave_spin_limit_ms           1 .. 600000 how long a workgroup of an in-launch hand-off (windows of few channels, tiles of an oversampled shaper) waits
+ *                                            for its predecessor before the launch gives up: the wait ends, the context's error word is set and the next
+ *                                            gdg_ctx_synchronize (or batch run) returns GDG_ERR_HIP -- the device never hangs.  RESULTS OF WINDOW CALLS ARE
+ *                                            VALID ONLY AFTER A gdg_ctx_synchronize THAT RETURNED GDG_OK; after such an error the units' state is undefined
+ *                                            (gdg_unit_reset them), the context itself stays usable (1000)
+ *   debug_stall_unit             -1, handle  test hook: in the next windows' first frame this unit withholds its hand-off, so that the bounded wait can
+ *                                            be seen to expire (-1)
  *   plan_patch                   0, 1        parameter changes patch the device descriptors in place instead of rebuilding the plan (1)
  *   scan_tables_max              >= 1        scan tables (one per distinct coefficient set) kept before a plan rebuild drops them all (1024)
  *   pcie_groups                  0 .. 16     channel groups of the host-buffer calls, 0 = by channel count (0)
