@@ -172,6 +172,7 @@ static const OptionDef g_options[] = {
     { "copy_threads", "GDG_COPY_THREADS", 1, 256, -1, &gdg_ctx::copy_threads, nullptr, false },
     { "numa", "GDG_NUMA", 0, 2, -1, &gdg_ctx::numa_mode, nullptr, false },
     { "tuner_parts", "GDG_TUNER_PARTS", 0, 24, GDG_KNOB_TUNER_PARTS, nullptr, nullptr, false },
+    { "tuner_poll_results", "GDG_TUNER_POLL", 0, 1, -1, &gdg_ctx::tuner_poll, nullptr, false },
     { "tuner_long_transform", "GDG_TUNER_LONG", 0, 1, -1, &gdg_ctx::tuner_long, nullptr, false },
     { "profile_attach", "GDG_PROFILE_ATTACH", 0, 1, -1, nullptr, &gdg_ctx::prof_attach, false },
 };

@@ -16,7 +16,10 @@ static int ensure_tuner(gdg_ctx *ctx) {
     HIP_TRY(ctx, hipMemcpy(ctx->d_note_freqs, GDG_NOTE_FREQS, GDG_NOTE_COUNT * sizeof(double), hipMemcpyHostToDevice));
     /* the results (16 bytes per channel) are written by the last kernel straight into pinned, device-mapped host memory: no copy command behind
      * the kernels, the caller only waits for the stream (a DMA of a few hundred bytes cost 8-10 us of a 62 us call at 32 channels) */
-    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_tuner_out, (size_t)ctx->nch * sizeof(gdg_tuner_out), hipHostMallocMapped));
+    /* ... and COHERENT (fine grained): every record ends with the number of its analysis, stored last at system scope, and the caller polls those
+     * words instead of waiting for the runtime to notice that the stream is idle (round 6: ~8 of the 20 us a 32-channel call spent outside its kernels) */
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_tuner_out, (size_t)ctx->nch * sizeof(gdg_tuner_out), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->h_tuner_out, 0, (size_t)ctx->nch * sizeof(gdg_tuner_out));
     HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->d_tuner_out, ctx->h_tuner_out, 0));
     ctx->tuner_wp = 0;
     return GDG_OK;
@@ -94,16 +97,23 @@ int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
     int rc = ensure_tuner(ctx);
     if (rc != GDG_OK) return rc;
     const int force_long = ctx->tuner_long;
+    const unsigned seq = ++ctx->tuner_seq ? ctx->tuner_seq : ++ctx->tuner_seq;          /* never 0: what a fresh record holds */
     if (!force_long && gdg_tuner_short_ok((double)ctx->tuner_sr, GDG_NOTE_FREQS[0])) {
         /* every standard rate: block-wise autocorrelation for the lags the analysis can look at; the ring is read once */
         double2 *tw4096, *tw2_4096;
         rc = fir_tables(ctx, 4096, &tw4096, &tw2_4096);
         if (rc != GDG_OK) return rc;
         const int parts = gdg_tuner_short_parts(ctx->nch);
-        if (parts > 1 && !ctx->d_tuner_part) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_part, (size_t)ctx->nch * 8 * 4096 * sizeof(double2)));
+        if (parts > 1 && parts > ctx->tuner_part_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ctx->d_tuner_part);
+            ctx->d_tuner_part = nullptr;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tuner_part, (size_t)ctx->nch * (size_t)std::max(parts, 8) * 4096 * sizeof(double2)));
+            ctx->tuner_part_cap = std::max(parts, 8);
+        }
         ProfScope ps(ctx, GDG_K_TUNER);
         HIP_TRY(ctx, gdg_launch_tuner_short(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, (double)ctx->tuner_sr, tw4096, tw2_4096,
-                                            ctx->d_note_freqs, GDG_NOTE_COUNT, ctx->d_tuner_out, ctx->d_tuner_part, parts, ctx->stream));
+                                            ctx->d_note_freqs, GDG_NOTE_COUNT, ctx->d_tuner_out, ctx->d_tuner_part, parts, ctx->stream, seq));
     } else {
         /* rates above ~252 kHz: the window reaches past lag 4096 -- the reference's own scheme, a 262144-point transform pair */
         if (!ctx->d_tuner_work) {
@@ -118,11 +128,24 @@ int gdg_tuner_analyze(gdg_ctx *ctx, gdg_tuner_result *results) {
         ProfScope ps(ctx, GDG_K_TUNER);
         HIP_TRY(ctx, gdg_launch_tuner_analyze(ctx->d_tuner_ring, ctx->nch, ctx->tuner_wp, (double)ctx->tuner_sr, ctx->d_tuner_work,
                                               ctx->d_tuner_twn, ctx->d_tuner_twm, tw512, tw256, ctx->d_note_freqs, GDG_NOTE_COUNT,
-                                              ctx->d_tuner_out, ctx->stream));
+                                              ctx->d_tuner_out, ctx->stream, seq));
     }
-    /* the results are in host memory when the stream is done (ensure_tuner: device-mapped pinned memory) */
+    /* The results are written by the last kernel straight into mapped, coherent host memory, each record's analysis number last (system-scope
+     * release): the caller polls those words -- a record that carries this call's number is complete -- and falls back to waiting for the stream
+     * when they do not show up within a few milliseconds (or when the kernels' events are being collected: profiling reads them at the sync). */
     gdg_tuner_out *host = ctx->h_tuner_out;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    bool seen = false;
+    if (!ctx->profiling && ctx->tuner_poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int c = 0, spins = 0;
+        for (;;) {
+            while (c < ctx->nch && __atomic_load_n(&host[c].seq, __ATOMIC_ACQUIRE) == seq) c++;
+            if (c == ctx->nch) { seen = true; break; }
+            __builtin_ia32_pause();
+            if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+    }
+    if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < ctx->nch; c++) {
         results[c].frequency = host[c].frequency;
         results[c].note_index = host[c].note_index;

@@ -243,6 +243,9 @@ struct gdg_ctx {
     double *d_note_freqs = nullptr;
     gdg_tuner_out *d_tuner_out = nullptr, *h_tuner_out = nullptr;      /* results: pinned host memory the kernels write directly (d_ = its device-side address) */
     double2 *d_tuner_work = nullptr, *d_tuner_twn = nullptr, *d_tuner_twm = nullptr;
+    int tuner_part_cap = 0;                    /* parts per channel d_tuner_part holds */
+    unsigned tuner_seq = 0;                    /* number of the last analysis (every result record carries it: api_tuner_spat.cpp) */
+    int tuner_poll = 1;                        /* option tuner_poll_results: the caller polls the records instead of waiting for the stream */
     double2 *d_tuner_part = nullptr;           /* partial sums of a short-lag analysis split over several workgroups per channel */
     std::vector<double> sp_az, sp_dist, sp_level;
     uint32_t sp_hist_sr = 96000;

@@ -222,17 +222,19 @@ hipError_t gdg_launch_spatializer(const gdg_spat_chan *d_chans, int nch, const d
  * ---------------------------------------------------------------------------------------------- */
 #define GDG_TUNER_RING 96000          /* tuner/tuner.go:16 */
 #define GDG_TUNER_FFT 262144          /* nextpow2(2 * 96000), tuner.go:388-390 */
-struct gdg_tuner_out { double frequency; int note_index; int cents; };
+/* seq: the analysis this record belongs to -- written LAST, at system scope, so that a host that finds the current number in a record of
+ * mapped, coherent host memory may read the record without waiting for the stream (api_tuner_spat.cpp) */
+struct gdg_tuner_out { double frequency; int note_index; int cents; unsigned seq; int pad; };
 hipError_t gdg_launch_tuner_enqueue(double *d_rings, int nch, int wp, const double *d_samples, int stride, int frames, hipStream_t s);
 hipError_t gdg_tuner_tables_create(double2 **d_tw_n, double2 **d_tw_m);
 int gdg_tuner_short_ok(double sample_rate, double lowest_note_frequency);
 /* parts > 1: a channel's blocks over `parts` workgroups, partial sums through d_partial ([nch][parts][4096] complex) */
 int gdg_tuner_short_parts(int nch);
 hipError_t gdg_launch_tuner_short(const double *d_rings, int nch, int wp, double sample_rate, const double2 *tw4096, const double2 *tw2_4096,
-                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, double2 *d_partial, int parts, hipStream_t s);
+                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, double2 *d_partial, int parts, hipStream_t s, unsigned seq = 0);
 hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, double sample_rate, double2 *d_work,
                                     const double2 *d_tw_n, const double2 *d_tw_m, const double2 *d_tw512, const double2 *d_tw256,
-                                    const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s);
+                                    const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s, unsigned seq = 0);
 
 /* ------------------------------------------------------------------------------------------------
  * io.hip: the data formats either side of the path: wave sample codecs, resample.Time,

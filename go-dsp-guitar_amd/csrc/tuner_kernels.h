@@ -176,7 +176,7 @@ __device__ __forceinline__ void tuner_lag_window(double sample_rate, const doubl
 
 template <class Corr>
 __device__ __forceinline__ void tuner_pick(Corr corr, double sample_rate, const double *__restrict__ note_freqs, int n_notes,
-                                           gdg_tuner_out *__restrict__ out_ch, double *s_val, int *s_idx) {
+                                           gdg_tuner_out *__restrict__ out_ch, double *s_val, int *s_idx, unsigned seq) {
     const int tid = threadIdx.x;
     const int n = GDG_TUNER_RING;
     long long low_idx, high_idx;
@@ -247,16 +247,19 @@ __device__ __forceinline__ void tuner_pick(Corr corr, double sample_rate, const 
         out_ch->frequency = freq;
         out_ch->note_index = s_idx[0];
         out_ch->cents = cents_int;
+        /* the record is complete for whoever reads `seq` (the host polls it in mapped host memory): system-scope release, then the number */
+        __threadfence_system();
+        __hip_atomic_store(&out_ch->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 __global__ void __launch_bounds__(256)
 tuner_pick_kernel(const cplx *__restrict__ R, double sample_rate, const double *__restrict__ note_freqs, int n_notes,
-                  gdg_tuner_out *__restrict__ out) {
+                  gdg_tuner_out *__restrict__ out, unsigned seq) {
     __shared__ double s_val[256];
     __shared__ int s_idx[256];
     const cplx *r = R + (size_t)blockIdx.x * TUNER_N;
-    tuner_pick([&](int lag) { return tuner_corr(r, lag); }, sample_rate, note_freqs, n_notes, out + blockIdx.x, s_val, s_idx);
+    tuner_pick([&](int lag) { return tuner_corr(r, lag); }, sample_rate, note_freqs, n_notes, out + blockIdx.x, s_val, s_idx, seq);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -364,7 +367,7 @@ __device__ __forceinline__ void tuner_accumulate_blocks(const double *ring, int 
 template <int LOGN>
 __device__ __forceinline__ void tuner_finish(const cplx (&sk)[(FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T], const cplx (&sn)[(FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T],
                                              double *s_all, double *s_val, int *s_idx, double sample_rate, const cplx *__restrict__ tw,
-                                             const cplx *__restrict__ tw2, const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *out_ch) {
+                                             const cplx *__restrict__ tw2, const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *out_ch, unsigned seq) {
     constexpr int N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
     double *sre = s_all, *sim = s_all + FftCfg<LOGN>::LDS;
     const int tid = threadIdx.x;
@@ -389,7 +392,7 @@ __device__ __forceinline__ void tuner_finish(const cplx (&sk)[(FftCfg<LOGN>::N /
         }
     }
     __syncthreads();
-    tuner_pick([&](int lag) { return s_all[lag]; }, sample_rate, note_freqs, n_notes, out_ch, s_val, s_idx);
+    tuner_pick([&](int lag) { return s_all[lag]; }, sample_rate, note_freqs, n_notes, out_ch, s_val, s_idx, seq);
 }
 
 #define TUNER_NBLK ((GDG_TUNER_RING + TUNER_BLK - 1) / TUNER_BLK)                                /* 24 */
@@ -397,7 +400,7 @@ __device__ __forceinline__ void tuner_finish(const cplx (&sk)[(FftCfg<LOGN>::N /
 /* one workgroup per channel: all 24 blocks, then the finish (a chip's worth of channels) */
 __global__ void __launch_bounds__(256)
 tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate, const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
-                   const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out) {
+                   const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out, unsigned seq) {
     constexpr int LOGN = 12, ITER = (FftCfg<LOGN>::N / 2) / FftCfg<LOGN>::T;                    /* 4096 complex points, 256 threads */
     __shared__ double s_all[2 * FftCfg<LOGN>::LDS];
     __shared__ double s_val[256];
@@ -407,7 +410,7 @@ tuner_short_kernel(const double *__restrict__ rings, int wp, double sample_rate,
 #pragma unroll
     for (int i = 0; i < ITER; i++) { sk[i] = sn[i] = make_double2(0.0, 0.0); }
     tuner_accumulate_blocks<LOGN>(rings + (size_t)ch * GDG_TUNER_RING, wp, 0, TUNER_NBLK, false, s_all, s_all + FftCfg<LOGN>::LDS, tw, tw2, sk, sn);
-    tuner_finish<LOGN>(sk, sn, s_all, s_val, s_idx, sample_rate, tw, tw2, note_freqs, n_notes, out + ch);
+    tuner_finish<LOGN>(sk, sn, s_all, s_val, s_idx, sample_rate, tw, tw2, note_freqs, n_notes, out + ch, seq);
 }
 
 /* Fewer channels than CUs (BASELINE config 5 on 8 GPUs: 32 tuners per GPU): a channel's 24 blocks are cut into `parts` runs, one workgroup
@@ -430,7 +433,7 @@ tuner_short_part_kernel(const double *__restrict__ rings, int wp, int parts, con
 
 __global__ void __launch_bounds__(256)
 tuner_short_finish_kernel(const cplx *__restrict__ partial, int parts, double sample_rate, const cplx *__restrict__ tw, const cplx *__restrict__ tw2,
-                          const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out) {
+                          const double *__restrict__ note_freqs, int n_notes, gdg_tuner_out *__restrict__ out, unsigned seq) {
     constexpr int LOGN = 12, N = FftCfg<LOGN>::N, T = FftCfg<LOGN>::T, ITER = (N / 2) / T;
     __shared__ double s_all[2 * FftCfg<LOGN>::LDS];
     __shared__ double s_val[256];
@@ -439,7 +442,24 @@ tuner_short_finish_kernel(const cplx *__restrict__ partial, int parts, double sa
     cplx sk[ITER], sn[ITER];
 #pragma unroll
     for (int i = 0; i < ITER; i++) { sk[i] = sn[i] = make_double2(0.0, 0.0); }
-    for (int p = 0; p < parts; p++) {                              /* in part order */
+    /* in part order; FOUR parts' loads (4 x 2 ITER sixteen-byte loads per lane) are in flight before the first is added: one part per round
+     * was eight exposed HBM latencies on the one CU that finishes a channel (12.6 us at 8 parts) */
+    int p = 0;
+#pragma unroll 1
+    for (; p + 4 <= parts; p += 4) {
+        cplx a[4][ITER], b[4][ITER];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const cplx *src = partial + ((size_t)ch * parts + p + q) * N;
+#pragma unroll
+            for (int i = 0; i < ITER; i++) { a[q][i] = gload(src + (2 * i) * T + tid); b[q][i] = gload(src + (2 * i + 1) * T + tid); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int i = 0; i < ITER; i++) { sk[i].x += a[q][i].x; sk[i].y += a[q][i].y; sn[i].x += b[q][i].x; sn[i].y += b[q][i].y; }
+    }
+    for (; p < parts; p++) {
         const cplx *src = partial + ((size_t)ch * parts + p) * N;
 #pragma unroll
         for (int i = 0; i < ITER; i++) {
@@ -447,7 +467,7 @@ tuner_short_finish_kernel(const cplx *__restrict__ partial, int parts, double sa
             sk[i].x += a.x; sk[i].y += a.y; sn[i].x += b.x; sn[i].y += b.y;
         }
     }
-    tuner_finish<LOGN>(sk, sn, s_all, s_val, s_idx, sample_rate, tw, tw2, note_freqs, n_notes, out + ch);
+    tuner_finish<LOGN>(sk, sn, s_all, s_val, s_idx, sample_rate, tw, tw2, note_freqs, n_notes, out + ch, seq);
 }
 
 hipError_t gdg_launch_tuner_enqueue(double *d_rings, int nch, int wp, const double *d_samples, int stride, int frames, hipStream_t s) {
@@ -471,30 +491,30 @@ int gdg_tuner_short_ok(double sample_rate, double lowest_note_frequency) {
 int gdg_tuner_short_parts(int nch) {
     const int forced = gdg_knob_get(GDG_KNOB_TUNER_PARTS);        /* 0: by channel count (gdg_ctx_set_option "tuner_parts") */
     int parts = forced > 0 ? forced : (nch >= cu_count() ? 1 : (cu_count() + nch - 1) / nch);
-    if (parts > 8) parts = 8;
+    if (parts > (forced > 0 ? TUNER_NBLK : 8)) parts = forced > 0 ? TUNER_NBLK : 8;
     return parts < 1 ? 1 : parts;
 }
 
 hipError_t gdg_launch_tuner_short(const double *d_rings, int nch, int wp, double sample_rate, const cplx *tw4096, const cplx *tw2_4096,
-                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, cplx *d_partial, int parts, hipStream_t s) {
+                                  const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, cplx *d_partial, int parts, hipStream_t s, unsigned seq) {
     if (parts <= 1 || !d_partial) {
-        tuner_short_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_rings, wp, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out);
+        tuner_short_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_rings, wp, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out, seq);
         return hipGetLastError();
     }
     tuner_short_part_kernel<<<dim3(nch * parts), dim3(256), 0, s>>>(d_rings, wp, parts, tw4096, tw2_4096, d_partial);
-    tuner_short_finish_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_partial, parts, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out);
+    tuner_short_finish_kernel<<<dim3(nch), dim3(256), 0, s>>>(d_partial, parts, sample_rate, tw4096, tw2_4096, d_note_freqs, n_notes, d_out, seq);
     return hipGetLastError();
 }
 
 hipError_t gdg_launch_tuner_analyze(const double *d_rings, int nch, int wp, double sample_rate, cplx *d_work,
                                     const cplx *d_tw_n, const cplx *d_tw_m, const cplx *tw512, const cplx *tw256,
-                                    const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s) {
+                                    const double *d_note_freqs, int n_notes, gdg_tuner_out *d_out, hipStream_t s, unsigned seq) {
     cplx *bufA = d_work, *bufB = d_work + (size_t)nch * TUNER_N;
     tuner_col_kernel<false, true><<<dim3(TUNER_N2 / TUNER_COLS_PER_WG, nch), dim3(256), 0, s>>>(d_rings, wp, nullptr, bufA, tw512, d_tw_n);
     tuner_row_kernel<false><<<dim3(TUNER_N1 / TUNER_ROWS_PER_WG, nch), dim3(256), 0, s>>>(bufA, tw256);
     tuner_square_kernel<<<dim3(TUNER_N / 2 / 256, nch), dim3(256), 0, s>>>(bufA, bufB, d_tw_m);
     tuner_col_kernel<true, false><<<dim3(TUNER_N2 / TUNER_COLS_PER_WG, nch), dim3(256), 0, s>>>(nullptr, 0, bufB, bufA, tw512, d_tw_n);
     tuner_row_kernel<true><<<dim3(TUNER_N1 / TUNER_ROWS_PER_WG, nch), dim3(256), 0, s>>>(bufA, tw256);
-    tuner_pick_kernel<<<dim3(nch), dim3(256), 0, s>>>(bufA, sample_rate, d_note_freqs, n_notes, d_out);
+    tuner_pick_kernel<<<dim3(nch), dim3(256), 0, s>>>(bufA, sample_rate, d_note_freqs, n_notes, d_out, seq);
     return hipGetLastError();
 }

@@ -120,6 +120,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   numa                         0, 1, 2     copy workers on the CPUs, pinned slabs from the memory, of a NUMA node: 2 the node the caller runs on when
  *                                            they are made, 1 the device's node, 0 wherever the scheduler and hipHostMalloc put them (2; set it before
  *                                            the first host-buffer call -- slabs that exist stay where they are)
+ *   tuner_poll_results           0, 1        gdg_tuner_analyze reads the result records (mapped host memory, each ending with its analysis number) as soon
+ *                                            as they carry this call's number instead of waiting for the stream to drain (1)
  *   tuner_long_transform         0, 1        every tuner analysis through the reference's 262144-point transform pair (0)
  *   profile_attach               0, 1        the fused convolution launch records its own begin / end events (1)
  * Process-wide (the transforms' and the tuner's launchers have no context; set them before the first call that uses them):
