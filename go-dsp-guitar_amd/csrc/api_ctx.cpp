@@ -148,6 +148,7 @@ static const OptionDef g_options[] = {
     /* the convolution */
     { "fir_fused", "GDG_FIR_FUSED", -1, 1, -1, &gdg_ctx::fir_fused, nullptr, true },                  /* -1: by channel count (fir_split_max) */
     { "fir_split_max_channels", "GDG_FIR_SPLIT_MAX", 0, 1 << 20, -1, &gdg_ctx::fir_split_max, nullptr, true },
+    { "fir_split_max_channels_one_amp", "GDG_FIR_SPLIT_MAX_ONE_AMP", 0, 1 << 20, -1, &gdg_ctx::fir_split_max_single, nullptr, true },
     { "fir_chain_adjacent_amps", "GDG_FIR_CHAIN", 0, 1, -1, nullptr, &gdg_ctx::fir_chain, true },
     { "fir_premac", "GDG_FIR_PREMAC", 0, 1, -1, &gdg_ctx::fir_premac, nullptr, true },
     { "fir_premac_min_partitions", "GDG_FIR_PREMAC_MIN", 1, 1 << 24, -1, &gdg_ctx::fir_premac_min, nullptr, true },
@@ -160,6 +161,7 @@ static const OptionDef g_options[] = {
     { "seg_two_per_cu", "GDG_SEG_FAST", 0, 1, -1, nullptr, &gdg_ctx::seg_fast, true },
     { "seg_two_per_cu_min_channels", "GDG_SEG_FAST_MIN", 0, 1 << 20, -1, &gdg_ctx::seg_fast_min, nullptr, true },
     { "seg_wave_max_channels", "GDG_SEG_WAVE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_max, nullptr, true },
+    { "seg_wave_release_max_channels", "GDG_SEG_WAVE_RELEASE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_release_max, nullptr, true },
     { "seg_os_tiles_max_channels", "GDG_SEG_OS_TILES_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_os_tiles_max, nullptr, true },
     { "seg_reverb_ahead_max_channels", "GDG_SEG_REVERB_AHEAD_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_reverb_ahead_max, nullptr, true },
     { "wave_spin_limit_ms", "GDG_WAVE_SPIN_LIMIT_MS", 1, 600000, -1, &gdg_ctx::wave_spin_ms, nullptr, false },

@@ -745,6 +745,8 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     ctx->patch_units.clear();                  /* this plan reads every unit's current parameters */
     ctx->plan_unit_fast.assign(ctx->units.size(), 0);
     ctx->plan_unit_fast_ok.assign(ctx->units.size(), 0);
+    ctx->plan_fir_steps = 0;
+    for (auto &kv : by_slot) if ((kv.first & 3) == K_FIR) ctx->plan_fir_steps++;
     for (auto &kv : by_slot) {
         const int kind = kv.first & 3;
         const bool is_fir = kind == K_FIR, is_os = kind == K_OS2 || kind == K_OS4;
@@ -815,7 +817,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
                         return fail(ctx, GDG_ERR_INVALID, "reverb delay line of %d cells, expected the longest tap + %d", du.jp[4], GDG_MAX_FRAMES);
                     /* a reverb behind an earlier general-kernel segment launch of the same call: that launch makes its wet path beside its own
                      * channels (extra workgroups: the channels are too few to fill the chip), the unit itself only mixes */
-                    if (du.type == GDG_UNIT_REVERB && !step_fast && !is_os && ahead_host >= 0 && n_act <= ctx->seg_reverb_ahead_max &&
+                    if (du.type == GDG_UNIT_REVERB && !step_fast && !is_os && ahead_host >= 0 && ctx->seg_reverb_ahead_max > 0 && n_act <= std::max(ctx->seg_reverb_ahead_max, 127) &&
                         reverb_ahead_ok(frames, sample_rate)) {
                         du.ip[7] = 1;
                         ahead_lists[(size_t)ahead_host].push_back((int)seg_units.size());
@@ -835,6 +837,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         st.os_factor = is_os ? (kind == K_OS2 ? 2 : 4) : 0;
         st.fast = step_fast;
         st.n = is_fir ? (int)fd.size() : (int)sd.size();
+        for (auto &d : sd) if ((unsigned)d.wave_mask >> 31) st.wave_release = true;
         st.offset = 0;
         if (!is_fir && seg_steps < GDG_WAVE_STEPS && G <= GDG_WAVE_GROUPS) st.wave_tickets = GDG_WAVE_GROUPS * seg_steps++;
         if (is_os) { st.os_flags = (int)wave_next; wave_next += sd.size(); }                /* one flag per channel of the launch (os_tiles_kernel) */
@@ -855,7 +858,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
             std::sort(hp.begin(), hp.end());
             st.shared_spectra = std::adjacent_find(hp.begin(), hp.end()) != hp.end();
             /* the terms k >= 1 ahead of the frame (premac): the split launch shape of few channels, one group, batch frames, every channel K >= 2 */
-            const bool split = ctx->fir_fused < 0 ? (st.n <= ctx->fir_split_max) : (ctx->fir_fused == 0);
+            const bool split = ctx->fir_fused < 0 ? (st.n <= fir_split_limit(ctx)) : (ctx->fir_fused == 0);
             long partitions = 0;
             for (auto &f : fd) partitions += f.K;
             st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && partitions >= ctx->fir_premac_min;
@@ -882,6 +885,13 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         ctx->steps.push_back(st);
         seg_descs.push_back(sd);
         fir_descs.push_back(fd);
+    }
+    {   /* the reverbs' wet paths as extra workgroups share the chip with the premac's launches: with both, fewer channels (ctx.h) */
+        bool any_premac = false;
+        for (auto &st : ctx->steps) any_premac = any_premac || (st.is_fir && st.premac_ok);
+        if (any_premac && (int)active.size() > ctx->seg_reverb_ahead_max) {
+            for (auto &l : ahead_lists) { for (int idx : l) seg_units[(size_t)idx].ip[7] = 0; l.clear(); }
+        }
     }
     {   /* the new filters' spectra, all together */
         const double tq = pnow();

@@ -230,7 +230,7 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                 const bool chained = si > 0 && ctx->steps[si - 1].chain_next;      /* the previous power amp's inverse made this one's spectrum */
                 if (!chained) { ProfScope ps(ctx, GDG_K_FIR_FWD, s); HIP_TRY(ctx, gdg_launch_fir_fwd(P2, frames, d, n, tw, tw2, shift, s)); }
                 const gdg_fir_chan *d_next = st.chain_next ? reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + ctx->steps[si + 1].offset) + first : nullptr;
-                const bool fused = ctx->fir_fused < 0 ? (n > ctx->fir_split_max) : (ctx->fir_fused != 0);
+                const bool fused = ctx->fir_fused < 0 ? (n > fir_split_limit(ctx)) : (ctx->fir_fused != 0);
                 if (fused) {
                     /* multiply-accumulate fused into the inverse transform's first stage (reported as the MAC kernel; its chained
                      * variant, which also makes the next amp's forward transform, under a kind of its own) */
@@ -262,7 +262,8 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                 /* one launch per window: a channel's workgroup walks its frames in order, the units' state runs through them */
                 /* ... unless the channels are few: then a workgroup per frame, the frames of a channel meeting unit by unit (seg.hip, WAVE) */
                 /* (by the CALL's channel count, not the group's: two groups of 256 channels fill the chip like one launch of 512) */
-                int *tickets = (window > 1 && (int)active.size() <= ctx->seg_wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
+                const int wave_max = st.wave_release ? std::min(ctx->seg_wave_max, ctx->seg_wave_release_max) : ctx->seg_wave_max;
+                int *tickets = (window > 1 && (int)active.size() <= wave_max && st.wave_tickets >= 0) ? ctx->d_wave + st.wave_tickets + g : nullptr;
                 const int epoch = tickets ? (ctx->wave_epoch = (ctx->wave_epoch % 0x3ffffff) + 1) : 0;          /* epoch * 32 + frame fits an int */
                 /* option debug_stall_unit: in a WAVE launch frame 0 of that unit's channel withholds the unit's counter (seg.hip) */
                 int stall = 0;

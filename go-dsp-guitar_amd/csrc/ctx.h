@@ -113,6 +113,7 @@ struct StepDesc {
     int os_flags = -1;                /* ... and its per-channel flags start here in d_wave */
     int ahead_n = 0;                  /* segment step (general kernel, one frame per launch): it also makes the wet paths of this many reverbs of LATER steps ... */
     size_t ahead_offset = 0;          /* ... whose indices into the plan's unit array start here in the blob (seg.hip REVERB_AHEAD) */
+    bool wave_release = false;        /* segment step: some channel's segment hands its state on through a write-back of the XCD's L2 (wave_mask bit 31) */
     int wave_tickets = -1;            /* segment step: first of its GDG_WAVE_GROUPS ticket counters in d_wave (seg.hip, WAVE), -1: none */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
 };
@@ -154,6 +155,9 @@ struct gdg_ctx {
      * 52 of the 77 us per frame).  0: never.  gdg_ctx_set_option("seg_wave_max_channels"), env GDG_SEG_WAVE_MAX. */
     int seg_os_tiles_max = 192;                /* calls of up to this many channels run oversampled shapers as launches of their own, a workgroup per tile
                                                 * (option "seg_os_tiles_max_channels"; 0: never) */
+    int seg_wave_release_max = 112;            /* ... of segments with a unit whose state leaves the CU through plain stores (flanger, phaser, delay, fuzz, auto-yoy, auto-wah,
+                                                * band pass, octaver, noise gate): every hand-off then writes the XCD's L2 back, and from ~128 channels on the walk
+                                                * is faster (192 channels 84 vs 66 us per frame, 448: 202 vs 145; profiles/shape_sweep_r06.txt) */
     int seg_wave_max = 448;                    /* W = 16, us per frame, walk -> a workgroup per frame: 64 channels 77 -> 48, 128: 102 -> 77, 256: 146 -> 138, 384: 222 -> 206;
                                                 * 512: 259 -> 263 (the walk wins once two workgroups per CU are all busy anyway) */
     int scan_tables_max = 1024;                /* scan tables kept before a plan rebuild drops them all (a caller sweeping a parameter) */
@@ -225,6 +229,9 @@ struct gdg_ctx {
     int fir_split_max = 128;          /* largest launch (channels) that takes the split shape.  Round 2 measured the two shapes equal at 128 channels
                                        * (220 us per step either way) and set 96; with the sums made ahead of the frame (premac, below) the split shape
                                        * takes 207 us there, at 192 channels the fused kernel wins again (252 vs 274) */
+    int fir_split_max_single = 112;   /* ... when the call has ONE power amp per channel: the premac has half as much to hide, and at 128 channels the fused kernel wins
+                                       * (one amp: 138.8 split vs 127.1 fused us per step, 96 channels 112 vs 125; profiles/shape_sweep_r06.txt) */
+    int plan_fir_steps = 0;           /* power-amp steps of the current plan */
     bool fir_chain = true;            /* GDG_FIR_CHAIN=0: adjacent power amps keep separate launches (A/B measurements, bit-identity tests) */
     double *d_os = nullptr;
     gdg_os_tables os;
@@ -327,6 +334,11 @@ static inline void enter(gdg_ctx *ctx, bool read_only = false) {
     hipSetDevice(ctx->device);
     join_groups(ctx);
     join_premac(ctx, read_only);
+}
+
+/* largest launch (channels) that takes the split convolution shape: by the number of power amps per channel in the plan */
+static inline int fir_split_limit(const gdg_ctx *ctx) {
+    return ctx->plan_fir_steps >= 2 ? ctx->fir_split_max : std::min(ctx->fir_split_max, ctx->fir_split_max_single);
 }
 
 #define HIP_TRY(ctx, call)                                                                          \

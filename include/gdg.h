@@ -86,6 +86,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   key                          values      meaning (default)
  *   fir_fused                    -1, 0, 1    spectrum multiply-accumulate inside the inverse transform's kernel: by channel count / never / always (-1)
  *   fir_split_max_channels       >= 0        with fir_fused = -1: launches of up to this many channels take the bin-tiled multiply-accumulate (128)
+ *   fir_split_max_channels_one_amp >= 0      ... and when the call has ONE power amp per channel the smaller of the two applies (112: with one amp the
+ *                                            fused kernel wins at 128 channels, profiles/shape_sweep_r06.txt)
  *   fir_chain_adjacent_amps      0, 1        a power amp's inverse transform also makes the forward transform of the amp behind it (1)
  *   fir_premac                   0, 1        per-frame calls of few channels (the split launch shape): when a call ends, the sums of the NEXT frame's
  *                                            convolution over the partitions that are already in the delay line (7 of 8 at 65536 taps) are launched on a
@@ -98,13 +100,17 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (128)
  *   seg_wave_max_channels        >= 0        windows (gdg_ctx_set_window) of up to this many channels per call: one workgroup per FRAME and channel, the
  *                                            frames of a channel meeting unit by unit -- fills the chip when the channels alone do not (448; 0: never)
+ *   seg_wave_release_max_channels >= 0       ... but segments holding a unit whose state leaves the CU through plain stores (flanger, phaser, delay,
+ *                                            fuzz, auto-yoy, auto-wah, band pass, octaver, noise gate: every hand-off writes the XCD's L2 back) only up
+ *                                            to this many channels (112)
  *   seg_os_tiles_max_channels    >= 0        calls of up to this many channels run every 2 x / 4 x oversampled shaper as a launch of its own, one workgroup
  *                                            per (channel, frame, tile of 4096 / 2048 samples) instead of one per channel (192; 0: never)
  *   seg_reverb_ahead_max_channels >= 0       per-frame calls of up to this many channels: the call's first segment launch also makes, with extra
  *                                            workgroups beside the channels' own, the wet path of every reverb of its LATER segment steps -- tapped
  *                                            sums and all-passes need nothing of the frame itself when every tap lies at least a frame back
- *                                            (8192-sample frames, 42.7 .. 194.9 kHz) -- and the reverb behind the power amps only mixes.  Same bits
- *                                            either way (80; 0: never)
+ *                                            (8192-sample frames, rates from 42.7 kHz) -- and the reverb behind the power amps only mixes.  The limit
+ *                                            applies to calls that also sum convolution terms ahead (fir_premac: its launches want the same idle CUs);
+ *                                            without them up to 127 channels.  Same bits either way (80; 0: never)
  *   wave_spin_limit_ms           1 .. 600000 how long a workgroup of an in-launch hand-off (windows of few channels, tiles of an oversampled shaper) waits
  *                                            for its predecessor before the launch gives up: the wait ends, the context's error word is set and the next
  *                                            gdg_ctx_synchronize (or batch run) returns GDG_ERR_HIP -- the device never hangs.  RESULTS OF WINDOW CALLS ARE
