@@ -465,7 +465,7 @@ def other_configs(pkg, device):
     ctx.spatialize_device(d_x, d_lr, frames)
     ctx.tuner_analyze()
     st_sp = robust_time(lambda: [ctx.spatialize_device(d_x, d_lr, frames) for _ in range(20)], ctx.synchronize, units=20)
-    st_an = robust_time(lambda: [ctx.tuner_analyze(raw=True) for _ in range(5)], ctx.synchronize, units=5)
+    st_an = robust_time(lambda: [ctx.tuner_analyze(raw=True) for _ in range(20)], ctx.synchronize, units=20)
     t_sp, t_an = st_sp["median"], st_an["median"]
     # the two kernels' own durations (HIP events on the launches) against SURVEY 8(d)'s algorithmic bytes: 768 kB per analysis (the ring,
     # read once), 8 B per channel-sample for the mix
@@ -504,7 +504,8 @@ def other_configs(pkg, device):
     for _ in range(13):
         ctx32.tuner_enqueue_device(d32, frames, sr)
     ctx32.tuner_analyze()
-    st32 = robust_time(lambda: [ctx32.tuner_analyze(raw=True) for _ in range(5)], ctx32.synchronize, units=5)
+    # (50 calls per repetition: the synchronize that brackets a repetition -- an error-word read-back + a stream wait, ~40 us -- is not part of an analysis)
+    st32 = robust_time(lambda: [ctx32.tuner_analyze(raw=True) for _ in range(50)], ctx32.synchronize, units=50)
     d32.free()
     ctx32.close()
     out["config5_32_tuners_per_gpu"] = {"value": 32 / st32["median"], "unit": "analyses/s", "us_per_32_analyses": st32["median"] * 1e6,
