@@ -162,6 +162,7 @@ static const OptionDef g_options[] = {
     { "seg_two_per_cu_min_channels", "GDG_SEG_FAST_MIN", 0, 1 << 20, -1, &gdg_ctx::seg_fast_min, nullptr, true },
     { "seg_wave_max_channels", "GDG_SEG_WAVE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_max, nullptr, true },
     { "seg_wave_release_max_channels", "GDG_SEG_WAVE_RELEASE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_release_max, nullptr, true },
+    { "seg_tile_max_channels", "GDG_SEG_TILE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_tile_max, nullptr, true },
     { "seg_os_tiles_max_channels", "GDG_SEG_OS_TILES_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_os_tiles_max, nullptr, true },
     { "seg_reverb_ahead_max_channels", "GDG_SEG_REVERB_AHEAD_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_reverb_ahead_max, nullptr, true },
     { "wave_spin_limit_ms", "GDG_WAVE_SPIN_LIMIT_MS", 1, 600000, -1, &gdg_ctx::wave_spin_ms, nullptr, false },
@@ -286,7 +287,7 @@ int gdg_ctx_destroy(gdg_ctx *ctx) {
     for (auto &kv : ctx->fir_tables) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (auto &p : ctx->prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error); hipFree(ctx->d_wave);
+    hipFree(ctx->d_w0); hipFree(ctx->d_w1); hipFree(ctx->d_scratch); hipFree(ctx->d_error); hipFree(ctx->d_wave); hipFree(ctx->d_tile_xch);
     hipFree(ctx->d_stage_in); hipFree(ctx->d_stage_out); hipFree(ctx->d_blob); hipFree(ctx->d_os);
     hipFree(ctx->d_tuner_ring); hipFree(ctx->d_sp_hist);
     hipFree(ctx->d_note_freqs); /* d_tuner_out is the device view of h_tuner_out */ hipFree(ctx->d_tuner_work); hipFree(ctx->d_tuner_part); hipFree(ctx->d_tuner_twn); hipFree(ctx->d_tuner_twm);

@@ -838,6 +838,21 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         st.fast = step_fast;
         st.n = is_fir ? (int)fd.size() : (int)sd.size();
         for (auto &d : sd) if ((unsigned)d.wave_mask >> 31) st.wave_release = true;
+        if (!is_fir && !is_os && !step_fast && frames == GDG_MAX_FRAMES && n_act <= ctx->seg_tile_max && !sd.empty()) {
+            /* a channel's frame on two workgroups in per-frame calls: unit types, no oversampling, the exchange ids of a segment within the area */
+            st.tile_ok = true;
+            for (auto &entry : kv.second) {
+                int xids = 0;
+                for (int h : entry.second.handles) {
+                    const Unit &tu = ctx->units[(size_t)h];
+                    const bool shaper = tu.type == GDG_UNIT_OVERDRIVE || tu.type == GDG_UNIT_DISTORTION || tu.type == GDG_UNIT_EXCESS;
+                    const int os_param = tu.type == GDG_UNIT_OVERDRIVE ? 5 : (tu.type == GDG_UNIT_DISTORTION ? 3 : 2);
+                    if (!gdg_segt_supported(tu.type) || (shaper && tu.params[os_param] != 0)) st.tile_ok = false;
+                    xids += gdg_segt_exchanges(tu.type);
+                }
+                if (xids > 32 || entry.second.handles.size() > 16 || entry.second.handles.empty()) st.tile_ok = false;
+            }
+        }
         st.offset = 0;
         if (!is_fir && seg_steps < GDG_WAVE_STEPS && G <= GDG_WAVE_GROUPS) st.wave_tickets = GDG_WAVE_GROUPS * seg_steps++;
         if (is_os) { st.os_flags = (int)wave_next; wave_next += sd.size(); }                /* one flag per channel of the launch (os_tiles_kernel) */
@@ -944,6 +959,18 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
      * os_tiles flag keeps its launch's epoch, a chorus "done" mark keeps epoch * 32 + f + 1).  Every stream is joined and drained here. */
     if (wave_next > ctx->d_wave_cap) return fail(ctx, GDG_ERR_INVALID, "counter layout of %zu words exceeds the %zu allocated", wave_next, ctx->d_wave_cap);
     if (ctx->d_wave) HIP_TRY(ctx, hipMemsetAsync(ctx->d_wave, 0, ctx->d_wave_cap * sizeof(int), ctx->stream));
+    {   /* the tiles' exchange area: one block per descriptor of the largest tile launch; zero with every plan (tags of another layout) */
+        size_t need = 0;
+        for (auto &st : ctx->steps) if (st.tile_ok) need = std::max(need, (size_t)st.n * gdg_segt_xch_words());
+        if (need > ctx->d_tile_xch_cap) {
+            hipFree(ctx->d_tile_xch);
+            ctx->d_tile_xch = nullptr;
+            ctx->d_tile_xch_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_xch, need * sizeof(unsigned long long)));
+            ctx->d_tile_xch_cap = need;
+        }
+        if (ctx->d_tile_xch && need > 0) HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_xch, 0, ctx->d_tile_xch_cap * sizeof(unsigned long long), ctx->stream));
+    }
     if (!ctx->blob.empty())
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, ctx->blob.data(), ctx->blob.size(), hipMemcpyHostToDevice, ctx->stream));
     ctx->plan_frames = frames;

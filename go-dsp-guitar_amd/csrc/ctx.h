@@ -113,6 +113,7 @@ struct StepDesc {
     int os_flags = -1;                /* ... and its per-channel flags start here in d_wave */
     int ahead_n = 0;                  /* segment step (general kernel, one frame per launch): it also makes the wet paths of this many reverbs of LATER steps ... */
     size_t ahead_offset = 0;          /* ... whose indices into the plan's unit array start here in the blob (seg.hip REVERB_AHEAD) */
+    bool tile_ok = false;             /* segment step: every unit of every channel can run with the frame on two workgroups (seg.hip SEG_TILE) */
     bool wave_release = false;        /* segment step: some channel's segment hands its state on through a write-back of the XCD's L2 (wave_mask bit 31) */
     int wave_tickets = -1;            /* segment step: first of its GDG_WAVE_GROUPS ticket counters in d_wave (seg.hip, WAVE), -1: none */
     std::vector<std::pair<int, int>> group_range;     /* per channel group: (first descriptor, count) */
@@ -153,6 +154,12 @@ struct gdg_ctx {
      * workgroup of its own, the frames meeting unit by unit through counters in HBM -- a GPU's share of the 512-channel job on eight GPUs is 64
      * channels, and one workgroup per channel walking the window leaves 3/4 of the CUs idle (64 channels, W = 16: 417 us per segment launch,
      * 52 of the 77 us per frame).  0: never.  gdg_ctx_set_option("seg_wave_max_channels"), env GDG_SEG_WAVE_MAX. */
+    int seg_tile_max = 64;                     /* per-frame calls of up to this many channels: a segment of compressor / shapers / tone stack / cabinet / chorus runs with
+                                                * a channel's frame on TWO workgroups (seg.hip SEG_TILE; same bits).  Per step (profiles/tile_ab_r06.txt): 16 channels
+                                                * 107.0 -> 101.3 us, 32: 124.3 -> 118.1, 64: 139.8 -> 139.5, config 3 107.7 -> 104.2; 80: 151.7 -> 155.7 (the
+                                                * two workgroups, the reverbs' extra workgroups and the premac no longer find the chip idle) */
+    unsigned long long *d_tile_xch = nullptr;  /* what crosses between the two workgroups of a channel: gdg_segt_xch_words() words per descriptor of a launch */
+    size_t d_tile_xch_cap = 0;
     int seg_os_tiles_max = 192;                /* calls of up to this many channels run oversampled shapers as launches of their own, a workgroup per tile
                                                 * (option "seg_os_tiles_max_channels"; 0: never) */
     int seg_wave_release_max = 112;            /* ... of segments with a unit whose state leaves the CU through plain stores (flanger, phaser, delay, fuzz, auto-yoy, auto-wah,

@@ -195,6 +195,15 @@ hipError_t gdg_launch_segf(const gdg_seg_chan *d_chans, int n_chans, const gdg_s
                            gdg_os_tables os, int *d_error, hipStream_t s, int *d_wave_ticket = nullptr, int epoch = 0, int ahead = 0,
                            const int *d_ahead_list = nullptr, int n_ahead = 0);
 int gdg_segf_supported(int unit_type);
+/* per-frame calls of few channels: a channel's frame on TWO workgroups (seg.hip compiled with -DSEG_TILE; same bits as gdg_launch_seg).  The
+ * segments may hold the unit types gdg_segt_supported says, without oversampling, and at most 32 exchange ids in all (gdg_segt_exchanges per
+ * unit); d_ticket: a counter that is zero between launches; d_xch: gdg_segt_xch_words() 8-byte words per descriptor, zero before first use;
+ * epoch: a number no earlier launch used on these words; d_ahead_list / n_ahead as in gdg_launch_seg */
+hipError_t gdg_launch_segt(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, gdg_shift shift, gdg_os_tables os, int *d_error,
+                           hipStream_t s, int *d_ticket, int epoch, unsigned long long *d_xch, const int *d_ahead_list, int n_ahead);
+int gdg_segt_supported(int unit_type);
+int gdg_segt_exchanges(int unit_type);
+size_t gdg_segt_xch_words(void);
 /* an oversampled shaper (overdrive / distortion / excess at 2 x or 4 x) as a launch of its own, one workgroup per (channel, frame, tile): the
  * descriptors are segment descriptors whose unit_begin names the shaper; d_flags: one int per channel, any value but `epoch` (seg.hip) */
 hipError_t gdg_launch_os_tiles(int factor, const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames,

@@ -38,6 +38,13 @@
  * Same source, same arithmetic, same state layout in HBM (a stream may move between the two from call to call); the association of the
  * workgroup scans differs (512 chunks of 16 instead of 1024 of 8), i.e. results differ by the scans' rounding (~1e-16).
  */
+/*   segt.o  (-DSEG_TILE)  round 6: per-frame calls of few channels with a channel's frame on SEG_TILES = 2 workgroups (512 threads, 8-sample
+ *                         chunks, a tile of 4096 samples each): the units of a per-frame segment of few channels are VALU-bound on ONE CU
+ *                         while 3/4 of the chip idles.  Same arithmetic, same chunks and -- the point -- THE SAME ASSOCIATION as the general
+ *                         kernel: a scan's 16 wave totals still meet in one 16-lane scan, only that eight of them now come from the other
+ *                         workgroup through HBM (tile_put / tile_get below): bit-identical results.  Units: compressor, shapers without
+ *                         oversampling, tone stack, cabinet, chorus; the launch also carries the extra workgroups of the general kernel
+ *                         (reverbs' wet paths, REVERB_AHEAD).  Two LDS frame buffers as in the general build. */
 #ifdef SEG_FAST
 #define GDG_CHK 16                        /* before gdg_internal.h: the scan-table layouts follow the chunk size */
 #endif
@@ -54,16 +61,28 @@
 #define seg_kernel segf_kernel
 #define gdg_launch_seg gdg_launch_segf
 #define gdg_seg_supported gdg_segf_supported
+#elif defined(SEG_TILE)
+#define SEG_T 512                         /* a tile of 4096 samples per workgroup, 8-sample chunks as in the general kernel */
+#define SEG_MIN_WAVES_PER_EU 2
+#define SEG_SCR 3328
+#define SEG_TILES 2
 #else
 #define SEG_T 1024                        /* 16 waves = 4 per SIMD: hides the FP64 / LDS / HBM latencies of one workgroup per CU */
 #define SEG_MIN_WAVES_PER_EU 4
 #define SEG_SCR 3328
 #endif
+#if defined(SEG_FAST) || defined(SEG_TILE)
+#define SEG_SUBSET                        /* a build that runs a subset of the units: the general kernel's other units and its side kernels live in seg.o */
+#endif
+#ifndef SEG_TILES
+#define SEG_TILES 1
+#endif
 #define SEG_WAVES (SEG_T / 64)
 #define SEG_LBUF (8192 + 256 + 8)
 #define LX(e) ((e) + ((e) >> 5))
-#define CHK (GDG_MAX_FRAMES / SEG_T)     /* samples per thread at the batch block size */
-static_assert(CHK * SEG_T == GDG_MAX_FRAMES, "chunk size");
+#define SEG_N (GDG_MAX_FRAMES / SEG_TILES)   /* samples a workgroup holds at the batch block size */
+#define CHK (SEG_N / SEG_T)                  /* samples per thread at the batch block size */
+static_assert(CHK * SEG_T * SEG_TILES == GDG_MAX_FRAMES, "chunk size");
 static_assert(CHK == GDG_CHK, "chunk size of the scan tables");
 
 /* the workgroup's LDS, at file scope so that the (non-inlined) unit functions address it as LDS, not through flat pointers */
@@ -259,6 +278,20 @@ __device__ __forceinline__ void tab_fetch(double *dst, const double *src_generic
     for (int i = seg_tid(); i < n; i += blockDim.x) dst[i] = *(const __attribute__((address_space(1))) double *)(src + i);
 }
 
+#ifdef SEG_TILE
+/* ---- a channel's frame on several workgroups (SEG_TILE): what crosses between them ---------------------------------------------------------
+ * Values travel as GRANULES (MI355X guide, hand-off price list): a naturally aligned 8-byte { 32 data bits | 32-bit tag } written by ONE
+ * agent-scope store and read by ONE agent-scope load -- no flag, no fence, no ordering between granules: a granule is either this launch's
+ * (its tag is the launch's epoch, a number no earlier launch of the context used for these cells) or it is not there yet.  A double is two
+ * granules.  Slot layout per channel (gdg_seg_chan.scratch): [exchange id][16 waves][2 values][2 granules].  Every wait is bounded in time
+ * (wave_spin_expired: the context's error word, never a hung device). */
+struct TileCtx { unsigned long long *xch; int *d_error; int tile; int epoch; int xid; int pad; };
+__shared__ TileCtx s_tc;
+#define GDG_TILE_XIDS 32                  /* exchange ids per segment (api_plan.cpp counts them: compressor 1, tone stack 4, cabinet 7, chorus 1) */
+__device__ __forceinline__ void tile_put(int xid, int wave, int value, double v);       /* (defined behind the hand-off primitives below) */
+__device__ __forceinline__ double tile_get(int xid, int wave, int value);
+#endif
+
 template <bool MAXOP>
 __device__ __forceinline__ double lin_comb(double acc, double f, double v) { return MAXOP ? fmax(acc, f * v) : fma(f, v, acc); }
 
@@ -272,9 +305,17 @@ __device__ __forceinline__ double lin_chunk_map(const double (&x)[CHK], const do
 }
 
 /* B = zero-state chunk result of this thread; *s0 (LDS) = state before the frame; returns the state at this thread's chunk start */
+/* SEG_TILE: `wave` is the wave's place in the FRAME (tile x 8 + its place in the workgroup); the totals of the waves of lower tiles come in
+ * through HBM (exchange id s_tc.xid + xslot), fetched by wave 0 in front of the scan's one barrier -- the 16-lane scan below then runs on the
+ * very 16 values it runs on in the general kernel */
 template <bool MAXOP>
-__device__ __forceinline__ double lin_scan(double B, const double *tab, const double *s0, double *xch) {
+__device__ __forceinline__ double lin_scan(double B, const double *tab, const double *s0, double *xch, const int xslot = 0) {
+#ifdef SEG_TILE
+    const int lane = seg_tid() & 63, lwave = seg_tid() >> 6, wave = s_tc.tile * SEG_WAVES + lwave;
+#else
     const int lane = seg_tid() & 63, wave = seg_tid() >> 6;
+    (void)xslot;
+#endif
     double I = B;
     I = lin_comb<MAXOP>(I, tab[LT_ST + 0], dpp0<DPP_ROW_SHR(1), 0xf>(I));
     I = lin_comb<MAXOP>(I, tab[LT_ST + 1], dpp0<DPP_ROW_SHR(2), 0xf>(I));
@@ -283,6 +324,10 @@ __device__ __forceinline__ double lin_scan(double B, const double *tab, const do
     I = lin_comb<MAXOP>(I, tab[LT_PA + (lane & 15)], dpp0<DPP_ROW_BCAST15, 0xa>(I));     /* rows 1, 3 <- totals of rows 0, 2 */
     I = lin_comb<MAXOP>(I, tab[LT_PB + (lane & 31)], dpp0<DPP_ROW_BCAST31, 0xc>(I));     /* rows 2, 3 <- total of rows 0..1 */
     if (lane == 63) xch[1 + wave] = I;
+#ifdef SEG_TILE
+    if (lane == 63 && s_tc.tile + 1 < SEG_TILES) tile_put(s_tc.xid + xslot, wave, 0, I);
+    if (lwave == 0 && lane < s_tc.tile * SEG_WAVES) xch[1 + lane] = tile_get(s_tc.xid + xslot, lane, 0);
+#endif
     __syncthreads();
     const double E = dpp0<DPP_WAVE_SHR1, 0xf>(I);                 /* exclusive inside the wave */
     double T = (lane == 0) ? *s0 : xch[lane & 15];                /* lanes 0..15: [s0, total of wave 0, ..., of wave 14] */
@@ -305,8 +350,13 @@ __device__ __forceinline__ void lin2_step(double &h, double &l, const double *m)
     lin2_comb(h, l, m, sh, sl);
 }
 /* (ch, cl): zero-state chunk result; s0h / s0l (LDS): state before the frame; returns the chunk start state in (ch, cl) */
-__device__ __forceinline__ void lin2_scan(double &ch, double &cl, const double *tab, const double *s0h, const double *s0l, double *xch) {
+__device__ __forceinline__ void lin2_scan(double &ch, double &cl, const double *tab, const double *s0h, const double *s0l, double *xch, const int xslot = 0) {
+#ifdef SEG_TILE
+    const int lane = seg_tid() & 63, lwave = seg_tid() >> 6, wave = s_tc.tile * SEG_WAVES + lwave;
+#else
     const int lane = seg_tid() & 63, wave = seg_tid() >> 6;
+    (void)xslot;
+#endif
     double h = ch, l = cl;
     lin2_step<DPP_ROW_SHR(1), 0xf>(h, l, tab + L2_ST + 0);
     lin2_step<DPP_ROW_SHR(2), 0xf>(h, l, tab + L2_ST + 3);
@@ -315,6 +365,10 @@ __device__ __forceinline__ void lin2_scan(double &ch, double &cl, const double *
     lin2_step<DPP_ROW_BCAST15, 0xa>(h, l, tab + L2_PA + 3 * (lane & 15));
     lin2_step<DPP_ROW_BCAST31, 0xc>(h, l, tab + L2_PB + 3 * (lane & 31));
     if (lane == 63) { xch[1 + wave] = h; xch[LX_SLOT + 1 + wave] = l; }
+#ifdef SEG_TILE
+    if (lane == 63 && s_tc.tile + 1 < SEG_TILES) { tile_put(s_tc.xid + xslot, wave, 0, h); tile_put(s_tc.xid + xslot, wave, 1, l); }
+    if (lwave == 0 && lane < s_tc.tile * SEG_WAVES) { xch[1 + lane] = tile_get(s_tc.xid + xslot, lane, 0); xch[LX_SLOT + 1 + lane] = tile_get(s_tc.xid + xslot, lane, 1); }
+#endif
     __syncthreads();
     const double eh = dpp0<DPP_WAVE_SHR1, 0xf>(h), el = dpp0<DPP_WAVE_SHR1, 0xf>(l);
     double th = (lane == 0) ? *s0h : xch[lane & 15];
@@ -412,6 +466,32 @@ __device__ __forceinline__ void wave_post(int *cell, int value, bool release) {
         __hip_atomic_store(as_global(cell), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+#ifdef SEG_TILE
+__device__ __forceinline__ unsigned long long *tile_slot(int xid, int wave, int value) {
+    return s_tc.xch + (((size_t)xid * 16 + (size_t)wave) * 2 + (size_t)value) * 2;
+}
+__device__ __forceinline__ void tile_put(int xid, int wave, int value, double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)(unsigned)s_tc.epoch << 32;
+    GDG_GLOBAL unsigned long long *p = (GDG_GLOBAL unsigned long long *)tile_slot(xid, wave, value);
+    __hip_atomic_store(p, (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double tile_get(int xid, int wave, int value) {
+    const GDG_GLOBAL unsigned long long *p = (const GDG_GLOBAL unsigned long long *)tile_slot(xid, wave, value);
+    const unsigned tag = (unsigned)s_tc.epoch;
+    int spins = 0;
+    unsigned long long t0 = 0, lo, hi;
+    for (;;) {
+        lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wave_spin_expired(spins, t0, s_tc.d_error)) { if (s_tc.d_error) atomicExch(s_tc.d_error, GDG_WAVE_TIMEOUT_CODE); break; }
+    }
+    return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+}
+#endif
 
 /* what a unit that meets its predecessor frame TWICE needs (the reverb: delay line, then all-pass rings): its second counter */
 struct WaveGate { int *cell; int wf, wf_next; bool release; int epoch; int *d_error; };
@@ -535,7 +615,11 @@ __device__ __forceinline__ ChunkT<true> full_chunk() {
     ChunkT<true> c;
     c.c0 = (int)seg_tid() * CHK;
     c.len = CHK;
+#ifdef SEG_TILE
+    c.last = seg_tid() == SEG_T - 1 && s_tc.tile == SEG_TILES - 1;       /* the frame's last sample: its thread leaves the unit's state */
+#else
     c.last = seg_tid() == SEG_T - 1;
+#endif
     return c;
 }
 template <class C>
@@ -869,7 +953,7 @@ __device__ __forceinline__ void shaper_oversampled(const Shaper &S, double *in, 
 
 /* returns 1 when the result is in the INPUT buffer (oversampled: in place), 0 when it is in the other one */
 /* (the general build keeps the call: the oversampled variants are large) */
-#ifdef SEG_FAST
+#ifdef SEG_SUBSET
 static __device__ __forceinline__ int unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
 #else
 __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tables &os) {
@@ -883,7 +967,7 @@ __device__ __attribute__((noinline)) int unit_shaper(UNIT_ARGS, const gdg_os_tab
         for (int i = seg_tid(); i < N; i += SEG_T) out[LX(i)] = shape(S, in[LX(i)]);
         return 0;
     }
-#ifndef SEG_FAST                                    /* the oversampled shapers stage a whole output frame in the second buffer */
+#ifndef SEG_SUBSET                                  /* the oversampled shapers stage a whole output frame in the second buffer (general build only) */
     if (f == 2) shaper_oversampled<2>(S, in, out, scr, U->hist, os.tapsP2, os.lanczos2, N, nullptr, wt);
     else shaper_oversampled<4>(S, in, out, scr, U->hist, os.tapsP4, os.lanczos4, N, nullptr, wt);
 #endif
@@ -989,7 +1073,7 @@ __device__ __forceinline__ void tonestack_full(const gdg_seg_unit *Ug, int flip,
         double h = 0.0, l = 0.0;
 #pragma unroll
         for (int i = 0; i < CHK; i++) { h = fma(tab[L2_W + 2 * i], x[i], h); l = fma(tab[L2_W + 2 * i + 1], x[i], l); }
-        lin2_scan(h, l, tab, &st[j], &st[4 + j], tmp + (j & 1) * 2 * LX_SLOT);
+        lin2_scan(h, l, tab, &st[j], &st[4 + j], tmp + (j & 1) * 2 * LX_SLOT, j);
 #pragma unroll
         for (int i = 0; i < CHK; i++) {
             double diff = x[i] - h;
@@ -1050,7 +1134,7 @@ __device__ __forceinline__ void cabinet_full(const gdg_seg_unit *Ug, int flip, c
     for (int p = 0; p < 7; p++) {
         const double *tab = scr + p * LT_SIZE;
         const double a = st[16 + p];
-        double s = lin_scan<false>(lin_chunk_map<false>(v, tab), tab, &st[p], tmp + (p & 1) * 2 * LX_SLOT);
+        double s = lin_scan<false>(lin_chunk_map<false>(v, tab), tab, &st[p], tmp + (p & 1) * 2 * LX_SLOT, p);
         if (p < 3) {
 #pragma unroll
             for (int i = 0; i < CHK; i++) { double diff = v[i] - s; s += diff * a; v[i] = diff; }          /* cabinet.go:114-118 */
@@ -1093,6 +1177,14 @@ UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
     GDG_GLOBAL double *ds = as_global(Uc->ds);
     const int wp = is[0];
     const double prev = ds[0];
+#ifdef SEG_TILE
+    /* a tile of the frame: its samples are g0 .. g0 + N - 1 of the frame; what it appends, the tiles behind it may tap (write-through) */
+    const int g0 = s_tc.tile * SEG_N;
+    const bool wts = true;
+#else
+    const int g0 = 0;
+    const bool wts = wt;
+#endif
     if (wt) {
         const int s_ok = ((mask + 1) - C - 2) / N - 1;
         if (s_ok >= 1 && s_ok <= 2 && gate.wf - s_ok - 1 >= 0) {
@@ -1103,21 +1195,31 @@ UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
     /* 1. append the frame (pairs where possible); cell 0 is mirrored into the guard cell mask + 1 */
     if ((N & 1) == 0 && (wp & 1) == 0) {
         for (int i = 2 * (int)seg_tid(); i < N; i += 2 * SEG_T) {
-            const int p = (wp + i) & mask;                          /* even, so p + 1 <= mask */
+            const int p = (wp + g0 + i) & mask;                     /* even, so p + 1 <= mask */
             seg_v2d v = { in[LX(i)], in[LX(i + 1)] };
-            st_v2d((GDG_GLOBAL seg_v2d *)(ring + p), v, wt);
-            if (p == 0) st_f64(ring + mask + 1, v.x, wt);
+            st_v2d((GDG_GLOBAL seg_v2d *)(ring + p), v, wts);
+            if (p == 0) st_f64(ring + mask + 1, v.x, wts);
         }
     } else {
         for (int i = seg_tid(); i < N; i += SEG_T) {
-            const int p = (wp + i) & mask;
+            const int p = (wp + g0 + i) & mask;
             const double v = in[LX(i)];
-            st_f64(ring + p, v, wt);
-            if (p == 0) st_f64(ring + mask + 1, v, wt);
+            st_f64(ring + p, v, wts);
+            if (p == 0) st_f64(ring + mask + 1, v, wts);
         }
     }
-    if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the sc1 pair stores are inline assembly: the compiler does not wait for them */
+    if (wts) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the sc1 pair stores are inline assembly: the compiler does not wait for them */
     __syncthreads();                                                /* the frame is in the ring (visible to the whole workgroup) */
+#ifdef SEG_TILE
+    /* the tiles behind this one tap what it appended (a tap reaches at most C + 1 samples back: never forwards); every wave has drained its
+     * write-through stores in front of the barrier above, so one granule says "tile t is in the ring" */
+    if (seg_tid() == 0) {
+        if (s_tc.tile + 1 < SEG_TILES) tile_put(s_tc.xid, s_tc.tile, 0, 1.0);
+        for (int lt = 0; lt < s_tc.tile; lt++) (void)tile_get(s_tc.xid, lt, 0);
+        if (s_tc.tile > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* ONE buffer_inv sc1: this CU's L1 holds none of the ring's old lines any more */
+    }
+    __syncthreads();
+#endif
     /* (this frame's taps read t = -C - 1 .. N - 1 relative to wp; frame f + j appends at wp + j N ..) */
     const int slack = wt ? ((mask + 1) - C - 2) / N - 1 : 0;        /* s: how many later frames may append while this one still reads */
     const bool early = wt && slack >= 1 && slack <= 2;
@@ -1134,18 +1236,24 @@ UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
     const double cj[5] = { 1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410, 0.30901699437494742410 };
     const double sj[5] = { 0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917, -0.95105651629515357212 };
     /* one sincos per thread: a thread's samples are SEG_T apart, so its LFO phase advances by a fixed angle from one to the
-     * next and (sin, cos) follow by rotation (error ~1e-16 per step, eight steps) */
-    double s0, c0, sd, cd;
-    {
-        double time = (double)seg_tid() / sr;
+     * next and (sin, cos) follow by rotation (error ~1e-16 per step, eight steps).  (SEG_TILE: the thread of the GENERAL kernel that owns a
+     * sample is its frame index mod 1024, and the value it uses is that thread's sincos rotated (index div 1024) times: the same here.) */
+    constexpr int LFO_STRIDE = SEG_T * SEG_TILES;
+    double sd, cd;
+    sincos(angular * ((double)LFO_STRIDE / sr), &sd, &cd);
+    auto lfo_start = [&](int index, double &s_, double &c_) {
+        double time = (double)index / sr;
         double zero_phase = fmod_2pi(prev + (angular * time));
-        sincos(zero_phase, &s0, &c0);
-        sincos(angular * ((double)SEG_T / sr), &sd, &cd);
-    }
+        sincos(zero_phase, &s_, &c_);
+    };
+    auto lfo_step = [&](double &s_, double &c_) {
+        double sn = (s_ * cd) + (c_ * sd), cn = (c_ * cd) - (s_ * sd);
+        s_ = sn; c_ = cn;
+    };
     /* G samples at a time: first every address and ALL 5 G tap loads (16 bytes each), then the arithmetic -- written as two
      * loops because the compiler otherwise waits for each load right where it is used: 40 exposed L2 / HBM latencies per thread
-     * were the whole cost of this unit (the ALU work is a third of it) */
-    auto samples = [&](const int (&idx)[2], int G) {
+     * were the whole cost of this unit (the ALU work is a third of it).  sv / cv: the LFO's (sin, cos) at the two samples */
+    auto samples = [&](const int (&idx)[2], int G, const double (&sv)[2], const double (&cv)[2]) {
         seg_v2d v[2][5];
         double frs[2][5];
 #pragma unroll
@@ -1153,18 +1261,16 @@ UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
             if (g < G) {
 #pragma unroll
                 for (int j = 0; j < 5; j++) {
-                    double offset = depth * ((s0 * cj[j]) + (c0 * sj[j]));
+                    double offset = depth * ((sv[g] * cj[j]) + (cv[g] * sj[j]));
                     double delay_time = 0.001 * (40.0 + offset);
                     double delay_samples = delay_time * sr;
                     /* chorus.go:63-90: early = floor, late = ceil, weights 1 - (d - early) and 1 - (late - d).  With fr = d - early
                      * (exact): fr != 0: late = early + 1 and the weights are exactly 1 - fr and fr; fr == 0: late = early, both 1 */
                     const double early = floor(delay_samples);
                     frs[g][j] = delay_samples - early;
-                    const int t = idx[g] - (int)early - 1;          /* the older neighbour; t >= -C - 1, and t = -C - 1 only with fr == 0 */
+                    const int t = g0 + idx[g] - (int)early - 1;     /* the older neighbour; t >= -C - 1, and t = -C - 1 only with fr == 0 */
                     v[g][j] = *(const GDG_GLOBAL seg_v2d *)(ring + ((wp + t) & mask));      /* (V[t], V[t + 1]) */
                 }
-                double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
-                s0 = sn; c0 = cn;
             }
         }
         /* an integral delay (both weights 1, the sample counted twice) is rare -- depth 0 or a lucky phase -- and costs six selects per
@@ -1203,27 +1309,66 @@ UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
             }
         }
     };
+#ifdef SEG_TILE
+    {
+        /* local samples tid + 512 q, q = 0 .. 7: frame index g0 + tid + 512 q = (tid + 512 (q & 1)) + 1024 (4 tile + q / 2): two LFO states per
+         * thread (the general kernel's threads tid and tid + 512), each already 4 x tile steps along when the tile starts */
+        double sa, ca, sb, cb;
+        lfo_start((int)seg_tid(), sa, ca);
+        lfo_start((int)seg_tid() + SEG_T, sb, cb);
+        for (int r = 0; r < 4 * s_tc.tile; r++) { lfo_step(sa, ca); lfo_step(sb, cb); }
+#pragma unroll
+        for (int q = 0; q < CHK; q += 2) {
+            const int idx[2] = { (int)seg_tid() + q * SEG_T, (int)seg_tid() + (q + 1) * SEG_T };
+            const double sv[2] = { sa, sb }, cv[2] = { ca, cb };
+            samples(idx, 2, sv, cv);
+            lfo_step(sa, ca);
+            lfo_step(sb, cb);
+        }
+    }
+#else
+    double s0, c0;
+    lfo_start((int)seg_tid(), s0, c0);
     if (N == CHK * SEG_T) {
 #pragma unroll
         for (int q = 0; q < CHK; q += 2) {                         /* the batch block size: a fixed trip count */
             const int idx[2] = { (int)seg_tid() + q * SEG_T, (int)seg_tid() + (q + 1) * SEG_T };
-            samples(idx, 2);
+            double sv[2], cv[2];
+            sv[0] = s0; cv[0] = c0;
+            lfo_step(s0, c0);
+            sv[1] = s0; cv[1] = c0;
+            lfo_step(s0, c0);
+            samples(idx, 2, sv, cv);
         }
     } else {
         for (int i = seg_tid(); i < N; i += 2 * SEG_T) {
             const int idx[2] = { i, i + SEG_T };
-            samples(idx, (i + SEG_T < N) ? 2 : 1);
+            double sv[2], cv[2];
+            sv[0] = s0; cv[0] = c0;
+            lfo_step(s0, c0);
+            sv[1] = s0; cv[1] = c0;
+            lfo_step(s0, c0);
+            samples(idx, (i + SEG_T < N) ? 2 : 1, sv, cv);
         }
     }
+#endif
+#ifdef SEG_TILE
+    if (seg_tid() == 0 && s_tc.tile == SEG_TILES - 1) {
+        /* the frame's last tile leaves the state: it has seen every other tile's "in the ring", which they posted after reading wp and the phase */
+        st_f64(ds, fmod(prev + (angular * ((double)C / sr)), GO_MATH_TWO_PI), false);
+        st_i32(is, (wp + GDG_MAX_FRAMES) & mask, false);
+    }
+#else
     if (seg_tid() == 0 && !early) {
         double buffer_time = (double)C / sr;          /* quirk: advances by the buffer length, not by N */
         st_f64(ds, fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI), wt);
         st_i32(is, (wp + N) & mask, wt);
     }
+#endif
     if (early) wave_post(gate.cell + 1 + (gate.wf & 3), gate.epoch * 32 + gate.wf + 1, false);      /* this frame's taps are done (nothing to publish: no release) */
 }
 
-#ifndef SEG_FAST
+#ifndef SEG_SUBSET
 /* ---- flanger / phaser: effects/flanger.go:19-119, effects/phaser.go:19-125 --------------------------------
  * dp0 depth (0..1), dp1 angular speed, dp2 sr, dp3 1/sr, dp4 dry factor, dp5 wet factor; jp0 ring capacity */
 UNIT_FN unit_flanger(UNIT_ARGS) {
@@ -1667,20 +1812,21 @@ static __device__ __forceinline__ void reverb_general(UNIT_ARGS, const WaveGate 
         return;
     }
     /* ring heads of the three all-passes first (in-order return: they are home before the tap loads below are consumed) */
-    const bool fast = min(M[1], N) <= 3 * SEG_T && min(M[2], N) <= SEG_T;
-    double pm_a[REVERB_QMAX], pm_b[3], pm_c[1];
+    constexpr int QB = 3 * 1024 / SEG_T, QC = 1024 / SEG_T;       /* ring values per thread of the two short all-passes (up to 3072 / 1024 values) */
+    const bool fast = min(M[1], N) <= QB * SEG_T && min(M[2], N) <= QC * SEG_T;
+    double pm_a[REVERB_QMAX], pm_b[QB], pm_c[QC];
     if (!wt) {
         if (M[0] >= 1) allpass_fetch<REVERB_QMAX>(ring[0], M[0], rp[0], N, pm_a);
         if (fast) {
-            if (M[1] >= 1) allpass_fetch<3>(ring[1], M[1], rp[1], N, pm_b);
-            if (M[2] >= 1) allpass_fetch<1>(ring[2], M[2], rp[2], N, pm_c);
+            if (M[1] >= 1) allpass_fetch<QB>(ring[1], M[1], rp[1], N, pm_b);
+            if (M[2] >= 1) allpass_fetch<QC>(ring[2], M[2], rp[2], N, pm_c);
         }
     } else {
         ring_append(dl_ring, DL, &is_state[0], in, N, true);       /* dl_wp above is the write position BEFORE the frame: the taps below count from it */
     }
     double dlr[REVERB_QMAX];
     /* tapped delay line over the input history (reverb.go:65-116) */
-    const bool pairs = N == CHK * SEG_T && taps[0] >= N && taps[1] >= N && taps[2] >= N && taps[3] >= N;
+    const bool pairs = N == GDG_MAX_FRAMES && taps[0] >= N && taps[1] >= N && taps[2] >= N && taps[3] >= N;
     if (pairs) {
         /* the usual case (taps 192..232 ms back, frames <= 43 ms, the batch block size): every tap lies in the HBM ring.  A thread
          * takes sample PAIRS (2p, 2p + 1), p = tid + q * SEG_T: one 16-byte load per tap and pair (8-byte aligned; the ring's
@@ -1750,16 +1896,16 @@ static __device__ __forceinline__ void reverb_general(UNIT_ARGS, const WaveGate 
         for (int k = 0; k < 3; k++) rp[k] = as_global(is_state)[1 + k];
         if (M[0] >= 1) allpass_fetch<REVERB_QMAX>(ring[0], M[0], rp[0], N, pm_a);
         if (fast) {
-            if (M[1] >= 1) allpass_fetch<3>(ring[1], M[1], rp[1], N, pm_b);
-            if (M[2] >= 1) allpass_fetch<1>(ring[2], M[2], rp[2], N, pm_c);
+            if (M[1] >= 1) allpass_fetch<QB>(ring[1], M[1], rp[1], N, pm_b);
+            if (M[2] >= 1) allpass_fetch<QC>(ring[2], M[2], rp[2], N, pm_c);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();                                            /* every old ring value is in a register before anyone overwrites the rings */
     }
     if (M[0] >= 1) allpass_chains<REVERB_QMAX>(out, ring[0], M[0], rp[0], N, pm_a, &is_state[1], wt);
     if (fast) {
-        if (M[1] >= 1) allpass_chains<3>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2], wt);
-        if (M[2] >= 1) allpass_chains<1>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3], wt);
+        if (M[1] >= 1) allpass_chains<QB>(out, ring[1], M[1], rp[1], N, pm_b, &is_state[2], wt);
+        if (M[2] >= 1) allpass_chains<QC>(out, ring[2], M[2], rp[2], N, pm_c, &is_state[3], wt);
     } else {
         if (M[1] >= 1) allpass_generic(out, ring[1], M[1], rp[1], N, &is_state[2], wt);
         if (M[2] >= 1) allpass_generic(out, ring[2], M[2], rp[2], N, &is_state[3], wt);
@@ -1899,7 +2045,7 @@ __device__ __forceinline__ IMap block_scan_imap(IMap mine, IMap identity, Compos
     return e;
 }
 
-#ifndef SEG_FAST          /* from here to the segment kernel: units of the general kernel only */
+#ifndef SEG_SUBSET        /* from here to the segment kernel: units of the general kernel only */
 /* ---- fuzz without oversampling: effects/fuzz.go:24-108 ------------------------------------------------------------------------
  * ip0 follow; dp0 bias, dp1 gain, dp2 fuzz, dp3 1 - fuzz, dp4 level, dp5 exp(-20/sr), dp6 1 - dp5; ds0 envelope, ds1 coupling cap */
 UNIT_FN unit_fuzz(UNIT_ARGS) {
@@ -2711,11 +2857,20 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
     if (tid < unit_count && tid < 16) s_types[tid] = my_type;
     __syncthreads();
     int flip = 0;                                   /* 0: s_a holds the current frame, 1: s_b */
+#ifdef SEG_TILE
+    int xid = 0;                                    /* the next unit's first exchange id (tile_put / tile_get) */
+#endif
     for (int u = 0; u < unit_count; u++) {
         double *out = flip ? s_a : s_b;
         const gdg_seg_unit *U = units + unit_begin + u;
         const int type = (u < 16) ? __builtin_amdgcn_readfirstlane(s_types[u]) : U->type;
         int inplace = 0;
+#ifdef SEG_TILE
+        /* (the barrier that ended the previous unit lies between its last read of s_tc.xid and this write; every unit has a barrier of its
+         * own between here and its first exchange) */
+        if (tid == 0) s_tc.xid = xid;
+        xid += type == GDG_UNIT_COMPRESSOR ? 1 : type == GDG_UNIT_TONESTACK ? 4 : type == GDG_UNIT_CABINET ? 7 : type == GDG_UNIT_CHORUS ? 1 : 0;
+#endif
         /* a unit that keeps nothing from frame to frame (a shaper without oversampling) meets nobody */
         const bool gated = WAVE && (u >= 15 || ((wave_mask >> u) & 1u));
         if (gated) wave_wait(wave + GDG_WAVE_CELLS * u, wf, u < 15 && ((wave_mask >> (16 + u)) & 1u), d_error);
@@ -2725,7 +2880,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         case GDG_UNIT_COMPRESSOR: unit_compressor(U, flip, N, WAVE); break;
         case GDG_UNIT_OVERDRIVE:
         case GDG_UNIT_DISTORTION:
-#ifdef SEG_FAST                                     /* no oversampling here: the six table pointers need not live across the unit calls */
+#ifdef SEG_SUBSET                                   /* no oversampling here: the six table pointers need not live across the unit calls */
         case GDG_UNIT_EXCESS: { gdg_os_tables none = {}; inplace = unit_shaper(U, flip, N, WAVE, none); break; }
 #else
         case GDG_UNIT_EXCESS: inplace = unit_shaper(U, flip, N, WAVE, os); break;
@@ -2739,6 +2894,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
             skip_post = WAVE && __builtin_amdgcn_readfirstlane(posted);
             break;
         }
+#ifndef SEG_TILE                                    /* (a tile sees a part of the frame: these three and the reverb keep to whole frames) */
         case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N, WAVE); break;
         case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N, WAVE); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N, WAVE); break;
@@ -2748,7 +2904,8 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
             second = WAVE ? 1 : 0;
             break;
         }
-#ifndef SEG_FAST                                    /* units that read other threads' cells of their input after writing output, or stage a frame: two buffers */
+#endif
+#ifndef SEG_SUBSET                                  /* units that read other threads' cells of their input after writing output, or stage a frame: two buffers */
         case GDG_UNIT_FLANGER:
         case GDG_UNIT_PHASER: unit_flanger(U, flip, N, WAVE); break;
         case GDG_UNIT_DELAY: unit_delay(U, flip, N, WAVE); break;
@@ -2790,6 +2947,63 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
 #else
 #define SEG_KERNEL_ATTR
 #endif
+#ifdef SEG_TILE
+/* ---- per-frame calls of few channels: a channel's frame on SEG_TILES workgroups (see the head of this file) ---------------------------------
+ * n_chans x SEG_TILES workgroups take (tile, channel) by TICKET, tile-major: a workgroup only ever waits for LOWER tiles of its channel, and
+ * those hold smaller tickets -- they are running or done whatever the order of dispatch.  Beyond them: one workgroup per listed reverb of a
+ * later segment step (REVERB_AHEAD, as in the general kernel).  xch: GDG_TILE_XCH_WORDS 8-byte words per descriptor of the launch. */
+#define GDG_TILE_XCH_WORDS (GDG_TILE_XIDS * 16 * 2 * 2)
+__global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU)
+segt_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, gdg_shift shift, gdg_os_tables os, int *d_error,
+            int n_chans, int *ticket, int epoch, unsigned long long *xch, const int *__restrict__ ahead_list) {
+    const int tid = seg_tid();
+    if ((int)blockIdx.x >= SEG_TILES * n_chans) {
+        const WaveGate none = {};
+        reverb_general<REVERB_AHEAD>(units + ahead_list[blockIdx.x - SEG_TILES * n_chans], 0, GDG_MAX_FRAMES, false, none);
+        return;
+    }
+    int *s_ticket = reinterpret_cast<int *>(s_tmp + SEG_STASH + 32) + 16;
+    if (tid == 0) {
+        const int t = atomicAdd(ticket, 1);
+        if (t == SEG_TILES * n_chans - 1) __hip_atomic_store(as_global(ticket), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     /* everybody has drawn: ready for the next launch */
+        *s_ticket = t;
+    }
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(*s_ticket);
+    const int tile = t / n_chans, block = t - tile * n_chans;
+    gdg_seg_chan ch = chans[block];
+    if (ch.flags & GDG_SRC_IS_INPUT) ch.src += shift.in;
+    if (ch.flags & GDG_DST_IS_OUTPUT) ch.dst += shift.out;
+    if (tid == 0) { s_tc.xch = xch + (size_t)block * GDG_TILE_XCH_WORDS; s_tc.d_error = d_error; s_tc.tile = tile; s_tc.epoch = epoch; s_tc.xid = 0; }
+    int my_type = 0;
+    if (tid < ch.unit_count && tid < 16) my_type = *(const GDG_GLOBAL int *)&units[ch.unit_begin + tid].type;
+    /* (seg_frame's barrier behind the frame load publishes s_tc to the workgroup) */
+    seg_frame<false>(ch.src + (size_t)tile * SEG_N, ch.dst + (size_t)tile * SEG_N, units, ch.unit_begin, ch.unit_count, SEG_N, os, d_error, my_type);
+}
+
+int gdg_segt_supported(int unit_type) {
+    switch (unit_type) {
+    case GDG_UNIT_COMPRESSOR: case GDG_UNIT_OVERDRIVE: case GDG_UNIT_DISTORTION: case GDG_UNIT_EXCESS: case GDG_UNIT_TONESTACK:
+    case GDG_UNIT_CABINET: case GDG_UNIT_CHORUS:
+        return 1;
+    default:
+        return 0;
+    }
+}
+/* exchange ids a unit of that type uses (the plan keeps a segment's sum within GDG_TILE_XIDS) */
+int gdg_segt_exchanges(int unit_type) {
+    return unit_type == GDG_UNIT_COMPRESSOR ? 1 : unit_type == GDG_UNIT_TONESTACK ? 4 : unit_type == GDG_UNIT_CABINET ? 7 : unit_type == GDG_UNIT_CHORUS ? 1 : 0;
+}
+size_t gdg_segt_xch_words(void) { return GDG_TILE_XCH_WORDS; }
+
+hipError_t gdg_launch_segt(const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, gdg_shift shift, gdg_os_tables os, int *d_error,
+                           hipStream_t s, int *d_ticket, int epoch, unsigned long long *d_xch, const int *d_ahead_list, int n_ahead) {
+    if (n_chans <= 0) return hipSuccess;
+    if (!d_ahead_list) n_ahead = 0;
+    hipLaunchKernelGGL(segt_kernel, dim3(SEG_TILES * n_chans + n_ahead), dim3(SEG_T), 0, s, d_chans, d_units, shift, os, d_error, n_chans, d_ticket, epoch, d_xch, d_ahead_list);
+    return hipGetLastError();
+}
+#else
 template <int MODE>             /* 0: one frame per launch; 1: the walk; 2: WAVE (a workgroup per frame, above) */
 __global__ void __launch_bounds__(SEG_T, SEG_MIN_WAVES_PER_EU) SEG_KERNEL_ATTR
 seg_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
@@ -2878,3 +3092,4 @@ hipError_t gdg_launch_seg(const gdg_seg_chan *d_chans, int n_chans, const gdg_se
     }
     return hipGetLastError();
 }
+#endif      /* SEG_TILE */

@@ -103,6 +103,10 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   seg_wave_release_max_channels >= 0       ... but segments holding a unit whose state leaves the CU through plain stores (flanger, phaser, delay,
  *                                            fuzz, auto-yoy, auto-wah, band pass, octaver, noise gate: every hand-off writes the XCD's L2 back) only up
  *                                            to this many channels (112)
+ *   seg_tile_max_channels        >= 0        per-frame calls of up to this many channels: a segment made of compressor, shapers without oversampling, tone
+ *                                            stack, cabinet and chorus runs with a channel's 8192-sample frame on TWO workgroups -- the units of such a
+ *                                            call are compute bound on one CU while most of the chip idles.  The scans keep the general kernel's
+ *                                            association (a scan's sixteen wave totals meet in one place, eight of them through HBM): same bits (64; 0: never)
  *   seg_os_tiles_max_channels    >= 0        calls of up to this many channels run every 2 x / 4 x oversampled shaper as a launch of its own, one workgroup
  *                                            per (channel, frame, tile of 4096 / 2048 samples) instead of one per channel (192; 0: never)
  *   seg_reverb_ahead_max_channels >= 0       per-frame calls of up to this many channels: the call's first segment launch also makes, with extra

@@ -31,7 +31,7 @@ SEG_FLAGS = ["-ffp-contract=off", "-mllvm", "-disable-machine-licm"]          # 
 def test_makefile_compiles_the_segment_kernels_with_these_flags():
     mk = open(os.path.join(CSRC, "Makefile")).read()
     assert "SEG_LICM := -mllvm -disable-machine-licm" in mk
-    assert mk.count("-ffp-contract=off $(SEG_LICM)") == 2
+    assert mk.count("-ffp-contract=off $(SEG_LICM)") == 3          # seg.o, segf.o (-DSEG_FAST), segt.o (-DSEG_TILE)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
@@ -55,6 +55,18 @@ def test_general_segment_kernel_calls_only_the_oversampled_units(tmp_path):
         assert scratch <= 128, (name, scratch)
     callees = sorted(k for k in res if "kernel" not in k)
     assert len(callees) == 3 and all(any(n in k for n in ("unit_shaper", "unit_fuzz_os", "allpass_generic")) for k in callees), callees
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_tile_segment_kernel_fits_512_threads_without_scratch(tmp_path):
+    """seg.hip -DSEG_TILE: a channel's frame on two workgroups of 512 threads (2 waves per SIMD: 256 registers per lane), every unit inlined"""
+    res = summary(tmp_path, "seg.hip", SEG_FLAGS + ["-DSEG_TILE"])
+    kernels = {k: v for k, v in res.items() if "segt_kernel" in k}
+    assert len(kernels) == 1, sorted(res)
+    for name, (vgprs, scratch) in kernels.items():
+        assert vgprs <= 256 and scratch == 0, (name, vgprs, scratch)
+    callees = sorted(k for k in res if "kernel" not in k)
+    assert all("allpass_generic" in k for k in callees), callees        # (the extra workgroups' reverb at rates far above 192 kHz)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
