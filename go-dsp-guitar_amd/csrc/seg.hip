@@ -1167,6 +1167,9 @@ UNIT_FN unit_cabinet(UNIT_ARGS) {
  * before it appends (s = 1 at 192 kHz: 32768 cells, C = 9600; s = 0, i.e. no overlap and the plain hand-off, at 96 kHz).  "Done" marks are
  * per frame (cell 2 + (f & 3)) and carry the launch's epoch, so a mark left by an earlier launch never passes for this one's.
  * *posted says to the caller that the unit's counter has been posted. */
+#ifdef SEG_TILE
+/* (the tile build's form: a tile of the frame per workgroup, two LFO states per thread; the other builds keep theirs, below, to the letter --
+ * moving the LFO's rotation out of the sample loop cost the two-per-CU kernel 2.5 us per launch at 512 channels) */
 UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
@@ -1367,6 +1370,147 @@ UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
 #endif
     if (early) wave_post(gate.cell + 1 + (gate.wf & 3), gate.epoch * 32 + gate.wf + 1, false);      /* this frame's taps are done (nothing to publish: no release) */
 }
+#else
+UNIT_FN unit_chorus(UNIT_ARGS, const WaveGate &gate, int *posted) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
+    const double depth = Uc->dp[0], angular = Uc->dp[1], sr = Uc->dp[2];
+    const int C = Uc->jp[0], mask = Uc->jp[1];
+    GDG_GLOBAL double *ring = as_global(Uc->hist);
+    GDG_GLOBAL int *is = as_global(Uc->is);
+    GDG_GLOBAL double *ds = as_global(Uc->ds);
+    const int wp = is[0];
+    const double prev = ds[0];
+    if (wt) {
+        const int s_ok = ((mask + 1) - C - 2) / N - 1;
+        if (s_ok >= 1 && s_ok <= 2 && gate.wf - s_ok - 1 >= 0) {
+            const int fd = gate.wf - s_ok - 1;                        /* the frame whose taps this frame's append would run into */
+            wave_wait(gate.cell + 1 + (fd & 3), gate.epoch * 32 + fd + 1, false, gate.d_error);
+        }
+    }
+    /* 1. append the frame (pairs where possible); cell 0 is mirrored into the guard cell mask + 1 */
+    if ((N & 1) == 0 && (wp & 1) == 0) {
+        for (int i = 2 * (int)seg_tid(); i < N; i += 2 * SEG_T) {
+            const int p = (wp + i) & mask;                          /* even, so p + 1 <= mask */
+            seg_v2d v = { in[LX(i)], in[LX(i + 1)] };
+            st_v2d((GDG_GLOBAL seg_v2d *)(ring + p), v, wt);
+            if (p == 0) st_f64(ring + mask + 1, v.x, wt);
+        }
+    } else {
+        for (int i = seg_tid(); i < N; i += SEG_T) {
+            const int p = (wp + i) & mask;
+            const double v = in[LX(i)];
+            st_f64(ring + p, v, wt);
+            if (p == 0) st_f64(ring + mask + 1, v, wt);
+        }
+    }
+    if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the sc1 pair stores are inline assembly: the compiler does not wait for them */
+    __syncthreads();                                                /* the frame is in the ring (visible to the whole workgroup) */
+    /* (this frame's taps read t = -C - 1 .. N - 1 relative to wp; frame f + j appends at wp + j N ..) */
+    const int slack = wt ? ((mask + 1) - C - 2) / N - 1 : 0;        /* s: how many later frames may append while this one still reads */
+    const bool early = wt && slack >= 1 && slack <= 2;
+    if (early) {
+        if (seg_tid() == 0) {
+            st_f64(ds, fmod(prev + (angular * ((double)C / sr)), GO_MATH_TWO_PI), true);      /* the end-of-unit update below, same expression */
+            st_i32(is, (wp + N) & mask, true);
+        }
+        wave_post(gate.cell - 1, gate.wf_next, gate.release);
+        *posted = 1;
+    }
+    /* sin(zero_phase + j 2pi/5) by the angle-addition formula from ONE sincos (the five LFOs are 72 degrees apart):
+     * differs from the reference's sin(fmod(zero_phase + j 2pi/5, 2pi)) by ~1e-16, i.e. ~1e-13 samples of delay */
+    const double cj[5] = { 1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410, 0.30901699437494742410 };
+    const double sj[5] = { 0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917, -0.95105651629515357212 };
+    /* one sincos per thread: a thread's samples are SEG_T apart, so its LFO phase advances by a fixed angle from one to the
+     * next and (sin, cos) follow by rotation (error ~1e-16 per step, eight steps) */
+    double s0, c0, sd, cd;
+    {
+        double time = (double)seg_tid() / sr;
+        double zero_phase = fmod_2pi(prev + (angular * time));
+        sincos(zero_phase, &s0, &c0);
+        sincos(angular * ((double)SEG_T / sr), &sd, &cd);
+    }
+    /* G samples at a time: first every address and ALL 5 G tap loads (16 bytes each), then the arithmetic -- written as two
+     * loops because the compiler otherwise waits for each load right where it is used: 40 exposed L2 / HBM latencies per thread
+     * were the whole cost of this unit (the ALU work is a third of it) */
+    auto samples = [&](const int (&idx)[2], int G) {
+        seg_v2d v[2][5];
+        double frs[2][5];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (g < G) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    double offset = depth * ((s0 * cj[j]) + (c0 * sj[j]));
+                    double delay_time = 0.001 * (40.0 + offset);
+                    double delay_samples = delay_time * sr;
+                    /* chorus.go:63-90: early = floor, late = ceil, weights 1 - (d - early) and 1 - (late - d).  With fr = d - early
+                     * (exact): fr != 0: late = early + 1 and the weights are exactly 1 - fr and fr; fr == 0: late = early, both 1 */
+                    const double early = floor(delay_samples);
+                    frs[g][j] = delay_samples - early;
+                    const int t = idx[g] - (int)early - 1;          /* the older neighbour; t >= -C - 1, and t = -C - 1 only with fr == 0 */
+                    v[g][j] = *(const GDG_GLOBAL seg_v2d *)(ring + ((wp + t) & mask));      /* (V[t], V[t + 1]) */
+                }
+                double sn = (s0 * cd) + (c0 * sd), cn = (c0 * cd) - (s0 * sd);
+                s0 = sn; c0 = cn;
+            }
+        }
+        /* an integral delay (both weights 1, the sample counted twice) is rare -- depth 0 or a lucky phase -- and costs six selects per
+         * tap: the wave asks once per sample pair whether any of its lanes has one and otherwise takes the plain interpolation (the same
+         * operations in the same order: the same bits) */
+        bool any_whole = false;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (g < G) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) any_whole |= frs[g][j] == 0.0;
+            }
+        }
+        const bool plain = __builtin_amdgcn_ballot_w64(any_whole) == 0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (g < G) {
+                double effected = 0.0;
+                if (plain) {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        const double fr = frs[g][j];
+                        effected += 0.2 * (((1.0 - fr) * v[g][j].y) + (fr * v[g][j].x));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        const double fr = frs[g][j];
+                        const bool whole = fr == 0.0;
+                        const double se = v[g][j].y, sl = whole ? v[g][j].y : v[g][j].x;
+                        const double we = whole ? 1.0 : 1.0 - fr, wl = whole ? 1.0 : fr;
+                        effected += 0.2 * ((we * se) + (wl * sl));
+                    }
+                }
+                out[LX(idx[g])] = (0.5 * in[LX(idx[g])]) + (0.5 * effected);
+            }
+        }
+    };
+    if (N == CHK * SEG_T) {
+#pragma unroll
+        for (int q = 0; q < CHK; q += 2) {                         /* the batch block size: a fixed trip count */
+            const int idx[2] = { (int)seg_tid() + q * SEG_T, (int)seg_tid() + (q + 1) * SEG_T };
+            samples(idx, 2);
+        }
+    } else {
+        for (int i = seg_tid(); i < N; i += 2 * SEG_T) {
+            const int idx[2] = { i, i + SEG_T };
+            samples(idx, (i + SEG_T < N) ? 2 : 1);
+        }
+    }
+    if (seg_tid() == 0 && !early) {
+        double buffer_time = (double)C / sr;          /* quirk: advances by the buffer length, not by N */
+        st_f64(ds, fmod(prev + (angular * buffer_time), GO_MATH_TWO_PI), wt);
+        st_i32(is, (wp + N) & mask, wt);
+    }
+    if (early) wave_post(gate.cell + 1 + (gate.wf & 3), gate.epoch * 32 + gate.wf + 1, false);      /* this frame's taps are done (nothing to publish: no release) */
+}
+#endif
 
 #ifndef SEG_SUBSET
 /* ---- flanger / phaser: effects/flanger.go:19-119, effects/phaser.go:19-125 --------------------------------
