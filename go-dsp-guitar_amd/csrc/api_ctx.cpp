@@ -164,6 +164,7 @@ static const OptionDef g_options[] = {
     { "seg_wave_release_max_channels", "GDG_SEG_WAVE_RELEASE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_wave_release_max, nullptr, true },
     { "seg_tile_max_channels", "GDG_SEG_TILE_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_tile_max, nullptr, true },
     { "seg_os_tiles_max_channels", "GDG_SEG_OS_TILES_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_os_tiles_max, nullptr, true },
+    { "seg_os_tiles_prefix", "GDG_SEG_OS_PREFIX", 0, 1, -1, nullptr, &gdg_ctx::seg_os_prefix, true },
     { "seg_reverb_ahead_max_channels", "GDG_SEG_REVERB_AHEAD_MAX", 0, 1 << 20, -1, &gdg_ctx::seg_reverb_ahead_max, nullptr, true },
     { "wave_spin_limit_ms", "GDG_WAVE_SPIN_LIMIT_MS", 1, 600000, -1, &gdg_ctx::wave_spin_ms, nullptr, false },
     { "debug_stall_unit", "GDG_DEBUG_STALL_UNIT", -1, 1 << 30, -1, &gdg_ctx::debug_stall_unit, nullptr, false },

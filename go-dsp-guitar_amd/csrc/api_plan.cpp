@@ -717,8 +717,8 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     (void)any_fir;
     /* counters of the WAVE launches: tickets per (segment step, channel group), then one frame counter per unit that sits in a segment */
     {
-        /* 8 cells per unit in a segment + one flag per oversampled shaper that is a launch of its own (each such unit is one descriptor of one step) */
-        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + 9 * ctx->units.size() + (size_t)nch + 64;
+        /* 8 cells per unit in a segment + a flag and an arrival counter per oversampled shaper that is a launch of its own (each such unit is one descriptor of one step) */
+        const size_t need = (size_t)GDG_WAVE_STEPS * GDG_WAVE_GROUPS + 10 * ctx->units.size() + (size_t)nch + 64;
         if (need > ctx->d_wave_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             hipFree(ctx->d_wave);
@@ -855,7 +855,22 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
         }
         st.offset = 0;
         if (!is_fir && seg_steps < GDG_WAVE_STEPS && G <= GDG_WAVE_GROUPS) st.wave_tickets = GDG_WAVE_GROUPS * seg_steps++;
-        if (is_os) { st.os_flags = (int)wave_next; wave_next += sd.size(); }                /* one flag per channel of the launch (os_tiles_kernel) */
+        if (is_os) { st.os_flags = (int)wave_next; wave_next += sd.size(); st.os_arrive = (int)wave_next; wave_next += sd.size(); }    /* a flag and an arrival counter per channel of the launch (os_tiles_kernel) */
+        if (is_os && ctx->seg_os_prefix && !ctx->steps.empty() && !ctx->steps.back().is_fir && !ctx->steps.back().os_factor && !ctx->steps.back().fast &&
+            ctx->steps.back().n == (int)sd.size() && seg_descs.back().size() == sd.size() && G == 1) {
+            /* the step in front of this launch: the same channels in the same order, each with ONE unit, a compressor, feeding this shaper */
+            bool lone = true;
+            for (size_t i = 0; i < sd.size(); i++) {
+                const gdg_seg_chan &pc = seg_descs.back()[i];
+                if (pc.unit_count != 1 || seg_units[(size_t)pc.unit_begin].type != GDG_UNIT_COMPRESSOR || pc.dst != sd[i].src) lone = false;
+            }
+            if (lone) {
+                st.os_prefix_step = (int)ctx->steps.size() - 1;
+                ctx->steps.back().absorbed_per_frame = true;
+                /* a step that per-frame calls do not launch cannot carry other steps' extra workgroups (nothing has been given to it yet: it is the step right in front) */
+                if (ahead_host == st.os_prefix_step) { ahead_host = -1; ahead_host_weight = 0.0; }
+            }
+        }
         /* descriptors are in `active` order, so every channel group owns one contiguous run of them */
         st.group_range.assign((size_t)G, std::make_pair(0, 0));
         {

@@ -250,12 +250,18 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                     { int rc = ensure_side_stream(ctx); if (rc != GDG_OK) return rc; }
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_fir_done, s));
                 }
+            } else if (st.absorbed_per_frame && window == 1 && G == 1) {
+                continue;                          /* the oversampled shaper's launch behind this step runs its compressor (os_tiles_kernel, pre_chans) */
             } else if (st.os_factor) {
                 /* an oversampled shaper of few channels: a workgroup per (channel, frame, tile) instead of one per channel */
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);
                 const int epoch = (ctx->wave_epoch = (ctx->wave_epoch % 0x3ffffff) + 1);
-                HIP_TRY(ctx, gdg_launch_os_tiles(st.os_factor, d, n, d_units, frames, window, shift, ctx->os, ctx->d_wave + st.os_flags + first, epoch, ctx->d_error, s));
+                /* a per-frame call: the lone compressor in front of the shaper runs inside this launch (the step itself was skipped above) */
+                const gdg_seg_chan *d_pre = (window == 1 && G == 1 && st.os_prefix_step >= 0)
+                                            ? reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + ctx->steps[(size_t)st.os_prefix_step].offset) + first : nullptr;
+                HIP_TRY(ctx, gdg_launch_os_tiles(st.os_factor, d, n, d_units, frames, window, shift, ctx->os, ctx->d_wave + st.os_flags + first, epoch, ctx->d_error, s,
+                                                 d_pre, ctx->d_wave + st.os_arrive + first));
             } else {
                 const gdg_seg_chan *d = reinterpret_cast<const gdg_seg_chan *>(ctx->d_blob + st.offset) + first;
                 ProfScope ps(ctx, GDG_K_SEGMENT, s);

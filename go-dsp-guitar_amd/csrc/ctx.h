@@ -111,6 +111,10 @@ struct StepDesc {
     bool premac_ok = false;           /* FIR step: split shape (few channels), 8192-sample frames, every channel with K >= 2: the terms k >= 1 can be summed ahead */
     int os_factor = 0;                /* 2 / 4: the step is ONE oversampled shaper per channel, run as a launch of its own (seg.hip os_tiles_kernel) */
     int os_flags = -1;                /* ... and its per-channel flags start here in d_wave */
+    int os_arrive = -1;               /* ... its per-channel arrival counters (a compressor step absorbed into the launch, below) */
+    int os_prefix_step = -1;          /* ... the step right in front of it when that is a lone compressor in every one of its channels: in per-frame calls the tiles'
+                                       * workgroups run it themselves and the step is not launched (seg.hip os_tiles_kernel, pre_chans) */
+    bool absorbed_per_frame = false;  /* segment step: a per-frame call skips it -- the oversampled shaper's launch behind it runs its compressor */
     int ahead_n = 0;                  /* segment step (general kernel, one frame per launch): it also makes the wet paths of this many reverbs of LATER steps ... */
     size_t ahead_offset = 0;          /* ... whose indices into the plan's unit array start here in the blob (seg.hip REVERB_AHEAD) */
     bool tile_ok = false;             /* segment step: every unit of every channel can run with the frame on two workgroups (seg.hip SEG_TILE) */
@@ -160,6 +164,7 @@ struct gdg_ctx {
                                                 * two workgroups, the reverbs' extra workgroups and the premac no longer find the chip idle) */
     unsigned long long *d_tile_xch = nullptr;  /* what crosses between the two workgroups of a channel: gdg_segt_xch_words() words per descriptor of a launch */
     size_t d_tile_xch_cap = 0;
+    bool seg_os_prefix = true;                 /* a lone compressor in front of an oversampled shaper's own launch runs inside that launch in per-frame calls (option seg_os_tiles_prefix) */
     int seg_os_tiles_max = 192;                /* calls of up to this many channels run oversampled shapers as launches of their own, a workgroup per tile
                                                 * (option "seg_os_tiles_max_channels"; 0: never) */
     int seg_wave_release_max = 112;            /* ... of segments with a unit whose state leaves the CU through plain stores (flanger, phaser, delay, fuzz, auto-yoy, auto-wah,

@@ -207,7 +207,10 @@ size_t gdg_segt_xch_words(void);
 /* an oversampled shaper (overdrive / distortion / excess at 2 x or 4 x) as a launch of its own, one workgroup per (channel, frame, tile): the
  * descriptors are segment descriptors whose unit_begin names the shaper; d_flags: one int per channel, any value but `epoch` (seg.hip) */
 hipError_t gdg_launch_os_tiles(int factor, const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames,
-                               gdg_shift shift, gdg_os_tables os, int *d_flags, int epoch, int *d_error, hipStream_t s);
+                               gdg_shift shift, gdg_os_tables os, int *d_flags, int epoch, int *d_error, hipStream_t s,
+                               const gdg_seg_chan *d_pre_chans = nullptr, int *d_arrive = nullptr);
+/* d_pre_chans (n_frames == 1): descriptor i = the segment step in front of d_chans[i]'s shaper, a lone compressor -- the tiles' workgroups run it
+ * themselves (that step is then not launched); d_arrive: one int per channel, zero between launches */
 hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_hist, double *d_up, double *d_down, gdg_os_tables os, hipStream_t s);
 /* 1 when seg.hip implements the unit type */
 int gdg_seg_supported(int unit_type);

@@ -734,7 +734,9 @@ __device__ __forceinline__ void compressor_body(const gdg_seg_unit *U, int flip,
     if (c.last) st_f64(as_global(U->ds), s, wt);
 }
 /* the batch block size: constant-coefficient scan (see lin_scan) */
-__device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip, const bool wt) {
+/* defer != NULL (an LDS cell): the unit's new state goes there instead of to HBM -- os_tiles_kernel runs the unit in every tile's workgroup
+ * and lets ONE of them store the state, once all have read the old one */
+__device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip, const bool wt, double *defer = nullptr) {
     UNIT_PROLOGUE
     const GDG_CONST gdg_seg_unit *U = uniform_unit(Ug);
     double *st = tmp + SEG_STASH;
@@ -768,7 +770,7 @@ __device__ __forceinline__ void compressor_full(const gdg_seg_unit *Ug, int flip
         x[i] = clip1(gain * x[i]);
     }
     chunk_store(out, c, x);
-    if (c.last) st_f64(ds, s, wt);
+    if (c.last) { if (defer) *defer = s; else st_f64(ds, s, wt); }
 }
 UNIT_FN unit_compressor(UNIT_ARGS) {
     if (N == CHK * SEG_T) compressor_full(U, flip, wt);
@@ -2853,10 +2855,15 @@ hipError_t gdg_launch_os_debug(int factor, const double *d_in, int n, double *d_
  * recomputed here from the previous frame's inputs for every frame but a call's first (the same expressions on the same operands: the same
  * bits); the call's first frame reads the unit's state, its last frame writes it.  One flag per channel orders that pair: the last
  * workgroup does not store before the first has loaded (a bounded spin; both are in flight together in every launch that has both). */
+/* pre_chans != NULL (a per-frame call, n_frames == 1; round 6): the segment step in FRONT of the shaper is a lone compressor in every channel
+ * (BASELINE config 3: compressor > 4 x overdrive > ...), pre_chans[c] its descriptor.  A launch of its own for it was 8.6 us of which 6.4 are a
+ * launch's fixed chain; here every tile's workgroup runs the compressor over the whole frame itself (2.6 us of vector work, the unit's own code:
+ * compressor_full) and takes its tile's inputs from LDS.  All tiles of a channel read the compressor's state; the channel's LAST workgroup stores the
+ * new one once an arrival counter (arrive[c], zero between launches) says that every tile has read the old one. */
 template <int F>
 __global__ void __launch_bounds__(SEG_T)
 os_tiles_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__restrict__ units, int N, int n_frames, gdg_shift shift,
-                gdg_os_tables os, int *__restrict__ flags, int epoch, int *d_error) {
+                gdg_os_tables os, int *__restrict__ flags, int epoch, int *d_error, const gdg_seg_chan *__restrict__ pre_chans, int *__restrict__ arrive) {
     constexpr int TAPS = OsCfg<F>::TAPS, BACK = OsCfg<F>::BACK, R = OsCfg<F>::R, TILE = OsCfg<F>::S, PH = OsCfg<F>::PH, HALO = BACK + 6;
     static_assert(TILE + HALO + 8 <= 8192 + 256, "a tile's inputs fit one frame buffer");
     const int tid = seg_tid();
@@ -2877,6 +2884,35 @@ os_tiles_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__re
     double *sin_ = s_a, *stage = s_b, *scr = s_scr;
     const bool first = f == 0, last = f == n_frames - 1 && tile == tiles - 1;
     const int o0 = tile * TILE, S_out = min(TILE, N - o0), I0 = o0 - BACK, b0 = I0 - 6;       /* b0: the lowest input index the tile touches */
+    double *pre_state = s_tmp + SEG_STASH + 30;              /* the compressor's new state, parked (cells the compressor itself does not use) */
+    double pre_keep = 0.0;
+    if (pre_chans) {
+        /* the whole frame through the compressor in front of the shaper (n_frames == 1: the launcher sees to it), then this tile's inputs
+         * out of its result */
+        gdg_seg_chan pch = pre_chans[blockIdx.y];
+        if (pch.flags & GDG_SRC_IS_INPUT) pch.src += shift.in;
+        const GDG_GLOBAL seg_v2d *s2 = (const GDG_GLOBAL seg_v2d *)pch.src;
+        seg_v2d fv[CHK / 2];
+#pragma unroll
+        for (int q = 0; q < CHK / 2; q++) fv[q] = s2[tid + q * SEG_T];
+#pragma unroll
+        for (int q = 0; q < CHK / 2; q++) { const int i = tid + q * SEG_T; s_a[LX(2 * i)] = fv[q].x; s_a[LX(2 * i + 1)] = fv[q].y; }
+        __syncthreads();
+        compressor_full(units + pch.unit_begin, 0, false, pre_state);      /* s_a -> s_b; its first barrier lies behind its read of the old state */
+        __syncthreads();
+        if (tid == 0) atomicAdd(arrive + blockIdx.y, 1);         /* this workgroup has read the compressor's state */
+        constexpr int NK = (TILE + HALO + SEG_T - 1) / SEG_T;    /* a tile's inputs per thread: 3 (4 x) / 5 (2 x) */
+        double keepv[NK];
+#pragma unroll
+        for (int q = 0; q < NK; q++) {
+            const int k = tid + q * SEG_T, i = b0 + k;
+            keepv[q] = (k < S_out + HALO) ? ((i >= 0) ? s_b[LX(i)] : ((i >= -8) ? hist[8 + i] : 0.0)) : 0.0;
+        }
+        if (last && tid < 8) pre_keep = s_b[LX(N - 8 + tid)];     /* the call's last 8 inputs of the shaper (its state for the next call) */
+        __syncthreads();                                         /* everybody holds its inputs: the frame buffers are free */
+#pragma unroll
+        for (int q = 0; q < NK; q++) { const int k = tid + q * SEG_T; if (k < S_out + HALO) sin_[LX(k)] = keepv[q]; }
+    } else {
     /* inputs b0 .. o0 + S_out - 1 -> sin_[0 ..]; below the call's first frame: the unit's 8-sample history, older ones are never used */
     for (int k = tid; k < S_out + HALO; k += SEG_T) {
         const int i = b0 + k;
@@ -2885,10 +2921,11 @@ os_tiles_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__re
         else v = (i >= -8) ? hist[8 + i] : 0.0;
         sin_[LX(k)] = v;
     }
+    }
     if (first && tile == 0) for (int q = tid; q < TAPS - 1; q += SEG_T) scr[q] = hist[8 + q];      /* the previous call's oversampled tail */
     double keep = 0.0;
     if (last && tid < 8) {                                  /* the last 8 inputs of the call (older frames of the row, or the old history, when N < 8 never happens: N = 8192) */
-        keep = src[N - 8 + tid];
+        keep = pre_chans ? pre_keep : src[N - 8 + tid];      /* (with the compressor in front: its output) */
     }
     __syncthreads();
     if (first && tile == 0 && tid == 0) {
@@ -2935,6 +2972,18 @@ os_tiles_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__re
                 if (wave_spin_expired(spins, t0, d_error)) { atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
             }
         }
+        if (pre_chans && tid == 0) {
+            /* ... and the compressor's: every tile of the channel has read the old state */
+            const int tiles_all = tiles * n_frames;
+            int spins = 0;
+            unsigned long long t0 = 0;
+            while (__hip_atomic_load(as_global(arrive + blockIdx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tiles_all) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wave_spin_expired(spins, t0, d_error)) { atomicExch(d_error, GDG_WAVE_TIMEOUT_CODE); break; }
+            }
+            __hip_atomic_store(as_global(arrive + blockIdx.y), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       /* ready for the next launch */
+            as_global(units[pre_chans[blockIdx.y].unit_begin].ds)[0] = *pre_state;
+        }
         __syncthreads();
         for (int q = tid; q < TAPS - 1; q += SEG_T) {
             const int m = F * N - (TAPS - 1) + q;
@@ -2956,13 +3005,17 @@ os_tiles_kernel(const gdg_seg_chan *__restrict__ chans, const gdg_seg_unit *__re
 
 /* n_chans x (n_frames x tiles) workgroups; d_flags: one int per channel of the launch (any value but this launch's epoch) */
 hipError_t gdg_launch_os_tiles(int factor, const gdg_seg_chan *d_chans, int n_chans, const gdg_seg_unit *d_units, int frames, int n_frames,
-                               gdg_shift shift, gdg_os_tables os, int *d_flags, int epoch, int *d_error, hipStream_t s) {
+                               gdg_shift shift, gdg_os_tables os, int *d_flags, int epoch, int *d_error, hipStream_t s,
+                               const gdg_seg_chan *d_pre_chans, int *d_arrive) {
     if (n_chans <= 0 || n_frames <= 0) return hipSuccess;
     if (frames != GDG_MAX_FRAMES) return hipErrorInvalidValue;
+    if (n_frames != 1 || !d_arrive) d_pre_chans = nullptr;
     if (factor == 2)
-        hipLaunchKernelGGL(os_tiles_kernel<2>, dim3(n_frames * (frames / OsCfg<2>::S), n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_flags, epoch, d_error);
+        hipLaunchKernelGGL(os_tiles_kernel<2>, dim3(n_frames * (frames / OsCfg<2>::S), n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_flags, epoch, d_error,
+                           d_pre_chans, d_arrive);
     else if (factor == 4)
-        hipLaunchKernelGGL(os_tiles_kernel<4>, dim3(n_frames * (frames / OsCfg<4>::S), n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_flags, epoch, d_error);
+        hipLaunchKernelGGL(os_tiles_kernel<4>, dim3(n_frames * (frames / OsCfg<4>::S), n_chans), dim3(SEG_T), 0, s, d_chans, d_units, frames, n_frames, shift, os, d_flags, epoch, d_error,
+                           d_pre_chans, d_arrive);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

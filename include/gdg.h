@@ -109,6 +109,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *                                            association (a scan's sixteen wave totals meet in one place, eight of them through HBM): same bits (64; 0: never)
  *   seg_os_tiles_max_channels    >= 0        calls of up to this many channels run every 2 x / 4 x oversampled shaper as a launch of its own, one workgroup
  *                                            per (channel, frame, tile of 4096 / 2048 samples) instead of one per channel (192; 0: never)
+ *   seg_os_tiles_prefix          0, 1        ... and when the step in front of such a launch is a lone compressor in every channel (compressor > 4 x overdrive:
+ *                                            BASELINE config 3), a per-frame call runs that compressor inside the tiles' workgroups instead of launching it (1)
  *   seg_reverb_ahead_max_channels >= 0       per-frame calls of up to this many channels: the call's first segment launch also makes, with extra
  *                                            workgroups beside the channels' own, the wet path of every reverb of its LATER segment steps -- tapped
  *                                            sums and all-passes need nothing of the frame itself when every tap lies at least a frame back

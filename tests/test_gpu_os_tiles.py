@@ -141,3 +141,50 @@ def test_switching_oversampling_off_and_on_in_window_mode_relays_the_counters(pk
         ctx.close()
     np.testing.assert_array_equal(outs[True], outs[False])
     assert np.isfinite(outs[True]).all() and np.abs(outs[True]).max() > 0.01
+
+
+@pytest.mark.parametrize("factor_index", [1, 2])
+@pytest.mark.parametrize("follow", [0, 1])
+def test_a_lone_compressor_in_front_runs_inside_the_tiles_launch(pkg, oracle, follow, factor_index):
+    """compressor > oversampled overdrive (BASELINE config 3's head): a per-frame call does not launch the compressor's step, every tile's workgroup
+    runs the unit itself (option seg_os_tiles_prefix) -- the compressor's own code on the same frame: the same bits, with its state handed on
+    from frame to frame, through windows in between and a reverb behind a power amp that wants an earlier launch to carry its wet path"""
+    nch, frames, sr, blocks = 3, 8192, 96000, 7
+    chain = [("compressor", [follow, 30, -20]), ("overdrive", [0, 20, 100, 0, 1, factor_index]), ("tone_stack", None), ("chorus", None),
+             ("power_amp", "ir"), ("cabinet", None), ("reverb", [50])]
+    x = np.stack([synth_signal(c + 1, frames * blocks, sr) * (1.0 if c else 0.3) for c in range(nch)])
+    outs = {}
+    for prefix in (0, 1):
+        ctx = build(pkg, nch, frames, chain, True)
+        ctx.set_option("seg_os_tiles_prefix", prefix)
+        ctx.set_window(2)
+        got = np.zeros_like(x)
+        d_in, d_out = ctx.alloc(nch, 2 * frames), ctx.alloc(nch, 2 * frames)
+        f_in, f_out = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
+
+        def per_frame(b):
+            f_in.upload(x[:, b * frames:(b + 1) * frames])
+            ctx.process_device(f_in, f_out, frames, sr)
+            got[:, b * frames:(b + 1) * frames] = f_out.download()
+
+        for b in (0, 1, 2):
+            per_frame(b)
+        d_in.upload(x[:, 3 * frames:5 * frames])
+        ctx.process_window_device(d_in.ptr, d_out.ptr, 2 * frames, 2, sr)          # a window: the compressor's step is launched as ever
+        got[:, 3 * frames:5 * frames] = d_out.download()
+        for b in (5, 6):
+            per_frame(b)
+        ctx.synchronize()
+        outs[prefix] = got
+        ctx.close()
+    bad = [b for b in range(blocks) if not np.array_equal(outs[1][:, b * frames:(b + 1) * frames], outs[0][:, b * frames:(b + 1) * frames])]
+    assert bad == [], "frames that differ: %s" % bad
+    np.testing.assert_array_equal(outs[1], outs[0])
+    ref = oracle.Chain()
+    for uname, p in chain:
+        if p == "ir":
+            ref.append_unit(uname, fir=synth_ir(9000, seed=3 + 2))
+        else:
+            ref.append_unit(uname, params=p)
+    want = np.concatenate([ref.process(x[2, b * frames:(b + 1) * frames], sr) for b in range(blocks)])
+    assert rms(outs[1][2] - want) <= TOL_RMS
