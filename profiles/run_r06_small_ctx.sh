@@ -1,6 +1,7 @@
 #!/bin/bash
-# bash profiles/run_r06_small_ctx.sh <tag>: per-frame calls of a GPU's share of the split job (64 / 96 / 127 channels, BASELINE config 3) with the
-# reverbs' wet paths made ahead of the frame (option seg_reverb_ahead_max_channels) off and on, and rocprofv3 kernel traces of both
+# bash profiles/run_r06_small_ctx.sh <tag>: per-frame calls of a GPU's share of the split job (32 .. 127 channels, BASELINE config 3) with round 6's
+# three shapes off ("before": the reverbs' wet paths in their own unit, one workgroup per channel, the compressor in front of an oversampled
+# shaper as a launch of its own) and at their defaults ("after"), and rocprofv3 kernel traces of both
 set -u
 TAG=${1:-r06a}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -8,29 +9,27 @@ OUT="$REPO/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 P="$REPO/profiles/probes/small_ctx.py"
+OFF="seg_reverb_ahead_max_channels=0,seg_tile_max_channels=0,seg_os_tiles_prefix=0"
 {
-  for NCH in 32 64 80 96 127; do
-    for A in 0 200; do
-      for H in 0 1; do
-        NCH=$NCH MODE=frame NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A,fir_premac_hosted=$H" python $P
-      done
-    done
+  for NCH in 16 32 64 80 96 127; do
+    NCH=$NCH MODE=frame NGROUPS_LIST=1 KINDS=0 OPTIONS="$OFF" python $P
+    NCH=$NCH MODE=frame NGROUPS_LIST=1 KINDS=0 python $P
   done
-  for A in 0 200; do NCH=64 MODE=frame CHAIN=config3 NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A" python $P; done
-} > "$OUT/${TAG}_reverb_ahead_ab.txt" 2>&1
-for A in 0 200; do
-  WHICH=$([ $A = 0 ] && echo before || echo after)
-  rm -rf /tmp/prof_s
-  NCH=64 MODE=frame NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A,fir_premac_hosted=$([ $A = 0 ] && echo 0 || echo 1)" rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $P > /tmp/s.log 2>&1
-  DB=$(find /tmp/prof_s -name '*.db' | head -1)
-  {
-    echo "# NCH=64 MODE=frame OPTIONS=seg_reverb_ahead_max_channels=$A,fir_premac_hosted=$([ $A = 0 ] && echo 0 || echo 1) rocprofv3 --kernel-trace --stats -- python profiles/probes/small_ctx.py  (bench chain, 2 x 65536 taps, 192 kHz)"
-    grep "groups:" /tmp/s.log
-    python "$REPO/profiles/summarize_rocprof.py" "$DB"
-  } > "$OUT/${TAG}_64ch_frame_rocprof_${WHICH}.txt" 2>&1
-  rm -rf /tmp/prof_s
-  NCH=64 MODE=frame CHAIN=config3 NGROUPS_LIST=1 KINDS=0 OPTIONS="seg_reverb_ahead_max_channels=$A" rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $P > /tmp/s.log 2>&1
-  DB=$(find /tmp/prof_s -name '*.db' | head -1)
-  { echo "# config 3 (64 ch, 96 kHz, 4x oversampling, 32768 taps), per-frame calls, seg_reverb_ahead_max_channels=$A"; grep "groups:" /tmp/s.log; python "$REPO/profiles/summarize_rocprof.py" "$DB"; } > "$OUT/${TAG}_config3_frame_rocprof_${WHICH}.txt" 2>&1
+  NCH=64 MODE=frame CHAIN=config3 NGROUPS_LIST=1 KINDS=0 OPTIONS="$OFF" python $P
+  NCH=64 MODE=frame CHAIN=config3 NGROUPS_LIST=1 KINDS=0 python $P
+} > "$OUT/${TAG}_small_shards_ab.txt" 2>&1
+for WHICH in before after; do
+  O=$([ $WHICH = before ] && echo "$OFF" || echo "")
+  for CH in bench config3; do
+    rm -rf /tmp/prof_s
+    NCH=64 MODE=frame CHAIN=$CH NGROUPS_LIST=1 KINDS=0 OPTIONS="$O" rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $P > /tmp/s.log 2>&1
+    DB=$(find /tmp/prof_s -name '*.db' | head -1)
+    NAME=$([ $CH = bench ] && echo 64ch || echo config3)
+    {
+      echo "# NCH=64 MODE=frame CHAIN=$CH OPTIONS=$O rocprofv3 --kernel-trace --stats -- python profiles/probes/small_ctx.py"
+      grep "groups:" /tmp/s.log
+      python "$REPO/profiles/summarize_rocprof.py" "$DB"
+    } > "$OUT/${TAG}_${NAME}_frame_rocprof_${WHICH}.txt" 2>&1
+  done
 done
 echo done
