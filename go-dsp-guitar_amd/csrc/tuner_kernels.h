@@ -490,7 +490,9 @@ int gdg_tuner_short_ok(double sample_rate, double lowest_note_frequency) {
  * on every CU (at most 8: three blocks + the repeated predecessor each) */
 int gdg_tuner_short_parts(int nch) {
     const int forced = gdg_knob_get(GDG_KNOB_TUNER_PARTS);        /* 0: by channel count (gdg_ctx_set_option "tuner_parts") */
-    int parts = forced > 0 ? forced : (nch >= cu_count() ? 1 : (cu_count() + nch - 1) / nch);
+    /* as many runs per channel as keep the launch within ONE workgroup per CU (floor: 48 channels x 6 runs = 288 workgroups on 256 CUs took 79 us where
+     * x 4 takes 62, profiles/tuner32_parts_poll_r06.txt) */
+    int parts = forced > 0 ? forced : (nch >= cu_count() ? 1 : cu_count() / nch);
     if (parts > (forced > 0 ? TUNER_NBLK : 8)) parts = forced > 0 ? TUNER_NBLK : 8;
     return parts < 1 ? 1 : parts;
 }
