@@ -732,6 +732,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
     int seg_steps = 0;
     /* blob layout: [step 0 descs][step 1 descs]...[seg units] */
     std::vector<gdg_seg_unit> seg_units;
+    std::vector<std::pair<int, int>> tile_conditional;     /* (step, index into seg_units) of reverbs in steps that could run tiled: they can if their wet path is made ahead */
     std::vector<std::vector<int>> ahead_lists; /* per step: reverbs of later steps (indices into seg_units) whose wet path the step's launch makes (seg.hip REVERB_AHEAD) */
     int ahead_host = -1;                       /* the general-kernel segment step, among those already laid out, that hosts them */
     double ahead_host_weight = 0.0;
@@ -848,6 +849,7 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
                     const bool shaper = tu.type == GDG_UNIT_OVERDRIVE || tu.type == GDG_UNIT_DISTORTION || tu.type == GDG_UNIT_EXCESS;
                     const int os_param = tu.type == GDG_UNIT_OVERDRIVE ? 5 : (tu.type == GDG_UNIT_DISTORTION ? 3 : 2);
                     if (!gdg_segt_supported(tu.type) || (shaper && tu.params[os_param] != 0)) st.tile_ok = false;
+                    if (gdg_segt_supported(tu.type) == 2) tile_conditional.push_back(std::make_pair((int)ctx->steps.size(), ctx->plan_unit_slot[(size_t)h]));   /* a reverb: only as a mix (below) */
                     xids += gdg_segt_exchanges(tu.type);
                 }
                 if (xids > 32 || entry.second.handles.size() > 16 || entry.second.handles.empty()) st.tile_ok = false;
@@ -923,6 +925,9 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
             for (auto &l : ahead_lists) { for (int idx : l) seg_units[(size_t)idx].ip[7] = 0; l.clear(); }
         }
     }
+    /* a tiled step runs a reverb only as the mix of a wet path made by an earlier launch (seg.hip unit_reverb_mix_tile) */
+    for (auto &tc : tile_conditional)
+        if (tc.second < 0 || !seg_units[(size_t)tc.second].ip[7]) ctx->steps[(size_t)tc.first].tile_ok = false;
     {   /* the new filters' spectra, all together */
         const double tq = pnow();
         int rc = flush_ir(ctx);

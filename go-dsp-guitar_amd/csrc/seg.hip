@@ -2077,6 +2077,50 @@ static __device__ __forceinline__ void reverb_general(UNIT_ARGS, const WaveGate 
     __syncthreads();
     if (!wt) ring_append(dl_ring, DL, &is_state[0], in, N);
 }
+#ifdef SEG_TILE
+/* The tile build runs a reverb only as the MIX of a wet path an earlier launch of the call made (REVERB_CONSUME above, api_plan.cpp): a tile's
+ * share of the sums, the mix, its share of the frame into the delay line.  Both tiles read the line's write position; the frame's last tile
+ * advances it once tile 0 has said (a granule) that it has read it. */
+UNIT_FN unit_reverb_mix_tile(UNIT_ARGS) {
+    UNIT_PROLOGUE
+    const GDG_CONST gdg_seg_unit *Uc = uniform_unit(U);
+    const int tid = seg_tid(), g0 = s_tc.tile * SEG_N;
+    const double dry = Uc->dp[0], half_wet = Uc->dp[1];
+    const int DL = Uc->jp[4];
+    GDG_GLOBAL double *g = as_global(Uc->hist);
+    GDG_GLOBAL int *is_state = as_global(Uc->is);
+    const int dl_wp = is_state[0];
+    int rings = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int M = Uc->jp[5 + k] - 1; rings += M > 0 ? M : 0; }
+    const GDG_GLOBAL double *ahead = g + ((DL + rings + 1) & ~1) + g0;       /* the sums of this tile's samples (reverb_general: `ahead`) */
+    seg_v2d sm[CHK / 2];
+#pragma unroll
+    for (int q = 0; q < CHK / 2; q++) sm[q] = *(const GDG_GLOBAL seg_v2d *)(ahead + 2 * (tid + q * SEG_T));
+    __syncthreads();                                               /* (the position is read: see below) */
+    if (tid == 0 && s_tc.tile + 1 < SEG_TILES) tile_put(s_tc.xid, s_tc.tile, 0, 1.0);
+#pragma unroll
+    for (int q = 0; q < CHK; q++) {
+        const int i = 2 * (tid + (q >> 1) * SEG_T) + (q & 1);
+        const double sum = (q & 1) ? sm[q >> 1].y : sm[q >> 1].x;
+        out[LX(i)] = clip1((dry * in[LX(i)]) + (half_wet * sum));
+    }
+    /* the tile's samples into the delay line (ring_append's pairs, offset by the tile's place in the frame) */
+#pragma unroll
+    for (int q = 0; q < CHK / 2; q++) {
+        const int i = 2 * (tid + q * SEG_T);
+        const int p = (dl_wp + g0 + i) % DL;
+        const double a = in[LX(i)], b = in[LX(i + 1)];
+        if (p + 1 < DL) { seg_v2d v = { a, b }; *(GDG_GLOBAL seg_v2d *)(g + p) = v; }
+        else { g[p] = a; g[0] = b; }
+    }
+    if (tid == 0 && s_tc.tile == SEG_TILES - 1) {
+        for (int lt = 0; lt < s_tc.tile; lt++) (void)tile_get(s_tc.xid, lt, 0);       /* every other tile has read the old position */
+        is_state[0] = (dl_wp + GDG_MAX_FRAMES) % DL;
+    }
+}
+#endif
+
 /* ahead: one frame per launch (kernel argument); ip[7]: an earlier launch of this call made the unit's wet path (api_plan.cpp build_plan) */
 UNIT_FN unit_reverb(UNIT_ARGS, const WaveGate &gate, const int ahead = 0) {
     if (!wt && ahead && uniform_unit(U)->ip[7]) reverb_general<REVERB_CONSUME>(U, flip, N, false, gate);
@@ -3066,7 +3110,7 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
         /* (the barrier that ended the previous unit lies between its last read of s_tc.xid and this write; every unit has a barrier of its
          * own between here and its first exchange) */
         if (tid == 0) s_tc.xid = xid;
-        xid += type == GDG_UNIT_COMPRESSOR ? 1 : type == GDG_UNIT_TONESTACK ? 4 : type == GDG_UNIT_CABINET ? 7 : type == GDG_UNIT_CHORUS ? 1 : 0;
+        xid += type == GDG_UNIT_COMPRESSOR ? 1 : type == GDG_UNIT_TONESTACK ? 4 : type == GDG_UNIT_CABINET ? 7 : (type == GDG_UNIT_CHORUS || type == GDG_UNIT_REVERB) ? 1 : 0;
 #endif
         /* a unit that keeps nothing from frame to frame (a shaper without oversampling) meets nobody */
         const bool gated = WAVE && (u >= 15 || ((wave_mask >> u) & 1u));
@@ -3091,7 +3135,10 @@ __device__ __forceinline__ void seg_frame(const double *src, double *dst, const 
             skip_post = WAVE && __builtin_amdgcn_readfirstlane(posted);
             break;
         }
-#ifndef SEG_TILE                                    /* (a tile sees a part of the frame: these three and the reverb keep to whole frames) */
+#ifdef SEG_TILE
+        case GDG_UNIT_REVERB: unit_reverb_mix_tile(U, flip, N, false); break;      /* (only reverbs whose wet path an earlier launch made come here: api_plan.cpp) */
+#endif
+#ifndef SEG_TILE                                    /* (a tile sees a part of the frame: these three and the whole reverb keep to whole frames) */
         case GDG_UNIT_RINGMODULATOR: unit_ringmod(U, flip, N, WAVE); break;
         case GDG_UNIT_TREMOLO: unit_tremolo(U, flip, N, WAVE); break;
         case GDG_UNIT_SIGNALGENERATOR: unit_siggen(U, flip, N, WAVE); break;
@@ -3183,13 +3230,16 @@ int gdg_segt_supported(int unit_type) {
     case GDG_UNIT_COMPRESSOR: case GDG_UNIT_OVERDRIVE: case GDG_UNIT_DISTORTION: case GDG_UNIT_EXCESS: case GDG_UNIT_TONESTACK:
     case GDG_UNIT_CABINET: case GDG_UNIT_CHORUS:
         return 1;
+    case GDG_UNIT_REVERB:
+        return 2;                           /* only as the mix of a wet path an earlier launch of the call makes (the plan checks) */
     default:
         return 0;
     }
 }
 /* exchange ids a unit of that type uses (the plan keeps a segment's sum within GDG_TILE_XIDS) */
 int gdg_segt_exchanges(int unit_type) {
-    return unit_type == GDG_UNIT_COMPRESSOR ? 1 : unit_type == GDG_UNIT_TONESTACK ? 4 : unit_type == GDG_UNIT_CABINET ? 7 : unit_type == GDG_UNIT_CHORUS ? 1 : 0;
+    return unit_type == GDG_UNIT_COMPRESSOR ? 1 : unit_type == GDG_UNIT_TONESTACK ? 4 : unit_type == GDG_UNIT_CABINET ? 7 :
+           (unit_type == GDG_UNIT_CHORUS || unit_type == GDG_UNIT_REVERB) ? 1 : 0;
 }
 size_t gdg_segt_xch_words(void) { return GDG_TILE_XCH_WORDS; }
 
