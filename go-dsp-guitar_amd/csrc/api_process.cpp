@@ -277,7 +277,7 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                     ctx->plan_unit_slot[(size_t)ctx->debug_stall_unit] >= 0) stall = 1 + ctx->plan_unit_slot[(size_t)ctx->debug_stall_unit];
                 if (st.fast) HIP_TRY(ctx, gdg_launch_segf(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch, stall));
                 else if (tickets) HIP_TRY(ctx, gdg_launch_seg(d, n, d_units, frames, window, shift, ctx->os, ctx->d_error, s, tickets, epoch, stall));
-                else if (st.tile_ok && window == 1 && G == 1 && st.wave_tickets >= 0 && ctx->d_tile_xch) {
+                else if (st.tile_ok && window == 1 && G == 1 && st.wave_tickets >= 0 && ctx->d_tile_xch && 2 * n + st.ahead_n <= GDG_TILE_WORKGROUP_BUDGET) {
                     /* a per-frame call of few channels: a channel's frame on two workgroups (seg.hip SEG_TILE; the bits of the general kernel),
                      * the reverbs' wet paths of later steps beside them as in the general launch below */
                     const int *d_ahead = st.ahead_n > 0 ? reinterpret_cast<const int *>(ctx->d_blob + st.ahead_offset) : nullptr;

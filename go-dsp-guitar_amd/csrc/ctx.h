@@ -158,10 +158,12 @@ struct gdg_ctx {
      * workgroup of its own, the frames meeting unit by unit through counters in HBM -- a GPU's share of the 512-channel job on eight GPUs is 64
      * channels, and one workgroup per channel walking the window leaves 3/4 of the CUs idle (64 channels, W = 16: 417 us per segment launch,
      * 52 of the 77 us per frame).  0: never.  gdg_ctx_set_option("seg_wave_max_channels"), env GDG_SEG_WAVE_MAX. */
-    int seg_tile_max = 64;                     /* per-frame calls of up to this many channels: a segment of compressor / shapers / tone stack / cabinet / chorus runs with
-                                                * a channel's frame on TWO workgroups (seg.hip SEG_TILE; same bits).  Per step (profiles/tile_ab_r06.txt): 16 channels
-                                                * 107.0 -> 101.3 us, 32: 124.3 -> 118.1, 64: 139.8 -> 139.5, config 3 107.7 -> 104.2; 80: 151.7 -> 155.7 (the
-                                                * two workgroups, the reverbs' extra workgroups and the premac no longer find the chip idle) */
+    int seg_tile_max = 112;                    /* per-frame calls of up to this many channels: a segment of compressor / shapers / tone stack / cabinet / chorus (/ the mix of a
+                                                * reverb made ahead) runs with a channel's frame on TWO workgroups (seg.hip SEG_TILE; same bits) -- as long as the launch's
+                                                * workgroups, 2 x channels + the reverbs' extra ones, leave the chip room (GDG_TILE_WORKGROUP_BUDGET) */
+#define GDG_TILE_WORKGROUP_BUDGET 224          /* of 256 CUs, one workgroup each.  Per step, tile kernel off / on (profiles/tile_ab_r06.txt, shape_sweep_r06.txt): bench chain 64
+                                                * channels (192 workgroups) 142.9 -> 138.4 us, 72 (216) 148.8 -> 146.6, 80 (240) 155.9 -> 158.0; no reverb, 96 channels (192)
+                                                * 111.5 -> 103.6; 96 kHz chain with a reverb, 96 channels (288) 110.9 -> 118.7 */
     unsigned long long *d_tile_xch = nullptr;  /* what crosses between the two workgroups of a channel: gdg_segt_xch_words() words per descriptor of a launch */
     size_t d_tile_xch_cap = 0;
     bool seg_os_prefix = true;                 /* a lone compressor in front of an oversampled shaper's own launch runs inside that launch in per-frame calls (option seg_os_tiles_prefix) */

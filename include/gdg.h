@@ -106,7 +106,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   seg_tile_max_channels        >= 0        per-frame calls of up to this many channels: a segment made of compressor, shapers without oversampling, tone
  *                                            stack, cabinet and chorus runs with a channel's 8192-sample frame on TWO workgroups -- the units of such a
  *                                            call are compute bound on one CU while most of the chip idles.  The scans keep the general kernel's
- *                                            association (a scan's sixteen wave totals meet in one place, eight of them through HBM): same bits (64; 0: never)
+ *                                            association (a scan's sixteen wave totals meet in one place, eight of them through HBM): same bits.  Applies while the launch's
+ *                                            workgroups -- 2 x channels + one per reverb whose wet path it carries -- stay within 224 of the 256 CUs (112; 0: never)
  *   seg_os_tiles_max_channels    >= 0        calls of up to this many channels run every 2 x / 4 x oversampled shaper as a launch of its own, one workgroup
  *                                            per (channel, frame, tile of 4096 / 2048 samples) instead of one per channel (192; 0: never)
  *   seg_os_tiles_prefix          0, 1        ... and when the step in front of such a launch is a lone compressor in every channel (compressor > 4 x overdrive:

@@ -5,7 +5,8 @@ For three chains -- no reverb; 96 kHz with a two-partition filter and a 4 x over
 two-per-CU kernel does not run) -- and channel counts 32 .. 512, the library's DEFAULT is timed against every single option flipped to the
 other side of its threshold (the shape it would take if the threshold were elsewhere):
 
-    per-frame calls:  fir_split_max_channels, fir_premac, seg_two_per_cu_min_channels, seg_os_tiles_max_channels, seg_reverb_ahead_max_channels
+    per-frame calls:  fir_split_max_channels, fir_premac, seg_two_per_cu_min_channels, seg_os_tiles_max_channels, seg_reverb_ahead_max_channels,
+                      seg_tile_max_channels
     windows of 16:    seg_wave_max_channels, seg_two_per_cu_min_channels, seg_os_tiles_max_channels
 
 A cell is a VIOLATION when the default is more than TOL (5 %) slower than an alternative -- after the pair has been measured again (the
@@ -35,7 +36,8 @@ CHAINS = {
     "c_flanger_delay_octaver": (192000, 65536, [("flanger", None), ("delay", None), ("octaver", None), ("power_amp", "cab"), ("phaser", None)]),
 }
 DEFAULTS = {"fir_split_max_channels": 128, "fir_split_max_channels_one_amp": 112, "fir_premac": 1, "seg_two_per_cu_min_channels": 128,
-            "seg_os_tiles_max_channels": 192, "seg_reverb_ahead_max_channels": 80, "seg_wave_max_channels": 448, "seg_wave_release_max_channels": 112}
+            "seg_os_tiles_max_channels": 192, "seg_reverb_ahead_max_channels": 80, "seg_wave_max_channels": 448, "seg_wave_release_max_channels": 112,
+            "seg_tile_max_channels": 112}
 RELEASE_UNITS = {"flanger", "phaser", "delay", "fuzz", "auto_yoy", "auto_wah", "bandpass", "octaver", "noise_gate"}
 
 
@@ -59,6 +61,7 @@ def flips(nch, window, defaults, chain):
             out.append(("fir_premac", {"fir_premac": 0 if defaults["fir_premac"] else 1}))
         taps_parts = None
         out.append(("seg_reverb_ahead_max_channels", None))          # resolved by the caller (needs the plan's premac state)
+        out.append(("seg_tile_max_channels", None))                  # resolved by the caller (the launch's workgroup budget)
     else:
         wave_keys = ["seg_wave_max_channels"] + (["seg_wave_release_max_channels"] if release else [])
         out.append(("seg_wave_max_channels", other(wave_keys, min(defaults[k] for k in wave_keys), True)))
@@ -125,6 +128,13 @@ def sweep(pkg, chains, channels, modes=("frame", "window"), log=print, tol=TOL, 
                         premac = defaults["fir_premac"] and nch <= split_thr and K >= 2 and nch * K >= 384
                         thr = defaults[label] if premac else max(defaults[label], 127)
                         opts = {label: 0 if nch <= thr else BIG}
+                    if label == "seg_tile_max_channels":
+                        # tiled while 2 x channels + the hosted reverbs fit 224 workgroups (ctx.h GDG_TILE_WORKGROUP_BUDGET) and channels <= the option;
+                        # the other side: the option 0.  (Where the budget says no, there is no option that forces it: nothing to flip.)
+                        hosted = nch if (has_rev and nch <= 127) else 0
+                        if nch > defaults[label] or 2 * nch + hosted > 224:
+                            continue
+                        opts = {label: 0}
                     t_alt = with_options(opts)
                     t_d = t_def
                     if t_d > (1.0 + tol) * t_alt:

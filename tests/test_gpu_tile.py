@@ -37,7 +37,7 @@ def oracle():
 
 def build(pkg, nch, chain, tile):
     ctx = pkg.Context(nch, FRAMES)
-    ctx.set_option("seg_tile_max_channels", 64 if tile else 0)
+    ctx.set_option("seg_tile_max_channels", 112 if tile else 0)
     for c in range(nch):
         for name, p in chain:
             if isinstance(p, str):
@@ -123,7 +123,7 @@ def test_a_channel_with_another_unit_keeps_the_whole_step_on_the_general_kernel(
     outs = {}
     for tile in (False, True):
         ctx = pkg.Context(nch, FRAMES)
-        ctx.set_option("seg_tile_max_channels", 64 if tile else 0)
+        ctx.set_option("seg_tile_max_channels", 112 if tile else 0)
         for c in range(nch):
             ctx.append_unit(c, "compressor")
             ctx.append_unit(c, "flanger" if c == 1 else "tone_stack")
