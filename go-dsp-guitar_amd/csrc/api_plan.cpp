@@ -925,6 +925,12 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
             for (auto &l : ahead_lists) { for (int idx : l) seg_units[(size_t)idx].ip[7] = 0; l.clear(); }
         }
     }
+    {   /* two power amps' sums made ahead stream twice as long beside the segments: the tile kernel then only pays up to the channel count the
+         * reverbs' extra workgroups pay to (bench chain, tile kernel off / on: 80 channels 162.4 -> 157.8 us, 96: 173.4 -> 177.4; one amp, 96: 112.9 -> 104.2) */
+        int premac_steps = 0;
+        for (auto &st : ctx->steps) premac_steps += (st.is_fir && st.premac_ok) ? 1 : 0;
+        if (premac_steps >= 2 && (int)active.size() > ctx->seg_reverb_ahead_max) for (auto &st : ctx->steps) st.tile_ok = false;
+    }
     /* a tiled step runs a reverb only as the mix of a wet path made by an earlier launch (seg.hip unit_reverb_mix_tile) */
     for (auto &tc : tile_conditional)
         if (tc.second < 0 || !seg_units[(size_t)tc.second].ip[7]) ctx->steps[(size_t)tc.first].tile_ok = false;
