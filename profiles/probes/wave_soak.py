@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Soak of the in-launch hand-offs (seg.hip WAVE, os_tiles_kernel, the premac) under UNEVEN load: the same streams through a context that uses them
+"""Soak of the in-launch hand-offs (seg.hip WAVE, os_tiles_kernel incl. its absorbed compressor, the premac, and round 6's: a frame on two workgroups
+with the scans' carries through HBM granules, the chorus's tile hand-off, the reverbs' wet paths as extra workgroups) under UNEVEN load: the same streams through a context that uses them
 and one that does not (walk, in-segment shaper, no premac), bit for bit, window after window and call after call, while a third context keeps the
 chip busy from another thread with 512-channel steps (HBM streams, both segment kernels) -- the situation in which a missing release or acquire
 shows (MI355X_MICROARCH.md: idle chips and L1-cold consumers hide such failures).
@@ -43,6 +44,9 @@ def pair(nch, chain, W):
             ctx.set_option("seg_wave_max_channels", 0)
             ctx.set_option("seg_os_tiles_max_channels", 0)
             ctx.set_option("fir_premac", 0)
+            ctx.set_option("seg_tile_max_channels", 0)
+            ctx.set_option("seg_reverb_ahead_max_channels", 0)
+            ctx.set_option("seg_os_tiles_prefix", 0)
         if W > 1:
             ctx.set_window(W)
         out.append((ctx, ctx.alloc(nch, W * frames), ctx.alloc(nch, W * frames)))
@@ -53,7 +57,9 @@ chain_os = [(n, ([0, 20, 100, 0, 1, 2] if n == "overdrive" else p)) for n, p in 
 cases = [("64 ch, W = 16, bench chain", pair(64, bench.CHAIN, 16), 64, 16),
          ("160 ch, W = 16, bench chain (two-per-CU build)", pair(160, bench.CHAIN, 16), 160, 16),
          ("48 ch, W = 8, 4x oversampled overdrive", pair(48, chain_os, 8), 48, 8),
-         ("64 ch, per-frame calls (premac)", pair(64, bench.CHAIN, 1), 64, 1)]
+         ("64 ch, per-frame calls (premac, two workgroups per frame, reverbs beside the first segment)", pair(64, bench.CHAIN, 1), 64, 1),
+         ("24 ch, per-frame calls, bench chain", pair(24, bench.CHAIN, 1), 24, 1),
+         ("64 ch, per-frame calls, 4x oversampled overdrive behind a compressor (absorbed into the tiles' launch)", pair(64, chain_os, 1), 64, 1)]
 th = threading.Thread(target=load)
 th.start()
 t0, rounds, bad = time.time(), 0, 0
