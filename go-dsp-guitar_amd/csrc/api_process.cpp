@@ -394,7 +394,8 @@ int check_device_error(gdg_ctx *ctx) {
         if (e == 0x57415645) {                  /* seg.hip GDG_WAVE_TIMEOUT_CODE: a frame waited ~1 s for its predecessor's counter */
             ctx->dirty = true;                  /* the next plan starts from fresh counters */
             if (ctx->d_wave) hipMemsetAsync(ctx->d_wave, 0, ctx->d_wave_cap * sizeof(int), ctx->stream);
-            return fail(ctx, GDG_ERR_HIP, "a window's segment launch timed out waiting for a frame counter (results of that window are invalid)");
+            return fail(ctx, GDG_ERR_HIP, "a segment launch timed out waiting for a hand-off between its workgroups -- a window's frame counter, a tile's carry "
+                                          "(the results of that call are invalid; reset the units)");
         }
         return fail(ctx, GDG_ERR_UNSUPPORTED, "segment kernel met unit type %d without a HIP implementation", e - 1);
     }
