@@ -6,7 +6,7 @@ two-per-CU kernel does not run) -- and channel counts 32 .. 512, the library's D
 other side of its threshold (the shape it would take if the threshold were elsewhere):
 
     per-frame calls:  fir_split_max_channels, fir_premac, seg_two_per_cu_min_channels, seg_os_tiles_max_channels, seg_reverb_ahead_max_channels,
-                      seg_tile_max_channels
+                      seg_tile_max_channels, seg_os_tiles_prefix
     windows of 16:    seg_wave_max_channels, seg_two_per_cu_min_channels, seg_os_tiles_max_channels
 
 A cell is a VIOLATION when the default is more than TOL (5 %) slower than an alternative -- after the pair has been measured again (the
@@ -37,7 +37,7 @@ CHAINS = {
 }
 DEFAULTS = {"fir_split_max_channels": 128, "fir_split_max_channels_one_amp": 112, "fir_premac": 1, "seg_two_per_cu_min_channels": 128,
             "seg_os_tiles_max_channels": 192, "seg_reverb_ahead_max_channels": 80, "seg_wave_max_channels": 448, "seg_wave_release_max_channels": 112,
-            "seg_tile_max_channels": 112}
+            "seg_tile_max_channels": 112, "seg_os_tiles_prefix": 1}
 RELEASE_UNITS = {"flanger", "phaser", "delay", "fuzz", "auto_yoy", "auto_wah", "bandpass", "octaver", "noise_gate"}
 
 
@@ -62,6 +62,8 @@ def flips(nch, window, defaults, chain):
         taps_parts = None
         out.append(("seg_reverb_ahead_max_channels", None))          # resolved by the caller (needs the plan's premac state)
         out.append(("seg_tile_max_channels", None))                  # resolved by the caller (the launch's workgroup budget)
+        if nch <= defaults["seg_os_tiles_max_channels"] and any(n == "overdrive" and p and p[5] for n, p in chain) and chain[0][0] == "compressor":
+            out.append(("seg_os_tiles_prefix", {"seg_os_tiles_prefix": 0}))       # the compressor in front of the shaper as a launch of its own again
     else:
         wave_keys = ["seg_wave_max_channels"] + (["seg_wave_release_max_channels"] if release else [])
         out.append(("seg_wave_max_channels", other(wave_keys, min(defaults[k] for k in wave_keys), True)))
