@@ -2097,7 +2097,8 @@ UNIT_FN unit_reverb_mix_tile(UNIT_ARGS) {
     seg_v2d sm[CHK / 2];
 #pragma unroll
     for (int q = 0; q < CHK / 2; q++) sm[q] = *(const GDG_GLOBAL seg_v2d *)(ahead + 2 * (tid + q * SEG_T));
-    __syncthreads();                                               /* (the position is read: see below) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              /* every lane HOLDS the write position (and its sums) before the workgroup says so */
+    __syncthreads();
     if (tid == 0 && s_tc.tile + 1 < SEG_TILES) tile_put(s_tc.xid, s_tc.tile, 0, 1.0);
 #pragma unroll
     for (int q = 0; q < CHK; q++) {
