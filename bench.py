@@ -1002,7 +1002,7 @@ def main():
                                                                    "predicted_realtime_factor": frames / sr / dtw}
                 extras["strong_split_legs"] = {"what": "one GPU running its share of the 512-channel job split over 8 / 4 / 2 GPUs "
                                                        "(channels are independent: the job's step time is the slowest shard's step time); launch shapes "
-                                                       "are the library's own by channel count: per-frame calls of <= 128 channels (option fir_split_max_channels) run the split multiply-accumulate with "
+                                                       "are the library's own by channel count: per-frame calls of <= 192 channels (option fir_split_max_channels) run the split multiply-accumulate with "
                                                        "the sums over the partitions already in the delay line made ahead of the frame (option fir_premac), windows of "
                                                        "<= 448 channels run a workgroup per frame and channel (option seg_wave_max_channels), oversampled shapers of calls of <= 192 channels "
                                                        "run as launches of their own, a workgroup per tile (option seg_os_tiles_max_channels)",

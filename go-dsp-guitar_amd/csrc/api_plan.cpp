@@ -895,6 +895,13 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
             for (auto &f : fd) partitions += f.K;
             st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && partitions >= ctx->fir_premac_min;
             for (auto &f : fd) if (f.K < 2 || f.hop != frames) st.premac_ok = false;
+            /* LDS the premac's workgroups ask for and never touch: such a workgroup does not fit on a CU beside a general or tile segment
+             * workgroup (159 KiB), and at most one fits beside a two-per-CU one (80 KiB), so the sums run on the CUs the segments leave idle
+             * and not among their waves.  Pays where the sums are neither a sliver nor the whole frame -- 5 .. 32 partitions per channel:
+             * 48 channels x 65536 taps 124.5 -> 119.9 us per frame, 128 channels 195.3 -> 185.2; 128 x 32768 taps 168 -> 172 and 64 x 1048576
+             * taps 305 -> 320 WITH it, hence the bounds (profiles/premac_loads_ab_r06.txt) */
+            const long per_channel = st.n > 0 ? partitions / st.n : 0;
+            st.premac_lds = ctx->fir_premac_lds >= 0 ? ctx->fir_premac_lds : ((per_channel >= 5 && per_channel <= 32) ? (st.n < 120 ? 16384 : 49152) : 0);
         }
         if (!is_fir && !is_os && !step_fast && !sd.empty()) {
             /* the host of later reverbs' wet paths: the earlier general-kernel launch that lives longest (the extra workgroups take ~15 us at

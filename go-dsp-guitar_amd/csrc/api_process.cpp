@@ -301,7 +301,8 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
             for (auto &sx : ctx->steps) {
                 if (!sx.is_fir || !sx.premac_ok || !sx.n) continue;
                 const gdg_fir_chan *dx = reinterpret_cast<const gdg_fir_chan *>(ctx->d_blob + sx.offset);
-                HIP_TRY(ctx, gdg_launch_fir_mac(P2, dx, sx.n, sx.shared_spectra ? 1 : 0, ctx->premac_stream, 1));
+                /* ... on the CUs the segments leave idle (premac_lds: api_plan.cpp) */
+                HIP_TRY(ctx, gdg_launch_fir_mac(P2, dx, sx.n, sx.shared_spectra ? 1 : 0, ctx->premac_stream, 1, sx.premac_lds));
             }
             HIP_TRY(ctx, hipEventRecord(ctx->ev_premac, ctx->premac_stream));
             ctx->premac_valid = true;

@@ -108,6 +108,7 @@ struct StepDesc {
     bool chain_next = false;          /* FIR step whose every channel feeds another power amp next (the following step): that amp's forward
                                        * transform rides on this step's inverse (fir_inv_kernel CHAIN) in per-frame calls */
     bool fast = false;                /* segment step: every unit of every channel works in place on 8192-sample frames -> the two-per-CU kernel (segf) */
+    int premac_lds = 0;               /* ... and the LDS its launch asks for without using it (api_plan.cpp) */
     bool premac_ok = false;           /* FIR step: split shape (few channels), 8192-sample frames, every channel with K >= 2: the terms k >= 1 can be summed ahead */
     int os_factor = 0;                /* 2 / 4: the step is ONE oversampled shaper per channel, run as a launch of its own (seg.hip os_tiles_kernel) */
     int os_flags = -1;                /* ... and its per-channel flags start here in d_wave */
@@ -197,6 +198,7 @@ struct gdg_ctx {
      * on the critical path instead of 2 K.  Every multiply-accumulate kernel sums k DESCENDING, so the split sum has the bits of the whole one.
      * The premac is speculative: any library call but a process call drops it (the next call then runs the whole sum). */
     int fir_premac = 1;                        /* option "fir_premac": 0 never */
+    int fir_premac_lds = -1;                   /* option "fir_premac_lds_bytes": -1 by channel count (api_process.cpp) */
     int fir_premac_min = 384;                  /* fewest partitions (sum of K over a launch's channels) worth it: the two cross-stream hops and the
                                                 * three extra spectra of the inverse kernel cost ~20 us per step -- the multiply-accumulate of 48 x 8
                                                 * partitions takes that long (16 x 8: 113.7 -> 123.4 us per step with it, 64 x 4 (config 3): 137 -> 141) */
@@ -240,9 +242,11 @@ struct gdg_ctx {
      * as its own bin-tiled kernel (32 workgroups per channel) followed by the inverse (profiles/channels_sweep_r02.txt).
      * GDG_FIR_FUSED=0 / 1 forces one shape (A/B measurements). */
     int fir_fused = -1;
-    int fir_split_max = 128;          /* largest launch (channels) that takes the split shape.  Round 2 measured the two shapes equal at 128 channels
+    int fir_split_max = 192;          /* largest launch (channels) that takes the split shape.  Round 2 measured the two shapes equal at 128 channels
                                        * (220 us per step either way) and set 96; with the sums made ahead of the frame (premac, below) the split shape
-                                       * takes 207 us there, at 192 channels the fused kernel wins again (252 vs 274) */
+                                       * took 207 us there and lost at 192 (252 vs 274), hence 128 until the premac stopped reading through the cache
+                                       * (fir.hip, fir_mac_kernel): 128 channels 181 vs 223 fused, 160 215 vs 236, 192 247 vs 257, 208 266 vs 264
+                                       * (profiles/shape_sweep_r06.txt, chain d) */
     int fir_split_max_single = 112;   /* ... when the call has ONE power amp per channel: the premac has half as much to hide, and at 128 channels the fused kernel wins
                                        * (one amp: 138.8 split vs 127.1 fused us per step, 96 channels 112 vs 125; profiles/shape_sweep_r06.txt) */
     int plan_fir_steps = 0;           /* power-amp steps of the current plan */

@@ -25,6 +25,7 @@
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 typedef double2 cplx;
@@ -735,10 +736,14 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P, int k_lo) {
      * frame exists: k = K - 1 .. K_LO with K_LO = 1 is the "premac" launch that runs beside the previous call's last segment, and the
      * inverse kernel then only adds the k = 0 term (fir_inv_kernel, FUSED = 4) -- the same additions in the same order, the same bits. */
     int k = K - 1;
-    for (; k - (UNROLL - 1) >= k_lo; k -= UNROLL) {
-        cplx x[UNROLL][BPT], h[UNROLL][BPT];
+    /* U partitions' loads are issued before any is used; all of them non-temporal when NT: a spectrum is read once per launch, and a cached
+     * read of one evicts what the kernels beside this one keep in L2 (the premac beside a small shard's segment: 96 channels 172 -> 148 us
+     * per frame when its tail stopped reading through the cache, profiles/premac_loads_ab_r06.txt) */
+    auto chunk = [&](auto u_tag) {
+        constexpr int U = decltype(u_tag)::value;
+        cplx x[U][BPT], h[U][BPT];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
+        for (int u = 0; u < U; u++) {
             int slot = cur - (k - u);
             if (slot < 0) slot += R;
 #pragma unroll
@@ -748,7 +753,7 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P, int k_lo) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
+        for (int u = 0; u < U; u++) {
 #pragma unroll
             for (int q = 0; q < BPT; q++) {
                 ar[q] += x[u][q].x * h[u][q].x - x[u][q].y * h[u][q].y;
@@ -757,18 +762,12 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P, int k_lo) {
             br += x[u][0].x * h[u][0].x;
             bi += x[u][0].y * h[u][0].y;
         }
-    }
-    for (; k >= k_lo; k--) {
-        int slot = cur - k;
-        if (slot < 0) slot += R;
-#pragma unroll
-        for (int q = 0; q < BPT; q++) {
-            cplx x = gload(fdl + (size_t)slot * P + q), h = gload(H + (size_t)k * P + q);
-            ar[q] += x.x * h.x - x.y * h.y;
-            ai[q] += x.x * h.y + x.y * h.x;
-            if (q == 0) { br += x.x * h.x; bi += x.y * h.y; }
-        }
-    }
+        k -= U;
+    };
+    constexpr int TAIL = UNROLL >= 6 ? 3 : (UNROLL >= 4 ? 2 : 1);
+    while (k - (UNROLL - 1) >= k_lo) chunk(std::integral_constant<int, UNROLL>());
+    if constexpr (TAIL > 1) { while (k - (TAIL - 1) >= k_lo) chunk(std::integral_constant<int, TAIL>()); }
+    while (k >= k_lo) chunk(std::integral_constant<int, 1>());
 #pragma unroll
     for (int q = 0; q < BPT; q++) gstore(ch.Y + b0 + q, (b0 + q == 0) ? make_double2(br, bi) : make_double2(ar[q], ai[q]));
 }
@@ -1662,20 +1661,23 @@ hipError_t gdg_launch_fir_raw_inv(int P, const gdg_fir_rawjob *d_jobs, int n_job
 }
 
 template <int UNROLL, int BPT, bool NT, bool SWAP = false, bool HNT = NT>
-static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s, int block = 256, int k_lo = 0) {
+static void launch_mac(int P, const gdg_fir_chan *d_chans, int n_chans, hipStream_t s, int block = 256, int k_lo = 0, int lds_bytes = 0) {
     int per_block = block * BPT;
     int threads = P < per_block ? (P / BPT) : block;
     if (threads < 1) threads = 1;
     unsigned tiles = (unsigned)((P + threads * BPT - 1) / (threads * BPT));
     dim3 grid = SWAP ? dim3((unsigned)n_chans, tiles) : dim3(tiles, (unsigned)n_chans);
-    fir_mac_kernel<UNROLL, BPT, NT, SWAP, HNT><<<grid, dim3(threads), 0, s>>>(d_chans, P, k_lo);
+    fir_mac_kernel<UNROLL, BPT, NT, SWAP, HNT><<<grid, dim3(threads), (size_t)lds_bytes, s>>>(d_chans, P, k_lo);
 }
 
-hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s, int k_lo) {
+hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s, int k_lo, int lds_bytes) {
     if (n_chans <= 0) return hipSuccess;
     /* IR spectra shared between channels are worth caching; private ones are read once: non-temporal like the delay line */
-    if (shared_spectra) { launch_mac<8, 1, true, false, false>(P, d_chans, n_chans, s, 256, k_lo); return hipGetLastError(); }
-    if (k_lo > 0) { launch_mac<8, 1, true>(P, d_chans, n_chans, s, 256, k_lo); return hipGetLastError(); }       /* the premac: the measured best shape */
+    if (shared_spectra) { launch_mac<8, 1, true, false, false>(P, d_chans, n_chans, s, 256, k_lo, lds_bytes); return hipGetLastError(); }
+    /* the premac (k_lo = 1, launched beside the segments of a small shard): seven partitions' loads in flight -- all of 65536 taps' terms but
+     * the newest -- and `lds_bytes` of LDS it never touches: a workgroup that asks for them does not fit on a CU beside a segment workgroup
+     * (159 KiB, or two of 80), so the sums run on the CUs the segments leave idle instead of among their waves (api_process.cpp) */
+    if (k_lo > 0) { launch_mac<7, 1, true>(P, d_chans, n_chans, s, 256, k_lo, lds_bytes); return hipGetLastError(); }
     /* GDG_MAC_VARIANT: tuning knob for profiles/mac_variants.py; the default is the measured best */
     const int variant = gdg_knob_get(GDG_KNOB_MAC_VARIANT);
     switch (variant) {

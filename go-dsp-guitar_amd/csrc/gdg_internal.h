@@ -72,7 +72,7 @@ hipError_t gdg_fir_tables_create(int P, double2 **d_tw, double2 **d_tw2);
 hipError_t gdg_launch_fir_fwd(int P, int hop, const gdg_fir_chan *d_chans, int n_chans, const double2 *d_tw, const double2 *d_tw2, gdg_shift shift, hipStream_t s);
 /* k_lo: the partitions k = K - 1 .. k_lo are summed (descending: the order of every multiply-accumulate kernel).  0 = the whole sum;
  * 1 = everything but the newest partition, i.e. what can be computed BEFORE the frame exists (the premac of small shards, api_process.cpp) */
-hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s, int k_lo = 0);
+hipError_t gdg_launch_fir_mac(int P, const gdg_fir_chan *d_chans, int n_chans, int shared_spectra, hipStream_t s, int k_lo = 0, int lds_bytes = 0);
 /* time blocking: a window of W (2, 4, 8 or 16) consecutive 8192-sample frames per channel; what = 0 forward transforms, 1 multiply-accumulate
  * (reads every spectrum once for the W frames), 2 inverse transforms, 3 history + frame counter.  chans[].src / dst: frame 0 of the
  * window, frame j at + j * 8192; chans[].Y holds W spectra; chans[].R >= K + W - 1. */

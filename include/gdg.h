@@ -85,7 +85,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  * on an option beyond the last bits (which association a sum takes); unknown keys and values out of range are GDG_ERR_INVALID.
  *   key                          values      meaning (default)
  *   fir_fused                    -1, 0, 1    spectrum multiply-accumulate inside the inverse transform's kernel: by channel count / never / always (-1)
- *   fir_split_max_channels       >= 0        with fir_fused = -1: launches of up to this many channels take the bin-tiled multiply-accumulate (128)
+ *   fir_split_max_channels       >= 0        with fir_fused = -1: launches of up to this many channels take the bin-tiled multiply-accumulate (192: with the
+ *                                            sums made ahead, fir_premac, it is the faster shape up to there when a channel has two power amps)
  *   fir_split_max_channels_one_amp >= 0      ... and when the call has ONE power amp per channel the smaller of the two applies (112: with one amp the
  *                                            fused kernel wins at 128 channels, profiles/shape_sweep_r06.txt)
  *   fir_chain_adjacent_amps      0, 1        a power amp's inverse transform also makes the forward transform of the amp behind it (1)
@@ -95,6 +96,9 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *                                            call but a process call, gdg_ctx_synchronize and gdg_ctx_stream drops them.  Same bits either way (1)
  *   fir_premac_min_partitions    >= 1        ... for launches of at least this many partitions (channels x ceil(taps / 8192)) (384 = 48 channels x 65536
  *                                            taps: below, the two cross-stream hops cost more than they hide)
+ *   fir_premac_lds_bytes         -1 .. 65536 ... whose workgroups ask for this much LDS they never touch, so that they land on the CUs the segments leave
+ *                                            idle instead of among the segments' waves; -1: 16384 below 120 channels, 49152 from there, 0 when a channel
+ *                                            has fewer than 5 or more than 32 partitions (-1)
  *   share_ir_spectra             0, 1        = gdg_ctx_share_ir_spectra (1)
  *   seg_two_per_cu               0, 1        segments of in-place units on 8192-sample frames take the 512-thread kernel, two workgroups per CU (1)
  *   seg_two_per_cu_min_channels  >= 0        ... from this many channels per call on (128)

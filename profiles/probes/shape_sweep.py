@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Do the library's launch-shape thresholds (include/gdg.h, gdg_ctx_set_option) pick the faster shape on chains the bench never runs?
 
-For three chains -- no reverb; 96 kHz with a two-partition filter and a 4 x oversampled overdrive; flanger + delay + octaver (units the
-two-per-CU kernel does not run) -- and channel counts 32 .. 512, the library's DEFAULT is timed against every single option flipped to the
+For four chains -- no reverb; 96 kHz with a two-partition filter and a 4 x oversampled overdrive; flanger + delay + octaver (units the
+two-per-CU kernel does not run); the bench's own (two power amps per channel) -- and channel counts 32 .. 512, the library's DEFAULT is timed against every single option flipped to the
 other side of its threshold (the shape it would take if the threshold were elsewhere):
 
     per-frame calls:  fir_split_max_channels, fir_premac, seg_two_per_cu_min_channels, seg_os_tiles_max_channels, seg_reverb_ahead_max_channels,
@@ -34,8 +34,9 @@ CHAINS = {
     "b_96k_K2_os4": (96000, 16384, [("compressor", [1, 30, -20]), ("overdrive", [0, 20, 100, 0, 1, 2]), ("tone_stack", None),
                                     ("power_amp", "cab"), ("cabinet", None), ("reverb", [50])]),
     "c_flanger_delay_octaver": (192000, 65536, [("flanger", None), ("delay", None), ("octaver", None), ("power_amp", "cab"), ("phaser", None)]),
+    "d_bench_two_amps": (192000, 65536, list(bench.CHAIN)),          # the bench's own chain: TWO power amps per channel (the other limit of the split convolution)
 }
-DEFAULTS = {"fir_split_max_channels": 128, "fir_split_max_channels_one_amp": 112, "fir_premac": 1, "seg_two_per_cu_min_channels": 128,
+DEFAULTS = {"fir_split_max_channels": 192, "fir_split_max_channels_one_amp": 112, "fir_premac": 1, "seg_two_per_cu_min_channels": 128,
             "seg_os_tiles_max_channels": 192, "seg_reverb_ahead_max_channels": 80, "seg_wave_max_channels": 448, "seg_wave_release_max_channels": 112,
             "seg_tile_max_channels": 112, "seg_os_tiles_prefix": 1}
 RELEASE_UNITS = {"flanger", "phaser", "delay", "fuzz", "auto_yoy", "auto_wah", "bandpass", "octaver", "noise_gate"}
@@ -79,7 +80,7 @@ def sweep(pkg, chains, channels, modes=("frame", "window"), log=print, tol=TOL, 
     for cname in chains:
         sr, taps, chain = CHAINS[cname]
         for nch in channels:
-            ctx = bench.make_context(pkg, nch, frames, device, taps, chain=chain, second_amp=False)
+            ctx = bench.make_context(pkg, nch, frames, device, taps, chain=chain, second_amp=any(p == "rev" for _, p in chain))
             defaults = {k: ctx.get_option(k) for k in DEFAULTS}
             d_in1, d_out1 = ctx.alloc(nch, frames), ctx.alloc(nch, frames)
             d_in1.upload(bench.synth_block(nch, frames, sr))
@@ -167,5 +168,5 @@ if __name__ == "__main__":
     channels = [int(v) for v in os.environ.get("CHANNELS", "32,64,96,128,192,256,448,512").split(",")]
     chains = [c for c in CHAINS if c[0] in os.environ.get("CHAINS", "a,b,c").split(",")]
     print("# default vs each launch-shape option flipped to the other side of its threshold; us per frame (per-frame calls / windows of 16)")
-    rows, bad = sweep(pkg, chains, channels)
+    rows, bad = sweep(pkg, chains, channels, modes=tuple(os.environ.get("MODES", "frame,window").split(",")))
     print("# %d cells, %d violations (default more than %.0f %% slower than an alternative, measured three times)" % (len(rows), len(bad), TOL * 100))

@@ -2,7 +2,7 @@
 """Small shards (a GPU's share of the 512-channel job on 8 / 4 GPUs): per-frame device calls and windows of 16 frames by number of
 free-running channel groups, with the per-kernel-kind HIP-event times of the one-group run.
 
-    NCH=64 MODE=frame|window GROUPS=1,2,4,8 [CHAIN=config3] python profiles/probes/small_ctx.py
+    NCH=64 MODE=frame|window GROUPS=1,2,4,8 [CHAIN=config3] [TAPS=65536 AMPS=2 DISTINCT=0] [OPTIONS=key=value,...] python profiles/probes/small_ctx.py
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,8 +19,8 @@ if os.environ.get("CHAIN", "") == "config3":
     sr, taps, second = 96000, 32768, False
     chain = [(n, ([0, 20, 100, 0, 1, 2] if n == "overdrive" else p)) for n, p in bench.CHAIN]
 else:
-    sr, taps, second, chain = 192000, 65536, True, bench.CHAIN
-ctx = bench.make_context(pkg, nch, frames, 0, taps, chain=chain, second_amp=second)
+    sr, taps, second, chain = 192000, int(os.environ.get("TAPS", "65536")), os.environ.get("AMPS", "2") == "2", bench.CHAIN
+ctx = bench.make_context(pkg, nch, frames, 0, taps, chain=chain, second_amp=second, n_distinct=int(os.environ.get("DISTINCT", "0")))
 opts = os.environ.get("OPTIONS", "")                 # "key=value,key=value": gdg_ctx_set_option before the first call
 for kv in [o for o in opts.split(",") if o]:
     k, v = kv.split("=")
