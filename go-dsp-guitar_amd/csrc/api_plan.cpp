@@ -893,7 +893,8 @@ int build_plan(gdg_ctx *ctx, const std::vector<int> &active, const double *d_in,
             const bool split = ctx->fir_fused < 0 ? (st.n <= fir_split_limit(ctx)) : (ctx->fir_fused == 0);
             long partitions = 0;
             for (auto &f : fd) partitions += f.K;
-            st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && partitions >= ctx->fir_premac_min;
+            const long premac_min = ctx->plan_fir_steps >= 2 ? std::min(ctx->fir_premac_min, ctx->fir_premac_min_two) : ctx->fir_premac_min;
+            st.premac_ok = ctx->fir_premac != 0 && split && G == 1 && frames == GDG_MAX_FRAMES && partitions >= premac_min;
             for (auto &f : fd) if (f.K < 2 || f.hop != frames) st.premac_ok = false;
             /* LDS the premac's workgroups ask for and never touch: such a workgroup does not fit on a CU beside a general or tile segment
              * workgroup (159 KiB), and at most one fits beside a two-per-CU one (80 KiB), so the sums run on the CUs the segments leave idle

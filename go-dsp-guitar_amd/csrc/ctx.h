@@ -202,6 +202,8 @@ struct gdg_ctx {
     int fir_premac_min = 384;                  /* fewest partitions (sum of K over a launch's channels) worth it: the two cross-stream hops and the
                                                 * three extra spectra of the inverse kernel cost ~20 us per step -- the multiply-accumulate of 48 x 8
                                                 * partitions takes that long (16 x 8: 113.7 -> 123.4 us per step with it, 64 x 4 (config 3): 137 -> 141) */
+    int fir_premac_min_two = 320;              /* ... with two or more power amps per channel the hops hide twice as much: 40 x 8 partitions per amp 120.6 -> 109.3 us
+                                                * per step with it, 32 x 8: 112.4 -> 109.6, 24 x 8: 107.2 -> 108.6 (profiles/premac_loads_ab_r06.txt) */
     hipStream_t premac_stream = nullptr;
     hipEvent_t ev_fir_done = nullptr, ev_premac = nullptr;
     bool premac_valid = false;                 /* Y of every premac step holds the terms k >= 1 of the plan's NEXT frame */

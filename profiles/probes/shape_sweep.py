@@ -128,7 +128,7 @@ def sweep(pkg, chains, channels, modes=("frame", "window"), log=print, tol=TOL, 
                         K = -(-taps // frames)
                         amps = sum(1 for n, _ in chain if n == "power_amp")
                         split_thr = min(defaults["fir_split_max_channels"], defaults["fir_split_max_channels_one_amp"]) if amps < 2 else defaults["fir_split_max_channels"]
-                        premac = defaults["fir_premac"] and nch <= split_thr and K >= 2 and nch * K >= 384
+                        premac = defaults["fir_premac"] and nch <= split_thr and K >= 2 and nch * K >= (320 if amps >= 2 else 384)
                         thr = defaults[label] if premac else max(defaults[label], 127)
                         opts = {label: 0 if nch <= thr else BIG}
                     if label == "seg_tile_max_channels":
