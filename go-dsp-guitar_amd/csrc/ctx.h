@@ -209,8 +209,9 @@ struct gdg_ctx {
     bool premac_valid = false;                 /* Y of every premac step holds the terms k >= 1 of the plan's NEXT frame */
     bool premac_outstanding = false;           /* ... and the context's stream has not been ordered behind that launch yet */
     /* reverbs' wet paths ahead of the frame (seg.hip REVERB_AHEAD): made by extra workgroups of an EARLIER segment launch of the same call */
-    int seg_reverb_ahead_max = 80;             /* most channels of a call that does it: 64 channels 156 -> 142 us per step, 96 channels 168 -> 175 (twice the
-                                                * workgroups in the first segment launch, and the premac's share of the chip with them) */
+    int seg_reverb_ahead_max = 72;             /* most channels of a call that does it: 64 channels 156 -> 142 us per step, 96 channels 168 -> 175 (twice the
+                                                * workgroups in the first segment launch, and the premac's share of the chip with them); with the premac's
+                                                * loads fixed: 64 channels 135.1 -> 125.7, 72: 135.6 -> 134.7, 80: 137.7 -> 140.0, 88: 143.3 -> 147.4 */
     int wave_spin_ms = 1000;                   /* how long a frame waits for its predecessor's counter before the launch gives up (seg.hip wave_spin_expired; d_error[1]) */
     int debug_stall_unit = -1;                 /* test hook: this unit's first counter of a WAVE launch stays away, so that the bounded wait expires */
     int wave_epoch = 0;                        /* a number per WAVE launch (seg.hip: "done" marks carry it) */

@@ -766,8 +766,25 @@ fir_mac_kernel(const gdg_fir_chan *__restrict__ chans, int P, int k_lo) {
     };
     constexpr int TAIL = UNROLL >= 6 ? 3 : (UNROLL >= 4 ? 2 : 1);
     while (k - (UNROLL - 1) >= k_lo) chunk(std::integral_constant<int, UNROLL>());
-    if constexpr (TAIL > 1) { while (k - (TAIL - 1) >= k_lo) chunk(std::integral_constant<int, TAIL>()); }
-    while (k >= k_lo) chunk(std::integral_constant<int, 1>());
+    if (k_lo > 0) {
+        /* the premac runs BESIDE other kernels: what is left goes the same way */
+        if constexpr (TAIL > 1) { while (k - (TAIL - 1) >= k_lo) chunk(std::integral_constant<int, TAIL>()); }
+        while (k >= k_lo) chunk(std::integral_constant<int, 1>());
+    }
+    /* the whole sum on the call's own stream (few channels, short filters): alone on the chip, and a small shard's spectra are few enough to
+     * still be in the last-level cache from the frame before -- through the cache (64 channels x 4 partitions, BASELINE config 3: 98.5 us per
+     * frame against 101.2 with non-temporal loads here too, profiles/premac_loads_ab_r06.txt) */
+    for (; k >= k_lo; k--) {
+        int slot = cur - k;
+        if (slot < 0) slot += R;
+#pragma unroll
+        for (int q = 0; q < BPT; q++) {
+            cplx x = gload(fdl + (size_t)slot * P + q), h = gload(H + (size_t)k * P + q);
+            ar[q] += x.x * h.x - x.y * h.y;
+            ai[q] += x.x * h.y + x.y * h.x;
+            if (q == 0) { br += x.x * h.x; bi += x.y * h.y; }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < BPT; q++) gstore(ch.Y + b0 + q, (b0 + q == 0) ? make_double2(br, bi) : make_double2(ar[q], ai[q]));
 }

@@ -122,7 +122,7 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *                                            sums and all-passes need nothing of the frame itself when every tap lies at least a frame back
  *                                            (8192-sample frames, rates from 42.7 kHz) -- and the reverb behind the power amps only mixes.  The limit
  *                                            applies to calls that also sum convolution terms ahead (fir_premac: its launches want the same idle CUs);
- *                                            without them up to 127 channels.  Same bits either way (80; 0: never)
+ *                                            without them up to 127 channels.  Same bits either way (72; 0: never)
  *   wave_spin_limit_ms           1 .. 600000 how long a workgroup of an in-launch hand-off (windows of few channels, tiles of an oversampled shaper) waits
  *                                            for its predecessor before the launch gives up: the wait ends, the context's error word is set and the next
  *                                            gdg_ctx_synchronize (or batch run) returns GDG_ERR_HIP -- the device never hangs.  RESULTS OF WINDOW CALLS ARE

@@ -37,7 +37,7 @@ CHAINS = {
     "d_bench_two_amps": (192000, 65536, list(bench.CHAIN)),          # the bench's own chain: TWO power amps per channel (the other limit of the split convolution)
 }
 DEFAULTS = {"fir_split_max_channels": 192, "fir_split_max_channels_one_amp": 112, "fir_premac": 1, "seg_two_per_cu_min_channels": 128,
-            "seg_os_tiles_max_channels": 192, "seg_reverb_ahead_max_channels": 80, "seg_wave_max_channels": 448, "seg_wave_release_max_channels": 112,
+            "seg_os_tiles_max_channels": 192, "seg_reverb_ahead_max_channels": 72, "seg_wave_max_channels": 448, "seg_wave_release_max_channels": 112,
             "seg_tile_max_channels": 112, "seg_os_tiles_prefix": 1}
 RELEASE_UNITS = {"flanger", "phaser", "delay", "fuzz", "auto_yoy", "auto_wah", "bandpass", "octaver", "noise_gate"}
 
