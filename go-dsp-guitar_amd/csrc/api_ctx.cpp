@@ -153,6 +153,7 @@ static const OptionDef g_options[] = {
     { "fir_premac", "GDG_FIR_PREMAC", 0, 1, -1, &gdg_ctx::fir_premac, nullptr, true },
     { "fir_premac_min_partitions", "GDG_FIR_PREMAC_MIN", 1, 1 << 24, -1, &gdg_ctx::fir_premac_min, nullptr, true },
     { "fir_premac_min_partitions_two_amps", "GDG_FIR_PREMAC_MIN_TWO", 1, 1 << 24, -1, &gdg_ctx::fir_premac_min_two, nullptr, true },
+    { "stat_premac_launches_used", "GDG_STAT_PREMAC_USED", 0, 0x7fffffff, -1, &gdg_ctx::stat_premac_used, nullptr, false },
     { "fir_premac_lds_bytes", "GDG_FIR_PREMAC_LDS", -1, 65536, -1, &gdg_ctx::fir_premac_lds, nullptr, true },
     { "share_ir_spectra", "GDG_SHARE_IR_SPECTRA", 0, 1, -1, nullptr, &gdg_ctx::share_spectra, false },
     { "fft_half_lds_mask", "GDG_FFT_HALF_LDS", 0, 63, GDG_KNOB_FFT_HALF_LDS, nullptr, nullptr, false },

@@ -241,6 +241,7 @@ int process_rows(gdg_ctx *ctx, const std::vector<int> &active, const double *d_i
                     if (ctx->premac_outstanding) { HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_premac, 0)); ctx->premac_outstanding = false; }
                     ProfScope ps(ctx, GDG_K_FIR_INV, s);
                     HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 4, shift, s, d_next));
+                    ctx->stat_premac_used++;
                 } else {
                     { ProfScope ps(ctx, GDG_K_FIR_MAC, s); HIP_TRY(ctx, gdg_launch_fir_mac(P2, d, n, st.shared_spectra ? 1 : 0, s)); }
                     { ProfScope ps(ctx, GDG_K_FIR_INV, s); HIP_TRY(ctx, gdg_launch_fir_inv(P2, d, n, tw, tw2, 0, shift, s, d_next)); }

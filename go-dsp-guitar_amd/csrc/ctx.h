@@ -206,6 +206,7 @@ struct gdg_ctx {
                                                 * per step with it, 32 x 8: 112.4 -> 109.6, 24 x 8: 107.2 -> 108.6 (profiles/premac_loads_ab_r06.txt) */
     hipStream_t premac_stream = nullptr;
     hipEvent_t ev_fir_done = nullptr, ev_premac = nullptr;
+    int stat_premac_used = 0;                  /* option "stat_premac_launches_used" (read it; tests): inverse launches that continued sums made ahead */
     bool premac_valid = false;                 /* Y of every premac step holds the terms k >= 1 of the plan's NEXT frame */
     bool premac_outstanding = false;           /* ... and the context's stream has not been ordered behind that launch yet */
     /* reverbs' wet paths ahead of the frame (seg.hip REVERB_AHEAD): made by extra workgroups of an EARLIER segment launch of the same call */

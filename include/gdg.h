@@ -97,6 +97,8 @@ int gdg_ctx_share_ir_spectra(gdg_ctx *ctx, int enable);
  *   fir_premac_min_partitions    >= 1        ... for launches of at least this many partitions (channels x ceil(taps / 8192)) (384 = 48 channels x 65536
  *                                            taps: below, the two cross-stream hops cost more than they hide)
  *   fir_premac_min_partitions_two_amps >= 1  ... and when a channel has two or more power amps, the smaller of the two (320 = 40 channels x 65536 taps)
+ *   stat_premac_launches_used    >= 0        a counter, not a setting: inverse-transform launches so far that continued sums made ahead (tests read it to
+ *                                            see that the path under test is the one that ran; setting it sets the count) (0)
  *   fir_premac_lds_bytes         -1 .. 65536 ... whose workgroups ask for this much LDS they never touch, so that they land on the CUs the segments leave
  *                                            idle instead of among the segments' waves; -1: 16384 below 120 channels, 49152 from there, 0 when a channel
  *                                            has fewer than 5 or more than 32 partitions (-1)
